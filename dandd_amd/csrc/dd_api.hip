@@ -1,0 +1,675 @@
+// dd_api.hip -- the C ABI of libdandd_hip.so (declared in include/dandd_hip.h).
+//
+// Host-side orchestration only: workspace management in HBM, job tables for the sweep,
+// stream/event plumbing.  Every entry point names the DandD command line it replaces in
+// include/dandd_hip.h.  There is no CPU fallback anywhere in this file.
+#include "../../include/dandd_hip.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "dd_common.h"
+#include "dd_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define DD_HIP(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(DD_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                        __LINE__);                                                            \
+    } while (0)
+
+struct DevBuf {  // grow-only device allocation
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n) {
+        if (n <= cap) return DD_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 8 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            p = nullptr;
+            return fail(DD_ENOMEM, "hipMalloc(%zu) failed", want);
+        }
+        cap = want;
+        return DD_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct HostBuf {  // grow-only pinned host staging
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n) {
+        if (n <= cap) return DD_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 8 + 256;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+            p = nullptr;
+            return fail(DD_ENOMEM, "hipHostMalloc(%zu) failed", want);
+        }
+        cap = want;
+        return DD_OK;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct TimedSpan {
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct dd_ctx {
+    int device = 0, p = 14, canonical = 1;
+    hipStream_t stream = nullptr;
+    bool timing = false;
+    std::vector<TimedSpan> spans[DD_KERNEL_COUNT];
+    std::vector<hipEvent_t> pool;
+    // workspaces
+    DevBuf tokens, scratch, tables, fasta, regs, ptrs, hist, est, ord;
+    HostBuf stage;
+    hipEvent_t stage_free = nullptr;  // signalled when the last upload from `stage` completed
+    // stats of the last sketch call
+    uint64_t st_tokens = 0, st_updates = 0;
+    int st_blocks = 0;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        (void)hipGetDevice(&prev);
+        if (prev != dev) (void)hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+hipEvent_t get_event(dd_ctx* c) {
+    if (!c->pool.empty()) {
+        hipEvent_t e = c->pool.back();
+        c->pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct Span {  // brackets a launch with events when timing is on
+    dd_ctx* c;
+    int which;
+    TimedSpan s{};
+    Span(dd_ctx* c_, int which_) : c(c_), which(which_) {
+        if (c->timing) {
+            s.a = get_event(c);
+            s.b = get_event(c);
+            (void)hipEventRecord(s.a, c->stream);
+        }
+    }
+    ~Span() {
+        if (c->timing) {
+            (void)hipEventRecord(s.b, c->stream);
+            c->spans[which].push_back(s);
+        }
+    }
+};
+
+// upload a host table through the pinned staging buffer (async on the stream)
+int upload(dd_ctx* c, void* dst_dev, const void* src, size_t bytes, size_t stage_off) {
+    memcpy(static_cast<char*>(c->stage.p) + stage_off, src, bytes);
+    DD_HIP(hipMemcpyAsync(dst_dev, static_cast<char*>(c->stage.p) + stage_off, bytes,
+                          hipMemcpyHostToDevice, c->stream));
+    return DD_OK;
+}
+
+int kclass_of(int k) { return k <= 16 ? 0 : (k <= 32 ? 1 : 2); }
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int check_ctx(dd_ctx* c) {
+    if (!c) return fail(DD_EINVAL, "null context");
+    return DD_OK;
+}
+
+// histograms already on the device -> estimates on the host (device MLE, bit-identical to the
+// host MLE: same IEEE operations, no contraction; asserted by tests/test_gpu_parity.py)
+int estimates_from_hist(dd_ctx* c, const uint32_t* hist_dev, size_t njobs, double* est_host) {
+    int rc = c->est.reserve(njobs * sizeof(double));
+    if (rc) return rc;
+    dd::launch_mle(hist_dev, njobs, c->p, static_cast<double*>(c->est.p), c->stream);
+    DD_HIP(hipGetLastError());
+    DD_HIP(hipMemcpyAsync(est_host, c->est.p, njobs * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    DD_HIP(hipStreamSynchronize(c->stream));
+    return DD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dd_abi_version(void) { return DD_ABI_VERSION; }
+
+const char* dd_last_error(void) { return g_err.c_str(); }
+
+dd_ctx* dd_create(int device, int log2m, int canonical) {
+    if (log2m < 4 || log2m > 20) {
+        fail(DD_EINVAL, "log2m=%d outside 4..20", log2m);
+        return nullptr;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        fail(DD_ENODEV, "no HIP device visible (%s): libdandd_hip has no CPU path",
+             e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) {
+        fail(DD_ENODEV, "device %d not in 0..%d", device, ndev - 1);
+        return nullptr;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        fail(DD_ENODEV, "hipGetDeviceProperties(%d) failed", device);
+        return nullptr;
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fail(DD_ENODEV, "device %d is %s; this library is built for gfx950 only", device,
+             prop.gcnArchName);
+        return nullptr;
+    }
+    dd_ctx* c = new dd_ctx();
+    c->device = device;
+    c->p = log2m;
+    c->canonical = canonical ? 1 : 0;
+    DeviceGuard g(device);
+    if (hipEventCreateWithFlags(&c->stage_free, hipEventDisableTiming) != hipSuccess) {
+        fail(DD_ENODEV, "hipEventCreate failed");
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+void dd_destroy(dd_ctx* c) {
+    if (!c) return;
+    DeviceGuard g(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& v : c->spans)
+        for (auto& s : v) {
+            (void)hipEventDestroy(s.a);
+            (void)hipEventDestroy(s.b);
+        }
+    for (auto e : c->pool) (void)hipEventDestroy(e);
+    if (c->stage_free) (void)hipEventDestroy(c->stage_free);
+    for (DevBuf* b : {&c->tokens, &c->scratch, &c->tables, &c->fasta, &c->regs, &c->ptrs, &c->hist,
+                      &c->est, &c->ord})
+        b->release();
+    c->stage.release();
+    delete c;
+}
+
+int dd_set_stream(dd_ctx* c, void* hip_stream) {
+    if (check_ctx(c)) return DD_EINVAL;
+    c->stream = static_cast<hipStream_t>(hip_stream);
+    return DD_OK;
+}
+
+int dd_synchronize(dd_ctx* c) {
+    if (check_ctx(c)) return DD_EINVAL;
+    DeviceGuard g(c->device);
+    DD_HIP(hipStreamSynchronize(c->stream));
+    return DD_OK;
+}
+
+// ------------------------------------------------------------------------------ sketch
+int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* nbytes, int ngenomes,
+                     int kmin, int kmax, uint8_t* regs_dev) {
+    if (check_ctx(c)) return DD_EINVAL;
+    if (ngenomes < 0 || !regs_dev || (ngenomes && (!fasta_dev || !nbytes)))
+        return fail(DD_EINVAL, "null argument");
+    if (kmin < 1 || kmax > 64 || kmin > kmax) return fail(DD_EINVAL, "k range %d..%d outside 1..64", kmin, kmax);
+    for (int g = 0; g < ngenomes; ++g) {
+        if (nbytes[g] && !fasta_dev[g]) return fail(DD_EINVAL, "genome %d: null buffer", g);
+        if (reinterpret_cast<uintptr_t>(fasta_dev[g]) & 15)
+            return fail(DD_EINVAL, "genome %d: device buffer must be 16-byte aligned", g);
+    }
+    DeviceGuard guard(c->device);
+    const int p = c->p, K = kmax - kmin + 1;
+    const size_t m = (size_t)1 << p;
+    hipStream_t st = c->stream;
+
+    DD_HIP(hipMemsetAsync(regs_dev, 0, (size_t)ngenomes * K * m, st));
+    if (!ngenomes) return DD_OK;
+
+    // ---- workspace: token streams of all genomes + one K0 scratch --------------------
+    std::vector<size_t> off_codes(ngenomes), off_bad(ngenomes), off_ntok(ngenomes);
+    size_t tot = 0, max_n = 0;
+    for (int g = 0; g < ngenomes; ++g) {
+        off_codes[g] = tot;
+        tot += align_up(dd::codes_words(nbytes[g]) * 4, 256);
+        off_bad[g] = tot;
+        tot += align_up(dd::bad_words(nbytes[g]) * 4, 256);
+        off_ntok[g] = tot;
+        tot += 256;
+        max_n = std::max(max_n, nbytes[g]);
+    }
+    int rc;
+    if ((rc = c->tokens.reserve(tot))) return rc;
+    if ((rc = c->scratch.reserve(dd::pack_scratch_bytes(max_n)))) return rc;
+    char* tb = static_cast<char*>(c->tokens.p);
+
+    // ---- K0: pack every genome ---------------------------------------------------------
+    std::vector<dd::SweepGenome> gtab(ngenomes);
+    uint64_t tokens_ub = 0;
+    for (int g = 0; g < ngenomes; ++g) {
+        dd::TokenStream ts{reinterpret_cast<uint32_t*>(tb + off_codes[g]),
+                           reinterpret_cast<uint32_t*>(tb + off_bad[g]),
+                           reinterpret_cast<unsigned long long*>(tb + off_ntok[g])};
+        {
+            Span sp(c, DD_KERNEL_PACK);
+            dd::launch_pack(fasta_dev[g], nbytes[g], ts, static_cast<long long*>(c->scratch.p), st);
+        }
+        gtab[g] = dd::SweepGenome{ts.codes, ts.bad, ts.ntok, regs_dev + (size_t)g * K * m};
+        tokens_ub += nbytes[g];
+    }
+    DD_HIP(hipGetLastError());
+
+    // ---- K1 job tables -----------------------------------------------------------------
+    const bool global_regs = m > (size_t)dd::sweep_max_lds_bytes();
+    const int slots = global_regs ? 64 : (int)std::min<size_t>(64, dd::sweep_max_lds_bytes() / m);
+    const int threads = 1024;
+    const size_t tile_tokens = (size_t)threads * dd::kSegTokens;
+
+    struct ClassJobs {
+        int kclass;
+        std::vector<dd::SweepJob> jobs;
+        int max_nk = 0;
+    };
+    std::vector<ClassJobs> classes;
+    for (int kc = 0; kc < 3; ++kc) {
+        const int ka = std::max(kmin, kc == 0 ? 1 : (kc == 1 ? 17 : 33));
+        const int kb = std::min(kmax, kc == 0 ? 16 : (kc == 1 ? 32 : 64));
+        if (ka > kb) continue;
+        const int nks = kb - ka + 1;
+        const int ngroups = (nks + slots - 1) / slots;
+        // aim for ~8 jobs per CU over the whole class so the dispatcher can balance the tail
+        size_t total_tiles = 0;
+        for (int g = 0; g < ngenomes; ++g) total_tiles += (nbytes[g] + tile_tokens - 1) / tile_tokens;
+        const size_t target_jobs = 256 * 8;
+        size_t tiles_per_job = std::max<size_t>(1, (total_tiles * ngroups + target_jobs - 1) / target_jobs);
+        ClassJobs cj;
+        cj.kclass = kc;
+        for (int g = 0; g < ngenomes; ++g) {
+            const size_t ntiles = (nbytes[g] + tile_tokens - 1) / tile_tokens;
+            for (size_t t0 = 0; t0 < ntiles; t0 += tiles_per_job) {
+                int kcur = ka;
+                for (int q = 0; q < ngroups; ++q) {
+                    const int nk = nks / ngroups + (q < nks % ngroups ? 1 : 0);
+                    dd::SweepJob j;
+                    j.genome = g;
+                    j.kfirst = kcur;
+                    j.nk = nk;
+                    j.krow = kcur - kmin;
+                    j.tile_begin = (unsigned)t0;
+                    j.tile_end = (unsigned)std::min(ntiles, t0 + tiles_per_job);
+                    cj.jobs.push_back(j);
+                    cj.max_nk = std::max(cj.max_nk, nk);
+                    kcur += nk;
+                }
+            }
+        }
+        if (!cj.jobs.empty()) classes.push_back(std::move(cj));
+    }
+
+    size_t table_bytes = align_up(sizeof(dd::SweepGenome) * ngenomes, 256);
+    std::vector<size_t> job_off(classes.size());
+    for (size_t i = 0; i < classes.size(); ++i) {
+        job_off[i] = table_bytes;
+        table_bytes += align_up(sizeof(dd::SweepJob) * classes[i].jobs.size(), 256);
+    }
+    if ((rc = c->tables.reserve(table_bytes))) return rc;
+    // the staging buffer may still be feeding a previous call's upload
+    DD_HIP(hipEventSynchronize(c->stage_free));
+    if ((rc = c->stage.reserve(table_bytes))) return rc;
+    char* tdev = static_cast<char*>(c->tables.p);
+    if ((rc = upload(c, tdev, gtab.data(), sizeof(dd::SweepGenome) * ngenomes, 0))) return rc;
+    for (size_t i = 0; i < classes.size(); ++i)
+        if ((rc = upload(c, tdev + job_off[i], classes[i].jobs.data(),
+                         sizeof(dd::SweepJob) * classes[i].jobs.size(), job_off[i])))
+            return rc;
+    DD_HIP(hipEventRecord(c->stage_free, st));
+
+    // ---- K1 launches -------------------------------------------------------------------
+    int blocks = 0;
+    for (size_t i = 0; i < classes.size(); ++i) {
+        dd::SweepPlan plan;
+        plan.log2m = p;
+        plan.canonical = c->canonical;
+        plan.threads = threads;
+        plan.lds_bytes = global_regs ? 0 : (int)((size_t)classes[i].max_nk * m);
+        Span sp(c, DD_KERNEL_SWEEP);
+        dd::launch_sweep(reinterpret_cast<const dd::SweepGenome*>(tdev),
+                         reinterpret_cast<const dd::SweepJob*>(tdev + job_off[i]),
+                         (int)classes[i].jobs.size(), classes[i].kclass, plan, st);
+        blocks += (int)classes[i].jobs.size();
+    }
+    DD_HIP(hipGetLastError());
+    c->st_tokens = tokens_ub;
+    c->st_updates = tokens_ub * (uint64_t)K;
+    c->st_blocks = blocks;
+    return DD_OK;
+}
+
+int dd_sketch_buffer(dd_ctx* c, const uint8_t* fasta, size_t nbytes, int kmin, int kmax, uint8_t* regs) {
+    if (check_ctx(c)) return DD_EINVAL;
+    if (!regs || (nbytes && !fasta)) return fail(DD_EINVAL, "null argument");
+    if (kmin < 1 || kmax > 64 || kmin > kmax) return fail(DD_EINVAL, "k range %d..%d outside 1..64", kmin, kmax);
+    DeviceGuard guard(c->device);
+    const size_t K = (size_t)(kmax - kmin + 1), m = (size_t)1 << c->p;
+    int rc;
+    if ((rc = c->fasta.reserve(nbytes + 16))) return rc;
+    if ((rc = c->regs.reserve(K * m))) return rc;
+    if (nbytes) DD_HIP(hipMemcpyAsync(c->fasta.p, fasta, nbytes, hipMemcpyHostToDevice, c->stream));
+    const uint8_t* ptrs[1] = {static_cast<const uint8_t*>(c->fasta.p)};
+    const size_t ns[1] = {nbytes};
+    if ((rc = dd_sketch_device(c, ptrs, ns, 1, kmin, kmax, static_cast<uint8_t*>(c->regs.p)))) return rc;
+    DD_HIP(hipMemcpyAsync(regs, c->regs.p, K * m, hipMemcpyDeviceToHost, c->stream));
+    DD_HIP(hipStreamSynchronize(c->stream));
+    return DD_OK;
+}
+
+int dd_sketch_fasta(dd_ctx* c, const char* path, int kmin, int kmax, uint8_t* regs) {
+    if (check_ctx(c)) return DD_EINVAL;
+    if (!path) return fail(DD_EINVAL, "null path");
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(DD_EIO, "cannot open %s", path);
+    std::vector<uint8_t> buf;
+    uint8_t head[2] = {0, 0};
+    size_t got = fread(head, 1, 2, f);
+    if (got == 2 && head[0] == 0x1f && head[1] == 0x8b) {
+        fclose(f);
+        return fail(DD_EIO, "%s is gzip-compressed: inflate it on the host first (gz ingestion is not in this build)", path);
+    }
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (sz < 0) {
+        fclose(f);
+        return fail(DD_EIO, "cannot size %s", path);
+    }
+    buf.resize((size_t)sz);
+    size_t rd = sz ? fread(buf.data(), 1, (size_t)sz, f) : 0;
+    fclose(f);
+    if (rd != (size_t)sz) return fail(DD_EIO, "short read on %s", path);
+    return dd_sketch_buffer(c, buf.data(), buf.size(), kmin, kmax, regs);
+}
+
+// ------------------------------------------------------------------------------- union
+int dd_union_device(dd_ctx* c, const uint8_t* const* in_dev, int n, size_t len, uint8_t* out_dev) {
+    if (check_ctx(c)) return DD_EINVAL;
+    if (n < 1 || !in_dev || !out_dev) return fail(DD_EINVAL, "bad argument");
+    if (len % 16) return fail(DD_EINVAL, "len must be a multiple of 16");
+    DeviceGuard guard(c->device);
+    int rc;
+    if ((rc = c->ptrs.reserve(sizeof(void*) * n))) return rc;
+    DD_HIP(hipEventSynchronize(c->stage_free));
+    if ((rc = c->stage.reserve(sizeof(void*) * n))) return rc;
+    if ((rc = upload(c, c->ptrs.p, in_dev, sizeof(void*) * n, 0))) return rc;
+    DD_HIP(hipEventRecord(c->stage_free, c->stream));
+    {
+        Span sp(c, DD_KERNEL_UNION);
+        dd::launch_union(static_cast<const uint8_t* const*>(c->ptrs.p), n, len, out_dev, c->stream);
+    }
+    DD_HIP(hipGetLastError());
+    return DD_OK;
+}
+
+int dd_union(dd_ctx* c, const uint8_t* const* in, int n, size_t len, uint8_t* out) {
+    if (check_ctx(c)) return DD_EINVAL;
+    if (n < 1 || !in || !out) return fail(DD_EINVAL, "bad argument");
+    if (len % 16) return fail(DD_EINVAL, "len must be a multiple of 16");
+    DeviceGuard guard(c->device);
+    int rc;
+    if ((rc = c->regs.reserve((size_t)(n + 1) * len))) return rc;
+    uint8_t* base = static_cast<uint8_t*>(c->regs.p);
+    std::vector<const uint8_t*> ptrs(n);
+    for (int i = 0; i < n; ++i) {
+        DD_HIP(hipMemcpyAsync(base + (size_t)i * len, in[i], len, hipMemcpyHostToDevice, c->stream));
+        ptrs[i] = base + (size_t)i * len;
+    }
+    if ((rc = dd_union_device(c, ptrs.data(), n, len, base + (size_t)n * len))) return rc;
+    DD_HIP(hipMemcpyAsync(out, base + (size_t)n * len, len, hipMemcpyDeviceToHost, c->stream));
+    DD_HIP(hipStreamSynchronize(c->stream));
+    return DD_OK;
+}
+
+// -------------------------------------------------------------------------------- card
+double dd_ertl_mle(const uint32_t hist[64], int log2m) {
+    return dd::ertl_mle(hist, log2m, dd::mle_relerr(log2m));
+}
+
+int dd_hist_batch_device(dd_ctx* c, const uint8_t* regs_dev, int njobs, uint32_t* hist) {
+    if (check_ctx(c)) return DD_EINVAL;
+    if (njobs < 0 || (njobs && (!regs_dev || !hist))) return fail(DD_EINVAL, "bad argument");
+    if (!njobs) return DD_OK;
+    DeviceGuard guard(c->device);
+    int rc;
+    if ((rc = c->hist.reserve((size_t)njobs * 64 * sizeof(uint32_t)))) return rc;
+    {
+        Span sp(c, DD_KERNEL_UNION);
+        dd::launch_hist(regs_dev, njobs, c->p, static_cast<uint32_t*>(c->hist.p), c->stream);
+    }
+    DD_HIP(hipGetLastError());
+    DD_HIP(hipMemcpyAsync(hist, c->hist.p, (size_t)njobs * 64 * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                          c->stream));
+    DD_HIP(hipStreamSynchronize(c->stream));
+    return DD_OK;
+}
+
+int dd_card_batch_device(dd_ctx* c, const uint8_t* regs_dev, int njobs, double* est) {
+    if (check_ctx(c)) return DD_EINVAL;
+    if (njobs < 0 || (njobs && (!regs_dev || !est))) return fail(DD_EINVAL, "bad argument");
+    if (!njobs) return DD_OK;
+    DeviceGuard guard(c->device);
+    int rc;
+    if ((rc = c->hist.reserve((size_t)njobs * 64 * sizeof(uint32_t)))) return rc;
+    {
+        Span sp(c, DD_KERNEL_UNION);
+        dd::launch_hist(regs_dev, njobs, c->p, static_cast<uint32_t*>(c->hist.p), c->stream);
+    }
+    DD_HIP(hipGetLastError());
+    return estimates_from_hist(c, static_cast<const uint32_t*>(c->hist.p), (size_t)njobs, est);
+}
+
+int dd_card_batch(dd_ctx* c, const uint8_t* regs, int njobs, double* est) {
+    if (check_ctx(c)) return DD_EINVAL;
+    if (njobs < 0 || (njobs && (!regs || !est))) return fail(DD_EINVAL, "bad argument");
+    if (!njobs) return DD_OK;
+    DeviceGuard guard(c->device);
+    const size_t bytes = (size_t)njobs << c->p;
+    int rc;
+    if ((rc = c->regs.reserve(bytes))) return rc;
+    DD_HIP(hipMemcpyAsync(c->regs.p, regs, bytes, hipMemcpyHostToDevice, c->stream));
+    return dd_card_batch_device(c, static_cast<const uint8_t*>(c->regs.p), njobs, est);
+}
+
+int dd_card(dd_ctx* c, const uint8_t* regs, double* est) { return dd_card_batch(c, regs, 1, est); }
+
+// ------------------------------------------------------------------------- progressive
+int dd_progressive_device(dd_ctx* c, const uint8_t* leaf_dev, int n, int K, const int32_t* orderings,
+                          int norder, double* card) {
+    if (check_ctx(c)) return DD_EINVAL;
+    if (n < 1 || K < 1 || norder < 1 || !leaf_dev || !orderings || !card)
+        return fail(DD_EINVAL, "bad argument");
+    for (size_t i = 0; i < (size_t)norder * n; ++i)
+        if (orderings[i] < 0 || orderings[i] >= n) return fail(DD_EINVAL, "ordering entry %d outside 0..%d", orderings[i], n - 1);
+    DeviceGuard guard(c->device);
+    const size_t njobs = (size_t)norder * n * K;
+    int rc;
+    if ((rc = c->hist.reserve(njobs * 64 * sizeof(uint32_t)))) return rc;
+    if ((rc = c->ord.reserve(sizeof(int32_t) * norder * n))) return rc;
+    DD_HIP(hipEventSynchronize(c->stage_free));
+    if ((rc = c->stage.reserve(sizeof(int32_t) * norder * n))) return rc;
+    if ((rc = upload(c, c->ord.p, orderings, sizeof(int32_t) * norder * n, 0))) return rc;
+    DD_HIP(hipEventRecord(c->stage_free, c->stream));
+    {
+        Span sp(c, DD_KERNEL_UNION);
+        dd::launch_progressive(leaf_dev, n, K, c->p, static_cast<const int32_t*>(c->ord.p), norder,
+                               static_cast<uint32_t*>(c->hist.p), c->stream);
+    }
+    DD_HIP(hipGetLastError());
+    return estimates_from_hist(c, static_cast<const uint32_t*>(c->hist.p), njobs, card);
+}
+
+int dd_progressive(dd_ctx* c, const uint8_t* leaf, int n, int K, const int32_t* orderings, int norder,
+                   double* card) {
+    if (check_ctx(c)) return DD_EINVAL;
+    if (n < 1 || K < 1 || !leaf) return fail(DD_EINVAL, "bad argument");
+    DeviceGuard guard(c->device);
+    const size_t bytes = ((size_t)n * K) << c->p;
+    int rc;
+    if ((rc = c->regs.reserve(bytes))) return rc;
+    DD_HIP(hipMemcpyAsync(c->regs.p, leaf, bytes, hipMemcpyHostToDevice, c->stream));
+    return dd_progressive_device(c, static_cast<const uint8_t*>(c->regs.p), n, K, orderings, norder, card);
+}
+
+// ---------------------------------------------------------------------------- pairwise
+int dd_pairwise_device(dd_ctx* c, const uint8_t* leaf_dev, int n, int K, double* card) {
+    if (check_ctx(c)) return DD_EINVAL;
+    if (n < 1 || K < 1 || !leaf_dev || !card) return fail(DD_EINVAL, "bad argument");
+    DeviceGuard guard(c->device);
+    const size_t njobs = (size_t)n * n * K;
+    int rc;
+    if ((rc = c->hist.reserve(njobs * 64 * sizeof(uint32_t)))) return rc;
+    {
+        Span sp(c, DD_KERNEL_UNION);
+        dd::launch_pairwise(leaf_dev, n, K, c->p, static_cast<uint32_t*>(c->hist.p), c->stream);
+    }
+    DD_HIP(hipGetLastError());
+    // lower triangle histograms are all-zero: give them the mirrored estimate afterwards
+    std::vector<double> tmp(njobs);
+    if ((rc = c->est.reserve(njobs * sizeof(double)))) return rc;
+    // only the upper triangle (i <= j) holds real histograms; estimate everything on the device
+    // would waste work on empty ones, so fill empties with m in bin 0 -> estimate 0 cheaply
+    dd::launch_mle(static_cast<const uint32_t*>(c->hist.p), njobs, c->p, static_cast<double*>(c->est.p),
+                   c->stream);
+    DD_HIP(hipGetLastError());
+    DD_HIP(hipMemcpyAsync(tmp.data(), c->est.p, njobs * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    DD_HIP(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            const int a = i <= j ? i : j, b = i <= j ? j : i;
+            memcpy(card + ((size_t)i * n + j) * K, tmp.data() + ((size_t)a * n + b) * K, sizeof(double) * K);
+        }
+    return DD_OK;
+}
+
+int dd_pairwise(dd_ctx* c, const uint8_t* leaf, int n, int K, double* card) {
+    if (check_ctx(c)) return DD_EINVAL;
+    if (n < 1 || K < 1 || !leaf) return fail(DD_EINVAL, "bad argument");
+    DeviceGuard guard(c->device);
+    const size_t bytes = ((size_t)n * K) << c->p;
+    int rc;
+    if ((rc = c->regs.reserve(bytes))) return rc;
+    DD_HIP(hipMemcpyAsync(c->regs.p, leaf, bytes, hipMemcpyHostToDevice, c->stream));
+    return dd_pairwise_device(c, static_cast<const uint8_t*>(c->regs.p), n, K, card);
+}
+
+// ------------------------------------------------------------------------- measurement
+int dd_timing_enable(dd_ctx* c, int on) {
+    if (check_ctx(c)) return DD_EINVAL;
+    c->timing = on != 0;
+    return DD_OK;
+}
+
+int dd_timing_reset(dd_ctx* c) {
+    if (check_ctx(c)) return DD_EINVAL;
+    DeviceGuard guard(c->device);
+    DD_HIP(hipStreamSynchronize(c->stream));
+    for (auto& v : c->spans) {
+        for (auto& s : v) {
+            c->pool.push_back(s.a);
+            c->pool.push_back(s.b);
+        }
+        v.clear();
+    }
+    return DD_OK;
+}
+
+int dd_timing_read(dd_ctx* c, int which, double* total_ms, int* launches) {
+    if (check_ctx(c)) return DD_EINVAL;
+    if (which < 0 || which >= DD_KERNEL_COUNT) return fail(DD_EINVAL, "bad kernel id %d", which);
+    DeviceGuard guard(c->device);
+    DD_HIP(hipStreamSynchronize(c->stream));
+    double tot = 0;
+    for (auto& s : c->spans[which]) {
+        float ms = 0;
+        DD_HIP(hipEventElapsedTime(&ms, s.a, s.b));
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = (int)c->spans[which].size();
+    return DD_OK;
+}
+
+int dd_last_sketch_stats(dd_ctx* c, uint64_t* tokens, uint64_t* updates, int* sweep_blocks) {
+    if (check_ctx(c)) return DD_EINVAL;
+    if (tokens) *tokens = c->st_tokens;
+    if (updates) *updates = c->st_updates;
+    if (sweep_blocks) *sweep_blocks = c->st_blocks;
+    return DD_OK;
+}
+
+// --------------------------------------------------------------------------- synthetic
+size_t dd_synth_size(uint64_t nbases, int nrec) {
+    if (nrec < 1) return 0;
+    return dd::synth_size(nbases, nrec);
+}
+
+int dd_synth_fasta_device(dd_ctx* c, uint64_t seed, int genome_index, uint64_t nbases, int nrec,
+                          uint8_t* out_dev) {
+    if (check_ctx(c)) return DD_EINVAL;
+    if (nrec < 1 || nrec > 65535 || genome_index < 0 || genome_index > 65535 || !out_dev)
+        return fail(DD_EINVAL, "bad argument");
+    DeviceGuard guard(c->device);
+    dd::launch_synth(seed, genome_index, nbases, nrec, out_dev, c->stream);
+    DD_HIP(hipGetLastError());
+    return DD_OK;
+}
+
+}  // extern "C"

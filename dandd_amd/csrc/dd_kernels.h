@@ -1,0 +1,78 @@
+// dd_kernels.h -- host-callable launchers of the gfx950 kernels behind the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace dd {
+
+// ---------------------------------------------------------------------------------------
+// Token stream of one genome in HBM (output of K0, input of K1).
+//   codes : 2 bits per token, token j of word w at bits [2j, 2j+1]   (16 tokens / u32)
+//   bad   : 1 bit per token, 1 = BREAK (non-ACGT byte or record boundary) (32 tokens / u32)
+//   ntok  : device scalar, number of tokens; the stream is padded with BREAKs to a
+//           multiple of 64 tokens (one K1 thread segment).
+// ---------------------------------------------------------------------------------------
+struct TokenStream {
+    uint32_t* codes;
+    uint32_t* bad;
+    unsigned long long* ntok;
+};
+
+constexpr int kPackThreads = 256;
+constexpr int kPackChunk = kPackThreads * 16;  // bytes of FASTA per K0 workgroup
+constexpr int kSegTokens = 64;                 // tokens per K1 thread segment
+
+// scratch for one K0 run over n bytes: 4 x int64 per chunk
+inline size_t pack_chunks(size_t n) { return (n + kPackChunk - 1) / kPackChunk; }
+inline size_t pack_scratch_bytes(size_t n) { return (pack_chunks(n) + 1) * 4 * sizeof(long long); }
+// capacity (in u32 words) of the code / bad arrays for an n-byte FASTA (tokens <= n)
+inline size_t codes_words(size_t n) { return ((n + 63) / 64 + 1) * 4; }
+inline size_t bad_words(size_t n) { return ((n + 63) / 64 + 1) * 2; }
+
+void launch_pack(const uint8_t* fa, size_t n, TokenStream out, long long* scratch, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------
+// K1: fused k-sweep sketch.
+// ---------------------------------------------------------------------------------------
+struct SweepGenome {            // one per genome, device-resident table
+    const uint32_t* codes;
+    const uint32_t* bad;
+    const unsigned long long* ntok;
+    uint8_t* regs;              // [K][m] for this genome
+};
+struct SweepJob {               // one per workgroup, device-resident table
+    int genome;
+    int kfirst;                 // first k of the group (consecutive ks)
+    int nk;                     // number of ks in the group (<= slots that fit LDS)
+    int krow;                   // row of kfirst in the genome's [K][m] slab
+    unsigned tile_begin, tile_end;  // tiles of (threads x 64) tokens
+};
+struct SweepPlan {
+    int log2m;
+    int canonical;
+    int threads;                // workgroup size
+    int lds_bytes;              // dynamic LDS per workgroup
+};
+void launch_sweep(const SweepGenome* genomes_dev, const SweepJob* jobs_dev, int njobs, int kclass,
+                  const SweepPlan& plan, hipStream_t st);
+int sweep_max_lds_bytes();
+
+// ---------------------------------------------------------------------------------------
+// K2: byte-max union + 64-bin histograms.
+// ---------------------------------------------------------------------------------------
+void launch_union(const uint8_t* const* in_dev, int n, size_t len, uint8_t* out_dev, hipStream_t st);
+void launch_hist(const uint8_t* regs_dev, int njobs, int log2m, uint32_t* hist_dev, hipStream_t st);
+// running max along each ordering; hist[(o*n + j)*K + kk][64]
+void launch_progressive(const uint8_t* leaf_dev, int n, int K, int log2m, const int32_t* ord_dev,
+                        int norder, uint32_t* hist_dev, hipStream_t st);
+// hist[((i*n)+j)*K + kk][64] for i <= j
+void launch_pairwise(const uint8_t* leaf_dev, int n, int K, int log2m, uint32_t* hist_dev,
+                     hipStream_t st);
+void launch_mle(const uint32_t* hist_dev, size_t njobs, int log2m, double* est_dev, hipStream_t st);
+
+// synthetic FASTA
+void launch_synth(uint64_t seed, int gi, uint64_t nbases, int nrec, uint8_t* out_dev, hipStream_t st);
+size_t synth_size(uint64_t nbases, int nrec);
+
+}  // namespace dd

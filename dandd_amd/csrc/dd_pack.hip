@@ -1,0 +1,308 @@
+// dd_pack.hip -- K0: FASTA bytes in HBM -> 2-bit token stream (+ 1-bit BREAK mask).
+//
+// First half of what one `dashing sketch` process does before hashing (kseq record parsing +
+// bonsai's 2-bit encoder; command built at /root/reference/lib/sketch_classes.py:351-366):
+// headers and newlines are dropped, A/C/G/T (either case) become 0..3, every other byte and
+// every record boundary becomes a BREAK that resets the k-mer windows.  The oracle's
+// statement of the same rules is oracle/dd_oracle.c:orc_tokenize.
+//
+// HBM-bound: reads each FASTA byte twice (stats pass + write pass; the second pass of a
+// <=256 MiB genome is served by the Infinity Cache) and writes 3 bits per token.  Three launches:
+//   pack_stats  : per 4 KiB chunk -> last newline position, token counts under both
+//                 possible incoming line states (inside a header line / inside sequence)
+//   pack_scan   : one workgroup; running max of newline positions + exclusive sum of token
+//                 counts over chunks (decides each chunk's incoming state by looking at the
+//                 byte after the last newline before it)
+//   pack_write  : per chunk -> tokens staged in LDS, packed 16/32 per word, partial boundary
+//                 words merged with atomicOr (pack_scan zeroed them)
+#include "dd_common.h"
+#include "dd_kernels.h"
+
+namespace dd {
+namespace {
+
+constexpr int T = kPackThreads;
+
+DD_D uint32_t base_code(uint32_t c) {
+    uint32_t x = c | 0x20u;
+    return x == 'a' ? 0u : x == 'c' ? 1u : x == 'g' ? 2u : x == 't' ? 3u : 4u;
+}
+
+struct Bytes16 {
+    uint32_t w[4];
+    DD_D uint32_t at(int i) const { return (w[i >> 2] >> ((i & 3) * 8)) & 0xFFu; }
+};
+
+// 16 bytes of this thread; bytes at or beyond n read as '\r' (emits nothing, changes nothing)
+DD_D Bytes16 load16(const uint8_t* fa, size_t n, size_t pos) {
+    Bytes16 b;
+    if (pos + 16 <= n) {
+        uint4 v = *reinterpret_cast<const uint4*>(fa + pos);
+        b.w[0] = v.x; b.w[1] = v.y; b.w[2] = v.z; b.w[3] = v.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                size_t p = pos + 4 * j + i;
+                uint32_t c = p < n ? fa[p] : (uint32_t)'\r';
+                w |= c << (8 * i);
+            }
+            b.w[j] = w;
+        }
+    }
+    return b;
+}
+
+// Line state machine over the thread's 16 bytes (same rules as orc_tokenize).
+//   prev_nl : the byte before this thread's first byte is '\n' (or there is none)
+//   hdr_in  : this thread starts inside a header line (ignored when prev_nl)
+template <bool EMIT>
+DD_D int scan16(const Bytes16& b, bool prev_nl, bool hdr_in, uint8_t* out) {
+    int cnt = 0;
+    bool hdr = hdr_in, ls = prev_nl;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        uint32_t c = b.at(i);
+        if (ls) hdr = (c == '>');
+        if (c == '\n') {
+            if (hdr) {
+                if (EMIT) out[cnt] = 4;
+                ++cnt;
+            }
+            hdr = false;
+            ls = true;
+        } else {
+            ls = false;
+            if (!(hdr || c == '\r')) {
+                if (EMIT) out[cnt] = (uint8_t)base_code(c);
+                ++cnt;
+            }
+        }
+    }
+    return cnt;
+}
+
+DD_D long long last_newline(const Bytes16& b, size_t pos) {
+    long long r = -1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (b.at(i) == '\n') r = (long long)(pos + i);
+    return r;
+}
+
+// ---- workgroup scans over T=256 threads (4 waves) ------------------------------------
+template <typename V, typename Op>
+DD_D V wave_incl(V v, Op op) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        V o = __shfl_up(v, d);
+        if (lane >= d) v = op(v, o);
+    }
+    return v;
+}
+
+struct MaxLL { DD_D long long operator()(long long a, long long b) const { return a > b ? a : b; } };
+struct SumLL { DD_D long long operator()(long long a, long long b) const { return a + b; } };
+
+// inclusive scan across the block; *total receives the block-wide reduction.
+// sm must hold blockDim.x/64 elements.  ident is the identity of op.
+template <typename Op>
+DD_D long long block_incl(long long v, Op op, long long ident, long long* sm, long long* total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    long long inc = wave_incl(v, op);
+    __syncthreads();
+    if (lane == 63) sm[wv] = inc;
+    __syncthreads();
+    long long pre = ident, tot = ident;
+    for (int i = 0; i < nw; ++i) {
+        long long x = sm[i];
+        if (i < wv) pre = op(pre, x);
+        tot = op(tot, x);
+    }
+    *total = tot;
+    return op(pre, inc);
+}
+
+// Is position `pos` (not at a line start) inside a header line, given N = position of the last
+// '\n' before pos (or -1)?  The line starts at N+1; it is a header iff it starts with '>'.
+DD_D bool line_is_header(const uint8_t* fa, long long N) { return fa[N + 1] == '>'; }
+
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(T) void pack_stats(const uint8_t* __restrict__ fa, size_t n,
+                                                long long* __restrict__ lastnl,
+                                                long long* __restrict__ cntH,
+                                                long long* __restrict__ cntS) {
+    __shared__ long long sm[T / 64];
+    const size_t c = blockIdx.x;
+    const size_t pos = c * (size_t)kPackChunk + (size_t)threadIdx.x * 16;
+    Bytes16 b = load16(fa, n, pos);
+    const bool prev_nl = (pos == 0) || (pos - 1 < n ? fa[pos - 1] == '\n' : false);
+    long long ln = last_newline(b, pos);
+    long long tot;
+    long long inc = block_incl(ln, MaxLL(), -1, sm, &tot);
+    long long before = __shfl_up(inc, 1);  // exclusive: previous thread's inclusive value
+    if ((threadIdx.x & 63) == 0) before = -1;
+    // cross-wave part of the exclusive value
+    {
+        long long pre = -1;
+        for (int i = 0; i < (int)(threadIdx.x >> 6); ++i) pre = pre > sm[i] ? pre : sm[i];
+        before = before > pre ? before : pre;
+    }
+    int tH, tS;
+    if (prev_nl) {
+        tH = tS = scan16<false>(b, true, false, nullptr);
+    } else if (before >= 0) {  // a newline earlier in this chunk decides the state
+        bool h = line_is_header(fa, before);
+        tH = tS = scan16<false>(b, false, h, nullptr);
+    } else {  // depends on the chunk's incoming state
+        tH = scan16<false>(b, false, true, nullptr);
+        tS = scan16<false>(b, false, false, nullptr);
+    }
+    long long sH, sS;
+    block_incl((long long)tH, SumLL(), 0, sm, &sH);
+    block_incl((long long)tS, SumLL(), 0, sm, &sS);
+    if (threadIdx.x == 0) {
+        lastnl[c] = tot;
+        cntH[c] = sH;
+        cntS[c] = sS;
+    }
+}
+
+// one workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void pack_scan(const uint8_t* __restrict__ fa, size_t n,
+                                                  size_t nchunks, long long* __restrict__ lastnl_Nin,
+                                                  const long long* __restrict__ cntH,
+                                                  const long long* __restrict__ cntS,
+                                                  long long* __restrict__ slot_base, TokenStream out) {
+    __shared__ long long sm[16];
+    long long carryN = -1, carryS = 0;
+    for (size_t blk = 0; blk < nchunks; blk += 1024) {
+        const size_t c = blk + threadIdx.x;
+        const bool live = c < nchunks;
+        long long ln = live ? lastnl_Nin[c] : -1;
+        long long totN;
+        long long incN = block_incl(ln, MaxLL(), -1, sm, &totN);
+        // exclusive = max over threads before me (and carry)
+        __syncthreads();
+        __shared__ long long tmp[1024];
+        tmp[threadIdx.x] = incN;
+        __syncthreads();
+        long long Nin = threadIdx.x ? tmp[threadIdx.x - 1] : -1;
+        Nin = Nin > carryN ? Nin : carryN;
+        long long cnt = 0;
+        if (live) {
+            const size_t pos = c * (size_t)kPackChunk;
+            bool hdr = false;
+            if (pos > 0 && fa[pos - 1] != '\n') hdr = line_is_header(fa, Nin);
+            cnt = hdr ? cntH[c] : cntS[c];
+            lastnl_Nin[c] = Nin;
+        }
+        long long totS;
+        long long incS = block_incl(cnt, SumLL(), 0, sm, &totS);
+        if (live) {
+            long long S = carryS + incS - cnt;
+            slot_base[c] = S;
+            out.codes[S >> 4] = 0;
+            out.bad[S >> 5] = 0;
+        }
+        carryN = carryN > totN ? carryN : totN;
+        carryS += totS;
+        __syncthreads();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const long long total = carryS;
+        slot_base[nchunks] = total;
+        *out.ntok = (unsigned long long)total;
+        const long long pad_end = (total + kSegTokens - 1) / kSegTokens * kSegTokens;
+        // the word holding `total` is a partial boundary word of the last chunk: zero it,
+        // then mark every padding token as BREAK
+        out.codes[total >> 4] = 0;
+        out.bad[total >> 5] = 0;
+        for (long long w = total >> 4; w < (pad_end >> 4); ++w) out.codes[w] = 0;
+        for (long long w = total >> 5; w < (pad_end >> 5); ++w)
+            out.bad[w] = (w == (total >> 5)) ? (~0u << (total & 31)) : ~0u;
+    }
+}
+
+__global__ __launch_bounds__(T) void pack_write(const uint8_t* __restrict__ fa, size_t n,
+                                                const long long* __restrict__ Nin,
+                                                const long long* __restrict__ slot_base,
+                                                TokenStream out) {
+    __shared__ long long sm[T / 64];
+    __shared__ uint8_t tok[kPackChunk];
+    const size_t c = blockIdx.x;
+    const size_t pos = c * (size_t)kPackChunk + (size_t)threadIdx.x * 16;
+    Bytes16 b = load16(fa, n, pos);
+    const bool prev_nl = (pos == 0) || (pos - 1 < n ? fa[pos - 1] == '\n' : false);
+    long long ln = last_newline(b, pos);
+    long long tot;
+    long long inc = block_incl(ln, MaxLL(), -1, sm, &tot);
+    long long before = __shfl_up(inc, 1);
+    if ((threadIdx.x & 63) == 0) before = -1;
+    {
+        long long pre = -1;
+        for (int i = 0; i < (int)(threadIdx.x >> 6); ++i) pre = pre > sm[i] ? pre : sm[i];
+        before = before > pre ? before : pre;
+    }
+    if (before < 0) before = Nin[c];
+    bool h = false;
+    if (!prev_nl && pos < n) h = line_is_header(fa, before);
+    int cnt = scan16<false>(b, prev_nl, h, nullptr);
+    long long total;
+    long long incS = block_incl((long long)cnt, SumLL(), 0, sm, &total);
+    int off = (int)(incS - cnt);
+    scan16<true>(b, prev_nl, h, tok + off);
+    __syncthreads();
+
+    const long long S = slot_base[c], E = S + total;  // global token range of this chunk
+    if (total == 0) return;
+    // 2-bit codes, 16 tokens per word
+    for (long long w = (S >> 4) + threadIdx.x; w <= ((E - 1) >> 4); w += T) {
+        uint32_t v = 0;
+        const long long t0 = w << 4;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            long long t = t0 + j;
+            if (t >= S && t < E) v |= (uint32_t)(tok[t - S] & 3u) << (2 * j);
+        }
+        if (t0 >= S && t0 + 16 <= E)
+            out.codes[w] = v;
+        else if (v)
+            atomicOr(&out.codes[w], v);
+    }
+    // BREAK mask, 32 tokens per word
+    for (long long w = (S >> 5) + threadIdx.x; w <= ((E - 1) >> 5); w += T) {
+        uint32_t v = 0;
+        const long long t0 = w << 5;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            long long t = t0 + j;
+            if (t >= S && t < E) v |= (uint32_t)(tok[t - S] >> 2) << j;
+        }
+        if (t0 >= S && t0 + 32 <= E)
+            out.bad[w] = v;
+        else if (v)
+            atomicOr(&out.bad[w], v);
+    }
+}
+
+}  // namespace
+
+void launch_pack(const uint8_t* fa, size_t n, TokenStream out, long long* scratch, hipStream_t st) {
+    const size_t nc = pack_chunks(n);
+    long long* lastnl = scratch;
+    long long* cntH = scratch + (nc + 1);
+    long long* cntS = scratch + 2 * (nc + 1);
+    long long* slot = scratch + 3 * (nc + 1);
+    if (nc)
+        hipLaunchKernelGGL(pack_stats, dim3((unsigned)nc), dim3(T), 0, st, fa, n, lastnl, cntH, cntS);
+    hipLaunchKernelGGL(pack_scan, dim3(1), dim3(1024), 0, st, fa, n, nc, lastnl, cntH, cntS, slot, out);
+    if (nc)
+        hipLaunchKernelGGL(pack_write, dim3((unsigned)nc), dim3(T), 0, st, fa, n, lastnl, slot, out);
+}
+
+}  // namespace dd

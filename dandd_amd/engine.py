@@ -1,0 +1,275 @@
+"""ctypes binding of libdandd_hip.so (include/dandd_hip.h) -- the only way Python reaches the GPU.
+
+This is the host-side stub a DandD maintainer would drop next to lib/sketch_classes.py in
+place of the `subprocess` calls at /root/reference/lib/sketch_classes.py:190,198,221,229,268,274
+and /root/reference/lib/huffman_dandd.py:233.
+
+There is NO CPU fallback: `Engine(...)` raises `EngineError` when the shared library is missing
+or no gfx950 device is usable.  numpy arrays are host buffers; device buffers are passed as
+integer addresses (e.g. `torch.Tensor.data_ptr()`), so no torch type crosses the C ABI.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdandd_hip.so")
+
+KERNEL_PACK, KERNEL_SWEEP, KERNEL_UNION = 0, 1, 2
+
+EXPORTS = [
+    "dd_abi_version", "dd_last_error", "dd_create", "dd_destroy", "dd_set_stream", "dd_synchronize",
+    "dd_sketch_buffer", "dd_sketch_fasta", "dd_sketch_device", "dd_union", "dd_union_device",
+    "dd_card", "dd_card_batch", "dd_card_batch_device", "dd_hist_batch_device", "dd_ertl_mle",
+    "dd_progressive", "dd_progressive_device", "dd_pairwise", "dd_pairwise_device",
+    "dd_timing_enable", "dd_timing_read", "dd_timing_reset", "dd_last_sketch_stats",
+    "dd_synth_size", "dd_synth_fasta_device",
+]
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libdandd_hip.so and declare every prototype.  Raises EngineError if absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise EngineError(
+            f"{p} not found: build it with `python -m dandd_amd.build` (hipcc, gfx950). "
+            "dandd_amd has no CPU implementation of the sketching path.")
+    try:
+        lib = C.CDLL(p)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise EngineError(f"cannot load {p}: {e}") from e
+    vp, sz, i32, u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint64
+    lib.dd_abi_version.restype = i32
+    lib.dd_abi_version.argtypes = []
+    lib.dd_last_error.restype = C.c_char_p
+    lib.dd_last_error.argtypes = []
+    lib.dd_create.restype = vp
+    lib.dd_create.argtypes = [i32, i32, i32]
+    lib.dd_destroy.restype = None
+    lib.dd_destroy.argtypes = [vp]
+    lib.dd_set_stream.restype = i32
+    lib.dd_set_stream.argtypes = [vp, vp]
+    lib.dd_synchronize.restype = i32
+    lib.dd_synchronize.argtypes = [vp]
+    lib.dd_sketch_buffer.restype = i32
+    lib.dd_sketch_buffer.argtypes = [vp, vp, sz, i32, i32, vp]
+    lib.dd_sketch_fasta.restype = i32
+    lib.dd_sketch_fasta.argtypes = [vp, C.c_char_p, i32, i32, vp]
+    lib.dd_sketch_device.restype = i32
+    lib.dd_sketch_device.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), i32, i32, i32, vp]
+    lib.dd_union.restype = i32
+    lib.dd_union.argtypes = [vp, C.POINTER(vp), i32, sz, vp]
+    lib.dd_union_device.restype = i32
+    lib.dd_union_device.argtypes = [vp, C.POINTER(vp), i32, sz, vp]
+    lib.dd_card.restype = i32
+    lib.dd_card.argtypes = [vp, vp, C.POINTER(C.c_double)]
+    lib.dd_card_batch.restype = i32
+    lib.dd_card_batch.argtypes = [vp, vp, i32, vp]
+    lib.dd_card_batch_device.restype = i32
+    lib.dd_card_batch_device.argtypes = [vp, vp, i32, vp]
+    lib.dd_hist_batch_device.restype = i32
+    lib.dd_hist_batch_device.argtypes = [vp, vp, i32, vp]
+    lib.dd_ertl_mle.restype = C.c_double
+    lib.dd_ertl_mle.argtypes = [vp, i32]
+    lib.dd_progressive.restype = i32
+    lib.dd_progressive.argtypes = [vp, vp, i32, i32, vp, i32, vp]
+    lib.dd_progressive_device.restype = i32
+    lib.dd_progressive_device.argtypes = [vp, vp, i32, i32, vp, i32, vp]
+    lib.dd_pairwise.restype = i32
+    lib.dd_pairwise.argtypes = [vp, vp, i32, i32, vp]
+    lib.dd_pairwise_device.restype = i32
+    lib.dd_pairwise_device.argtypes = [vp, vp, i32, i32, vp]
+    lib.dd_timing_enable.restype = i32
+    lib.dd_timing_enable.argtypes = [vp, i32]
+    lib.dd_timing_read.restype = i32
+    lib.dd_timing_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(i32)]
+    lib.dd_timing_reset.restype = i32
+    lib.dd_timing_reset.argtypes = [vp]
+    lib.dd_last_sketch_stats.restype = i32
+    lib.dd_last_sketch_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(i32)]
+    lib.dd_synth_size.restype = sz
+    lib.dd_synth_size.argtypes = [u64, i32]
+    lib.dd_synth_fasta_device.restype = i32
+    lib.dd_synth_fasta_device.argtypes = [vp, u64, i32, u64, i32, vp]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def ertl_mle(hist, log2m):
+    """Host-side Ertl ML estimate of one 64-bin histogram (no device needed)."""
+    h = np.ascontiguousarray(hist, dtype=np.uint32)
+    if h.size != 64:
+        raise ValueError("histogram must have 64 bins")
+    return float(load_library().dd_ertl_mle(h.ctypes.data, int(log2m)))
+
+
+def synth_size(nbases, nrec=1):
+    return int(load_library().dd_synth_size(int(nbases), int(nrec)))
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+class Engine:
+    """One context = one GPU, one HLL size (log2m), canonical or not."""
+
+    def __init__(self, device=0, log2m=14, canonical=True):
+        self._lib = load_library()
+        self.log2m = int(log2m)
+        self.m = 1 << self.log2m
+        self.canonical = bool(canonical)
+        self.device = int(device)
+        self._ctx = self._lib.dd_create(self.device, self.log2m, int(self.canonical))
+        if not self._ctx:
+            raise EngineError("dd_create failed: " + self._lib.dd_last_error().decode())
+
+    # -- lifetime -------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.dd_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError(f"libdandd_hip error {rc}: {self._lib.dd_last_error().decode()}")
+
+    def set_stream(self, hip_stream):
+        self._check(self._lib.dd_set_stream(self._ctx, C.c_void_p(int(hip_stream) if hip_stream else 0)))
+
+    def synchronize(self):
+        self._check(self._lib.dd_synchronize(self._ctx))
+
+    # -- sketch ---------------------------------------------------------------------------
+    def sketch_buffer(self, fasta, kmin, kmax):
+        """FASTA bytes (host) -> registers [K][m] uint8."""
+        a = _u8(np.frombuffer(fasta, dtype=np.uint8) if not isinstance(fasta, np.ndarray) else fasta)
+        regs = np.empty((kmax - kmin + 1, self.m), dtype=np.uint8)
+        self._check(self._lib.dd_sketch_buffer(self._ctx, a.ctypes.data, a.size, kmin, kmax, regs.ctypes.data))
+        return regs
+
+    def sketch_fasta(self, path, kmin, kmax):
+        regs = np.empty((kmax - kmin + 1, self.m), dtype=np.uint8)
+        self._check(self._lib.dd_sketch_fasta(self._ctx, os.fsencode(path), kmin, kmax, regs.ctypes.data))
+        return regs
+
+    def sketch_device(self, fasta_ptrs, nbytes, kmin, kmax, regs_ptr):
+        """Batched HBM-resident sketch: device addresses in, regs_ptr[ng][K][m] device address out."""
+        n = len(fasta_ptrs)
+        ptrs = (C.c_void_p * n)(*[int(x) for x in fasta_ptrs])
+        ns = (C.c_size_t * n)(*[int(x) for x in nbytes])
+        self._check(self._lib.dd_sketch_device(self._ctx, ptrs, ns, n, kmin, kmax, C.c_void_p(int(regs_ptr))))
+
+    # -- union / card ---------------------------------------------------------------------
+    def union(self, sketches):
+        arrs = [_u8(s) for s in sketches]
+        n = arrs[0].size
+        if any(a.size != n for a in arrs):
+            raise ValueError("union inputs differ in size")
+        out = np.empty_like(arrs[0])
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        self._check(self._lib.dd_union(self._ctx, ptrs, len(arrs), n, out.ctypes.data))
+        return out
+
+    def union_device(self, in_ptrs, nbytes, out_ptr):
+        ptrs = (C.c_void_p * len(in_ptrs))(*[int(x) for x in in_ptrs])
+        self._check(self._lib.dd_union_device(self._ctx, ptrs, len(in_ptrs), int(nbytes), C.c_void_p(int(out_ptr))))
+
+    def card(self, regs):
+        r = _u8(regs)
+        if r.size != self.m:
+            raise ValueError(f"expected {self.m} registers, got {r.size}")
+        est = C.c_double()
+        self._check(self._lib.dd_card(self._ctx, r.ctypes.data, C.byref(est)))
+        return est.value
+
+    def card_batch(self, regs):
+        r = _u8(regs).reshape(-1, self.m)
+        est = np.empty(r.shape[0], dtype=np.float64)
+        self._check(self._lib.dd_card_batch(self._ctx, r.ctypes.data, r.shape[0], est.ctypes.data))
+        return est
+
+    def card_batch_device(self, regs_ptr, njobs):
+        est = np.empty(njobs, dtype=np.float64)
+        self._check(self._lib.dd_card_batch_device(self._ctx, C.c_void_p(int(regs_ptr)), njobs, est.ctypes.data))
+        return est
+
+    def hist_batch_device(self, regs_ptr, njobs):
+        h = np.empty((njobs, 64), dtype=np.uint32)
+        self._check(self._lib.dd_hist_batch_device(self._ctx, C.c_void_p(int(regs_ptr)), njobs, h.ctypes.data))
+        return h
+
+    # -- progressive / pairwise -----------------------------------------------------------
+    def progressive(self, leaf, orderings):
+        """leaf [n][K][m] uint8 (host), orderings [o][n] int -> card [o][n][K] float64."""
+        leaf = _u8(leaf)
+        n, K = leaf.shape[0], leaf.shape[1]
+        ords = np.ascontiguousarray(orderings, dtype=np.int32).reshape(-1, n)
+        card = np.empty((ords.shape[0], n, K), dtype=np.float64)
+        self._check(self._lib.dd_progressive(self._ctx, leaf.ctypes.data, n, K, ords.ctypes.data,
+                                             ords.shape[0], card.ctypes.data))
+        return card
+
+    def progressive_device(self, leaf_ptr, n, K, orderings):
+        ords = np.ascontiguousarray(orderings, dtype=np.int32).reshape(-1, n)
+        card = np.empty((ords.shape[0], n, K), dtype=np.float64)
+        self._check(self._lib.dd_progressive_device(self._ctx, C.c_void_p(int(leaf_ptr)), n, K,
+                                                    ords.ctypes.data, ords.shape[0], card.ctypes.data))
+        return card
+
+    def pairwise(self, leaf):
+        leaf = _u8(leaf)
+        n, K = leaf.shape[0], leaf.shape[1]
+        card = np.empty((n, n, K), dtype=np.float64)
+        self._check(self._lib.dd_pairwise(self._ctx, leaf.ctypes.data, n, K, card.ctypes.data))
+        return card
+
+    def pairwise_device(self, leaf_ptr, n, K):
+        card = np.empty((n, n, K), dtype=np.float64)
+        self._check(self._lib.dd_pairwise_device(self._ctx, C.c_void_p(int(leaf_ptr)), n, K, card.ctypes.data))
+        return card
+
+    # -- measurement ----------------------------------------------------------------------
+    def timing_enable(self, on=True):
+        self._check(self._lib.dd_timing_enable(self._ctx, int(bool(on))))
+
+    def timing_reset(self):
+        self._check(self._lib.dd_timing_reset(self._ctx))
+
+    def timing_read(self, which):
+        ms, n = C.c_double(), C.c_int()
+        self._check(self._lib.dd_timing_read(self._ctx, which, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def last_sketch_stats(self):
+        t, u, b = C.c_uint64(), C.c_uint64(), C.c_int()
+        self._check(self._lib.dd_last_sketch_stats(self._ctx, C.byref(t), C.byref(u), C.byref(b)))
+        return t.value, u.value, b.value
+
+    def synth_fasta_device(self, seed, genome_index, nbases, nrec, out_ptr):
+        self._check(self._lib.dd_synth_fasta_device(self._ctx, int(seed), int(genome_index), int(nbases),
+                                                    int(nrec), C.c_void_p(int(out_ptr))))

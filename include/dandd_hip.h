@@ -1,0 +1,127 @@
+/*
+ * dandd_hip.h -- C ABI of libdandd_hip.so: the MI355X (gfx950) delta-sketching engine
+ * that replaces DandD's shell-outs to `dashing sketch|union|card` and GNU `parallel`.
+ *
+ * Boundary being replaced (reference = jessicabonnie/dandd, paths under /root/reference):
+ *   the seven subprocess call sites lib/sketch_classes.py:190,198 (leaf sketch),
+ *   :221,229 (union), :268,274 (card) and lib/huffman_dandd.py:233 (the
+ *   `parallel -j 95% '<cmd {}>' ::: k...` k-batch).  The reference has no FFI; its
+ *   "plugin API" is a CLI + filesystem + stdout contract.  Each
+ *   entry point below names the command line(s) it stands in for.  INTEGRATION.md
+ *   shows the ctypes stub a DandD maintainer would add to lib/sketch_classes.py.
+ *
+ * Conventions: every function returns 0 on success or a negative DD_E* code; the
+ * message is available from dd_last_error() (thread-local).  The caller owns every
+ * buffer.  `dd_ctx` is opaque, bound to one GPU, and not thread-safe (one context
+ * per thread/device).  There is NO CPU fallback: dd_create fails loudly when no
+ * gfx950 device is usable.  Pointers named *_dev are device (HBM) addresses on the
+ * context's GPU; all others are host addresses.  No torch types cross this boundary.
+ *
+ * Register layout: one byte per HyperLogLog register, m = 2^log2m registers per
+ * sketch, `[K][m]` row-major for a k-sweep kmin..kmax (K = kmax-kmin+1).
+ */
+#ifndef DANDD_HIP_H
+#define DANDD_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DD_ABI_VERSION 1
+
+#define DD_OK 0
+#define DD_EINVAL (-1)   /* bad argument */
+#define DD_ENODEV (-2)   /* no usable gfx950 device / HIP runtime error at create */
+#define DD_EHIP (-3)     /* HIP runtime error during a call */
+#define DD_EIO (-4)      /* file could not be read */
+#define DD_ENOMEM (-5)
+
+typedef struct dd_ctx dd_ctx;
+
+int dd_abi_version(void);
+const char *dd_last_error(void);
+
+/* Replaces the per-process configuration of `dashing sketch -S <log2m> [--no-canon]`
+ * (lib/sketch_classes.py:358-365; canon_command :20-29).  log2m in 4..20, k in 1..64
+ * (Dashing itself stops at k=32, lib/huffman_dandd.py:109; 33..64 is this engine's
+ * documented extension).  Returns NULL on failure. */
+dd_ctx *dd_create(int device, int log2m, int canonical);
+void dd_destroy(dd_ctx *);
+/* Run all of this context's work on the given hipStream_t (NULL = default stream). */
+int dd_set_stream(dd_ctx *, void *hip_stream);
+int dd_synchronize(dd_ctx *);
+
+/* ---- leaf sketch over a whole k-sweep ------------------------------------------
+ * Replaces   parallel -j 95% ' dashing sketch -k{} -S <R> --prefix <dir> <fasta> ' ::: kmin..kmax
+ * (lib/huffman_dandd.py:214-218 + lib/sketch_classes.py:351-366): ONE pass over the
+ * FASTA bytes instead of one process per k.  regs[K][m] is overwritten. */
+int dd_sketch_buffer(dd_ctx *, const uint8_t *fasta, size_t nbytes, int kmin, int kmax,
+                     uint8_t *regs);
+int dd_sketch_fasta(dd_ctx *, const char *path, int kmin, int kmax, uint8_t *regs);
+/* Batched, HBM-resident form: ngenomes FASTA byte buffers already on the device,
+ * regs_dev[ngenomes][K][m] on the device.  Asynchronous on the context's stream. */
+int dd_sketch_device(dd_ctx *, const uint8_t *const *fasta_dev, const size_t *nbytes,
+                     int ngenomes, int kmin, int kmax, uint8_t *regs_dev);
+
+/* ---- union -----------------------------------------------------------------------
+ * Replaces   dashing union -z -o <out> <in1> ... <inN>   (lib/sketch_classes.py:368-373):
+ * out[i] = max_j in[j][i], len bytes (any multiple of m, e.g. a whole [K][m] slab). */
+int dd_union(dd_ctx *, const uint8_t *const *in, int n, size_t len, uint8_t *out);
+int dd_union_device(dd_ctx *, const uint8_t *const *in_dev, int n, size_t len, uint8_t *out_dev);
+
+/* ---- cardinality -----------------------------------------------------------------
+ * Replaces   dashing card --presketched <path...>   (lib/sketch_classes.py:306-321):
+ * 64-bin register histogram + Ertl maximum-likelihood estimate, one double per sketch. */
+int dd_card(dd_ctx *, const uint8_t *regs, double *est);
+int dd_card_batch(dd_ctx *, const uint8_t *regs /*[njobs][m]*/, int njobs, double *est);
+int dd_card_batch_device(dd_ctx *, const uint8_t *regs_dev, int njobs, double *est /*host*/);
+/* histogram only (device kernel), hist[njobs][64] on the host */
+int dd_hist_batch_device(dd_ctx *, const uint8_t *regs_dev, int njobs, uint32_t *hist);
+/* Ertl MLE of one 64-bin histogram (host arithmetic, IEEE double, no device needed) */
+double dd_ertl_mle(const uint32_t hist[64], int log2m);
+
+/* ---- progressive unions ----------------------------------------------------------
+ * Replaces the flat prefix unions of DeltaTree.sketch_ordering
+ * (lib/huffman_dandd.py:644-663): for ordering o and prefix length j,
+ * card[o][j-1][kk] = |union of leaf[ord[o][0..j-1]]| at k = kmin+kk, computed as a
+ * running byte-max (max is associative, so it equals the flat union bit for bit). */
+int dd_progressive(dd_ctx *, const uint8_t *leaf /*[n][K][m]*/, int n, int K,
+                   const int32_t *orderings /*[norder][n]*/, int norder,
+                   double *card /*[norder][n][K]*/);
+int dd_progressive_device(dd_ctx *, const uint8_t *leaf_dev, int n, int K,
+                          const int32_t *orderings, int norder, double *card);
+
+/* ---- all-pairs unions ------------------------------------------------------------
+ * Replaces the 2-way unions of DeltaTree.pairwise_spiders (lib/huffman_dandd.py:666-695):
+ * card[i][j][kk] for i<j is |leaf_i U leaf_j|; card[i][i][kk] is |leaf_i|; the lower
+ * triangle mirrors the upper. */
+int dd_pairwise(dd_ctx *, const uint8_t *leaf /*[n][K][m]*/, int n, int K,
+                double *card /*[n][n][K]*/);
+int dd_pairwise_device(dd_ctx *, const uint8_t *leaf_dev, int n, int K, double *card);
+
+/* ---- measurement hooks (bench.py) -------------------------------------------------
+ * When enabled, every launch of kernel `which` is bracketed by HIP events on the
+ * context's stream.  dd_timing_read synchronises the stream and returns the summed
+ * device time and the number of launches since the last reset. */
+#define DD_KERNEL_PACK 0
+#define DD_KERNEL_SWEEP 1
+#define DD_KERNEL_UNION 2
+#define DD_KERNEL_COUNT 3
+int dd_timing_enable(dd_ctx *, int on);
+int dd_timing_read(dd_ctx *, int which, double *total_ms, int *launches);
+int dd_timing_reset(dd_ctx *);
+/* per-call statistics of the last dd_sketch_* call: tokens (bases + breaks) packed,
+ * register updates issued (tokens x K upper bound), number of sweep workgroups */
+int dd_last_sketch_stats(dd_ctx *, uint64_t *tokens, uint64_t *updates, int *sweep_blocks);
+
+/* ---- synthetic FASTA on the device (bench / tests) ----------
+ * Byte-identical to oracle/dd_oracle.c:orc_synth_fasta for the same arguments. */
+size_t dd_synth_size(uint64_t nbases, int nrec);
+int dd_synth_fasta_device(dd_ctx *, uint64_t seed, int genome_index, uint64_t nbases, int nrec,
+                          uint8_t *out_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,369 @@
+/*
+ * dd_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY; see dd_oracle.h).
+ * PARITY UNPINNED against Dashing/KMC (neither is present; the reference has
+ * no golden vectors) -- pinned by tests/golden KATs and the exact counter.
+ *
+ * Plain C99 + unsigned __int128, scalar, single-threaded: one pass per
+ * (FASTA, k), exactly the granularity at which DandD launches `dashing sketch`
+ * (/root/reference/lib/huffman_dandd.py:214-218).
+ */
+#include "dd_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef unsigned __int128 u128;
+
+/* ------------------------------------------------------------------ hash */
+
+/* Thomas Wang 64-bit mix == sketch::hash::WangHash.
+ * KATs: wang(0)=0x77cfa1eef01bca90 wang(1)=0x5bca7c69b794f8ce */
+uint64_t orc_wang64(uint64_t key) {
+    key = (~key) + (key << 21);
+    key = key ^ (key >> 24);
+    key = (key + (key << 3)) + (key << 8); /* * 265 */
+    key = key ^ (key >> 14);
+    key = (key + (key << 2)) + (key << 4); /* * 21 */
+    key = key ^ (key >> 28);
+    key = key + (key << 31);
+    return key;
+}
+
+uint64_t orc_fold128(uint64_t hi, uint64_t lo) { return lo ^ (hi * 0x9E3779B97F4A7C15ull); }
+
+/* sketch::hll::hllbase_t::add: index = top p bits, rho = leading
+ * zeros of the remaining q=64-p bits (with a sentinel) + 1. */
+void orc_idx_rho(uint64_t h, int p, uint32_t *idx, uint8_t *rho) {
+    uint64_t w = ((h << 1) | 1) << (p - 1);
+    *idx = (uint32_t)(h >> (64 - p));
+    *rho = (uint8_t)(__builtin_clzll(w) + 1);
+}
+
+/* ------------------------------------------------------------- tokenizer */
+
+static const int8_t *code_lut(void) {
+    static int8_t lut[256];
+    static int init = 0;
+    if (!init) {
+        memset(lut, 4, sizeof lut);
+        lut['A'] = lut['a'] = 0;
+        lut['C'] = lut['c'] = 1;
+        lut['G'] = lut['g'] = 2;
+        lut['T'] = lut['t'] = 3;
+        init = 1;
+    }
+    return lut;
+}
+
+size_t orc_tokenize(const uint8_t *fa, size_t n, uint8_t *out) {
+    const int8_t *lut = code_lut();
+    size_t nt = 0;
+    int line_start = 1, in_header = 0;
+    for (size_t i = 0; i < n; ++i) {
+        uint8_t c = fa[i];
+        if (c == '\n') {
+            if (in_header) { /* one BREAK per header line */
+                if (out) out[nt] = 4;
+                ++nt;
+            }
+            in_header = 0;
+            line_start = 1;
+            continue;
+        }
+        if (line_start && c == '>') in_header = 1;
+        line_start = 0;
+        if (in_header || c == '\r') continue;
+        if (out) out[nt] = (uint8_t)lut[c];
+        ++nt;
+    }
+    return nt;
+}
+
+/* ---------------------------------------------------------------- sketch */
+
+/* k-mer stream of bonsai's unspaced/unwindowed encoder (A.1): rolling forward
+ * window, rolling reverse-complement window, canonical = min(fw, rc). */
+typedef void (*kmer_fn)(void *ctx, uint64_t hi, uint64_t lo);
+
+static void for_each_kmer(const uint8_t *fa, size_t n, int k, int canonical, kmer_fn fn, void *ctx) {
+    const int8_t *lut = code_lut();
+    const u128 mask = (k == 64) ? ~(u128)0 : (((u128)1 << (2 * k)) - 1);
+    u128 fw = 0, rc = 0;
+    int run = 0, line_start = 1, in_header = 0;
+    for (size_t i = 0; i < n; ++i) {
+        uint8_t ch = fa[i];
+        if (ch == '\n') {
+            if (in_header) run = 0;
+            in_header = 0;
+            line_start = 1;
+            continue;
+        }
+        if (line_start && ch == '>') in_header = 1;
+        line_start = 0;
+        if (in_header || ch == '\r') continue;
+        int c = lut[ch];
+        if (c > 3) {
+            run = 0;
+            continue;
+        }
+        fw = ((fw << 2) | (u128)c) & mask;
+        rc = (rc >> 2) | ((u128)(3 - c) << (2 * (k - 1)));
+        if (++run >= k) {
+            u128 x = (canonical && rc < fw) ? rc : fw;
+            fn(ctx, (uint64_t)(x >> 64), (uint64_t)x);
+        }
+    }
+}
+
+struct hll_ctx {
+    uint8_t *regs;
+    int p, k;
+};
+
+static void hll_add(void *vctx, uint64_t hi, uint64_t lo) {
+    struct hll_ctx *c = (struct hll_ctx *)vctx;
+    uint64_t x = (c->k <= 32) ? lo : orc_fold128(hi, lo);
+    uint32_t idx;
+    uint8_t rho;
+    orc_idx_rho(orc_wang64(x), c->p, &idx, &rho);
+    if (rho > c->regs[idx]) c->regs[idx] = rho;
+}
+
+/* Same stream as for_each_kmer, k <= 32, 64-bit windows, everything inlined:
+ * this is the loop a tuned single-threaded `dashing sketch` job spends its time
+ * in, so it is also what bench.py times as the CPU baseline. */
+static void sketch64(const uint8_t *fa, size_t n, int k, int p, int canonical, uint8_t *regs) {
+    const int8_t *lut = code_lut();
+    const uint64_t mask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1);
+    const int rsh = 2 * (k - 1), q = 64 - p;
+    uint64_t fw = 0, rc = 0;
+    int run = 0, line_start = 1, in_header = 0;
+    for (size_t i = 0; i < n; ++i) {
+        uint8_t ch = fa[i];
+        if (ch == '\n') {
+            if (in_header) run = 0;
+            in_header = 0;
+            line_start = 1;
+            continue;
+        }
+        if (line_start && ch == '>') in_header = 1;
+        line_start = 0;
+        if (in_header || ch == '\r') continue;
+        int c = lut[ch];
+        if (c > 3) {
+            run = 0;
+            continue;
+        }
+        fw = ((fw << 2) | (uint64_t)c) & mask;
+        rc = (rc >> 2) | ((uint64_t)(3 - c) << rsh);
+        if (++run >= k) {
+            uint64_t x = (canonical && rc < fw) ? rc : fw;
+            uint64_t h = orc_wang64(x);
+            uint32_t idx = (uint32_t)(h >> q);
+            uint8_t rho = (uint8_t)(__builtin_clzll(((h << 1) | 1) << (p - 1)) + 1);
+            if (rho > regs[idx]) regs[idx] = rho;
+        }
+    }
+}
+
+int orc_sketch(const uint8_t *fa, size_t n, int k, int p, int canonical, uint8_t *regs) {
+    if (k < 1 || k > 64 || p < 4 || p > 24) return -1;
+    if (k <= 32) {
+        sketch64(fa, n, k, p, canonical, regs);
+        return 0;
+    }
+    struct hll_ctx c = {regs, p, k};
+    for_each_kmer(fa, n, k, canonical, hll_add, &c);
+    return 0;
+}
+
+/* always the generic 128-bit stream (used by tests to cross-check sketch64) */
+int orc_sketch_generic(const uint8_t *fa, size_t n, int k, int p, int canonical, uint8_t *regs) {
+    if (k < 1 || k > 64 || p < 4 || p > 24) return -1;
+    struct hll_ctx c = {regs, p, k};
+    for_each_kmer(fa, n, k, canonical, hll_add, &c);
+    return 0;
+}
+
+int orc_sketch_sweep(const uint8_t *fa, size_t n, int kmin, int kmax, int p, int canonical,
+                     uint8_t *regs) {
+    if (kmin < 1 || kmax > 64 || kmin > kmax) return -1;
+    for (int k = kmin; k <= kmax; ++k) {
+        int rc = orc_sketch(fa, n, k, p, canonical, regs + ((size_t)(k - kmin) << p));
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+/* ----------------------------------------------------------- union / card */
+
+void orc_union(uint8_t *dst, const uint8_t *src, size_t m) {
+    for (size_t i = 0; i < m; ++i)
+        if (src[i] > dst[i]) dst[i] = src[i];
+}
+
+void orc_hist(const uint8_t *regs, size_t m, uint32_t hist[64]) {
+    memset(hist, 0, 64 * sizeof(uint32_t));
+    for (size_t i = 0; i < m; ++i) hist[regs[i] & 63]++;
+}
+
+/* Ertl 2017, "New cardinality estimation algorithms for HyperLogLog sketches",
+ * Algorithm 8 (ML estimator, secant iteration), relative tolerance 1e-2/sqrt(m)
+ * -- dashing's default `ERTL_MLE`.  IEEE double throughout;
+ * build with -ffp-contract=off so the product's copy agrees bit for bit. */
+double orc_ertl_mle(const uint32_t c[64], int p) {
+    const int q = 64 - p;
+    const uint64_t m = 1ull << p;
+    if (c[q + 1] == m) return INFINITY;
+    int kmin, kmax;
+    for (kmin = 0; c[kmin] == 0; ++kmin) {}
+    int kminp = kmin > 1 ? kmin : 1;
+    for (kmax = q + 1; kmax && c[kmax] == 0; --kmax) {}
+    int kmaxp = kmax < q ? kmax : q;
+    double z = 0.0;
+    for (int k = kmaxp; k >= kminp; --k) z = 0.5 * z + (double)c[k];
+    z = ldexp(z, -kminp);
+    double cprime = (double)c[q + 1];
+    if (q >= 1) cprime += (double)c[kmaxp];
+    double a = z + (double)c[0];
+    double mprime = (double)(m - c[0]);
+    double b = z + ldexp((double)c[q + 1], -q);
+    double x = (b <= 1.5 * a) ? mprime / (0.5 * b + a) : (mprime / b) * log1p(b / a);
+    double dx = x, gprev = 0.0;
+    const double relerr = 1e-2 / sqrt((double)m);
+    while (dx > x * relerr) {
+        int kappam1;
+        frexp(x, &kappam1);
+        int sh = (kmaxp + 1 > kappam1 + 2) ? kmaxp + 1 : kappam1 + 2;
+        double xp = ldexp(x, -sh);
+        double xp2 = xp * xp;
+        double h = xp - xp2 / 3.0 + (xp2 * xp2) * (1.0 / 45.0 - xp2 / 472.5);
+        for (int k = kappam1; k >= kmaxp; --k) {
+            double hp = 1.0 - h;
+            h = (xp + h * hp) / (xp + hp);
+            xp += xp;
+        }
+        double g = cprime * h;
+        for (int k = kmaxp - 1; k >= kminp; --k) {
+            double hp = 1.0 - h;
+            h = (xp + h * hp) / (xp + hp);
+            xp += xp;
+            g += (double)c[k] * h;
+        }
+        g += x * a;
+        if (gprev < g && g <= mprime)
+            dx *= (g - mprime) / (gprev - g);
+        else
+            dx = 0.0;
+        x += dx;
+        gprev = g;
+    }
+    return x * (double)m;
+}
+
+double orc_card(const uint8_t *regs, int p) {
+    uint32_t hist[64];
+    orc_hist(regs, (size_t)1 << p, hist);
+    return orc_ertl_mle(hist, p);
+}
+
+/* ----------------------------------------------------------- exact count */
+
+struct vec128 {
+    u128 *v;
+    size_t n, cap;
+};
+
+static void vec_push(void *vctx, uint64_t hi, uint64_t lo) {
+    struct vec128 *s = (struct vec128 *)vctx;
+    if (s->n == s->cap) {
+        s->cap = s->cap ? s->cap * 2 : (1u << 16);
+        s->v = (u128 *)realloc(s->v, s->cap * sizeof(u128));
+        if (!s->v) abort();
+    }
+    s->v[s->n++] = ((u128)hi << 64) | lo;
+}
+
+static int cmp128(const void *a, const void *b) {
+    u128 x = *(const u128 *)a, y = *(const u128 *)b;
+    return x < y ? -1 : (x > y);
+}
+
+/* `kmc -ci1 -cs2 -k K [-b]` + `kmc_tools complex (+)` + `kmc_tools info` (A.5):
+ * number of distinct (canonical) k-mers over all inputs. */
+int orc_exact_count(const uint8_t *const *fas, const size_t *ns, int nbuf, int k, int canonical,
+                    uint64_t *distinct) {
+    if (k < 1 || k > 64) return -1;
+    struct vec128 s = {0, 0, 0};
+    for (int i = 0; i < nbuf; ++i) for_each_kmer(fas[i], ns[i], k, canonical, vec_push, &s);
+    qsort(s.v, s.n, sizeof(u128), cmp128);
+    uint64_t d = 0;
+    for (size_t i = 0; i < s.n; ++i)
+        if (i == 0 || s.v[i] != s.v[i - 1]) ++d;
+    free(s.v);
+    *distinct = d;
+    return 0;
+}
+
+/* -------------------------------------------------------- synthetic FASTA */
+
+uint64_t orc_splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+#define SYN_HDR 16
+#define SYN_LINE 80
+
+static uint64_t rec_len(uint64_t nbases, int nrec, int r) {
+    uint64_t per = nbases / (uint64_t)nrec;
+    return (r == nrec - 1) ? nbases - per * (uint64_t)(nrec - 1) : per;
+}
+
+size_t orc_synth_size(uint64_t nbases, int nrec) {
+    size_t tot = 0;
+    for (int r = 0; r < nrec; ++r) {
+        uint64_t L = rec_len(nbases, nrec, r);
+        tot += SYN_HDR + L + (L + SYN_LINE - 1) / SYN_LINE;
+    }
+    return tot;
+}
+
+static uint8_t synth_base(uint64_t seed, uint64_t seed_g, uint64_t pos) {
+    static const char up[4] = {'A', 'C', 'G', 'T'};
+    uint32_t b = (uint32_t)(orc_splitmix64(seed ^ pos) & 3);
+    uint64_t r = orc_splitmix64(seed_g ^ pos);
+    if (r % 100 == 0) b = (b + 1 + (uint32_t)((r >> 32) % 3)) & 3;
+    uint8_t ch = (uint8_t)up[b];
+    if (orc_splitmix64(seed_g ^ 0x4E4E4E4E00000000ull ^ (pos / 100)) % 1000 == 0) ch = 'N';
+    if (orc_splitmix64(seed_g ^ 0x6C6C6C6C00000000ull ^ (pos / 500)) % 10 == 0) ch |= 0x20;
+    return ch;
+}
+
+size_t orc_synth_fasta(uint64_t seed, int gi, uint64_t nbases, int nrec, uint8_t *out) {
+    static const char hexd[] = "0123456789abcdef";
+    const uint64_t seed_g = orc_splitmix64(seed + (uint64_t)gi + 1);
+    size_t o = 0;
+    uint64_t pos = 0;
+    for (int r = 0; r < nrec; ++r) {
+        uint64_t L = rec_len(nbases, nrec, r);
+        /* ">gGGGG.rRRRR   \n" */
+        uint8_t *h = out + o;
+        h[0] = '>';
+        h[1] = 'g';
+        for (int d = 0; d < 4; ++d) h[2 + d] = (uint8_t)hexd[(gi >> (12 - 4 * d)) & 15];
+        h[6] = '.';
+        h[7] = 'r';
+        for (int d = 0; d < 4; ++d) h[8 + d] = (uint8_t)hexd[(r >> (12 - 4 * d)) & 15];
+        h[12] = h[13] = h[14] = ' ';
+        h[15] = '\n';
+        o += SYN_HDR;
+        for (uint64_t j = 0; j < L; ++j) {
+            out[o++] = synth_base(seed, seed_g, pos++);
+            if (j % SYN_LINE == SYN_LINE - 1 || j == L - 1) out[o++] = '\n';
+        }
+    }
+    return o;
+}

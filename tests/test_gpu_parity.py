@@ -1,0 +1,211 @@
+"""GPU parity: every HIP path called through the C ABI, compared bit-for-bit with the CPU oracle
+on the same inputs (registers, histograms) and, for the Ertl MLE, double-for-double."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0xD4ADD
+
+
+def _sweep_check(eng, orc, fa, kmin, kmax, canonical=True):
+    got = eng.sketch_buffer(fa, kmin, kmax)
+    want = orc.sketch_sweep(fa, kmin, kmax, eng.log2m, canonical)
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, f"{bad.shape[0]} registers differ, first at (k={kmin + bad[0][0]}, idx={bad[0][1]}): got {got[tuple(bad[0])]} want {want[tuple(bad[0])]}"
+    return got
+
+
+def test_synth_bytes_match_oracle(engine_factory, torch_cuda, orc):
+    torch = torch_cuda
+    eng = engine_factory()
+    for gi, nb, nrec in [(0, 1000, 1), (3, 12345, 4), (7, 200000, 5), (1, 80, 1), (2, 81, 2), (5, 160, 2)]:
+        from dandd_amd.engine import synth_size
+        n = synth_size(nb, nrec)
+        want = orc.synth_fasta(SEED, gi, nb, nrec)
+        assert n == want.size
+        buf = torch.empty(n, dtype=torch.uint8, device="cuda")
+        eng.synth_fasta_device(SEED, gi, nb, nrec, buf.data_ptr())
+        eng.synchronize()
+        torch.cuda.synchronize()
+        assert np.array_equal(buf.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("canonical", [True, False])
+def test_sweep_parity_k4_40(engine_factory, orc, canonical):
+    eng = engine_factory(14, canonical)
+    fa = orc.synth_fasta(SEED, 0, 300000, 3)
+    _sweep_check(eng, orc, fa, 4, 40, canonical)
+
+
+def test_sweep_parity_full_k_range(engine_factory, orc):
+    eng = engine_factory(12, True)
+    fa = orc.synth_fasta(SEED, 2, 60000, 2)
+    _sweep_check(eng, orc, fa, 1, 64, True)
+
+
+@pytest.mark.parametrize("p", [4, 8, 10, 16, 17, 18, 20])
+def test_sweep_parity_register_sizes(engine_factory, orc, p):
+    eng = engine_factory(p, True)
+    fa = orc.synth_fasta(SEED, 1, 150000, 2)
+    _sweep_check(eng, orc, fa, 14, 18, True)
+    _sweep_check(eng, orc, fa, 31, 34, True)
+
+
+RAGGED = {
+    "empty": b"",
+    "header_only": b">only a header\n",
+    "header_no_newline": b">x",
+    "no_header": b"ACGTACGTTTGACCA\nACGTTGCA\n",
+    "no_trailing_newline": b">a\nACGTACGTACGGATCGATCGGGATTTAGC",
+    "crlf": b">a desc\r\nACGTAGCTAGCTAGCTAGGATCGATCGA\r\nTTGACGATCGATGCAGCAGCATCGAC\r\n>b\r\nGGGATCGAGCTAGCATCGAC\r\n",
+    "lower_and_n": b">a\nacgtagctagNNNNctagctaggatcgRYatcgattgacgatcgatgcagcagcatcgac\n",
+    "short_records": b">a\nACG\n>b\nAC\n>c\n\n>d\nACGTTGCAGT\n>e\nA\n",
+    "gt_midline": b">a\nACGTAGCTAG>CTAGGATCGATCGATTGACG\nACGT>ACGTAGCATCGATCGA\n",
+    "blank_lines": b">a\n\n\nACGTAGCTAGCTAGC\n\nTAGGATCGATCGATTGACG\n\n",
+    "poly": b">a\n" + b"A" * 100 + b"\n" + b"T" * 100 + b"\n" + b"ACGT" * 30 + b"\n",
+}
+
+
+@pytest.mark.parametrize("name", sorted(RAGGED))
+def test_sweep_parity_ragged(engine_factory, orc, name):
+    eng = engine_factory(10, True)
+    fa = RAGGED[name]
+    _sweep_check(eng, orc, np.frombuffer(fa, dtype=np.uint8), 1, 40, True)
+
+
+def test_sweep_parity_long_lines_and_headers(engine_factory, orc):
+    """A 20 kB header and a 50 kB single sequence line cross several 4 KiB pack chunks."""
+    rng = np.random.default_rng(5)
+    seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=50000).tobytes()
+    hdr = b">" + rng.choice(np.frombuffer(b"ACGT >xyz", dtype=np.uint8), size=20000).tobytes()
+    seq2 = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=9000).tobytes()
+    fa = b">r1\n" + seq + b"\n" + hdr + b"\n" + seq2 + b"\n" + hdr
+    eng = engine_factory(10, True)
+    _sweep_check(eng, orc, np.frombuffer(fa, dtype=np.uint8), 2, 36, True)
+
+
+def test_sweep_parity_many_tiles(engine_factory, orc):
+    """5 Mbp: 77 tiles of 64 Ki tokens -> exercises multi-tile jobs, halos and the HBM merge."""
+    eng = engine_factory(14, True)
+    fa = orc.synth_fasta(SEED, 4, 5_000_000, 5)
+    got = _sweep_check(eng, orc, fa, 10, 33, True)
+    # HLL accuracy against the exact counter (3 sigma, sigma = 1.04/sqrt(m))
+    for k in (12, 20, 31):
+        est = eng.card(got[k - 10])
+        exact = orc.exact_count([fa], k)
+        assert abs(est - exact) / exact < 3 * 1.04 / np.sqrt(eng.m)
+
+
+def test_union_and_card_match_oracle(engine_factory, orc):
+    eng = engine_factory(14, True)
+    fas = [orc.synth_fasta(SEED, g, 100000, 2) for g in range(4)]
+    sk = [orc.sketch_sweep(f, 8, 12, 14) for f in fas]
+    got = eng.union(sk)
+    want = orc.union(*sk)
+    assert np.array_equal(got, want)
+    for kk in range(5):
+        assert eng.card(got[kk]) == orc.card(want[kk])
+    est = eng.card_batch(np.stack(sk))
+    want_est = np.array([orc.card(s[kk]) for s in sk for kk in range(5)])
+    assert np.array_equal(est, want_est)
+
+
+def test_device_mle_bit_exact_vs_host(engine_factory, torch_cuda, orc):
+    """K3 on the device must produce the same doubles as the host copy and the oracle."""
+    from dandd_amd.engine import ertl_mle
+    torch = torch_cuda
+    rng = np.random.default_rng(11)
+    for p in (10, 14):
+        eng = engine_factory(p, True)
+        m = 1 << p
+        regs = []
+        for load in (0.0, 0.01, 0.3, 1.0, 7.0, 100.0, 5000.0, 1e6):
+            n = int(load * m)
+            r = np.zeros(m, dtype=np.uint8)
+            if n:
+                idx = rng.integers(0, m, size=n)
+                rho = np.minimum(rng.geometric(0.5, size=n), 64 - p + 1).astype(np.uint8)
+                np.maximum.at(r, idx, rho)
+            regs.append(r)
+        regs.append(np.full(m, 64 - p + 1, dtype=np.uint8))  # saturated -> inf
+        regs = np.stack(regs)
+        t = torch.from_numpy(regs).cuda()
+        dev = eng.card_batch_device(t.data_ptr(), regs.shape[0])
+        hists = eng.hist_batch_device(t.data_ptr(), regs.shape[0])
+        for i in range(regs.shape[0]):
+            assert np.array_equal(hists[i], orc.hist(regs[i]))
+            host = ertl_mle(hists[i], p)
+            want = orc.ertl_mle(hists[i], p)
+            assert host == want or (np.isinf(host) and np.isinf(want))
+            assert dev[i] == want or (np.isinf(dev[i]) and np.isinf(want)), (p, i, dev[i], want)
+
+
+def test_progressive_matches_flat_unions(engine_factory, orc):
+    eng = engine_factory(12, True)
+    n, kmin, kmax = 6, 9, 13
+    K = kmax - kmin + 1
+    fas = [orc.synth_fasta(SEED, g, 60000, 1) for g in range(n)]
+    leaf = np.stack([orc.sketch_sweep(f, kmin, kmax, 12) for f in fas])
+    rng = np.random.default_rng(3)
+    ords = np.stack([rng.permutation(n) for _ in range(4)]).astype(np.int32)
+    got = eng.progressive(leaf, ords)
+    for o in range(ords.shape[0]):
+        for j in range(n):
+            flat = orc.union(*[leaf[g] for g in ords[o, : j + 1]])
+            for kk in range(K):
+                assert got[o, j, kk] == orc.card(flat[kk])
+
+
+def test_pairwise_matches_oracle(engine_factory, orc):
+    eng = engine_factory(12, True)
+    n, kmin, kmax = 5, 7, 10
+    K = kmax - kmin + 1
+    fas = [orc.synth_fasta(SEED, g, 40000, 1) for g in range(n)]
+    leaf = np.stack([orc.sketch_sweep(f, kmin, kmax, 12) for f in fas])
+    got = eng.pairwise(leaf)
+    for i in range(n):
+        for j in range(n):
+            u = orc.union(leaf[i], leaf[j])
+            for kk in range(K):
+                assert got[i, j, kk] == orc.card(u[kk])
+
+
+def test_batched_device_sketch(engine_factory, torch_cuda, orc):
+    """dd_sketch_device over several HBM-resident genomes of different sizes."""
+    torch = torch_cuda
+    eng = engine_factory(14, True)
+    sizes = [(0, 70000, 2), (1, 250000, 3), (2, 1000, 1), (3, 0, 1)]
+    fas = [orc.synth_fasta(SEED, g, nb, nr) for g, nb, nr in sizes]
+    bufs = [torch.from_numpy(f.copy()).cuda() if f.size else torch.empty(16, dtype=torch.uint8, device="cuda") for f in fas]
+    K = 6
+    regs = torch.empty((len(fas), K, eng.m), dtype=torch.uint8, device="cuda")
+    eng.sketch_device([b.data_ptr() for b in bufs], [f.size for f in fas], 15, 20, regs.data_ptr())
+    eng.synchronize()
+    got = regs.cpu().numpy()
+    for g, f in enumerate(fas):
+        assert np.array_equal(got[g], orc.sketch_sweep(f, 15, 20, 14))
+
+
+def test_sketch_is_deterministic(engine_factory, orc):
+    eng = engine_factory(14, True)
+    fa = orc.synth_fasta(SEED, 9, 400000, 2)
+    a = eng.sketch_buffer(fa, 5, 30)
+    b = eng.sketch_buffer(fa, 5, 30)
+    assert np.array_equal(a, b)
+
+
+def test_sketch_fasta_file(engine_factory, orc, tmp_path):
+    eng = engine_factory(14, True)
+    fa = orc.synth_fasta(SEED, 6, 50000, 2)
+    p = tmp_path / "g.fasta"
+    p.write_bytes(fa.tobytes())
+    got = eng.sketch_fasta(str(p), 10, 12)
+    assert np.array_equal(got, orc.sketch_sweep(fa, 10, 12, 14))
+    from dandd_amd.engine import EngineError
+    with pytest.raises(EngineError):
+        eng.sketch_fasta(str(tmp_path / "missing.fa"), 10, 12)
+    with pytest.raises(EngineError):
+        eng.sketch_buffer(fa, 0, 12)
+    with pytest.raises(EngineError):
+        eng.sketch_buffer(fa, 10, 65)
