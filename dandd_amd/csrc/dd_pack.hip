@@ -152,7 +152,9 @@ __global__ __launch_bounds__(T) void pack_stats(const uint8_t* __restrict__ fa, 
         before = before > pre ? before : pre;
     }
     int tH, tS;
-    if (prev_nl) {
+    if (pos >= n) {  // tail of the last chunk: nothing to tokenise
+        tH = tS = 0;
+    } else if (prev_nl) {
         tH = tS = scan16<false>(b, true, false, nullptr);
     } else if (before >= 0) {  // a newline earlier in this chunk decides the state
         bool h = line_is_header(fa, before);

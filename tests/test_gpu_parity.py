@@ -120,14 +120,14 @@ def test_device_mle_bit_exact_vs_host(engine_factory, torch_cuda, orc):
         eng = engine_factory(p, True)
         m = 1 << p
         regs = []
-        for load in (0.0, 0.01, 0.3, 1.0, 7.0, 100.0, 5000.0, 1e6):
-            n = int(load * m)
-            r = np.zeros(m, dtype=np.uint8)
-            if n:
-                idx = rng.integers(0, m, size=n)
-                rho = np.minimum(rng.geometric(0.5, size=n), 64 - p + 1).astype(np.uint8)
-                np.maximum.at(r, idx, rho)
-            regs.append(r)
+        for load in (0.0, 0.01, 0.3, 1.0, 7.0, 100.0, 5000.0, 1e6, 1e12):
+            # register = max of Poisson(load) geometric(1/2) draws, sampled directly by inverting
+            # P(max < j) = exp(-load * 2^-(j-1)); O(m) memory whatever the load
+            u = rng.random(m)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                r = np.floor(np.log2(load) - np.log2(-np.log(u))) + 1 if load > 0 else np.zeros(m)
+            r = np.clip(np.nan_to_num(r, nan=0.0, posinf=64 - p + 1, neginf=0.0), 0, 64 - p + 1)
+            regs.append(r.astype(np.uint8))
         regs.append(np.full(m, 64 - p + 1, dtype=np.uint8))  # saturated -> inf
         regs = np.stack(regs)
         t = torch.from_numpy(regs).cuda()
