@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X delta-sketching engine.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1], per GPU): 10 synthetic 50-Mbp FASTAs resident in HBM,
+HyperLogLog log2m=14, k-sweep 4..40 (K=37).  One STEP = one pass of the whole hot path over that
+batch: K0 pack + K1 fused k-sweep sketch of every genome, K2 N-way root union (+ RCCL max
+all-reduce of the root when N>1), K2/K3 cardinalities of every leaf and of the root, delta =
+max_k card/k on the host.  Metric: Gbp/s = bases sketched over the whole k-sweep / wall time,
+aggregated over all ranks (weak scaling: every rank owns its own 10 genomes).
+
+Extra objects on the JSON line (see DESIGN.md "Measurement"):
+  roofline     -- dominant kernel (K1 sweep): algorithmic bytes / its HIP-event time vs 8 TB/s,
+                  plus the VALU-issue bound that actually binds it
+  cpu_baseline -- the CPU oracle run the way DandD drives Dashing (one job per (genome, k),
+                  each re-parsing the FASTA, floor(0.95*nproc) jobs in flight) on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED = 0xD4ADD
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_PEAK_LANEOPS = 78.6e12    # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+
+
+def cpu_baseline(nbases, nrec, kmin, kmax, log2m):
+    """Oracle stand-in for `parallel -j 95% 'dashing sketch -k{} ...' ::: kmin..kmax` on this host."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import dd_oracle as orc
+    path = None
+    try:  # native-arch build for a fair timing; fall back to the portable build
+        path = orc.build(arch="native", out=os.path.join("/tmp", f"liboracle_native_{os.getpid()}.so"))
+        lib = orc.lib(path)
+    except Exception:
+        lib = orc.lib()
+    fa = orc.synth_fasta(SEED, 0, nbases, nrec)
+    ncpu = os.cpu_count() or 1
+    jobs = max(1, int(0.95 * ncpu))
+    ks = list(range(kmin, kmax + 1))
+    regs = np.zeros((len(ks), 1 << log2m), dtype=np.uint8)
+
+    def one(i):
+        # ctypes releases the GIL for the duration of the C call: real thread parallelism
+        lib.orc_sketch(fa.ctypes.data, fa.size, ks[i], log2m, 1, regs[i].ctypes.data)
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        list(ex.map(one, range(len(ks))))
+    dt = time.perf_counter() - t0
+    if path and os.path.exists(path):
+        os.remove(path)
+    return {
+        "value": nbases / dt / 1e9,
+        "unit": "Gbp/s",
+        "cores": min(jobs, len(ks)),
+        "kind": "port",
+        "sample": f"1 synthetic genome x {nbases/1e6:g} Mbp, k {kmin}-{kmax}, log2m={log2m}: one single-threaded "
+                  f"oracle job per k (each re-parses the FASTA), {jobs} jobs in flight on {ncpu} host CPUs, {dt:.1f} s wall",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--genomes", type=int, default=10)
+    ap.add_argument("--mbp", type=float, default=50.0)
+    ap.add_argument("--kmin", type=int, default=4)
+    ap.add_argument("--kmax", type=int, default=40)
+    ap.add_argument("--log2m", type=int, default=14)
+    ap.add_argument("--nrec", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-mbp", type=float, default=16.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch through torch.distributed.run (one rank per GPU)")
+
+    # CPU baseline first (rank 0, N=1 only), before this process touches the GPU
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(int(args.cpu_sample_mbp * 1e6), args.nrec, args.kmin, args.kmax, args.log2m)
+
+    import torch
+    import torch.distributed as dist
+    from dandd_amd.engine import Engine, synth_size, KERNEL_PACK, KERNEL_SWEEP, KERNEL_UNION
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    ng, nb = args.genomes, int(args.mbp * 1e6)
+    kmin, kmax, p = args.kmin, args.kmax, args.log2m
+    K, m = kmax - kmin + 1, 1 << p
+    eng = Engine(device=local_rank, log2m=p, canonical=True)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    # synthetic genomes generated on the device (never cross PCIe); rank r owns genomes r*ng..
+    nbytes = synth_size(nb, args.nrec)
+    fasta = [torch.empty(nbytes + 16, dtype=torch.uint8, device="cuda") for _ in range(ng)]
+    for g in range(ng):
+        eng.synth_fasta_device(SEED, rank * ng + g, nb, args.nrec, fasta[g].data_ptr())
+    regs = torch.empty((ng + 1, K, m), dtype=torch.uint8, device="cuda")  # leaves + root
+    ptrs = [f.data_ptr() for f in fasta]
+    sizes = [nbytes] * ng
+    leaf_ptrs = [regs[g].data_ptr() for g in range(ng)]
+    ks = np.arange(kmin, kmax + 1, dtype=np.float64)
+
+    def step():
+        eng.sketch_device(ptrs, sizes, kmin, kmax, regs.data_ptr())                 # K0 + K1
+        eng.union_device(leaf_ptrs, K * m, regs[ng].data_ptr())                      # K2 root union
+        if world > 1:
+            dist.all_reduce(regs[ng], op=dist.ReduceOp.MAX)                          # RCCL over xGMI
+        card = eng.card_batch_device(regs.data_ptr(), (ng + 1) * K).reshape(ng + 1, K)  # K2 + K3
+        return (card / ks).max(axis=1), (card / ks).argmax(axis=1) + kmin            # delta, argmax-k
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    eng.timing_enable(True)
+    eng.timing_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        delta, bestk = step()
+    fence()
+    dt = time.perf_counter() - t0
+    sweep_ms, sweep_n = eng.timing_read(KERNEL_SWEEP)
+    pack_ms, pack_n = eng.timing_read(KERNEL_PACK)
+    union_ms, union_n = eng.timing_read(KERNEL_UNION)
+    eng.timing_enable(False)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        steps = args.steps
+        total_bases = world * ng * nb * steps
+        # algorithmic bytes of one step on one GPU: FASTA read once + registers written once
+        alg_bytes = ng * nbytes + ng * K * m
+        sweep_s_per_step = sweep_ms / 1e3 / steps
+        achieved_gbs = alg_bytes / sweep_s_per_step / 1e9
+        updates_per_s = ng * nb * K / sweep_s_per_step
+        out = {
+            "metric": "Gbp/s sketched over k-sweep",
+            "value": total_bases / dt / 1e9,
+            "unit": "Gbp/s",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"cfg2: {ng} x {args.mbp:g} Mbp synthetic FASTA per GPU resident in HBM, HLL log2m={p}, "
+                            f"k-sweep {kmin}-{kmax} (K={K}), leaf sketches + root union + all cardinalities + delta",
+                "genomes_per_gpu": ng, "bases_per_genome": nb, "kmin": kmin, "kmax": kmax, "log2m": p,
+                "parallelism": f"genomes sharded over {world} GPU(s)" + ("; RCCL max all-reduce of the root" if world > 1 else ""),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "sweep_kernel (K1, all k-class launches of one step)",
+                "achieved": achieved_gbs,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved_gbs / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_step": alg_bytes,
+                "kernel_ms_per_step": sweep_ms / steps,
+                "launches_per_step": sweep_n / steps,
+                "avg_launch_ms": sweep_ms / max(1, sweep_n),
+                "register_updates_per_s": updates_per_s,
+                "valu_lane_ops_peak": VALU_PEAK_LANEOPS,
+                "note": "integer-VALU bound (hash per (base,k)); see DESIGN.md for ops/update and the VALU fraction",
+            },
+            "other_kernels_ms_per_step": {"pack_K0": pack_ms / steps, "union_hist_K2": union_ms / steps},
+            "delta_genome0": float(delta[0]), "argmax_k_genome0": int(bestk[0]),
+            "delta_root": float(delta[ng]), "argmax_k_root": int(bestk[ng]),
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,94 @@
+"""CPU tests of the C-ABI boundary: the library builds, loads, exports exactly what
+include/dandd_hip.h declares, its host-only functions agree with the oracle, and the product
+refuses to run without a GPU instead of falling back to anything."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from dandd_amd import build, engine
+    build.build()
+    return engine.load_library()
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "dandd_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dd_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree(lib):
+    from dandd_amd import engine
+    decl = declared_symbols()
+    assert decl, "no declarations parsed"
+    assert sorted(engine.EXPORTS) == decl
+    for name in decl:
+        assert hasattr(lib, name), f"{name} declared in include/dandd_hip.h but not exported"
+    assert lib.dd_abi_version() == 1
+
+
+def test_exported_symbols_are_plain_c(lib):
+    from dandd_amd import engine
+    out = subprocess.check_output(["nm", "-D", "--defined-only", engine.LIB_PATH], text=True)
+    names = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert set(declared_symbols()) <= names
+
+
+def test_host_mle_matches_oracle(lib, orc):
+    from dandd_amd.engine import ertl_mle
+    rng = np.random.default_rng(4)
+    for p in (4, 10, 14, 20):
+        m = 1 << p
+        for load in (0.0, 0.2, 3.0, 1e3, 1e7):
+            u = rng.random(m)
+            with np.errstate(divide="ignore"):
+                r = np.floor(np.log2(load) - np.log2(-np.log(u))) + 1 if load > 0 else np.zeros(m)
+            r = np.clip(r, 0, 64 - p + 1).astype(np.uint8)
+            h = orc.hist(r)
+            assert ertl_mle(h, p) == orc.ertl_mle(h, p)
+
+
+def test_synth_size_matches_oracle(lib, orc):
+    from dandd_amd.engine import synth_size
+    for nb, nrec in [(0, 1), (1, 1), (80, 1), (81, 2), (1000, 3), (50_000_000, 5)]:
+        assert synth_size(nb, nrec) == orc.lib().orc_synth_size(nb, nrec)
+
+
+def test_no_gpu_means_loud_failure(lib):
+    """On a box without a GPU the product must raise, not fall back (run in a subprocess so a
+    GPU-equipped box can hide its devices)."""
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from dandd_amd.engine import Engine, EngineError\n"
+        "try:\n"
+        "    Engine(0, 14, True)\n"
+        "except EngineError as e:\n"
+        "    print('RAISED', e)\n"
+        "else:\n"
+        "    print('NO ERROR')\n" % ROOT
+    )
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert "RAISED" in out.stdout, out.stdout + out.stderr
+    assert "no CPU path" in out.stdout or "HIP" in out.stdout
+
+
+def test_product_never_imports_oracle():
+    """The product tree must not reference the oracle in any way."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "dandd_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                for line in text.splitlines():
+                    s = line.strip()
+                    if s.startswith(("#include", "import", "from")):
+                        assert "oracle" not in s, f"{f}: {s}"
+                assert "liboracle" not in text and "dd_oracle.py" not in text, f
