@@ -7,6 +7,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -288,30 +289,47 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         tot += 256;
         max_n = std::max(max_n, nbytes[g]);
     }
+    std::vector<size_t> off_scratch(ngenomes);
+    size_t scratch_tot = 0;
+    for (int g = 0; g < ngenomes; ++g) {
+        off_scratch[g] = scratch_tot;
+        scratch_tot += align_up(dd::pack_scratch_bytes(nbytes[g]), 256);
+    }
     int rc;
     if ((rc = c->tokens.reserve(tot))) return rc;
-    if ((rc = c->scratch.reserve(dd::pack_scratch_bytes(max_n)))) return rc;
+    if ((rc = c->scratch.reserve(scratch_tot))) return rc;
     char* tb = static_cast<char*>(c->tokens.p);
+    char* sb = static_cast<char*>(c->scratch.p);
 
-    // ---- K0: pack every genome ---------------------------------------------------------
+    // ---- K0 / K1 genome tables -----------------------------------------------------------
     std::vector<dd::SweepGenome> gtab(ngenomes);
+    std::vector<dd::PackGenome> ptab(ngenomes);
     uint64_t tokens_ub = 0;
+    size_t max_chunks = 0;
     for (int g = 0; g < ngenomes; ++g) {
         dd::TokenStream ts{reinterpret_cast<uint32_t*>(tb + off_codes[g]),
                            reinterpret_cast<uint32_t*>(tb + off_bad[g]),
                            reinterpret_cast<unsigned long long*>(tb + off_ntok[g])};
-        {
-            Span sp(c, DD_KERNEL_PACK);
-            dd::launch_pack(fasta_dev[g], nbytes[g], ts, static_cast<long long*>(c->scratch.p), st);
-        }
+        ptab[g] = dd::PackGenome{fasta_dev[g], nbytes[g], dd::pack_chunks(nbytes[g]),
+                                 reinterpret_cast<long long*>(sb + off_scratch[g]), ts};
+        max_chunks = std::max(max_chunks, ptab[g].nchunks);
         gtab[g] = dd::SweepGenome{ts.codes, ts.bad, ts.ntok, regs_dev + (size_t)g * K * m};
         tokens_ub += nbytes[g];
     }
-    DD_HIP(hipGetLastError());
+    (void)max_n;
 
     // ---- K1 job tables -----------------------------------------------------------------
     const bool global_regs = m > (size_t)dd::sweep_max_lds_bytes();
-    const int slots = global_regs ? 64 : (int)std::min<size_t>(64, dd::sweep_max_lds_bytes() / m);
+    // development knobs (environment, read per call): LDS budget per workgroup and jobs per CU
+    // 80 KiB per workgroup = two 1024-thread workgroups (8 waves per SIMD) per CU: measured
+    // 1.35x faster than one 160 KiB workgroup (4 waves per SIMD cannot cover the LDS latency of
+    // the dependent hash -> read -> compare chain); a single array larger than that takes what it needs.
+    size_t lds_budget = 80 * 1024;
+    if (const char* e = getenv("DD_LDS_KB")) lds_budget = std::min<size_t>((size_t)dd::sweep_max_lds_bytes(), (size_t)atoi(e) * 1024);
+    if (lds_budget < m) lds_budget = m;
+    size_t jobs_per_cu = 32;
+    if (const char* e = getenv("DD_JOBS_PER_CU")) jobs_per_cu = std::max(1, atoi(e));
+    const int slots = global_regs ? 64 : (int)std::min<size_t>(64, lds_budget / m);
     const int threads = 1024;
     const size_t tile_tokens = (size_t)threads * dd::kSegTokens;
 
@@ -330,13 +348,18 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         // aim for ~8 jobs per CU over the whole class so the dispatcher can balance the tail
         size_t total_tiles = 0;
         for (int g = 0; g < ngenomes; ++g) total_tiles += (nbytes[g] + tile_tokens - 1) / tile_tokens;
-        const size_t target_jobs = 256 * 8;
+        const size_t target_jobs = 256 * jobs_per_cu;
         size_t tiles_per_job = std::max<size_t>(1, (total_tiles * ngroups + target_jobs - 1) / target_jobs);
         ClassJobs cj;
         cj.kclass = kc;
-        for (int g = 0; g < ngenomes; ++g) {
-            const size_t ntiles = (nbytes[g] + tile_tokens - 1) / tile_tokens;
-            for (size_t t0 = 0; t0 < ntiles; t0 += tiles_per_job) {
+        // Tile-major order: workgroups that run concurrently work on different (genome, k-group)
+        // slabs, so each slab has been warmed by its earlier tiles when its later jobs start.
+        size_t max_tiles = 0;
+        for (int g = 0; g < ngenomes; ++g) max_tiles = std::max(max_tiles, (nbytes[g] + tile_tokens - 1) / tile_tokens);
+        for (size_t t0 = 0; t0 < max_tiles; t0 += tiles_per_job) {
+            for (int g = 0; g < ngenomes; ++g) {
+                const size_t ntiles = (nbytes[g] + tile_tokens - 1) / tile_tokens;
+                if (t0 >= ntiles) continue;
                 int kcur = ka;
                 for (int q = 0; q < ngroups; ++q) {
                     const int nk = nks / ngroups + (q < nks % ngroups ? 1 : 0);
@@ -357,6 +380,8 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     }
 
     size_t table_bytes = align_up(sizeof(dd::SweepGenome) * ngenomes, 256);
+    const size_t pack_off = table_bytes;
+    table_bytes += align_up(sizeof(dd::PackGenome) * ngenomes, 256);
     std::vector<size_t> job_off(classes.size());
     for (size_t i = 0; i < classes.size(); ++i) {
         job_off[i] = table_bytes;
@@ -368,11 +393,20 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     if ((rc = c->stage.reserve(table_bytes))) return rc;
     char* tdev = static_cast<char*>(c->tables.p);
     if ((rc = upload(c, tdev, gtab.data(), sizeof(dd::SweepGenome) * ngenomes, 0))) return rc;
+    if ((rc = upload(c, tdev + pack_off, ptab.data(), sizeof(dd::PackGenome) * ngenomes, pack_off))) return rc;
     for (size_t i = 0; i < classes.size(); ++i)
         if ((rc = upload(c, tdev + job_off[i], classes[i].jobs.data(),
                          sizeof(dd::SweepJob) * classes[i].jobs.size(), job_off[i])))
             return rc;
     DD_HIP(hipEventRecord(c->stage_free, st));
+
+    // ---- K0: pack every genome of the batch (three launches) -------------------------------
+    {
+        Span sp(c, DD_KERNEL_PACK);
+        dd::launch_pack_batch(reinterpret_cast<const dd::PackGenome*>(tdev + pack_off), ngenomes,
+                              max_chunks, st);
+    }
+    DD_HIP(hipGetLastError());
 
     // ---- K1 launches -------------------------------------------------------------------
     int blocks = 0;

@@ -30,7 +30,15 @@ inline size_t pack_scratch_bytes(size_t n) { return (pack_chunks(n) + 1) * 4 * s
 inline size_t codes_words(size_t n) { return ((n + 63) / 64 + 1) * 4; }
 inline size_t bad_words(size_t n) { return ((n + 63) / 64 + 1) * 2; }
 
-void launch_pack(const uint8_t* fa, size_t n, TokenStream out, long long* scratch, hipStream_t st);
+struct PackGenome {             // one per genome, device-resident table
+    const uint8_t* fa;          // FASTA bytes, 16-byte aligned
+    size_t n;                   // bytes
+    size_t nchunks;             // pack_chunks(n)
+    long long* scratch;         // pack_scratch_bytes(n)
+    TokenStream out;
+};
+// gridDim.y = genome: every genome of the batch is packed by the same three launches
+void launch_pack_batch(const PackGenome* tab_dev, int ngenomes, size_t max_chunks, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------
 // K1: fused k-sweep sketch.

@@ -131,12 +131,26 @@ DD_D long long block_incl(long long v, Op op, long long ident, long long* sm, lo
 DD_D bool line_is_header(const uint8_t* fa, long long N) { return fa[N + 1] == '>'; }
 
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(T) void pack_stats(const uint8_t* __restrict__ fa, size_t n,
-                                                long long* __restrict__ lastnl,
-                                                long long* __restrict__ cntH,
-                                                long long* __restrict__ cntS) {
+// scratch layout of one genome: four arrays of (nchunks + 1) int64
+struct Scratch {
+    long long *lastnl, *cntH, *cntS, *slot;
+    DD_D explicit Scratch(const PackGenome& g)
+        : lastnl(g.scratch), cntH(g.scratch + (g.nchunks + 1)), cntS(g.scratch + 2 * (g.nchunks + 1)),
+          slot(g.scratch + 3 * (g.nchunks + 1)) {}
+};
+
+// grid = (max chunks over the batch, genomes)
+__global__ __launch_bounds__(T) void pack_stats(const PackGenome* __restrict__ tab) {
     __shared__ long long sm[T / 64];
+    const PackGenome G = tab[blockIdx.y];
     const size_t c = blockIdx.x;
+    if (c >= G.nchunks) return;
+    const uint8_t* __restrict__ fa = G.fa;
+    const size_t n = G.n;
+    const Scratch S(G);
+    long long* lastnl = S.lastnl;
+    long long* cntH = S.cntH;
+    long long* cntS = S.cntS;
     const size_t pos = c * (size_t)kPackChunk + (size_t)threadIdx.x * 16;
     Bytes16 b = load16(fa, n, pos);
     const bool prev_nl = (pos == 0) || (pos - 1 < n ? fa[pos - 1] == '\n' : false);
@@ -173,13 +187,18 @@ __global__ __launch_bounds__(T) void pack_stats(const uint8_t* __restrict__ fa, 
     }
 }
 
-// one workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void pack_scan(const uint8_t* __restrict__ fa, size_t n,
-                                                  size_t nchunks, long long* __restrict__ lastnl_Nin,
-                                                  const long long* __restrict__ cntH,
-                                                  const long long* __restrict__ cntS,
-                                                  long long* __restrict__ slot_base, TokenStream out) {
+// one workgroup of 1024 threads per genome
+__global__ __launch_bounds__(1024) void pack_scan(const PackGenome* __restrict__ tab) {
     __shared__ long long sm[16];
+    const PackGenome G = tab[blockIdx.x];
+    const uint8_t* __restrict__ fa = G.fa;
+    const size_t nchunks = G.nchunks;
+    const Scratch SC(G);
+    long long* lastnl_Nin = SC.lastnl;
+    const long long* cntH = SC.cntH;
+    const long long* cntS = SC.cntS;
+    long long* slot_base = SC.slot;
+    const TokenStream out = G.out;
     long long carryN = -1, carryS = 0;
     for (size_t blk = 0; blk < nchunks; blk += 1024) {
         const size_t c = blk + threadIdx.x;
@@ -230,13 +249,18 @@ __global__ __launch_bounds__(1024) void pack_scan(const uint8_t* __restrict__ fa
     }
 }
 
-__global__ __launch_bounds__(T) void pack_write(const uint8_t* __restrict__ fa, size_t n,
-                                                const long long* __restrict__ Nin,
-                                                const long long* __restrict__ slot_base,
-                                                TokenStream out) {
+__global__ __launch_bounds__(T) void pack_write(const PackGenome* __restrict__ tab) {
     __shared__ long long sm[T / 64];
     __shared__ uint8_t tok[kPackChunk];
+    const PackGenome G = tab[blockIdx.y];
     const size_t c = blockIdx.x;
+    if (c >= G.nchunks) return;
+    const uint8_t* __restrict__ fa = G.fa;
+    const size_t n = G.n;
+    const Scratch SC(G);
+    const long long* Nin = SC.lastnl;
+    const long long* slot_base = SC.slot;
+    const TokenStream out = G.out;
     const size_t pos = c * (size_t)kPackChunk + (size_t)threadIdx.x * 16;
     Bytes16 b = load16(fa, n, pos);
     const bool prev_nl = (pos == 0) || (pos - 1 < n ? fa[pos - 1] == '\n' : false);
@@ -294,17 +318,12 @@ __global__ __launch_bounds__(T) void pack_write(const uint8_t* __restrict__ fa, 
 
 }  // namespace
 
-void launch_pack(const uint8_t* fa, size_t n, TokenStream out, long long* scratch, hipStream_t st) {
-    const size_t nc = pack_chunks(n);
-    long long* lastnl = scratch;
-    long long* cntH = scratch + (nc + 1);
-    long long* cntS = scratch + 2 * (nc + 1);
-    long long* slot = scratch + 3 * (nc + 1);
-    if (nc)
-        hipLaunchKernelGGL(pack_stats, dim3((unsigned)nc), dim3(T), 0, st, fa, n, lastnl, cntH, cntS);
-    hipLaunchKernelGGL(pack_scan, dim3(1), dim3(1024), 0, st, fa, n, nc, lastnl, cntH, cntS, slot, out);
-    if (nc)
-        hipLaunchKernelGGL(pack_write, dim3((unsigned)nc), dim3(T), 0, st, fa, n, lastnl, slot, out);
+void launch_pack_batch(const PackGenome* tab_dev, int ngenomes, size_t max_chunks, hipStream_t st) {
+    if (ngenomes <= 0) return;
+    const dim3 grid((unsigned)max_chunks, (unsigned)ngenomes);
+    if (max_chunks) hipLaunchKernelGGL(pack_stats, grid, dim3(T), 0, st, tab_dev);
+    hipLaunchKernelGGL(pack_scan, dim3((unsigned)ngenomes), dim3(1024), 0, st, tab_dev);
+    if (max_chunks) hipLaunchKernelGGL(pack_write, grid, dim3(T), 0, st, tab_dev);
 }
 
 }  // namespace dd

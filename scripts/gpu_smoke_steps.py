@@ -1,7 +1,7 @@
 """Staged GPU smoke: each step logs before/after so a hang or crash is attributable."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 T0 = time.time()
 def log(*a):
     print(f"[{time.time()-T0:7.2f}s]", *a, flush=True)

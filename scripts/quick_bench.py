@@ -2,7 +2,7 @@
 import sys, time
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dandd_amd.engine import Engine, synth_size, KERNEL_PACK, KERNEL_SWEEP
 
 ng = int(sys.argv[1]) if len(sys.argv) > 1 else 4
