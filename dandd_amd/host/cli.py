@@ -1,0 +1,145 @@
+"""`dandd tree | progressive | kij` on the MI355X engine: same sub-commands, flags, defaults and
+output files as /root/reference/lib/dandd_cmd.py (flags :141-286, handlers :43-132); only the
+sketching backend differs.  Run as  python -m dandd_amd.host.cli <subcommand> ...
+"""
+import argparse
+import os
+import pickle
+import sys
+
+from . import deltatree
+from .deltatree import write_listdict_to_csv
+
+
+def tree_command(args):
+    if not (args.genomedir or args.flist_loc):
+        print("ERROR: You must provide either a datadirectory or a fasta file list!")
+        sys.exit(1)
+    if not args.sketchdir:
+        args.sketchdir = os.path.join(args.outdir, "sketchdb")
+        os.makedirs(args.sketchdir, exist_ok=True)
+    if args.exact:
+        sys.exit("ERROR: --exact (KMC) is not part of this engine; the reference's own --exact path "
+                 "recurses forever at this commit (lib/sketch_classes.py:289 <-> :413).")
+    ksweep = (int(args.mink), int(args.maxk)) if args.ksweep else None
+    os.makedirs(args.outdir, exist_ok=True)
+    tree = deltatree.create_delta_tree(
+        tag=args.tag, genomedir=args.genomedir, sketchdir=args.sketchdir, kstart=args.kstart,
+        nchildren=args.nchildren, registers=int(args.registers), flist_loc=args.flist_loc,
+        canonicalize=args.canonicalize, tool="dashing", debug=args.debug, nthreads=int(args.nthreads),
+        safety=args.safety, fast=args.fast, verbose=args.verbose, ksweep=ksweep, lowmem=args.lowmem)
+    prefix = tree.make_prefix(outdir=args.outdir, tag=args.tag, label=args.label)
+    tree.save(fileprefix=prefix, fast=args.fast)
+
+
+def _load_tree(path):
+    with open(path, "rb") as f:
+        return pickle.load(f)
+
+
+def progressive_command(args):
+    tree = _load_tree(args.delta_tree)
+    if not args.tag:
+        args.tag = tree.speciesinfo.tag
+    outfile = tree.make_prefix(tag=args.tag, label=f"progu{args.norderings}", outdir=args.outdir)
+    exp = tree.experiment
+    exp.update(debug=args.debug, safety=args.safety, fast=args.fast, verbose=args.verbose, lowmem=args.lowmem,
+               baseset=set(), ksweep=(int(args.mink), int(args.maxk)) if args.ksweep else None)
+    tree.speciesinfo.update(tool=exp["tool"])
+    results, summary = tree.progressive_wrapper(flist_loc=args.flist_loc, count=args.norderings,
+                                                ordering_file=args.ordering_file, step=args.step)
+    write_listdict_to_csv(outfile + ".csv", results)
+    write_listdict_to_csv(outfile + "summary.csv", summary)
+    tree.save(fileprefix=outfile)
+
+
+def kij_command(args):
+    tree = _load_tree(args.delta_tree)
+    tree.speciesinfo.update(tool=tree.experiment["tool"])
+    if not args.tag:
+        args.tag = tree.speciesinfo.tag
+    outfile = tree.make_prefix(tag=args.tag, label=args.label, outdir=args.outdir)
+    if args.flist_loc:
+        with open(args.flist_loc) as f:
+            wanted = {line.strip() for line in f}
+        sub = [n for n in tree.leaf_nodes() if n.fastas[0] in wanted or os.path.basename(n.fastas[0]) in wanted]
+    else:
+        sub = []
+    if args.ksweep:
+        tree.experiment["ksweep"] = (int(args.mink), int(args.maxk))
+    tree.ksweep(mink=int(args.mink), maxk=int(args.maxk))
+    kij_rows, j_rows = tree.pairwise_spiders(sublist=sub, mink=args.mink, maxk=args.maxk, jaccard=args.jaccard)
+    write_listdict_to_csv(outfile + ".kij.csv", kij_rows)
+    if args.jaccard:
+        write_listdict_to_csv(outfile + ".j.csv", j_rows)
+    tree.speciesinfo.save_cardkey(tree.experiment["tool"])
+    tree.speciesinfo.save_references(fast=False)
+    if args.afproject:
+        with open(outfile + "_AFtuples.pickle", "wb") as f:
+            pickle.dump(tree.prepare_AFproject(kij_rows, j_rows), f)
+
+
+def build_parser():
+    common = argparse.ArgumentParser(add_help=False)
+    common.add_argument("--version", action="version", version="%(prog)s 1.0.0 (dandd_amd / MI355X)")
+    common.add_argument("--verbose", "-v", action="store_true", default=False)
+    common.add_argument("--debug", action="store_true", default=False)
+    common.add_argument("--lowmem", action="store_true", default=False)
+    common.add_argument("--safe", action="store_true", default=False, dest="safety")
+    common.add_argument("--fast", action="store_true", default=False)
+    sweep = argparse.ArgumentParser(add_help=False)
+    sweep.add_argument("--ksweep", dest="ksweep", default=None, action="store_true")
+    sweep.add_argument("--mink", dest="mink", default=2, type=int)
+    sweep.add_argument("--maxk", dest="maxk", default=32, type=int)
+
+    parser = argparse.ArgumentParser(prog="DandD", parents=[common],
+                                     description="delta values for a set of fasta files (MI355X sketching engine)")
+    subs = parser.add_subparsers(title="subcommands")
+    subs.required = True
+
+    t = subs.add_parser("tree", parents=[common, sweep])
+    t.add_argument("-s", "--tag", dest="tag", type=str, default="dandd")
+    t.add_argument("-x", "--exact", dest="exact", default=False, action="store_true")
+    t.add_argument("-d", "--datadir", dest="genomedir", default=None, type=str)
+    t.add_argument("-o", "--out", dest="outdir", default=os.getcwd(), type=str)
+    t.add_argument("-c", "--sketchdir", dest="sketchdir", default=None, type=str)
+    t.add_argument("-k", "--kstart", dest="kstart", default=12, type=int)
+    t.add_argument("-f", "--fastas", dest="flist_loc", type=str, default=None)
+    t.add_argument("-l", "--label", dest="label", default="")
+    t.add_argument("-n", "--nchildren", dest="nchildren", type=int, default=None)
+    t.add_argument("-r", "--registers", dest="registers", default=20)
+    t.add_argument("-e", "--nthreads", dest="nthreads", type=int, default=0)
+    t.add_argument("-C", "--no-canon", action="store_false", default=True, dest="canonicalize")
+    t.set_defaults(func=tree_command)
+
+    p = subs.add_parser("progressive", parents=[common, sweep])
+    p.add_argument("-d", "--dtree", dest="delta_tree", required=True)
+    p.add_argument("-s", "--tag", dest="tag", type=str)
+    p.add_argument("-r", "--orderings", dest="ordering_file", type=str, default=None)
+    p.add_argument("-f", "--fastas", dest="flist_loc", default=None, type=str)
+    p.add_argument("-n", "--norderings", dest="norderings", default=0, type=int)
+    p.add_argument("-o", "--outdir", dest="outdir", default=os.getcwd(), type=str)
+    p.add_argument("-l", "--label", dest="label", default="")
+    p.add_argument("--step", dest="step", default=1, type=int)
+    p.set_defaults(func=progressive_command)
+
+    k = subs.add_parser("kij", parents=[common, sweep])
+    k.add_argument("-d", "--dtree", dest="delta_tree", required=True)
+    k.add_argument("-s", "--tag", dest="tag", type=str)
+    k.add_argument("-f", "--fastas", dest="flist_loc", default=None, type=str)
+    k.add_argument("-o", "--outdir", dest="outdir", default=os.getcwd(), type=str)
+    k.add_argument("-l", "--label", dest="label", default="")
+    k.add_argument("--afproject", dest="afproject", default=False, action="store_true")
+    k.add_argument("--jaccard", dest="jaccard", default=False, action="store_true")
+    k.set_defaults(func=kij_command)
+    return parser
+
+
+def main(argv=None):
+    args = build_parser().parse_args(sys.argv[1:] if argv is None else argv)
+    args.func(args)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

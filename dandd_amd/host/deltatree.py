@@ -1,0 +1,628 @@
+"""DandD's experiment layer (delta trees, progressive unions, K-independent Jaccard) on top of the
+MI355X sketching engine.
+
+Behavioural mirror of /root/reference/lib/huffman_dandd.py and the SketchObj lifecycle of
+/root/reference/lib/sketch_classes.py:124-373 -- same class and attribute names (the CLI pickles
+these objects), same argmax-k hill-climb (ties move on, `kstart` is mutated as the climb proceeds,
+lib/huffman_dandd.py:106-146), same tree shapes, same CSV rows -- with every `subprocess` call
+replaced by a backend object (dandd_amd.host.backend.HipBackend: the GPU).  The goldens in
+tests/golden/ref_*.json were produced by running the reference itself; tests/test_host_golden.py
+replays them against this module.
+
+Differences that are deliberate:
+  * a leaf k-batch is ONE fused GPU pass over the FASTA instead of `parallel` over k;
+  * `Sketch.cmd` holds a descriptive string instead of a shell line;
+  * k < 1 is never sketched (the reference would create a k=-1 placeholder when a climb reaches k=0).
+"""
+import csv
+import os
+import pickle
+import sys
+from itertools import permutations
+from math import factorial
+from random import sample, shuffle
+
+from .store import Catalog, SketchPath, sketch_exists
+
+# ---------------------------------------------------------------------------------------------
+# backend plumbing: objects of this module are pickled, the GPU context is not
+# ---------------------------------------------------------------------------------------------
+_backend_factory = None
+_backends = {}
+
+
+def set_backend_factory(factory):
+    """factory(registers:int, canonicalize:bool) -> backend.  None restores the GPU default."""
+    global _backend_factory
+    _backend_factory = factory
+    _backends.clear()
+
+
+def backend_for(experiment):
+    key = (int(experiment["registers"]), bool(experiment["canonicalize"]))
+    if key not in _backends:
+        if _backend_factory is not None:
+            _backends[key] = _backend_factory(*key)
+        else:
+            from .backend import HipBackend  # fails loudly without libdandd_hip.so / a gfx950 GPU
+            _backends[key] = HipBackend(log2m=key[0], canonical=key[1])
+    return _backends[key]
+
+
+def write_listdict_to_csv(outfile, listdict, suffix="", last_col=None):
+    """Rows as CSV, union of keys as header, `fastas`/`files` last (they may contain commas)."""
+    names = sorted({k for row in listdict for k in row})
+    for special in ("fastas", "files"):
+        if special in names:
+            last_col = special
+    if last_col in names:
+        names.remove(last_col)
+        names.append(last_col)
+    out = sys.stdout if outfile in (None, "-") else open(outfile + suffix, "w", newline="")
+    try:
+        w = csv.DictWriter(out, fieldnames=names)
+        w.writeheader()
+        w.writerows(listdict)
+    finally:
+        if out is not sys.stdout:
+            out.close()
+
+
+def permute(length, norder, preexist=frozenset(), exhaust=False, verbose=False):
+    """`norder` distinct orderings of range(length), extending `preexist`
+    (lib/huffman_dandd.py:36-60: shuffled full enumeration below 7!+1, rejection sampling above)."""
+    total = factorial(length)
+    result = set(preexist)
+    norder = min(norder, total)
+    if total < 5041 or norder == total or exhaust:
+        pool = list(permutations(range(length)))
+        shuffle(pool)
+    else:
+        pool = []
+        while len(pool) < norder:
+            pool.extend(tuple(sample(range(length), length)) for _ in range(norder))
+            pool = list(set(pool))
+    for cand in pool:
+        if len(result) >= norder:
+            break
+        result.add(cand)
+    return result
+
+
+# ---------------------------------------------------------------------------------------------
+class Sketch:
+    """One (set of FASTAs, k) sketch: file on disk + cached cardinality (the reference's SketchObj)."""
+
+    def __init__(self, kval, sfp, speciesinfo, experiment, presketches=()):
+        self.kval = kval
+        self.sfp = sfp
+        self.sketch = None
+        self.cmd = None
+        self.card = 0
+        self.delta_pos = 0
+        self.speciesinfo = speciesinfo
+        self.experiment = experiment
+        self._presketches = list(presketches)
+        experiment["baseset"].add(sfp.base)
+        if kval > 0:
+            self.create_sketch()
+            self.card = self.check_cardinality()
+            self.delta_pos = self.card / kval
+
+    def __lt__(self, other):
+        return self.delta_pos < other.delta_pos
+
+    def __gt__(self, other):
+        return self.delta_pos > other.delta_pos
+
+    def __repr__(self):
+        return f"['sketch loc: {self.sketch}', k: {self.kval}, pos delta: {self.delta_pos}, cardinality: {self.card}, command: {self.cmd}  ]"
+
+    def sketch_check(self, path=None):
+        return sketch_exists(path or self.sfp.full)
+
+    def _build(self):
+        be = backend_for(self.experiment)
+        if self.sfp.ngen == 1:
+            be.leaf(self.sfp.ffiles[0], [self.kval], [self.sfp.full])
+        else:
+            be.union(self._presketches, self.sfp.full)
+
+    def create_sketch(self, just_do_it=False):
+        if self.sfp.ngen < 1:
+            raise RuntimeError("For some reason you are trying to sketch an empty list of files. Don't do that.")
+        be = backend_for(self.experiment)
+        op = "sketch" if self.sfp.ngen == 1 else "union"
+        self.cmd = be.describe(op, k=self.kval, out=os.path.basename(self.sfp.full)) if hasattr(be, "describe") else op
+        if just_do_it or not self.sketch_check():
+            if just_do_it or not (self.experiment["lowmem"] and self.check_cardinality() > 0):
+                self._build()
+        self.sketch = self.sfp.full
+        return self.sketch
+
+    def individual_card(self):
+        if self.kval == 0:
+            return
+        be = backend_for(self.experiment)
+        try:
+            value = be.card(self.sfp.full)
+        except Exception:
+            print(f"Recreating sketch {self.sfp.full}")
+            self.create_sketch(just_do_it=True)
+            value = be.card(self.sfp.full)
+        self.speciesinfo.cardkey[self.sfp.full] = float(value)
+
+    def check_cardinality(self):
+        key, cards = self.sfp.full, self.speciesinfo.cardkey
+        if key not in cards and self.experiment["lowmem"]:
+            return 0
+        if key not in cards or cards[key] is None or float(cards[key]) == 0:
+            if not self.sketch_check():
+                return 0
+            self.individual_card()
+        self.card = float(cards[key])
+        self.delta_pos = self.card / int(self.kval)
+        return float(self.card)
+
+    def remove_sketch(self):
+        import glob
+        pattern = self.sfp.full.replace("{}", "*") if self.kval == 0 else self.sfp.full
+        for f in glob.glob(pattern):
+            try:
+                os.remove(f)
+            except FileNotFoundError:
+                pass
+
+
+# ---------------------------------------------------------------------------------------------
+class DeltaTreeNode:
+    def __init__(self, node_title, children, speciesinfo, experiment, progeny=None):
+        self.experiment = experiment
+        self.speciesinfo = speciesinfo
+        self.children = children
+        self.mink = self.maxk = 0
+        if experiment["ksweep"] is not None:
+            self.mink, self.maxk = experiment["ksweep"]
+        self.bestk = 0
+        self.delta = 0
+        self.ksketches = [None] * max(100, self.maxk + 2)
+        if progeny:
+            self.node_title = node_title
+            self.progeny = list(progeny)
+        else:  # a leaf is its own progeny; its title is the file name without the last extension
+            self.progeny = [self]
+            self.fastas = [node_title]
+            self.node_title = os.path.splitext(os.path.basename(node_title))[0]
+        self.fastas = [leaf.fastas[0] for leaf in self.progeny]
+        self.ngen = len(self.progeny)
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}['{self.node_title}', k: {self.bestk}, delta: {self.delta}, ngen: {self.ngen}, children: {self.children!r} ]"
+
+    def __lt__(self, other):
+        return self.ngen < other.ngen
+
+    def _grow(self, k):
+        if k >= len(self.ksketches):
+            self.ksketches.extend([None] * (k - len(self.ksketches) + 2))
+
+    # ---- sketch files for a k range (the reference's `parallel` batch, lib/huffman_dandd.py:148-239)
+    def ksweep_update_node(self, mink, maxk):
+        mink, maxk = int(mink), int(maxk)
+        self._grow(maxk)
+        template = SketchPath(self.fastas, 0, self.speciesinfo, self.experiment)
+        if self.ksketches[0] is None:
+            self.ksketches[0] = Sketch(0, template, self.speciesinfo, self.experiment)
+        ks = [k for k in range(max(1, mink), maxk + 1)]
+        for k in ks:
+            os.makedirs(template.dir.replace("{}", str(k)), exist_ok=True)
+            self.experiment["baseset"].add(template.base.replace("{}", str(k)))
+        for child in (self.children if self.ngen > 1 else []):
+            child.ksweep_update_node(mink, maxk)
+        cards = self.speciesinfo.cardkey
+        todo = []
+        for k in ks:
+            path = template.with_k(k)
+            if sketch_exists(path):
+                continue
+            if self.experiment["lowmem"] and self.ngen > 1 and float(cards.get(path) or 0) > 0:
+                continue
+            todo.append(k)
+        if not todo:
+            return
+        be = backend_for(self.experiment)
+        if self.ngen == 1:
+            be.leaf(self.fastas[0], todo, [template.with_k(k) for k in todo])  # one fused GPU pass
+        else:
+            for k in todo:
+                ins = [c.ksketches[0].sfp.with_k(k) for c in self.children]
+                be.union(ins, template.with_k(k))
+
+    def update_node(self, kval):
+        """Sketch object (file + cardinality) for k at this node and, first, at every descendant."""
+        window = self.experiment["ksweep"]
+        if window is not None and not (window[0] <= kval <= window[1]):
+            print(f"k={kval} is outside of ksweep range ", window)
+            return
+        self._grow(kval)
+        if self.ksketches[kval]:
+            return
+        sfp = SketchPath(self.fastas, kval, self.speciesinfo, self.experiment)
+        inputs = []
+        if self.ngen > 1:
+            for child in self.children:
+                child.update_node(kval)
+                inputs.append(child.ksketches[kval].sketch)
+        self.ksketches[kval] = Sketch(kval, sfp, self.speciesinfo, self.experiment, presketches=inputs)
+
+    def node_ksweep(self, mink, maxk):
+        self.ksweep_update_node(mink, maxk)
+        for k in range(max(1, mink), maxk + 1):
+            if self.ksketches[k] is None:
+                self.update_node(k)
+        self.mink, self.maxk = mink, maxk
+
+    # ---- argmax-k local search (lib/huffman_dandd.py:106-146) --------------------------------------
+    def find_delta_helper(self, kval, direction=1):
+        if self.experiment["tool"] == "dashing" and kval > 32 and not self.experiment.get("allow_k64"):
+            raise ValueError("Exploratory k value is too high for dashing. Either something is amiss "
+                             "with your data or you need to be using --exact mode")
+        if kval < 1:
+            return
+        self._grow(kval + 1)
+        self.node_ksweep(mink=kval - 1, maxk=kval + 1)
+        self.update_node(kval)
+        if direction < 0:
+            self.mink = kval
+        else:
+            self.maxk = kval
+        candidate = self.ksketches[kval].delta_pos
+        if self.delta <= candidate:  # ties keep climbing
+            self.speciesinfo.kstart = kval
+            self.bestk = kval
+            self.delta = candidate
+            self.find_delta_helper(kval + direction, direction)
+
+    def find_delta(self, kval):
+        self.find_delta_helper(kval, 1)
+        self.find_delta_helper(kval, -1)
+        self.card = self.ksketches[self.bestk].card
+
+    def summarize(self, mink=0, maxk=0, ordering_number=0):
+        rows = []
+        for k in range(mink, maxk + 1):
+            s = self.ksketches[k]
+            rows.append({"ngen": self.ngen, "kval": k, "card": s.card, "delta_pos": s.delta_pos,
+                         "title": self.node_title, "command": s.cmd, "ordering": ordering_number})
+        return rows
+
+
+# ---------------------------------------------------------------------------------------------
+DEFAULT_EXPERIMENT = {"tool": "dashing", "registers": 20, "canonicalize": True, "debug": False, "nthreads": 0,
+                      "baseset": set(), "safety": False, "fast": False, "verbose": False, "ksweep": None,
+                      "lowmem": False}
+
+
+class DeltaTree:
+    def __init__(self, fasta_files, speciesinfo, nchildren=2, leafnodes=(), experiment=None, padding=True):
+        self.experiment = experiment if experiment is not None else dict(DEFAULT_EXPERIMENT, baseset=set())
+        self.mink = self.maxk = 0
+        if self.experiment["ksweep"] is not None:
+            self.mink, self.maxk = self.experiment["ksweep"]
+        self.kstart = speciesinfo.kstart
+        self.speciesinfo = speciesinfo
+        if self.experiment["verbose"]:
+            print("Now making tree for fastas: " + ", ".join(fasta_files))
+        self._build_tree(fasta_files, nchildren)
+        self.fill_tree(padding=padding)
+        self.ngen = len(fasta_files)
+        self.root = self._dt[-1]
+        self.delta = self.root_delta()
+        self.fastas = fasta_files
+        if self.experiment["ksweep"] is None:
+            speciesinfo.kstart = self.root_k()
+        speciesinfo.save_references(fast=self.experiment["fast"])
+        speciesinfo.save_cardkey(tool=self.experiment["tool"])
+
+    def __sub__(self, other):
+        print("Larger Tree Delta: ", self.delta)
+        print("Subtree Delta: ", other.delta)
+        print("Subtraction Result: ", self.delta - other.delta)
+        return self.delta - other.delta
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}(FASTAS: {self.fastas}, NODES: {self._dt[-1]!r})"
+
+    def root_delta(self):
+        return self._dt[-1].delta
+
+    def root_k(self):
+        return self._dt[-1].bestk
+
+    def _solve(self, node):
+        if self.experiment["ksweep"] is None:
+            node.find_delta(self.speciesinfo.kstart)
+        else:
+            node.node_ksweep(mink=self.mink, maxk=self.maxk)
+
+    def _build_tree(self, symbol, nchildren, leafnodes=()):
+        """Leaves first (in the order given; the sort by ngen is stable), then unions of `nchildren`
+        consecutive nodes, each new union inserted behind the nodes that are not larger than it
+        (lib/huffman_dandd.py:377-438, including its end-of-list widening of the last union)."""
+        nodes = list(leafnodes) or [DeltaTreeNode(s, [], self.speciesinfo, self.experiment) for s in symbol]
+        nodes.sort()
+        for leaf in nodes:
+            self._solve(leaf)
+        self._dt = nodes
+        insert_at = 0
+        current = 0
+        while current != len(self._dt) - 1:
+            step = nchildren - 1
+            kids = self._dt[current:current + nchildren]
+            union = DeltaTreeNode("_".join(k.node_title for k in kids), kids, self.speciesinfo, self.experiment,
+                                  progeny=[leaf for k in kids for leaf in k.progeny])
+            self._solve(union)
+            while insert_at < len(self._dt) - step and self._dt[insert_at + step].ngen <= union.ngen:
+                insert_at += step
+            cut = insert_at + step
+            self._dt = self._dt[:cut] + [union] + self._dt[cut:]
+            current += nchildren
+            if cut > len(self._dt) - 1:
+                nchildren = len(self._dt) - current
+
+    def print_list(self):
+        print(" -> ".join(f"'{n.node_title}'({n.ngen}'({' '.join(p.node_title for p in n.progeny)})" for n in self._dt))
+
+    def fill_tree(self, padding=False):
+        root = self._dt[-1]
+        if self.experiment["ksweep"] is None:
+            for k in sorted({n.bestk for n in self._dt} - {0}):
+                root.update_node(k)
+        else:
+            self.ksweep(*self.experiment["ksweep"])
+
+    def leaf_nodes(self):
+        return [n for n in self._dt if n.ngen == 1]
+
+    def delete_sketches(self):
+        for node in self._dt[:-1]:
+            if node.ngen > 1:
+                for s in node.ksketches:
+                    if s is not None:
+                        s.remove_sketch()
+
+    def make_prefix(self, tag, label="", outdir=None):
+        outdir = outdir or os.getcwd()
+        label = "_" + label if label else ""
+        return os.path.join(outdir, f"{tag}{label}_{self.ngen}_{self.experiment['tool']}")
+
+    def save(self, fileprefix, fast=False):
+        filepath = fileprefix + "_dtree.pickle"
+        if not fast:
+            with open(filepath, "wb") as f:
+                pickle.dump(self, f)
+            print("Tree Pickle saved to: " + filepath)
+            mapping = fileprefix + "_sketchdb.txt"
+            write_listdict_to_csv(mapping, [self.speciesinfo.sketchinfo[b] for b in self.experiment["baseset"]])
+            print(f"Output Sketch/DB mapping saved to {mapping}.")
+        deltapath = fileprefix + "_deltas.csv"
+        write_listdict_to_csv(deltapath, self.report_deltas())
+        print("Deltas saved to: " + deltapath)
+        return filepath
+
+    def report_deltas(self):
+        rows = []
+
+        def visit(node):
+            best = node.ksketches[node.bestk]
+            rows.append({"delta": node.delta, "k": node.bestk, "title": node.node_title, "ngen": node.ngen,
+                         "sketchloc": best.sketch, "card": best.card, "fastas": "|".join(node.fastas)})
+            for child in node.children or []:
+                visit(child)
+
+        visit(self._dt[-1])
+        return rows
+
+    def nodes_from_fastas(self, fasta_list):
+        return [n for n in self.leaf_nodes() if n.fastas[0] in fasta_list]
+
+    def find_delta_delta(self, fasta_subset):
+        rest = [f for f in self.fastas if f not in fasta_subset]
+        small = SubSpider(self.nodes_from_fastas(rest), self.speciesinfo, self.experiment)
+        print("Full Tree Delta: ", self.delta)
+        print("Subtree Delta: ", small.delta)
+        return self - small
+
+    def ksweep(self, mink, maxk):
+        for node in self._dt:
+            node.node_ksweep(mink=mink, maxk=maxk)
+
+    # ---- progressive unions (lib/huffman_dandd.py:574-663) -------------------------------------------
+    def orderings_list(self, ordering_file=None, flist_loc=None, count=0):
+        fastas = self.fastas
+        fastas.sort()
+        if flist_loc:
+            with open(flist_loc) as f:
+                wanted = [line.strip() for line in f]
+            present = set(fastas)
+            fastas = [f for f in wanted if f in present]
+        if count == 1:
+            return fastas, [tuple(range(len(fastas)))]
+        default = os.path.join(self.speciesinfo.sketchdir, f"{self.speciesinfo.tag}_{len(fastas)}_orderings.pickle")
+        ordering_file = ordering_file or default
+        orderings = set()
+        if os.path.exists(ordering_file):
+            with open(ordering_file, "rb") as f:
+                orderings = pickle.load(f)
+            if count == 0:
+                return fastas, list(orderings)
+            if count <= len(orderings):
+                return fastas, list(orderings)[:count]
+        elif count < 1:
+            raise ValueError("You must provide a value for count when there is no default ordering file")
+        orderings = permute(len(fastas), count, preexist=orderings, verbose=self.experiment["verbose"])
+        with open(ordering_file, "wb") as f:
+            pickle.dump(orderings, f)
+        return fastas, list(orderings)
+
+    def progressive_wrapper(self, flist_loc=None, count=30, ordering_file=None, step=1, debug=False):
+        fastas, orderings = self.orderings_list(ordering_file=ordering_file, flist_loc=flist_loc, count=count)
+        return self.progressive_union(flist=fastas, orderings=orderings, step=step)
+
+    def progressive_union(self, flist, orderings, step):
+        spider = DeltaSpider(fasta_files=flist, speciesinfo=self.speciesinfo, experiment=self.experiment)
+        results, summary = [], []
+        for i, ordering in enumerate(orderings):
+            if self.experiment["verbose"]:
+                print(f"Now sweeping for ordering {i + 1}")
+            rows, srows = spider.sketch_ordering(ordering, ordering_number=i + 1, step=step)
+            results.extend(rows)
+            summary.extend(srows)
+            self.speciesinfo.save_references(fast=self.experiment["fast"])
+            self.speciesinfo.save_cardkey(tool=self.experiment["tool"], fast=self.experiment["fast"])
+        return results, summary
+
+    def sketch_ordering(self, ordering, ordering_number, step=1):
+        """Flat union of every prefix of the ordering (NOT previous union + one)."""
+        krange = self.experiment["ksweep"] or (self.mink, self.maxk)
+        lo, hi = int(krange[0]), int(krange[1])
+        rows, summary = [], []
+        for i in range(1, len(ordering) + 1):
+            if i % step:
+                continue
+            prefix = [self.fastas[j] for j in ordering[:i]]
+            sub = SubSpider(self.nodes_from_fastas(prefix), self.speciesinfo, self.experiment)
+            sub.ksweep(mink=lo, maxk=hi)
+            rows.append({"ngen": i, "kval": sub.root_k(), "delta": sub.delta, "ordering": ordering_number,
+                         "fastas": prefix})
+            summary.extend(sub.root.summarize(mink=lo, maxk=hi, ordering_number=ordering_number))
+        return rows, summary
+
+    # ---- K-independent Jaccard (lib/huffman_dandd.py:666-695) -----------------------------------------
+    def pairwise_spiders(self, sublist=(), mink=0, maxk=0, jaccard=True):
+        leaves = list(sublist) or self.leaf_nodes()
+        pair_exp = dict(self.experiment)
+        pair_exp.update({"fast": True, "safe": False, "ksweep": None})
+        if jaccard and (mink == 0 or maxk == 0):
+            if self.experiment["ksweep"]:
+                mink, maxk = self.experiment["ksweep"]
+                print("WARNING: If EITHER minimum OR maximum k are not provided with --mink and --maxk flags, "
+                      "DandD will default to the --ksweep values embedded in the delta-tree input.")
+            else:
+                print("WARNING: If BOTH minimum AND maximum k are not provided either by the input delta-tree or "
+                      "using --mink and --maxk, the --jaccard flag will be ignored.")
+                jaccard = False
+        kij_rows, j_rows = [], []
+        for i, a in enumerate(leaves):
+            for b in leaves[i + 1:]:
+                pair = SubSpider([a, b], self.speciesinfo, pair_exp)
+                pair.root.find_delta(self.root_k())
+                kij_rows.append(pair.kij_summarize())
+                if jaccard:
+                    pair.ksweep(mink=mink, maxk=maxk)
+                    j_rows.extend(pair.jaccard_summarize(mink=mink, maxk=maxk))
+        return kij_rows, j_rows
+
+    def prepare_AFproject(self, kijsummary, jsummary):
+        tool = self.experiment["tool"]
+        out = set()
+        for d in kijsummary:
+            out.add((tool, d["Atitle"], d["Btitle"], 0, d["KIJ"], d["Ak"], d["Bk"], d["ABk"]))
+        for d in jsummary:
+            out.add((tool, d["Atitle"], d["Btitle"], d["kval"], d["jaccard"], None, None, None))
+        return list(out)
+
+
+class SubSpider(DeltaTree):
+    """Existing leaf nodes under one new union node."""
+
+    def __init__(self, leafnodes, speciesinfo, experiment):
+        self.speciesinfo = speciesinfo
+        self.fastahex = speciesinfo.fastahex
+        self.experiment = experiment
+        self.kstart = speciesinfo.kstart
+        if experiment["ksweep"] is not None:
+            self.mink, self.maxk = experiment["ksweep"]
+        self._build_tree(leafnodes)
+        self.root = self._dt[-1]
+        self.fastas = self.root.fastas
+        self.ngen = len(self.fastas)
+        self.delta = None
+        self.fill_tree()
+        if experiment["ksweep"] is None:
+            self.delta = self.root_delta()
+        else:
+            self.mink, self.maxk = experiment["ksweep"]
+
+    def _build_tree(self, leafnodes):
+        kids = list(leafnodes)
+        body = DeltaTreeNode("_".join(os.path.basename(c.node_title) for c in kids), kids, self.speciesinfo,
+                             self.experiment, progeny=[leaf for c in kids for leaf in c.progeny])
+        if self.experiment["ksweep"] is None:
+            body.find_delta(kval=self.speciesinfo.kstart)
+        else:
+            body.node_ksweep(mink=self.mink, maxk=self.maxk)
+        self.mink, self.maxk = body.mink, body.maxk
+        self._dt = kids + [body]
+
+    def kij_summarize(self):
+        if len(self.fastas) != 2:
+            raise ValueError("KIJ can only be calculated on spider/trees with 2 children")
+        self.root.update_node(self.root.bestk)
+        a, b = self._dt[0], self._dt[1]
+        a.update_node(a.bestk)
+        b.update_node(b.bestk)
+        if [a.node_title, b.node_title] != sorted([a.node_title, b.node_title]):
+            a, b = b, a
+        row = {"A": a.fastas[0], "B": b.fastas[0], "Adelta": a.delta, "Bdelta": b.delta, "Ak": a.bestk,
+               "Bk": b.bestk, "ABdelta": self.root.delta, "ABk": self.root.bestk, "Atitle": a.node_title,
+               "Btitle": b.node_title}
+        row["KIJ"] = (row["Adelta"] + row["Bdelta"] - row["ABdelta"]) / row["ABdelta"]
+        return row
+
+    def jaccard_summarize(self, mink=2, maxk=32):
+        if len(self.fastas) != 2:
+            raise ValueError("KIJ can only be calculated on spider/trees with 2 or more children")
+        a, b = self._dt[0], self._dt[1]  # tree order, never swapped (lib/huffman_dandd.py:804)
+        self.ksweep(mink=mink, maxk=maxk)
+        rows = []
+        for k in range(mink, maxk + 1):
+            row = {"A": a.fastas[0], "B": b.fastas[0], "Atitle": a.node_title, "Btitle": b.node_title, "kval": k,
+                   "Acard": a.ksketches[k].card, "Bcard": b.ksketches[k].card, "ABcard": self.root.ksketches[k].card}
+            row["jaccard"] = (row["Acard"] + row["Bcard"] - row["ABcard"]) / row["ABcard"]
+            rows.append(row)
+        return rows
+
+
+class DeltaSpider(DeltaTree):
+    """All leaves directly under one root."""
+
+    def __init__(self, fasta_files, speciesinfo, experiment, padding=False):
+        super().__init__(fasta_files=fasta_files, speciesinfo=speciesinfo, experiment=experiment,
+                         nchildren=len(fasta_files), padding=padding)
+
+
+def create_delta_tree(tag, genomedir, sketchdir, kstart, nchildren=None, registers=0, flist_loc=None,
+                      canonicalize=True, tool="dashing", debug=False, nthreads=0, safety=False, fast=False,
+                      verbose=False, ksweep=None, lowmem=False):
+    experiment = {"registers": registers, "canonicalize": canonicalize, "tool": tool, "nthreads": int(nthreads),
+                  "debug": debug, "baseset": set(), "safety": safety, "fast": fast, "verbose": verbose,
+                  "ksweep": ksweep, "lowmem": lowmem}
+    speciesinfo = Catalog(tag=tag, genomedir=genomedir, sketchdir=sketchdir, kstart=kstart, tool=tool,
+                          flist_loc=flist_loc)
+    if flist_loc:
+        with open(flist_loc) as f:
+            fastas = [line.strip() for line in f]
+    elif genomedir and os.path.exists(genomedir):
+        fastas = speciesinfo.retrieve_fasta_files(full=True)
+    else:
+        raise ValueError("You must provide either an existing directory of fastas or a file listing the paths "
+                         f"of the desired fastas. The directory you provided was {genomedir}.")
+    fastas.sort()
+    if nchildren:
+        tree = DeltaTree(fasta_files=fastas, speciesinfo=speciesinfo, nchildren=nchildren, experiment=experiment)
+    else:
+        tree = DeltaSpider(fasta_files=fastas, speciesinfo=speciesinfo, experiment=experiment)
+    speciesinfo.save_cardkey(tool=tool, fast=fast)
+    speciesinfo.save_references(fast=fast)
+    return tree

@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Generates the orchestration goldens under tests/golden/ by RUNNING THE REFERENCE's own Python
+(/root/reference/lib/dandd, imported/executed in this container only -- it never travels) with the
+three external executables it shells out to replaced by shims on PATH:
+
+  dashing   sketch / union / card implemented with this repo's CPU oracle (oracle/dd_oracle.py)
+            -- or, with DD_SHIM_BACKEND=exact, an exact distinct-canonical-k-mer counter
+            (the KMC stand-in; the reference's own --exact branch recurses forever at this commit,
+            /root/reference/lib/sketch_classes.py:289 <-> :413)
+  parallel  GNU-parallel's  -j N '<cmd with {}>' ::: a b c  form
+            (/root/reference/lib/huffman_dandd.py:217)
+
+What is committed: the input FASTAs (tests/golden/fasta/*.fasta, synthetic, seeded), and the rows
+of every CSV the reference wrote (tests/golden/ref_*.json) with paths reduced to basenames.  No
+reference source text is stored.  Run from the repo root:  python tests/golden/make_golden.py
+"""
+import csv
+import json
+import os
+import pickle
+import shutil
+import stat
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/lib/dandd"
+sys.path.insert(0, ROOT)
+
+DASHING_SHIM = r'''#!/usr/bin/env python3
+import json, os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from oracle import dd_oracle as orc
+BACKEND = os.environ.get("DD_SHIM_BACKEND", "hll")
+LOG = os.environ.get("DD_SHIM_LOG")
+a = sys.argv[1:]
+if LOG:
+    with open(LOG, "a") as f:
+        f.write("dashing " + " ".join(a) + "\n")
+def load(p):
+    with open(p, "rb") as f:
+        return json.loads(f.read())
+def save(p, obj):
+    with open(p, "w") as f:
+        json.dump(obj, f)
+cmd = a[0]
+if cmd == "sketch":
+    canon, k, S, prefix, fasta = True, None, None, None, None
+    i = 1
+    while i < len(a):
+        t = a[i]
+        if t == "--no-canon": canon = False
+        elif t.startswith("-k"): k = int(t[2:])
+        elif t == "-S": i += 1; S = int(a[i])
+        elif t == "--prefix": i += 1; prefix = a[i]
+        elif t: fasta = t
+        i += 1
+    out = os.path.join(prefix, os.path.basename(fasta) + ".w.%%d.spacing.%%d.hll" %% (k, S))
+    obj = {"k": k, "S": S, "canon": canon, "fastas": [fasta]}
+    if BACKEND == "hll":
+        fa = np.fromfile(fasta, dtype=np.uint8)
+        obj["regs"] = orc.sketch(fa, k, S, canon).tolist()
+    save(out, obj)
+elif cmd == "union":
+    assert a[1] == "-z" and a[2] == "-o"
+    out, ins = a[3], [load(p) for p in a[4:]]
+    obj = dict(ins[0])
+    obj["fastas"] = sorted(set(f for s in ins for f in s["fastas"]))
+    if BACKEND == "hll":
+        obj["regs"] = orc.union(*[np.array(s["regs"], dtype=np.uint8) for s in ins]).tolist()
+    save(out, obj)
+elif cmd == "card":
+    assert a[1] == "--presketched"
+    print("#Path\tSize (est.)")
+    for p in a[2:]:
+        s = load(p)
+        if BACKEND == "hll":
+            v = orc.card(np.array(s["regs"], dtype=np.uint8), s["S"])
+        else:
+            v = float(orc.exact_count([np.fromfile(f, dtype=np.uint8) for f in s["fastas"]], s["k"], s["canon"]))
+        print("%%s\t%%r" %% (p, v))
+else:
+    sys.exit("dashing shim: unknown command " + cmd)
+'''
+
+PARALLEL_SHIM = r'''#!/usr/bin/env python3
+import subprocess, sys
+a = sys.argv[1:]
+assert a[0] == "-j", a
+cmd = a[2]
+sep = a.index(":::")
+for x in a[sep + 1:]:
+    subprocess.call(cmd.replace("{}", x), shell=True)
+'''
+
+
+def write_exec(path, text):
+    with open(path, "w") as f:
+        f.write(text)
+    os.chmod(path, os.stat(path).st_mode | stat.S_IEXEC | stat.S_IXGRP | stat.S_IXOTH)
+
+
+def norm_value(key, v):
+    """CSV cell -> JSON value; absolute paths reduced to basenames."""
+    if v is None:
+        return None
+    if key in ("fastas", "files"):
+        if v.startswith("["):  # list repr (progressive rows)
+            return [os.path.basename(x) for x in eval(v)]
+        return [os.path.basename(x) for x in v.split("|")]
+    if key in ("A", "B", "sketchloc"):
+        return os.path.basename(v) if v else v
+    if key == "command":
+        return None  # the reference stores its shell line; the engine stores a descriptive string
+    return v
+
+
+def read_csv(path):
+    with open(path, newline="") as f:
+        return [{k: norm_value(k, v) for k, v in row.items() if k != "command"} for row in csv.DictReader(f)]
+
+
+def make_fastas(fdir):
+    from oracle import dd_oracle as orc
+    os.makedirs(fdir, exist_ok=True)
+    names = []
+    for g in range(5):
+        fa = orc.synth_fasta(0xD4ADD, g, 20000, 2)
+        name = f"g{g}.fasta"
+        with open(os.path.join(fdir, name), "wb") as f:
+            f.write(fa.tobytes())
+        names.append(name)
+    return names
+
+
+def run_ref(args, env, cwd):
+    r = subprocess.run([sys.executable, REF] + args, env=env, cwd=cwd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"reference failed: {args}\n{r.stdout}\n{r.stderr}")
+    return r.stdout
+
+
+def scenario(backend, fdir, registers):
+    """One full walk through the reference CLI; returns every CSV it wrote as rows."""
+    work = tempfile.mkdtemp(prefix="ddgold_")
+    try:
+        bindir = os.path.join(work, "bin")
+        os.makedirs(bindir)
+        write_exec(os.path.join(bindir, "dashing"), DASHING_SHIM % {"root": ROOT})
+        write_exec(os.path.join(bindir, "parallel"), PARALLEL_SHIM)
+        env = dict(os.environ, PATH=bindir + os.pathsep + os.environ["PATH"], DD_SHIM_BACKEND=backend,
+                   DD_SHIM_LOG=os.path.join(work, "trace.log"))
+        data = os.path.join(work, "data")
+        shutil.copytree(fdir, data)
+        out = {}
+
+        def outdir(name):
+            d = os.path.join(work, name)
+            os.makedirs(d, exist_ok=True)
+            return d
+
+        # 1. tree, default spider (all leaves under one root), hill-climb from kstart
+        o = outdir("t1")
+        run_ref(["tree", "-d", data, "-o", o, "-s", "gold", "-k", "10", "-r", str(registers)], env, work)
+        out["tree_spider_k10"] = read_csv(os.path.join(o, "gold_5_dashing_deltas.csv"))
+        tree_pickle = os.path.join(o, "gold_5_dashing_dtree.pickle")
+        # 2. progressive on that tree with fixed orderings (pre-seeded orderings pickle), ksweep 8..14
+        sketchdir = os.path.join(o, "sketchdb")
+        orderings = {(0, 1, 2, 3, 4), (4, 2, 0, 3, 1), (1, 3, 4, 0, 2)}
+        with open(os.path.join(sketchdir, "gold_5_orderings.pickle"), "wb") as f:
+            pickle.dump(orderings, f)
+        o2 = outdir("p1")
+        run_ref(["progressive", "-d", tree_pickle, "-o", o2, "--ksweep", "--mink", "8", "--maxk", "14"], env, work)
+        out["progressive_ksweep_8_14"] = read_csv(os.path.join(o2, "gold_progu0_5_dashing.csv"))
+        out["progressive_ksweep_8_14_summary"] = read_csv(os.path.join(o2, "gold_progu0_5_dashingsummary.csv"))
+        # 2b. progressive without ksweep (hill-climb per prefix)
+        o2b = outdir("p2")
+        run_ref(["progressive", "-d", tree_pickle, "-o", o2b], env, work)
+        out["progressive_hillclimb"] = read_csv(os.path.join(o2b, "gold_progu0_5_dashing.csv"))
+        # 3. kij with jaccard on that tree
+        o3 = outdir("k1")
+        run_ref(["kij", "-d", tree_pickle, "-o", o3, "--jaccard", "--mink", "8", "--maxk", "12"], env, work)
+        out["kij"] = read_csv(os.path.join(o3, "gold_5_dashing.kij.csv"))
+        out["kij_jaccard_8_12"] = read_csv(os.path.join(o3, "gold_5_dashing.j.csv"))
+        # 4. tree with nchildren=2 (Huffman-like shape) in a fresh sketchdir
+        o4 = outdir("t2")
+        run_ref(["tree", "-d", data, "-o", o4, "-s", "gold", "-k", "12", "-r", str(registers), "-n", "2"], env, work)
+        out["tree_n2_k12"] = read_csv(os.path.join(o4, "gold_5_dashing_deltas.csv"))
+        # 5. tree --ksweep (no hill-climb), non-canonical
+        o5 = outdir("t3")
+        run_ref(["tree", "-d", data, "-o", o5, "-s", "gold", "-r", str(registers), "--ksweep", "--mink", "9",
+                 "--maxk", "12", "-C"], env, work)
+        out["tree_ksweep_9_12_nocanon"] = read_csv(os.path.join(o5, "gold_5_dashing_deltas.csv"))
+        with open(os.path.join(work, "trace.log")) as f:
+            out["_n_external_commands"] = sum(1 for _ in f)
+        return out
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def main():
+    fdir = os.path.join(HERE, "fasta")
+    make_fastas(fdir)
+    for backend, registers in (("hll", 12), ("exact", 12)):
+        res = scenario(backend, fdir, registers)
+        path = os.path.join(HERE, f"ref_{backend}.json")
+        with open(path, "w") as f:
+            json.dump({"backend": backend, "registers": registers, "scenarios": res}, f, indent=1, sort_keys=True)
+        print("wrote", path, {k: (len(v) if isinstance(v, list) else v) for k, v in res.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,146 @@
+"""Shared helpers for the host-layer golden replays: checker backends (CPU oracle / exact counter)
+that plug into dandd_amd.host.deltatree through the same three-method backend contract as the GPU
+backend, and the scenario driver that mirrors tests/golden/make_golden.py."""
+import csv
+import json
+import os
+import pickle
+import shutil
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+
+class OracleBackend:
+    """dashing sketch/union/card restated by the CPU oracle (test infrastructure)."""
+    name = "oracle"
+
+    def __init__(self, log2m, canonical):
+        from oracle import dd_oracle
+        from dandd_amd.host import backend as B
+        self.orc, self.B, self.log2m, self.canonical = dd_oracle, B, int(log2m), bool(canonical)
+
+    def describe(self, op, **kw):
+        return f"oracle:{op}"
+
+    def leaf(self, fasta, ks, out_paths):
+        fa = np.fromfile(fasta, dtype=np.uint8)
+        for k, out in zip(ks, out_paths):
+            self.B.write_sketch_file(out, self.orc.sketch(fa, int(k), self.log2m, self.canonical), self.log2m, int(k), self.canonical)
+
+    def union(self, in_paths, out_path):
+        parts = [self.B.read_sketch_file(p) for p in in_paths]
+        self.B.write_sketch_file(out_path, self.orc.union(*[p[0] for p in parts]), self.log2m, parts[0][2], self.canonical)
+
+    def card(self, path):
+        regs, log2m, _, _ = self.B.read_sketch_file(path)
+        return self.orc.card(regs, log2m)
+
+
+class ExactBackend:
+    """KMC stand-in: a 'sketch' is the list of FASTAs, its cardinality the exact distinct count."""
+    name = "exact"
+
+    def __init__(self, log2m, canonical):
+        from oracle import dd_oracle
+        self.orc, self.canonical = dd_oracle, bool(canonical)
+
+    def describe(self, op, **kw):
+        return f"exact:{op}"
+
+    def leaf(self, fasta, ks, out_paths):
+        for k, out in zip(ks, out_paths):
+            with open(out, "w") as f:
+                json.dump({"k": int(k), "fastas": [fasta]}, f)
+
+    def union(self, in_paths, out_path):
+        parts = [json.load(open(p)) for p in in_paths]
+        with open(out_path, "w") as f:
+            json.dump({"k": parts[0]["k"], "fastas": sorted({x for p in parts for x in p["fastas"]})}, f)
+
+    def card(self, path):
+        s = json.load(open(path))
+        return float(self.orc.exact_count([np.fromfile(f, dtype=np.uint8) for f in s["fastas"]], s["k"], self.canonical))
+
+
+def _norm(key, v):
+    if v is None:
+        return None
+    if key in ("fastas", "files"):
+        if v.startswith("["):
+            return [os.path.basename(x) for x in eval(v)]
+        return [os.path.basename(x) for x in v.split("|")]
+    if key in ("A", "B", "sketchloc"):
+        return os.path.basename(v) if v else v
+    return v
+
+
+def read_rows(path):
+    with open(path, newline="") as f:
+        return [{k: _norm(k, v) for k, v in row.items() if k != "command"} for row in csv.DictReader(f)]
+
+
+def run_scenarios(work, registers):
+    """The same CLI walk as make_golden.scenario(), through dandd_amd.host.cli."""
+    from dandd_amd.host import cli
+    data = os.path.join(work, "data")
+    shutil.copytree(os.path.join(GOLD, "fasta"), data)
+    out = {}
+
+    def od(name):
+        d = os.path.join(work, name)
+        os.makedirs(d, exist_ok=True)
+        return d
+
+    o = od("t1")
+    cli.main(["tree", "-d", data, "-o", o, "-s", "gold", "-k", "10", "-r", str(registers)])
+    out["tree_spider_k10"] = read_rows(os.path.join(o, "gold_5_dashing_deltas.csv"))
+    tree_pickle = os.path.join(o, "gold_5_dashing_dtree.pickle")
+    with open(os.path.join(o, "sketchdb", "gold_5_orderings.pickle"), "wb") as f:
+        pickle.dump({(0, 1, 2, 3, 4), (4, 2, 0, 3, 1), (1, 3, 4, 0, 2)}, f)
+    o2 = od("p1")
+    cli.main(["progressive", "-d", tree_pickle, "-o", o2, "--ksweep", "--mink", "8", "--maxk", "14"])
+    out["progressive_ksweep_8_14"] = read_rows(os.path.join(o2, "gold_progu0_5_dashing.csv"))
+    out["progressive_ksweep_8_14_summary"] = read_rows(os.path.join(o2, "gold_progu0_5_dashingsummary.csv"))
+    o2b = od("p2")
+    cli.main(["progressive", "-d", tree_pickle, "-o", o2b])
+    out["progressive_hillclimb"] = read_rows(os.path.join(o2b, "gold_progu0_5_dashing.csv"))
+    o3 = od("k1")
+    cli.main(["kij", "-d", tree_pickle, "-o", o3, "--jaccard", "--mink", "8", "--maxk", "12"])
+    out["kij"] = read_rows(os.path.join(o3, "gold_5_dashing.kij.csv"))
+    out["kij_jaccard_8_12"] = read_rows(os.path.join(o3, "gold_5_dashing.j.csv"))
+    o4 = od("t2")
+    cli.main(["tree", "-d", data, "-o", o4, "-s", "gold", "-k", "12", "-r", str(registers), "-n", "2"])
+    out["tree_n2_k12"] = read_rows(os.path.join(o4, "gold_5_dashing_deltas.csv"))
+    o5 = od("t3")
+    cli.main(["tree", "-d", data, "-o", o5, "-s", "gold", "-r", str(registers), "--ksweep", "--mink", "9", "--maxk", "12", "-C"])
+    out["tree_ksweep_9_12_nocanon"] = read_rows(os.path.join(o5, "gold_5_dashing_deltas.csv"))
+    return out
+
+
+def same_cell(a, b):
+    if a == b:
+        return True
+    try:
+        return float(a) == float(b)
+    except (TypeError, ValueError):
+        return False
+
+
+def compare(got, want):
+    """-> list of human-readable differences between two scenario dicts"""
+    diffs = []
+    for name, rows in want.items():
+        if name.startswith("_"):
+            continue
+        g = got.get(name)
+        if g is None or len(g) != len(rows):
+            diffs.append(f"{name}: {None if g is None else len(g)} rows, expected {len(rows)}")
+            continue
+        for i, (r, w) in enumerate(zip(g, rows)):
+            for key in w:
+                if not same_cell(r.get(key), w[key]):
+                    diffs.append(f"{name}[{i}].{key}: got {r.get(key)!r}, expected {w[key]!r}")
+    return diffs

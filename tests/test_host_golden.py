@@ -1,0 +1,104 @@
+"""The host layer (dandd_amd.host: tree / progressive / kij) must write the same CSV rows as the
+reference's own Python did when tests/golden/make_golden.py ran it (goldens in tests/golden/ref_*.json).
+
+CPU: checker backends (oracle HLL, exact counter) behind the backend contract -> pins the
+orchestration (hill-climb, tree shapes, naming, progressive prefixes, KIJ / Jaccard formulas).
+GPU: the real HipBackend -> pins the whole drop-in path against the same goldens.
+"""
+import json
+import os
+
+import pytest
+
+import hostcheck
+
+
+def _golden(name):
+    with open(os.path.join(hostcheck.GOLD, name)) as f:
+        return json.load(f)
+
+
+@pytest.fixture
+def host():
+    from dandd_amd.host import deltatree
+    yield deltatree
+    deltatree.set_backend_factory(None)
+
+
+@pytest.mark.parametrize("which", ["hll", "exact"])
+def test_cli_rows_match_reference_with_checker_backend(host, tmp_path, which):
+    gold = _golden(f"ref_{which}.json")
+    factory = hostcheck.OracleBackend if which == "hll" else hostcheck.ExactBackend
+    host.set_backend_factory(lambda registers, canon: factory(registers, canon))
+    got = hostcheck.run_scenarios(str(tmp_path), gold["registers"])
+    diffs = hostcheck.compare(got, gold["scenarios"])
+    assert not diffs, "\n".join(diffs[:40])
+
+
+@pytest.mark.gpu
+def test_cli_rows_match_reference_on_gpu(host, tmp_path, torch_cuda):
+    gold = _golden("ref_hll.json")
+    host.set_backend_factory(None)  # the product default: HipBackend on cuda:0
+    got = hostcheck.run_scenarios(str(tmp_path), gold["registers"])
+    diffs = hostcheck.compare(got, gold["scenarios"])
+    assert not diffs, "\n".join(diffs[:40])
+
+
+def test_second_run_is_served_from_cache(host, tmp_path):
+    """All caches warm -> no backend call at all (the reference launches zero subprocesses)."""
+    gold = _golden("ref_hll.json")
+    calls = []
+
+    class Counting(hostcheck.OracleBackend):
+        def leaf(self, *a):
+            calls.append("leaf")
+            return super().leaf(*a)
+
+        def union(self, *a):
+            calls.append("union")
+            return super().union(*a)
+
+        def card(self, *a):
+            calls.append("card")
+            return super().card(*a)
+
+    host.set_backend_factory(lambda r, c: Counting(r, c))
+    from dandd_amd.host import cli
+    import shutil
+    data = os.path.join(str(tmp_path), "data")
+    shutil.copytree(os.path.join(hostcheck.GOLD, "fasta"), data)
+    out = os.path.join(str(tmp_path), "o")
+    args = ["tree", "-d", data, "-o", out, "-s", "gold", "-k", "10", "-r", str(gold["registers"])]
+    cli.main(args)
+    first = len(calls)
+    assert first > 0
+    del calls[:]
+    cli.main(args)
+    assert calls == []
+    rows = hostcheck.read_rows(os.path.join(out, "gold_5_dashing_deltas.csv"))
+    assert not hostcheck.compare({"tree_spider_k10": rows}, {"tree_spider_k10": gold["scenarios"]["tree_spider_k10"]})
+
+
+def test_tree_shapes_for_nchildren(host, tmp_path):
+    """Shapes the reference builds for (N, nchildren) -- SURVEY.md section 4.3 probe facts."""
+    import shutil
+    host.set_backend_factory(lambda r, c: hostcheck.ExactBackend(r, c))
+    src = os.path.join(hostcheck.GOLD, "fasta")
+
+    def shape(n, nchildren):
+        d = os.path.join(str(tmp_path), f"d{n}_{nchildren}")
+        os.makedirs(d)
+        for i in range(n):
+            shutil.copy(os.path.join(src, f"g{i % 5}.fasta"), os.path.join(d, f"g{i}.fasta"))
+            with open(os.path.join(d, f"g{i}.fasta"), "ab") as f:  # make the copies distinct files
+                f.write(b">x%d\nACGTTGCA%s\n" % (i, b"A" * i))
+        t = host.create_delta_tree(tag="s", genomedir=d, sketchdir=os.path.join(d, "sk"), kstart=8, nchildren=nchildren,
+                                   registers=10, ksweep=(8, 8))
+        os.makedirs(os.path.join(d, "sk"), exist_ok=True)
+        return [[c.node_title for c in n.children] for n in t._dt if n.children]
+
+    os.makedirs(os.path.join(str(tmp_path), "x"), exist_ok=True)
+    s52 = shape(5, 2)
+    assert s52 == [["g0", "g1"], ["g2", "g3"], ["g4", "g0_g1"], ["g2_g3", "g4_g0_g1"]]
+    s73 = shape(7, 3)
+    assert s73[0] == ["g0", "g1", "g2"] and s73[-1] == ["g3", "g4", "g5", "g6", "g0_g1_g2"]
