@@ -99,6 +99,7 @@ def main():
 
     import torch
     import torch.distributed as dist
+    from dandd_amd import dist as ddist
     from dandd_amd.engine import Engine, synth_size, KERNEL_PACK, KERNEL_SWEEP, KERNEL_UNION
 
     torch.cuda.set_device(local_rank)
@@ -128,7 +129,7 @@ def main():
         eng.sketch_device(ptrs, sizes, kmin, kmax, regs.data_ptr())                 # K0 + K1
         eng.union_device(leaf_ptrs, K * m, regs[ng].data_ptr())                      # K2 root union
         if world > 1:
-            dist.all_reduce(regs[ng], op=dist.ReduceOp.MAX)                          # RCCL over xGMI
+            ddist.allreduce_max_u8(regs[ng])                                         # RCCL max over xGMI
         card = eng.card_batch_device(regs.data_ptr(), (ng + 1) * K).reshape(ng + 1, K)  # K2 + K3
         return (card / ks).max(axis=1), (card / ks).argmax(axis=1) + kmin            # delta, argmax-k
 
@@ -153,10 +154,7 @@ def main():
     union_ms, union_n = eng.timing_read(KERNEL_UNION)
     eng.timing_enable(False)
 
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = ddist.max_over_ranks(dt, device="cuda")
 
     if rank == 0:
         steps = args.steps

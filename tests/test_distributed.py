@@ -1,0 +1,62 @@
+"""N>1 path on CPU: world_size-2 gloo run of dandd_amd.dist (sharding plan, MAX all-reduce of the
+root slab, card gather) checked against a single-process oracle computation."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_plan_is_balanced_and_deterministic():
+    from dandd_amd.dist import shard_by_weight
+    w = [50, 10, 40, 30, 20, 60, 5]
+    plan = shard_by_weight(w, 3)
+    assert sorted(i for p in plan for i in p) == list(range(len(w)))
+    loads = [sum(w[i] for i in p) for p in plan]
+    assert max(loads) - min(loads) <= max(w)
+    assert plan == shard_by_weight(w, 3)
+    assert shard_by_weight(w, 1) == [list(range(len(w)))]
+    assert shard_by_weight([], 4) == [[], [], [], []]
+
+
+def test_two_rank_gloo_sweep_matches_single_process(orc, tmp_path):
+    kmin, kmax, p = 9, 13, 10
+    fastas = []
+    for g, nb in enumerate([30000, 8000, 22000, 15000, 4000]):
+        path = tmp_path / f"g{g}.fasta"
+        path.write_bytes(orc.synth_fasta(0xD4ADD, g, nb, 2).tobytes())
+        fastas.append(str(path))
+    out = str(tmp_path / "res")
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(HERE, "dist_worker.py"), out, str(kmin), str(kmax), str(p)] + fastas
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = [json.load(open(f"{out}.{rank}")) for rank in range(2)]
+    # every genome sketched exactly once across the two ranks
+    assert sorted(res[0]["touched"] + res[1]["touched"]) == sorted(os.path.basename(f) for f in fastas)
+    assert res[0]["touched"] and res[1]["touched"]
+    leaves = [orc.sketch_sweep(np.fromfile(f, dtype=np.uint8), kmin, kmax, p) for f in fastas]
+    root = orc.union(*leaves)
+    want_leaf = [[orc.card(l[kk], p) for kk in range(kmax - kmin + 1)] for l in leaves]
+    want_root = [orc.card(root[kk], p) for kk in range(kmax - kmin + 1)]
+    for rr in res:  # both ranks end with the full answer
+        assert rr["world"] == 2 and rr["slowest"] == 2.0
+        assert rr["leaf_card"] == want_leaf
+        assert rr["root_card"] == want_root
+        assert rr["root_sha"] == int(root.astype(np.uint64).sum())
