@@ -98,7 +98,7 @@ struct dd_ctx {
     std::vector<TimedSpan> spans[DD_KERNEL_COUNT];
     std::vector<hipEvent_t> pool;
     // workspaces
-    DevBuf tokens, scratch, tables, fasta, regs, ptrs, hist, est, ord;
+    DevBuf tokens, scratch, tables, fasta, regs, ptrs, hist, est, ord, bitmaps;
     HostBuf stage;
     hipEvent_t stage_free = nullptr;  // signalled when the last upload from `stage` completed
     // stats of the last sketch call
@@ -238,7 +238,7 @@ void dd_destroy(dd_ctx* c) {
     for (auto e : c->pool) (void)hipEventDestroy(e);
     if (c->stage_free) (void)hipEventDestroy(c->stage_free);
     for (DevBuf* b : {&c->tokens, &c->scratch, &c->tables, &c->fasta, &c->regs, &c->ptrs, &c->hist,
-                      &c->est, &c->ord})
+                      &c->est, &c->ord, &c->bitmaps})
         b->release();
     c->stage.release();
     delete c;
@@ -301,6 +301,17 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     char* tb = static_cast<char*>(c->tokens.p);
     char* sb = static_cast<char*>(c->scratch.p);
 
+    // presence bitmaps for the small-k class (k <= 9), zeroed per call
+    const bool use_bitmaps = kmin <= dd::kBitmapMaxK && !getenv("DD_NO_BITMAP");
+    const int kb_last = std::min(kmax, dd::kBitmapMaxK);
+    uint32_t* bitmap_base = nullptr;
+    if (use_bitmaps) {
+        const size_t bbytes = (size_t)ngenomes * dd::kBitmapStride * sizeof(uint32_t);
+        if ((rc = c->bitmaps.reserve(bbytes))) return rc;
+        bitmap_base = static_cast<uint32_t*>(c->bitmaps.p);
+        DD_HIP(hipMemsetAsync(bitmap_base, 0, bbytes, st));
+    }
+
     // ---- K0 / K1 genome tables -----------------------------------------------------------
     std::vector<dd::SweepGenome> gtab(ngenomes);
     std::vector<dd::PackGenome> ptab(ngenomes);
@@ -313,7 +324,8 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         ptab[g] = dd::PackGenome{fasta_dev[g], nbytes[g], dd::pack_chunks(nbytes[g]),
                                  reinterpret_cast<long long*>(sb + off_scratch[g]), ts};
         max_chunks = std::max(max_chunks, ptab[g].nchunks);
-        gtab[g] = dd::SweepGenome{ts.codes, ts.bad, ts.ntok, regs_dev + (size_t)g * K * m};
+        gtab[g] = dd::SweepGenome{ts.codes, ts.bad, ts.ntok, regs_dev + (size_t)g * K * m,
+                                  bitmap_base ? bitmap_base + (size_t)g * dd::kBitmapStride : nullptr};
         tokens_ub += nbytes[g];
     }
     (void)max_n;
@@ -339,12 +351,13 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         int max_nk = 0;
     };
     std::vector<ClassJobs> classes;
-    for (int kc = 0; kc < 3; ++kc) {
-        const int ka = std::max(kmin, kc == 0 ? 1 : (kc == 1 ? 17 : 33));
-        const int kb = std::min(kmax, kc == 0 ? 16 : (kc == 1 ? 32 : 64));
+    for (int kc = 0; kc < 4; ++kc) {  // 3 = small-k bitmap class, 0..2 = hashed classes
+        const int lo0 = use_bitmaps ? dd::kBitmapMaxK + 1 : 1;
+        const int ka = std::max(kmin, kc == 3 ? 1 : (kc == 0 ? lo0 : (kc == 1 ? 17 : 33)));
+        const int kb = std::min(kmax, kc == 3 ? (use_bitmaps ? dd::kBitmapMaxK : 0) : (kc == 0 ? 16 : (kc == 1 ? 32 : 64)));
         if (ka > kb) continue;
         const int nks = kb - ka + 1;
-        const int ngroups = (nks + slots - 1) / slots;
+        const int ngroups = kc == 3 ? 1 : (nks + slots - 1) / slots;
         // aim for ~8 jobs per CU over the whole class so the dispatcher can balance the tail
         size_t total_tiles = 0;
         for (int g = 0; g < ngenomes; ++g) total_tiles += (nbytes[g] + tile_tokens - 1) / tile_tokens;
@@ -417,9 +430,17 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         plan.threads = threads;
         plan.lds_bytes = global_regs ? 0 : (int)((size_t)classes[i].max_nk * m);
         Span sp(c, DD_KERNEL_SWEEP);
-        dd::launch_sweep(reinterpret_cast<const dd::SweepGenome*>(tdev),
-                         reinterpret_cast<const dd::SweepJob*>(tdev + job_off[i]),
-                         (int)classes[i].jobs.size(), classes[i].kclass, plan, st);
+        if (classes[i].kclass == 3) {
+            dd::launch_bitmap(reinterpret_cast<const dd::SweepGenome*>(tdev),
+                              reinterpret_cast<const dd::SweepJob*>(tdev + job_off[i]),
+                              (int)classes[i].jobs.size(), c->canonical, st);
+            dd::launch_bitmap_finish(reinterpret_cast<const dd::SweepGenome*>(tdev), ngenomes, kmin, kb_last,
+                                     kmin, p, st);
+        } else {
+            dd::launch_sweep(reinterpret_cast<const dd::SweepGenome*>(tdev),
+                             reinterpret_cast<const dd::SweepJob*>(tdev + job_off[i]),
+                             (int)classes[i].jobs.size(), classes[i].kclass, plan, st);
+        }
         blocks += (int)classes[i].jobs.size();
     }
     DD_HIP(hipGetLastError());

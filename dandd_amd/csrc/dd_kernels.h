@@ -48,7 +48,21 @@ struct SweepGenome {            // one per genome, device-resident table
     const uint32_t* bad;
     const unsigned long long* ntok;
     uint8_t* regs;              // [K][m] for this genome
+    uint32_t* bitmap;           // presence bitmaps of the canonical k-mers, k = 1..kBitmapMaxK (or null)
 };
+
+// Small-k path: for k <= kBitmapMaxK there are at most 4^k <= 262144 distinct k-mers, so K1 only
+// records WHICH k-mers occur (one LDS bit each) and hashes every distinct one once afterwards.
+constexpr int kBitmapMaxK = 9;
+constexpr int kBitmapWords = 10924;      // sum over k = 1..9 of max(1, 4^k / 32)
+constexpr int kBitmapStride = 11008;     // words per genome (256-byte multiple)
+// first word of k's bitmap inside a genome's block
+inline constexpr int bitmap_offset(int k) {
+    int off = 0;
+    for (int j = 1; j < k; ++j) off += (j < 3) ? 1 : (1 << (2 * j - 5));
+    return off;
+}
+inline constexpr int bitmap_words(int k) { return (k < 3) ? 1 : (1 << (2 * k - 5)); }
 struct SweepJob {               // one per workgroup, device-resident table
     int genome;
     int kfirst;                 // first k of the group (consecutive ks)
@@ -65,6 +79,12 @@ struct SweepPlan {
 void launch_sweep(const SweepGenome* genomes_dev, const SweepJob* jobs_dev, int njobs, int kclass,
                   const SweepPlan& plan, hipStream_t st);
 int sweep_max_lds_bytes();
+// small-k class: jobs carry ks <= kBitmapMaxK; records k-mer presence in genome.bitmap
+void launch_bitmap(const SweepGenome* genomes_dev, const SweepJob* jobs_dev, int njobs, int canonical,
+                   hipStream_t st);
+// one workgroup per (genome, k in [kfirst, klast]): hash every recorded k-mer once into slab row k-kmin
+void launch_bitmap_finish(const SweepGenome* genomes_dev, int ngenomes, int kfirst, int klast, int kmin,
+                          int log2m, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------
 // K2: byte-max union + 64-bin histograms.

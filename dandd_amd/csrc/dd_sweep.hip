@@ -212,13 +212,16 @@ struct Windows<2> {
 // every k of the group for the token just pushed
 template <int KC, bool CANON, bool CHECK, typename MakeRegs>
 DD_D void sweep_token(const Windows<KC>& win, int run, int kfirst, int nk, int p, const MakeRegs& slot) {
-    // ks ascend, so a lane whose run is too short for k is also too short for every later k
+    // The loop counter stays wave-uniform in both variants (k-dependent masks and shifts are then
+    // scalar); in the CHECK variant lanes whose run is too short for k are simply predicated off.
     int j = 0;
 #pragma unroll 1
     for (; j + 1 < nk; j += 2) {
         const int k = kfirst + j;
-        if (CHECK && run < k + 1) break;
-        hll_update2(slot(j), win.template hash<CANON>(k), slot(j + 1), win.template hash<CANON>(k + 1), p);
+        if (!CHECK || run >= k + 1)
+            hll_update2(slot(j), win.template hash<CANON>(k), slot(j + 1), win.template hash<CANON>(k + 1), p);
+        else if (run >= k)
+            hll_update(slot(j), win.template hash<CANON>(k), p);
     }
     if (j < nk && (!CHECK || run >= kfirst + j)) hll_update(slot(j), win.template hash<CANON>(kfirst + j), p);
 }
@@ -324,6 +327,133 @@ __global__ __launch_bounds__(1024) void sweep_kernel(const SweepGenome* __restri
     }
 }
 
+// ---- small-k class (k <= kBitmapMaxK): presence bitmaps instead of hashing every occurrence -----
+// The sketch depends only on the SET of canonical k-mers, and for k <= 9 that set has at most
+// 4^9 members, so per (token, k) this kernel only does: mask/shift, canonical min, one LDS word
+// read and a bit test (an LDS atomic OR the first time a k-mer is seen).  bitmap_finish_kernel then
+// hashes each recorded k-mer exactly once.  Registers are bit-identical to hashing every occurrence.
+__constant__ int c_bitmap_off[kBitmapMaxK + 2] = {0, bitmap_offset(1), bitmap_offset(2), bitmap_offset(3),
+                                                 bitmap_offset(4), bitmap_offset(5), bitmap_offset(6),
+                                                 bitmap_offset(7), bitmap_offset(8), bitmap_offset(9),
+                                                 kBitmapWords};
+
+// amdgpu_num_sgpr: above 80 SGPRs only 7 waves per SIMD are admitted, i.e. ONE 1024-thread
+// workgroup per CU instead of two (MI355X_MICROARCH.md, residency) -- measured 2x on this kernel.
+template <bool CANON>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void bitmap_kernel(const SweepGenome* __restrict__ genomes,
+                                                     const SweepJob* __restrict__ jobs) {
+    uint32_t* const bits = reinterpret_cast<uint32_t*>(g_lds);
+    const SweepJob job = jobs[blockIdx.x];
+    const SweepGenome g = genomes[job.genome];
+    const int kfirst = job.kfirst, klast = job.kfirst + job.nk - 1;
+    const unsigned long long ntok = *g.ntok;
+    const int w0 = c_bitmap_off[kfirst], w1 = c_bitmap_off[klast + 1];
+    const uint32_t kmask = __builtin_amdgcn_readfirstlane(((2u << klast) - 1u) & ~((1u << kfirst) - 1u));  // bit k set: k in the job
+    // warm start from what earlier jobs recorded (any snapshot is a subset of the final set)
+    for (int i = w0 + (int)threadIdx.x; i < w1; i += blockDim.x) bits[i] = g.bitmap[i];
+    __syncthreads();
+
+    const int prime = klast - 1;
+    const uint4* codes4 = reinterpret_cast<const uint4*>(g.codes);
+    const uint2* bad2 = reinterpret_cast<const uint2*>(g.bad);
+    for (unsigned tile = job.tile_begin; tile < job.tile_end; ++tile) {
+        const unsigned long long seg = (unsigned long long)tile * blockDim.x + threadIdx.x;
+        if (seg * kSegTokens >= ntok) continue;
+        uint32_t fw = 0, rc = 0;
+        int run = 0;
+        if (seg > 0) {
+            const uint4 hc = codes4[seg - 1];
+            const uint2 hb = bad2[seg - 1];
+            const uint32_t cw = hc.w, bw = hb.y >> 16;  // last 16 tokens of the halo (prime <= 8)
+#pragma unroll 1
+            for (int i = 16 - prime; i < 16; ++i) {
+                const uint32_t c = (cw >> (2 * i)) & 3u;
+                run = ((bw >> i) & 1u) ? 0 : run + 1;
+                fw = (fw << 2) | c;
+                rc = (rc >> 2) | ((3u - c) << 30);
+            }
+        }
+        const uint4 sc = codes4[seg];
+        const uint2 sb = bad2[seg];
+        const uint32_t cws[4] = {sc.x, sc.y, sc.z, sc.w};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t bw = ((w & 2) ? sb.y : sb.x) >> ((w & 1) * 16);
+#pragma unroll 1
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t c = (cws[w] >> (2 * i)) & 3u;
+                run = ((bw >> i) & 1u) ? 0 : run + 1;
+                fw = (fw << 2) | c;
+                rc = (rc >> 2) | ((3u - c) << 30);
+                // fully unrolled over k so masks, shifts and bitmap offsets are immediates and the
+                // LDS word reads of all ks are in flight together; `need` collects the (rare) lanes
+                // that saw a new k-mer
+                uint32_t xs[kBitmapMaxK + 1], seen[kBitmapMaxK + 1];
+                uint32_t all_seen = 1u;  // bit 0 stays set while every k-mer of this token is known
+#pragma unroll
+                for (int k = 1; k <= kBitmapMaxK; ++k) {
+                    if (!((kmask >> k) & 1u)) continue;  // wave-uniform (one scalar bit test, no live SGPR pair per k)
+                    uint32_t x = fw & ((1u << (2 * k)) - 1u);
+                    if (CANON) {
+                        const uint32_t r = rc >> (32 - 2 * k);
+                        x = x < r ? x : r;
+                    }
+                    xs[k] = x;
+                    seen[k] = bits[bitmap_offset(k) + (x >> 5)];
+                    all_seen &= seen[k] >> (x & 31u);
+                }
+                // Validity (run >= k) is only consulted on the rare path: an invalid window near a
+                // BREAK can at worst send its lane there for nothing.
+                if (!(all_seen & 1u)) {
+#pragma unroll
+                    for (int k = 1; k <= kBitmapMaxK; ++k) {
+                        if (!((kmask >> k) & 1u) || run < k) continue;
+                        if (!((seen[k] >> (xs[k] & 31u)) & 1u))
+                            atomicOr(&bits[bitmap_offset(k) + (xs[k] >> 5)], 1u << (xs[k] & 31u));
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = w0 + (int)threadIdx.x; i < w1; i += blockDim.x) {
+        const uint32_t mine = bits[i];
+        if (mine & ~g.bitmap[i]) atomicOr(&g.bitmap[i], mine);
+    }
+}
+
+// grid = (ks, genomes); registers of the row are built in LDS (or in place when they do not fit)
+template <bool CANON_UNUSED>
+__global__ __launch_bounds__(1024) void bitmap_finish_kernel(const SweepGenome* __restrict__ genomes,
+                                                            int kfirst, int kmin, int p, int in_lds) {
+    const SweepGenome g = genomes[blockIdx.y];
+    const int k = kfirst + (int)blockIdx.x;
+    const uint32_t m = 1u << p;
+    uint8_t* const row = g.regs + ((size_t)(k - kmin) << p);
+    if (in_lds) {
+        uint4* z = reinterpret_cast<uint4*>(g_lds);
+        for (uint32_t i = threadIdx.x; i < (m >> 4); i += blockDim.x) z[i] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    const uint32_t* bm = g.bitmap + c_bitmap_off[k];
+    const int nw = c_bitmap_off[k + 1] - c_bitmap_off[k];
+    for (int w = threadIdx.x; w < nw; w += blockDim.x) {
+        uint32_t v = bm[w];
+        while (v) {
+            const uint32_t b = (uint32_t)__builtin_ctz(v);
+            v &= v - 1;
+            const uint64_t h = wang64_fast<true>(((uint32_t)w << 5) | b);
+            if (in_lds) hll_update(RegsLds{0u}, h, p);
+            else hll_update(RegsGlobal{row}, h, p);
+        }
+    }
+    __syncthreads();
+    if (in_lds) {
+        const uint4* l4 = reinterpret_cast<const uint4*>(g_lds);
+        for (uint32_t i = threadIdx.x; i < (m >> 4); i += blockDim.x) reinterpret_cast<uint4*>(row)[i] = l4[i];
+    }
+}
+
 template <int KC, bool CANON, bool GLOBAL>
 void launch_one(const SweepGenome* genomes, const SweepJob* jobs, int njobs, const SweepPlan& plan,
                 hipStream_t st) {
@@ -341,6 +471,31 @@ void launch_one(const SweepGenome* genomes, const SweepJob* jobs, int njobs, con
 }  // namespace
 
 int sweep_max_lds_bytes() { return 160 * 1024; }
+
+void launch_bitmap(const SweepGenome* genomes, const SweepJob* jobs, int njobs, int canonical, hipStream_t st) {
+    if (njobs <= 0) return;
+    const size_t lds = (size_t)kBitmapWords * 4;
+    if (canonical)
+        hipLaunchKernelGGL(bitmap_kernel<true>, dim3((unsigned)njobs), dim3(1024), lds, st, genomes, jobs);
+    else
+        hipLaunchKernelGGL(bitmap_kernel<false>, dim3((unsigned)njobs), dim3(1024), lds, st, genomes, jobs);
+}
+
+void launch_bitmap_finish(const SweepGenome* genomes, int ngenomes, int kfirst, int klast, int kmin, int log2m,
+                          hipStream_t st) {
+    if (ngenomes <= 0 || klast < kfirst) return;
+    const size_t m = (size_t)1 << log2m;
+    const int in_lds = m <= (size_t)sweep_max_lds_bytes() ? 1 : 0;
+    auto kern = bitmap_finish_kernel<true>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, sweep_max_lds_bytes());
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(klast - kfirst + 1), (unsigned)ngenomes), dim3(1024),
+                       in_lds ? m : 0, st, genomes, kfirst, kmin, log2m, in_lds);
+}
 
 void launch_sweep(const SweepGenome* genomes, const SweepJob* jobs, int njobs, int kclass,
                   const SweepPlan& plan, hipStream_t st) {
