@@ -84,6 +84,37 @@ DD_D int scan16(const Bytes16& b, bool prev_nl, bool hdr_in, uint8_t* out) {
     return cnt;
 }
 
+// Same state machine, but the thread's tokens are assembled in registers: 2-bit codes in `codes`
+// (token j at bits 2j..2j+1) and BREAK flags in `bad` (bit j).  Returns the token count (<= 16).
+DD_D int scan16_pack(const Bytes16& b, bool prev_nl, bool hdr_in, uint32_t& codes, uint32_t& bad) {
+    int cnt = 0;
+    bool hdr = hdr_in, ls = prev_nl;
+    codes = 0;
+    bad = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        uint32_t c = b.at(i);
+        if (ls) hdr = (c == '>');
+        if (c == '\n') {
+            if (hdr) {
+                bad |= 1u << cnt;
+                ++cnt;
+            }
+            hdr = false;
+            ls = true;
+        } else {
+            ls = false;
+            if (!(hdr || c == '\r')) {
+                const uint32_t code = base_code(c);
+                codes |= (code & 3u) << (2 * cnt);
+                bad |= (code >> 2) << cnt;
+                ++cnt;
+            }
+        }
+    }
+    return cnt;
+}
+
 DD_D long long last_newline(const Bytes16& b, size_t pos) {
     long long r = -1;
 #pragma unroll
@@ -251,7 +282,8 @@ __global__ __launch_bounds__(1024) void pack_scan(const PackGenome* __restrict__
 
 __global__ __launch_bounds__(T) void pack_write(const PackGenome* __restrict__ tab) {
     __shared__ long long sm[T / 64];
-    __shared__ uint8_t tok[kPackChunk];
+    __shared__ uint32_t lcodes[kPackChunk / 16 + 2];  // <= 4096 tokens -> <= 257 code words (+1 spill)
+    __shared__ uint32_t lbad[kPackChunk / 32 + 2];
     const PackGenome G = tab[blockIdx.y];
     const size_t c = blockIdx.x;
     if (c >= G.nchunks) return;
@@ -277,39 +309,46 @@ __global__ __launch_bounds__(T) void pack_write(const PackGenome* __restrict__ t
     if (before < 0) before = Nin[c];
     bool h = false;
     if (!prev_nl && pos < n) h = line_is_header(fa, before);
-    int cnt = scan16<false>(b, prev_nl, h, nullptr);
+    uint32_t my_codes, my_bad;
+    const int cnt = scan16_pack(b, prev_nl, h, my_codes, my_bad);
     long long total;
-    long long incS = block_incl((long long)cnt, SumLL(), 0, sm, &total);
-    int off = (int)(incS - cnt);
-    scan16<true>(b, prev_nl, h, tok + off);
-    __syncthreads();
-
+    const long long incS = block_incl((long long)cnt, SumLL(), 0, sm, &total);
     const long long S = slot_base[c], E = S + total;  // global token range of this chunk
     if (total == 0) return;
-    // 2-bit codes, 16 tokens per word
-    for (long long w = (S >> 4) + threadIdx.x; w <= ((E - 1) >> 4); w += T) {
-        uint32_t v = 0;
-        const long long t0 = w << 4;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            long long t = t0 + j;
-            if (t >= S && t < E) v |= (uint32_t)(tok[t - S] & 3u) << (2 * j);
+
+    // The chunk's words are built in LDS at their final bit positions: a thread ORs its <=16
+    // tokens (one 32-bit code piece, one 16-bit BREAK piece, each possibly straddling two words),
+    // then the words are copied out; only the chunk's first and last word can be shared with a
+    // neighbouring chunk and go out through atomicOr (pack_scan zeroed them).
+    const long long cw0 = S >> 4, bw0 = S >> 5;
+    const int ncw = (int)(((E - 1) >> 4) - cw0) + 1, nbw = (int)(((E - 1) >> 5) - bw0) + 1;
+    for (int i = threadIdx.x; i < ncw + 1; i += T) lcodes[i] = 0;
+    for (int i = threadIdx.x; i < nbw + 1; i += T) lbad[i] = 0;
+    __syncthreads();
+    if (cnt) {
+        const long long t0 = S + (incS - cnt);  // global index of this thread's first token
+        const int wi = (int)((t0 >> 4) - cw0), sh = (int)(t0 & 15) * 2;
+        atomicOr(&lcodes[wi], my_codes << sh);
+        if (sh && (my_codes >> (32 - sh))) atomicOr(&lcodes[wi + 1], my_codes >> (32 - sh));
+        const int bi = (int)((t0 >> 5) - bw0), bs = (int)(t0 & 31);
+        if (my_bad) {
+            atomicOr(&lbad[bi], my_bad << bs);
+            if (bs > 16 && (my_bad >> (32 - bs))) atomicOr(&lbad[bi + 1], my_bad >> (32 - bs));
         }
-        if (t0 >= S && t0 + 16 <= E)
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ncw; i += T) {
+        const long long w = cw0 + i;
+        const uint32_t v = lcodes[i];
+        if ((w << 4) >= S && (w << 4) + 16 <= E)
             out.codes[w] = v;
         else if (v)
             atomicOr(&out.codes[w], v);
     }
-    // BREAK mask, 32 tokens per word
-    for (long long w = (S >> 5) + threadIdx.x; w <= ((E - 1) >> 5); w += T) {
-        uint32_t v = 0;
-        const long long t0 = w << 5;
-#pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            long long t = t0 + j;
-            if (t >= S && t < E) v |= (uint32_t)(tok[t - S] >> 2) << j;
-        }
-        if (t0 >= S && t0 + 32 <= E)
+    for (int i = threadIdx.x; i < nbw; i += T) {
+        const long long w = bw0 + i;
+        const uint32_t v = lbad[i];
+        if ((w << 5) >= S && (w << 5) + 32 <= E)
             out.bad[w] = v;
         else if (v)
             atomicOr(&out.bad[w], v);
