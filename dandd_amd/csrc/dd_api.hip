@@ -10,8 +10,14 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <zlib.h>
+
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "dd_common.h"
@@ -158,7 +164,38 @@ int upload(dd_ctx* c, void* dst_dev, const void* src, size_t bytes, size_t stage
     return DD_OK;
 }
 
-int kclass_of(int k) { return k <= 16 ? 0 : (k <= 32 ? 1 : 2); }
+// Whole FASTA file into memory; gzip (any number of members) or plain, decided by zlib itself.
+bool read_fasta_file(const char* path, std::vector<uint8_t>& out, std::string& err) {
+    gzFile f = gzopen(path, "rb");
+    if (!f) {
+        err = std::string("cannot open ") + path;
+        return false;
+    }
+    gzbuffer(f, 1u << 20);
+    out.clear();
+    size_t cap = 1u << 22;
+    out.resize(cap);
+    size_t len = 0;
+    for (;;) {
+        if (len == cap) {
+            cap *= 2;
+            out.resize(cap);
+        }
+        const unsigned want = (unsigned)std::min<size_t>(cap - len, 1u << 30);
+        const int got = gzread(f, out.data() + len, want);
+        if (got < 0) {
+            int code = 0;
+            err = std::string("read error on ") + path + ": " + gzerror(f, &code);
+            gzclose(f);
+            return false;
+        }
+        if (got == 0) break;
+        len += (size_t)got;
+    }
+    gzclose(f);
+    out.resize(len);
+    return true;
+}
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -471,27 +508,86 @@ int dd_sketch_buffer(dd_ctx* c, const uint8_t* fasta, size_t nbytes, int kmin, i
 int dd_sketch_fasta(dd_ctx* c, const char* path, int kmin, int kmax, uint8_t* regs) {
     if (check_ctx(c)) return DD_EINVAL;
     if (!path) return fail(DD_EINVAL, "null path");
-    FILE* f = fopen(path, "rb");
-    if (!f) return fail(DD_EIO, "cannot open %s", path);
     std::vector<uint8_t> buf;
-    uint8_t head[2] = {0, 0};
-    size_t got = fread(head, 1, 2, f);
-    if (got == 2 && head[0] == 0x1f && head[1] == 0x8b) {
-        fclose(f);
-        return fail(DD_EIO, "%s is gzip-compressed: inflate it on the host first (gz ingestion is not in this build)", path);
-    }
-    fseek(f, 0, SEEK_END);
-    long sz = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    if (sz < 0) {
-        fclose(f);
-        return fail(DD_EIO, "cannot size %s", path);
-    }
-    buf.resize((size_t)sz);
-    size_t rd = sz ? fread(buf.data(), 1, (size_t)sz, f) : 0;
-    fclose(f);
-    if (rd != (size_t)sz) return fail(DD_EIO, "short read on %s", path);
+    std::string err;
+    if (!read_fasta_file(path, buf, err)) return fail(DD_EIO, "%s", err.c_str());
     return dd_sketch_buffer(c, buf.data(), buf.size(), kmin, kmax, regs);
+}
+
+// Many FASTA files (plain or .gz, as DandD's species directories hold them,
+// /root/reference/lib/species_specifics.py:93): loader threads read + inflate ahead while the
+// GPU sketches the files already in memory, in order; regs is [nfiles][K][m] on the host.
+int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, int kmax, uint8_t* regs,
+                    int nthreads) {
+    if (check_ctx(c)) return DD_EINVAL;
+    if (nfiles < 0 || (nfiles && (!paths || !regs))) return fail(DD_EINVAL, "null argument");
+    if (kmin < 1 || kmax > 64 || kmin > kmax) return fail(DD_EINVAL, "k range %d..%d outside 1..64", kmin, kmax);
+    for (int i = 0; i < nfiles; ++i)
+        if (!paths[i]) return fail(DD_EINVAL, "null path at index %d", i);
+    if (!nfiles) return DD_OK;
+    if (nthreads <= 0) nthreads = (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+    nthreads = std::min(nthreads, nfiles);
+    const size_t slab = (size_t)(kmax - kmin + 1) << c->p;
+
+    struct Slot {
+        std::vector<uint8_t> data;
+        std::string err;
+        bool ok = false, done = false;
+    };
+    std::vector<Slot> slots(nfiles);
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<int> next{0};
+    // bound the read-ahead so a directory of whole genomes cannot exhaust host memory
+    const int window = std::max(2 * nthreads, 4);
+    std::atomic<int> consumed{0};
+    auto loader = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= nfiles) return;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return i < consumed.load() + window; });
+            }
+            Slot local;
+            local.ok = read_fasta_file(paths[i], local.data, local.err);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                slots[i].data.swap(local.data);
+                slots[i].err.swap(local.err);
+                slots[i].ok = local.ok;
+                slots[i].done = true;
+            }
+            cv.notify_all();
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthreads; ++t) pool.emplace_back(loader);
+
+    int rc = DD_OK;
+    std::string first_err;
+    for (int i = 0; i < nfiles; ++i) {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return slots[i].done; });
+        }
+        if (rc == DD_OK) {
+            if (!slots[i].ok) {
+                rc = DD_EIO;
+                first_err = slots[i].err;
+            } else {
+                rc = dd_sketch_buffer(c, slots[i].data.data(), slots[i].data.size(), kmin, kmax,
+                                      regs + (size_t)i * slab);
+                if (rc != DD_OK) first_err = g_err;
+            }
+        }
+        std::vector<uint8_t>().swap(slots[i].data);
+        consumed.store(i + 1);
+        cv.notify_all();
+    }
+    for (auto& t : pool) t.join();
+    if (rc != DD_OK) return fail(rc, "%s", first_err.c_str());
+    return DD_OK;
 }
 
 // ------------------------------------------------------------------------------- union

@@ -20,7 +20,7 @@ KERNEL_PACK, KERNEL_SWEEP, KERNEL_UNION = 0, 1, 2
 
 EXPORTS = [
     "dd_abi_version", "dd_last_error", "dd_create", "dd_destroy", "dd_set_stream", "dd_synchronize",
-    "dd_sketch_buffer", "dd_sketch_fasta", "dd_sketch_device", "dd_union", "dd_union_device",
+    "dd_sketch_buffer", "dd_sketch_fasta", "dd_sketch_files", "dd_sketch_device", "dd_union", "dd_union_device",
     "dd_card", "dd_card_batch", "dd_card_batch_device", "dd_hist_batch_device", "dd_ertl_mle",
     "dd_progressive", "dd_progressive_device", "dd_pairwise", "dd_pairwise_device",
     "dd_timing_enable", "dd_timing_read", "dd_timing_reset", "dd_last_sketch_stats",
@@ -66,6 +66,8 @@ def load_library(path=None):
     lib.dd_sketch_buffer.argtypes = [vp, vp, sz, i32, i32, vp]
     lib.dd_sketch_fasta.restype = i32
     lib.dd_sketch_fasta.argtypes = [vp, C.c_char_p, i32, i32, vp]
+    lib.dd_sketch_files.restype = i32
+    lib.dd_sketch_files.argtypes = [vp, C.POINTER(C.c_char_p), i32, i32, i32, vp, i32]
     lib.dd_sketch_device.restype = i32
     lib.dd_sketch_device.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), i32, i32, i32, vp]
     lib.dd_union.restype = i32
@@ -175,6 +177,14 @@ class Engine:
     def sketch_fasta(self, path, kmin, kmax):
         regs = np.empty((kmax - kmin + 1, self.m), dtype=np.uint8)
         self._check(self._lib.dd_sketch_fasta(self._ctx, os.fsencode(path), kmin, kmax, regs.ctypes.data))
+        return regs
+
+    def sketch_files(self, paths, kmin, kmax, nthreads=0):
+        """Plain or .gz FASTA files -> registers [n][K][m]; read/inflate overlaps the GPU work."""
+        n = len(paths)
+        arr = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+        regs = np.empty((n, kmax - kmin + 1, self.m), dtype=np.uint8)
+        self._check(self._lib.dd_sketch_files(self._ctx, arr, n, kmin, kmax, regs.ctypes.data, int(nthreads)))
         return regs
 
     def sketch_device(self, fasta_ptrs, nbytes, kmin, kmax, regs_ptr):

@@ -58,7 +58,15 @@ int dd_synchronize(dd_ctx *);
  * FASTA bytes instead of one process per k.  regs[K][m] is overwritten. */
 int dd_sketch_buffer(dd_ctx *, const uint8_t *fasta, size_t nbytes, int kmin, int kmax,
                      uint8_t *regs);
+/* path may be plain or gzip-compressed (DandD's inputs are .fa/.fasta/.fna[.gz],
+ * lib/species_specifics.py:93); inflated on the host with zlib. */
 int dd_sketch_fasta(dd_ctx *, const char *path, int kmin, int kmax, uint8_t *regs);
+/* Ingestion pipeline for a whole directory of genomes: `nthreads` loader threads (0 = auto) read
+ * and inflate ahead (bounded window) while the GPU sketches the files already in memory, in
+ * order.  regs[nfiles][K][m] on the host.  Replaces the reference's sequential per-genome loop
+ * (lib/huffman_dandd.py:402-407), each iteration of which re-inflates the file once per k. */
+int dd_sketch_files(dd_ctx *, const char *const *paths, int nfiles, int kmin, int kmax,
+                    uint8_t *regs, int nthreads);
 /* Batched, HBM-resident form: ngenomes FASTA byte buffers already on the device,
  * regs_dev[ngenomes][K][m] on the device.  Asynchronous on the context's stream. */
 int dd_sketch_device(dd_ctx *, const uint8_t *const *fasta_dev, const size_t *nbytes,

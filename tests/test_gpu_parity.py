@@ -209,3 +209,32 @@ def test_sketch_fasta_file(engine_factory, orc, tmp_path):
         eng.sketch_buffer(fa, 0, 12)
     with pytest.raises(EngineError):
         eng.sketch_buffer(fa, 10, 65)
+
+
+def test_sketch_files_gz_and_plain(engine_factory, orc, tmp_path):
+    """Ingestion pipeline: gzip (single- and multi-member) and plain files, several loader threads."""
+    import gzip
+    from dandd_amd.engine import EngineError
+    eng = engine_factory(12, True)
+    paths, fas = [], []
+    for g in range(7):
+        fa = orc.synth_fasta(SEED, g, 30000 + 7000 * g, 1 + g % 3)
+        fas.append(fa)
+        if g % 3 == 0:
+            p = tmp_path / f"g{g}.fasta"
+            p.write_bytes(fa.tobytes())
+        elif g % 3 == 1:
+            p = tmp_path / f"g{g}.fa.gz"
+            p.write_bytes(gzip.compress(fa.tobytes()))
+        else:  # two gzip members back to back
+            p = tmp_path / f"g{g}.fna.gz"
+            raw = fa.tobytes()
+            p.write_bytes(gzip.compress(raw[:10000]) + gzip.compress(raw[10000:]))
+        paths.append(str(p))
+    got = eng.sketch_files(paths, 9, 14, nthreads=3)
+    for g, fa in enumerate(fas):
+        assert np.array_equal(got[g], orc.sketch_sweep(fa, 9, 14, 12)), g
+    assert np.array_equal(eng.sketch_fasta(paths[1], 9, 14), got[1])
+    with pytest.raises(EngineError):
+        eng.sketch_files(paths[:2] + [str(tmp_path / "nope.fa.gz")] + paths[2:], 9, 14, nthreads=2)
+    assert eng.sketch_files([], 9, 14).shape == (0, 6, 1 << 12)
