@@ -104,7 +104,7 @@ struct dd_ctx {
     std::vector<TimedSpan> spans[DD_KERNEL_COUNT];
     std::vector<hipEvent_t> pool;
     // workspaces
-    DevBuf tokens, scratch, tables, fasta, regs, ptrs, hist, est, ord, bitmaps;
+    DevBuf tokens, scratch, tables, fasta, regs, ptrs, hist, est, ord, bitmaps, exact;
     HostBuf stage;
     hipEvent_t stage_free = nullptr;  // signalled when the last upload from `stage` completed
     // stats of the last sketch call
@@ -275,7 +275,7 @@ void dd_destroy(dd_ctx* c) {
     for (auto e : c->pool) (void)hipEventDestroy(e);
     if (c->stage_free) (void)hipEventDestroy(c->stage_free);
     for (DevBuf* b : {&c->tokens, &c->scratch, &c->tables, &c->fasta, &c->regs, &c->ptrs, &c->hist,
-                      &c->est, &c->ord, &c->bitmaps})
+                      &c->est, &c->ord, &c->bitmaps, &c->exact})
         b->release();
     c->stage.release();
     delete c;
@@ -588,6 +588,126 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
     for (auto& t : pool) t.join();
     if (rc != DD_OK) return fail(rc, "%s", first_err.c_str());
     return DD_OK;
+}
+
+// ------------------------------------------------------------------------- exact count
+int dd_exact_count_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* nbytes, int n, int k,
+                          uint64_t* distinct) {
+    if (check_ctx(c)) return DD_EINVAL;
+    if (n < 0 || !distinct || (n && (!fasta_dev || !nbytes))) return fail(DD_EINVAL, "null argument");
+    if (k < 1 || k > 64) return fail(DD_EINVAL, "k=%d outside 1..64", k);
+    for (int g = 0; g < n; ++g) {
+        if (nbytes[g] && !fasta_dev[g]) return fail(DD_EINVAL, "input %d: null buffer", g);
+        if (reinterpret_cast<uintptr_t>(fasta_dev[g]) & 15)
+            return fail(DD_EINVAL, "input %d: device buffer must be 16-byte aligned", g);
+    }
+    *distinct = 0;
+    if (!n) return DD_OK;
+    DeviceGuard guard(c->device);
+    hipStream_t st = c->stream;
+    int rc;
+
+    // token streams (K0), laid out like dd_sketch_device does
+    std::vector<size_t> off_codes(n), off_bad(n), off_ntok(n), off_scratch(n);
+    size_t tot = 0, scratch_tot = 0, slots = 0, max_segments = 0, max_chunks = 0;
+    std::vector<unsigned long long> base(n);
+    for (int g = 0; g < n; ++g) {
+        off_codes[g] = tot;
+        tot += align_up(dd::codes_words(nbytes[g]) * 4, 256);
+        off_bad[g] = tot;
+        tot += align_up(dd::bad_words(nbytes[g]) * 4, 256);
+        off_ntok[g] = tot;
+        tot += 256;
+        off_scratch[g] = scratch_tot;
+        scratch_tot += align_up(dd::pack_scratch_bytes(nbytes[g]), 256);
+        base[g] = slots;
+        const size_t segs = (nbytes[g] + dd::kSegTokens - 1) / dd::kSegTokens;
+        slots += segs * dd::kSegTokens;
+        max_segments = std::max(max_segments, segs);
+        max_chunks = std::max(max_chunks, dd::pack_chunks(nbytes[g]));
+    }
+    if (!slots) return DD_OK;
+    const bool wide = k > 32;
+    const size_t key_bytes = slots * sizeof(uint64_t);
+    const size_t temp_bytes = dd::exact_sort_temp_bytes(slots, k);
+    const size_t arrays = wide ? 4 : 2;
+    if ((rc = c->tokens.reserve(tot))) return rc;
+    if ((rc = c->scratch.reserve(scratch_tot))) return rc;
+    if ((rc = c->exact.reserve(arrays * align_up(key_bytes, 256) + temp_bytes + 256))) return rc;
+    char* tb = static_cast<char*>(c->tokens.p);
+    char* sb = static_cast<char*>(c->scratch.p);
+    char* eb = static_cast<char*>(c->exact.p);
+    unsigned long long* counters = reinterpret_cast<unsigned long long*>(eb);
+    const size_t stride = align_up(key_bytes, 256);
+    uint64_t* lo = reinterpret_cast<uint64_t*>(eb + 256);
+    uint64_t* lo_alt = reinterpret_cast<uint64_t*>(eb + 256 + stride);
+    uint64_t* hi = wide ? reinterpret_cast<uint64_t*>(eb + 256 + 2 * stride) : nullptr;
+    uint64_t* hi_alt = wide ? reinterpret_cast<uint64_t*>(eb + 256 + 3 * stride) : nullptr;
+    void* temp = eb + 256 + arrays * stride;
+
+    std::vector<dd::PackGenome> ptab(n);
+    std::vector<dd::ExactGenome> etab(n);
+    for (int g = 0; g < n; ++g) {
+        dd::TokenStream ts{reinterpret_cast<uint32_t*>(tb + off_codes[g]), reinterpret_cast<uint32_t*>(tb + off_bad[g]),
+                           reinterpret_cast<unsigned long long*>(tb + off_ntok[g])};
+        ptab[g] = dd::PackGenome{fasta_dev[g], nbytes[g], dd::pack_chunks(nbytes[g]),
+                                 reinterpret_cast<long long*>(sb + off_scratch[g]), ts};
+        etab[g] = dd::ExactGenome{ts.codes, ts.bad, ts.ntok, base[g]};
+    }
+    const size_t pbytes = align_up(sizeof(dd::PackGenome) * n, 256), ebytes = align_up(sizeof(dd::ExactGenome) * n, 256);
+    if ((rc = c->tables.reserve(pbytes + ebytes))) return rc;
+    DD_HIP(hipEventSynchronize(c->stage_free));
+    if ((rc = c->stage.reserve(pbytes + ebytes))) return rc;
+    char* tdev = static_cast<char*>(c->tables.p);
+    if ((rc = upload(c, tdev, ptab.data(), sizeof(dd::PackGenome) * n, 0))) return rc;
+    if ((rc = upload(c, tdev + pbytes, etab.data(), sizeof(dd::ExactGenome) * n, pbytes))) return rc;
+    DD_HIP(hipEventRecord(c->stage_free, st));
+
+    DD_HIP(hipMemsetAsync(counters, 0, 256, st));
+    DD_HIP(hipMemsetAsync(lo, 0xFF, key_bytes, st));  // unwritten slots read as the all-ones sentinel
+    if (wide) DD_HIP(hipMemsetAsync(hi, 0xFF, key_bytes, st));
+    {
+        Span sp(c, DD_KERNEL_PACK);
+        dd::launch_pack_batch(reinterpret_cast<const dd::PackGenome*>(tdev), n, max_chunks, st);
+    }
+    dd::launch_kmer_extract(reinterpret_cast<const dd::ExactGenome*>(tdev + pbytes), n, max_segments, k,
+                            c->canonical, lo, hi, counters, st);
+    DD_HIP(hipGetLastError());
+    DD_HIP(dd::launch_exact_sort_count(lo, hi, lo_alt, hi_alt, slots, k, temp, temp_bytes, counters, st));
+    unsigned long long h[3] = {0, 0, 0};
+    DD_HIP(hipMemcpyAsync(h, counters, sizeof h, hipMemcpyDeviceToHost, st));
+    DD_HIP(hipStreamSynchronize(st));
+    // the all-ones group holds the sentinels of unwritten slots and/or genuine T^k k-mers
+    const bool sentinel_present = h[0] < (unsigned long long)slots, all_t = h[1] != 0;
+    *distinct = h[2] - ((sentinel_present || all_t) ? 1 : 0) + (all_t ? 1 : 0);
+    return DD_OK;
+}
+
+int dd_exact_count(dd_ctx* c, const char* const* paths, int n, int k, uint64_t* distinct) {
+    if (check_ctx(c)) return DD_EINVAL;
+    if (n < 0 || !distinct || (n && !paths)) return fail(DD_EINVAL, "null argument");
+    DeviceGuard guard(c->device);
+    std::vector<size_t> sizes(n), offs(n);
+    std::vector<std::vector<uint8_t>> bufs(n);
+    size_t tot = 0;
+    for (int i = 0; i < n; ++i) {
+        std::string err;
+        if (!paths[i] || !read_fasta_file(paths[i], bufs[i], err)) return fail(DD_EIO, "%s", err.c_str());
+        sizes[i] = bufs[i].size();
+        offs[i] = tot;
+        tot += align_up(sizes[i] + 16, 256);
+    }
+    int rc;
+    if ((rc = c->fasta.reserve(tot + 16))) return rc;
+    std::vector<const uint8_t*> ptrs(n);
+    for (int i = 0; i < n; ++i) {
+        ptrs[i] = static_cast<const uint8_t*>(c->fasta.p) + offs[i];
+        if (sizes[i])
+            DD_HIP(hipMemcpyAsync(const_cast<uint8_t*>(ptrs[i]), bufs[i].data(), sizes[i], hipMemcpyHostToDevice, c->stream));
+    }
+    DD_HIP(hipStreamSynchronize(c->stream));  // host vectors are pageable; release them before the sort
+    bufs.clear();
+    return dd_exact_count_device(c, ptrs.data(), sizes.data(), n, k, distinct);
 }
 
 // ------------------------------------------------------------------------------- union

@@ -99,6 +99,24 @@ void launch_pairwise(const uint8_t* leaf_dev, int n, int K, int log2m, uint32_t*
                      hipStream_t st);
 void launch_mle(const uint32_t* hist_dev, size_t njobs, int log2m, double* est_dev, hipStream_t st);
 
+// ---------------------------------------------------------------------------------------
+// exact distinct k-mer count (KMC stand-in): extract -> radix sort -> count distinct
+// ---------------------------------------------------------------------------------------
+struct ExactGenome {
+    const uint32_t* codes;
+    const uint32_t* bad;
+    const unsigned long long* ntok;
+    unsigned long long base;    // first slot of this genome in the k-mer arrays
+};
+// counters[0] += valid k-mers written, counters[1] |= 1 if a valid k-mer is all-ones (T^k, non-canonical)
+void launch_kmer_extract(const ExactGenome* tab_dev, int ng, size_t max_segments, int k, int canonical,
+                         uint64_t* lo, uint64_t* hi, unsigned long long* counters, hipStream_t st);
+size_t exact_sort_temp_bytes(size_t n, int k);
+// counters[2] += number of distinct values among the n slots (unwritten slots hold all-ones)
+hipError_t launch_exact_sort_count(uint64_t* lo, uint64_t* hi, uint64_t* lo_alt, uint64_t* hi_alt, size_t n,
+                                   int k, void* temp, size_t temp_bytes, unsigned long long* counters,
+                                   hipStream_t st);
+
 // synthetic FASTA
 void launch_synth(uint64_t seed, int gi, uint64_t nbases, int nrec, uint8_t* out_dev, hipStream_t st);
 size_t synth_size(uint64_t nbases, int nrec);

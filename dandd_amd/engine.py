@@ -23,6 +23,7 @@ EXPORTS = [
     "dd_sketch_buffer", "dd_sketch_fasta", "dd_sketch_files", "dd_sketch_device", "dd_union", "dd_union_device",
     "dd_card", "dd_card_batch", "dd_card_batch_device", "dd_hist_batch_device", "dd_ertl_mle",
     "dd_progressive", "dd_progressive_device", "dd_pairwise", "dd_pairwise_device",
+    "dd_exact_count", "dd_exact_count_device",
     "dd_timing_enable", "dd_timing_read", "dd_timing_reset", "dd_last_sketch_stats",
     "dd_synth_size", "dd_synth_fasta_device",
 ]
@@ -92,6 +93,10 @@ def load_library(path=None):
     lib.dd_pairwise.argtypes = [vp, vp, i32, i32, vp]
     lib.dd_pairwise_device.restype = i32
     lib.dd_pairwise_device.argtypes = [vp, vp, i32, i32, vp]
+    lib.dd_exact_count.restype = i32
+    lib.dd_exact_count.argtypes = [vp, C.POINTER(C.c_char_p), i32, i32, C.POINTER(u64)]
+    lib.dd_exact_count_device.restype = i32
+    lib.dd_exact_count_device.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), i32, i32, C.POINTER(u64)]
     lib.dd_timing_enable.restype = i32
     lib.dd_timing_enable.argtypes = [vp, i32]
     lib.dd_timing_read.restype = i32
@@ -262,6 +267,22 @@ class Engine:
         card = np.empty((n, n, K), dtype=np.float64)
         self._check(self._lib.dd_pairwise_device(self._ctx, C.c_void_p(int(leaf_ptr)), n, K, card.ctypes.data))
         return card
+
+    # -- exact distinct k-mer count (KMC stand-in) ----------------------------------------
+    def exact_count(self, paths, k):
+        """Distinct (canonical per the context) k-mers over all the FASTA files together."""
+        arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+        d = C.c_uint64()
+        self._check(self._lib.dd_exact_count(self._ctx, arr, len(paths), int(k), C.byref(d)))
+        return d.value
+
+    def exact_count_device(self, fasta_ptrs, nbytes, k):
+        n = len(fasta_ptrs)
+        ptrs = (C.c_void_p * n)(*[int(x) for x in fasta_ptrs])
+        ns = (C.c_size_t * n)(*[int(x) for x in nbytes])
+        d = C.c_uint64()
+        self._check(self._lib.dd_exact_count_device(self._ctx, ptrs, ns, n, int(k), C.byref(d)))
+        return d.value
 
     # -- measurement ----------------------------------------------------------------------
     def timing_enable(self, on=True):

@@ -48,6 +48,53 @@ def read_sketch_file(path):
     return regs, log2m, k, bool(canonical)
 
 
+class HipExactBackend:
+    """`--exact`: the KMC branch of the reference (lib/sketch_classes.py:377-465), which counts
+    distinct canonical k-mers exactly.  A "database" here is a small JSON file naming the FASTAs it
+    covers; the cardinality is computed on the GPU (sort + distinct, dd_exact_count).  The
+    reference's own KMC branch recurses forever at this commit; this one works."""
+
+    name = "hip-exact"
+
+    def __init__(self, log2m=20, canonical=True, device=0):
+        from ..engine import Engine
+        self.canonical = bool(canonical)
+        self.engine = Engine(device=device, log2m=14, canonical=self.canonical)
+
+    def describe(self, op, **kw):
+        args = " ".join(f"{k}={v}" for k, v in kw.items())
+        return f"hip-exact:{op} canonical={int(self.canonical)} {args}".strip()
+
+    @staticmethod
+    def _write(path, k, fastas):
+        import json
+        tmp = path + ".tmp"
+        with open(tmp, "w") as f:
+            json.dump({"k": int(k), "fastas": sorted(set(fastas))}, f)
+        os.replace(tmp, path)
+
+    @staticmethod
+    def _read(path):
+        import json
+        with open(path) as f:
+            return json.load(f)
+
+    def leaf(self, fasta, ks, out_paths):
+        for k, out in zip(ks, out_paths):
+            self._write(out, k, [os.path.abspath(fasta)])
+
+    def union(self, in_paths, out_path):
+        parts = [self._read(p) for p in in_paths]
+        self._write(out_path, parts[0]["k"], [f for p in parts for f in p["fastas"]])
+
+    def card(self, path):
+        db = self._read(path)
+        return float(self.engine.exact_count(db["fastas"], db["k"]))
+
+    def close(self):
+        self.engine.close()
+
+
 class HipBackend:
     """GPU backend: fused k-sweep leaf sketches, byte-max unions, Ertl-MLE cardinalities."""
 

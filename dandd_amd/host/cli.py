@@ -18,15 +18,16 @@ def tree_command(args):
     if not args.sketchdir:
         args.sketchdir = os.path.join(args.outdir, "sketchdb")
         os.makedirs(args.sketchdir, exist_ok=True)
-    if args.exact:
-        sys.exit("ERROR: --exact (KMC) is not part of this engine; the reference's own --exact path "
-                 "recurses forever at this commit (lib/sketch_classes.py:289 <-> :413).")
+    tool = "dashing"
+    if args.exact:  # exact distinct k-mer counts on the GPU (the reference's KMC branch, :51-53)
+        tool = "kmc"
+        args.registers = 20
     ksweep = (int(args.mink), int(args.maxk)) if args.ksweep else None
     os.makedirs(args.outdir, exist_ok=True)
     tree = deltatree.create_delta_tree(
         tag=args.tag, genomedir=args.genomedir, sketchdir=args.sketchdir, kstart=args.kstart,
         nchildren=args.nchildren, registers=int(args.registers), flist_loc=args.flist_loc,
-        canonicalize=args.canonicalize, tool="dashing", debug=args.debug, nthreads=int(args.nthreads),
+        canonicalize=args.canonicalize, tool=tool, debug=args.debug, nthreads=int(args.nthreads),
         safety=args.safety, fast=args.fast, verbose=args.verbose, ksweep=ksweep, lowmem=args.lowmem)
     prefix = tree.make_prefix(outdir=args.outdir, tag=args.tag, label=args.label)
     tree.save(fileprefix=prefix, fast=args.fast)

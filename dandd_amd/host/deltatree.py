@@ -39,13 +39,16 @@ def set_backend_factory(factory):
 
 
 def backend_for(experiment):
-    key = (int(experiment["registers"]), bool(experiment["canonicalize"]))
+    exact = experiment.get("tool") == "kmc"
+    key = (int(experiment["registers"]), bool(experiment["canonicalize"]), exact)
     if key not in _backends:
         if _backend_factory is not None:
-            _backends[key] = _backend_factory(*key)
+            _backends[key] = _backend_factory(key[0], key[1])
         else:
-            from .backend import HipBackend  # fails loudly without libdandd_hip.so / a gfx950 GPU
-            _backends[key] = HipBackend(log2m=key[0], canonical=key[1])
+            # both fail loudly without libdandd_hip.so / a gfx950 GPU
+            from .backend import HipBackend, HipExactBackend
+            cls = HipExactBackend if exact else HipBackend
+            _backends[key] = cls(log2m=key[0], canonical=key[1])
     return _backends[key]
 
 

@@ -108,6 +108,15 @@ int dd_pairwise(dd_ctx *, const uint8_t *leaf /*[n][K][m]*/, int n, int K,
                 double *card /*[n][n][K]*/);
 int dd_pairwise_device(dd_ctx *, const uint8_t *leaf_dev, int n, int K, double *card);
 
+/* ---- exact distinct k-mer count (the KMC stand-in) --------------------------------------
+ * Replaces   kmc -ci1 -cs2 -k<K> [-b] -fm <fasta> <db> <tmp>   +   kmc_tools complex (set union)
+ * +   kmc_tools info <db> | grep 'total k-mers'   (lib/sketch_classes.py:395,444-448,453-465):
+ * number of distinct (canonical, per the context) k-mers over ALL n inputs together, k in 1..64.
+ * Uses 16 (k<=32) or 32 (k>32) bytes of HBM per input byte. */
+int dd_exact_count_device(dd_ctx *, const uint8_t *const *fasta_dev, const size_t *nbytes, int n,
+                          int k, uint64_t *distinct);
+int dd_exact_count(dd_ctx *, const char *const *paths, int n, int k, uint64_t *distinct);
+
 /* ---- measurement hooks (bench.py) -------------------------------------------------
  * When enabled, every launch of kernel `which` is bracketed by HIP events on the
  * context's stream.  dd_timing_read synchronises the stream and returns the summed

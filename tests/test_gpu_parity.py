@@ -238,3 +238,27 @@ def test_sketch_files_gz_and_plain(engine_factory, orc, tmp_path):
     with pytest.raises(EngineError):
         eng.sketch_files(paths[:2] + [str(tmp_path / "nope.fa.gz")] + paths[2:], 9, 14, nthreads=2)
     assert eng.sketch_files([], 9, 14).shape == (0, 6, 1 << 12)
+
+
+@pytest.mark.parametrize("canonical", [True, False])
+def test_exact_count_matches_oracle(engine_factory, orc, tmp_path, canonical):
+    """GPU exact distinct-k-mer counter (KMC stand-in) == the oracle's sort+unique, single files and
+    unions, k across the 64/128-bit boundary, T^k edge cases in non-canonical mode."""
+    eng = engine_factory(12, canonical)
+    fas = [orc.synth_fasta(SEED, g, 40000 + 9000 * g, 1 + g) for g in range(3)]
+    poly = np.frombuffer(b">p\n" + b"T" * 200 + b"\nACGTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTT\n", dtype=np.uint8)
+    fas.append(poly)
+    paths = []
+    for i, fa in enumerate(fas):
+        p = tmp_path / f"e{i}.fasta"
+        p.write_bytes(fa.tobytes())
+        paths.append(str(p))
+    for k in (1, 4, 11, 16, 21, 31, 32, 33, 40, 63, 64):
+        for sel in ([0], [3], [0, 1, 2], [1, 3]):
+            want = orc.exact_count([fas[i] for i in sel], k, canonical)
+            got = eng.exact_count([paths[i] for i in sel], k)
+            assert got == want, (k, sel, got, want)
+    empty = tmp_path / "empty.fasta"
+    empty.write_bytes(b">nothing\n")
+    assert eng.exact_count([str(empty)], 5) == 0
+    assert eng.exact_count([], 5) == 0

@@ -44,6 +44,26 @@ def test_cli_rows_match_reference_on_gpu(host, tmp_path, torch_cuda):
     assert not diffs, "\n".join(diffs[:40])
 
 
+@pytest.mark.gpu
+def test_cli_exact_on_gpu_matches_exact_goldens(host, tmp_path, torch_cuda):
+    """`tree --exact` (GPU sort+distinct behind the KMC branch) gives the cards/deltas/argmax-k that the
+    reference's orchestration produced over an exact counter (ref_exact.json); only names differ."""
+    import shutil
+    from dandd_amd.host import cli
+    gold = _golden("ref_exact.json")["scenarios"]["tree_spider_k10"]
+    host.set_backend_factory(None)
+    data = os.path.join(str(tmp_path), "data")
+    shutil.copytree(os.path.join(hostcheck.GOLD, "fasta"), data)
+    out = os.path.join(str(tmp_path), "o")
+    cli.main(["tree", "-d", data, "-o", out, "-s", "gold", "-k", "10", "--exact"])
+    rows = hostcheck.read_rows(os.path.join(out, "gold_5_kmc_deltas.csv"))
+    assert len(rows) == len(gold)
+    for r, w in zip(rows, gold):
+        for key in ("card", "delta", "k", "ngen", "title", "fastas"):
+            assert hostcheck.same_cell(r[key], w[key]), (key, r[key], w[key])
+        assert r["sketchloc"].endswith(f"_k{w['k']}") or "n5k" in r["sketchloc"]
+
+
 def test_second_run_is_served_from_cache(host, tmp_path):
     """All caches warm -> no backend call at all (the reference launches zero subprocesses)."""
     gold = _golden("ref_hll.json")
