@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--log2m", type=int, default=14)
     ap.add_argument("--nrec", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-accuracy", action="store_true")
     ap.add_argument("--cpu-sample-mbp", type=float, default=16.0)
     args = ap.parse_args()
 
@@ -156,6 +157,23 @@ def main():
 
     dt = ddist.max_over_ranks(dt, device="cuda")
 
+    # accuracy half of the metric (outside the timed region, rank 0): delta of genome 0 from the HLL
+    # sweep vs delta from the GPU exact counter (the KMC --exact stand-in) over the same k range
+    accuracy = None
+    if rank == 0 and not args.no_accuracy:
+        card0 = eng.card_batch_device(regs[0].data_ptr(), K)
+        exact0 = np.array([eng.exact_count_device([ptrs[0]], [nbytes], k) for k in range(kmin, kmax + 1)],
+                          dtype=np.float64)
+        d_hll, d_exact = (card0 / ks).max(), (exact0 / ks).max()
+        accuracy = {
+            "delta_hll": float(d_hll), "delta_exact": float(d_exact),
+            "delta_rel_err": float(abs(d_hll - d_exact) / d_exact),
+            "argmax_k_hll": int((card0 / ks).argmax() + kmin), "argmax_k_exact": int((exact0 / ks).argmax() + kmin),
+            "max_card_rel_err_over_k": float(np.max(np.abs(card0 - exact0) / exact0)),
+            "hll_sigma": 1.04 / float(np.sqrt(m)),
+            "what": "genome 0, exact = GPU sort+distinct of canonical k-mers (dd_exact_count_device)",
+        }
+
     if rank == 0:
         steps = args.steps
         total_bases = world * ng * nb * steps
@@ -203,6 +221,8 @@ def main():
             "delta_genome0": float(delta[0]), "argmax_k_genome0": int(bestk[0]),
             "delta_root": float(delta[ng]), "argmax_k_root": int(bestk[ng]),
         }
+        if accuracy is not None:
+            out["accuracy_vs_exact"] = accuracy
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

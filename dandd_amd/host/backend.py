@@ -132,5 +132,24 @@ class HipBackend:
             raise ValueError(f"{path}: log2m {log2m} does not match the backend's {self.log2m}")
         return float(self.engine.card(regs))
 
+    # ---- whole union schedules in one launch (no reference equivalent: the reference runs one
+    # `dashing union` + one `dashing card` process per (set, k)) -----------------------------------
+    def _leaf_slab(self, leaf_paths):
+        """leaf_paths[n][K] -> uint8 [n][K][m]"""
+        n, K = len(leaf_paths), len(leaf_paths[0])
+        slab = np.empty((n, K, 1 << self.log2m), dtype=np.uint8)
+        for i, row in enumerate(leaf_paths):
+            for kk, p in enumerate(row):
+                slab[i, kk] = read_sketch_file(p)[0]
+        return slab
+
+    def pairwise_cards(self, leaf_paths):
+        """|leaf_i U leaf_j| for all pairs and every k column: float64 [n][n][K]"""
+        return self.engine.pairwise(self._leaf_slab(leaf_paths))
+
+    def progressive_cards(self, leaf_paths, orderings):
+        """|union of the first j+1 leaves of ordering o| : float64 [o][n][K]"""
+        return self.engine.progressive(self._leaf_slab(leaf_paths), orderings)
+
     def close(self):
         self.engine.close()

@@ -138,7 +138,10 @@ class Sketch:
         op = "sketch" if self.sfp.ngen == 1 else "union"
         self.cmd = be.describe(op, k=self.kval, out=os.path.basename(self.sfp.full)) if hasattr(be, "describe") else op
         if just_do_it or not self.sketch_check():
-            if just_do_it or not (self.experiment["lowmem"] and self.check_cardinality() > 0):
+            # a union whose cardinality was already computed by a batched GPU schedule
+            # (prefetch_union_cards) is not materialised as a file, exactly like --lowmem
+            trusted = self.experiment["lowmem"] or (self.sfp.ngen > 1 and self.experiment.get("prefetched"))
+            if just_do_it or not (trusted and self.check_cardinality() > 0):
                 self._build()
         self.sketch = self.sfp.full
         return self.sketch
@@ -228,7 +231,8 @@ class DeltaTreeNode:
             path = template.with_k(k)
             if sketch_exists(path):
                 continue
-            if self.experiment["lowmem"] and self.ngen > 1 and float(cards.get(path) or 0) > 0:
+            if (self.experiment["lowmem"] or self.experiment.get("prefetched")) and self.ngen > 1 \
+                    and float(cards.get(path) or 0) > 0:
                 continue
             todo.append(k)
         if not todo:
@@ -440,6 +444,65 @@ class DeltaTree:
         for node in self._dt:
             node.node_ksweep(mink=mink, maxk=maxk)
 
+    # ---- batched GPU union schedules ------------------------------------------------------------------
+    def _leaf_files(self, leaves, lo, hi):
+        """Make sure every leaf has its sketch file for k in [lo, hi] (one fused GPU pass per leaf)
+        and return the paths as [leaf][k]."""
+        rows = []
+        for leaf in leaves:
+            leaf.ksweep_update_node(lo, hi)
+            tmpl = leaf.ksketches[0].sfp
+            rows.append([tmpl.with_k(k) for k in range(lo, hi + 1)])
+        return rows
+
+    def prefetch_union_cards(self, groups, lo, hi, experiment):
+        """Cardinalities of the unions `groups` (lists of leaf nodes) for k in [lo, hi], computed by
+        ONE batched GPU launch per schedule instead of one union + one card per (set, k), and stored
+        in the cardinality cache under the names the union sketches would have.  A backend without
+        batch entry points (the CPU checkers used in tests) makes this a no-op."""
+        be = backend_for(experiment)
+        if lo < 1 or hi < lo or not groups or os.environ.get("DD_NO_PREFETCH"):
+            return 0
+        pair_mode = all(len(g) == 2 for g in groups)
+        if not hasattr(be, "pairwise_cards" if pair_mode else "progressive_cards"):
+            return 0
+        leaves = []
+        for g in groups:
+            for leaf in g:
+                if leaf not in leaves:
+                    leaves.append(leaf)
+        index = {id(leaf): i for i, leaf in enumerate(leaves)}
+        paths = self._leaf_files(leaves, lo, hi)
+        cards = self.speciesinfo.cardkey
+        filled = 0
+        if pair_mode:
+            table = be.pairwise_cards(paths)
+            for a, b in groups:
+                for kk, k in enumerate(range(lo, hi + 1)):
+                    sfp = SketchPath([a.fastas[0], b.fastas[0]], k, self.speciesinfo, experiment)
+                    cards[sfp.full] = float(table[index[id(a)], index[id(b)], kk])
+                    filled += 1
+        else:
+            # every group is treated as an ordering; prefixes of length >= 2 are unions
+            n = len(leaves)
+            ords, used = [], []
+            for g in groups:
+                if len(g) == n:
+                    ords.append([index[id(leaf)] for leaf in g])
+                    used.append(g)
+            if not ords:
+                return 0
+            table = be.progressive_cards(paths, ords)
+            for o, g in enumerate(used):
+                for j in range(1, n):
+                    fastas = [leaf.fastas[0] for leaf in g[: j + 1]]
+                    for kk, k in enumerate(range(lo, hi + 1)):
+                        sfp = SketchPath(fastas, k, self.speciesinfo, experiment)
+                        cards[sfp.full] = float(table[o, j, kk])
+                        filled += 1
+        experiment["prefetched"] = True
+        return filled
+
     # ---- progressive unions (lib/huffman_dandd.py:574-663) -------------------------------------------
     def orderings_list(self, ordering_file=None, flist_loc=None, count=0):
         fastas = self.fastas
@@ -474,6 +537,18 @@ class DeltaTree:
 
     def progressive_union(self, flist, orderings, step):
         spider = DeltaSpider(fasta_files=flist, speciesinfo=self.speciesinfo, experiment=self.experiment)
+        # all prefix unions of all orderings in one GPU launch (running max == flat union)
+        if step == 1 and len(flist) > 1:
+            by_fasta = {leaf.fastas[0]: leaf for leaf in spider.leaf_nodes()}
+            if self.experiment["ksweep"] is not None:
+                lo, hi = self.experiment["ksweep"]
+            else:  # the hill-climbs stay within a few k of the leaves' and the root's argmax
+                lo = max(1, min(leaf.bestk for leaf in by_fasta.values()) - 2)
+                hi = spider.root.bestk + 3
+                if self.experiment["tool"] == "dashing":
+                    hi = min(hi, 32)
+            groups = [[by_fasta[spider.fastas[j]] for j in ordering] for ordering in orderings]
+            spider.prefetch_union_cards(groups, int(lo), int(hi), self.experiment)
         results, summary = [], []
         for i, ordering in enumerate(orderings):
             if self.experiment["verbose"]:
@@ -483,6 +558,7 @@ class DeltaTree:
             summary.extend(srows)
             self.speciesinfo.save_references(fast=self.experiment["fast"])
             self.speciesinfo.save_cardkey(tool=self.experiment["tool"], fast=self.experiment["fast"])
+        self.experiment.pop("prefetched", None)  # the trust flag must not outlive this run (the tree is pickled)
         return results, summary
 
     def sketch_ordering(self, ordering, ordering_number, step=1):
@@ -516,6 +592,11 @@ class DeltaTree:
                       "using --mink and --maxk, the --jaccard flag will be ignored.")
                 jaccard = False
         kij_rows, j_rows = [], []
+        # every 2-way union of every pair at every k in one GPU launch
+        if mink and maxk and len(leaves) > 1:
+            hi = min(int(maxk), 32) if self.experiment["tool"] == "dashing" else int(maxk)
+            self.prefetch_union_cards([[a, b] for i, a in enumerate(leaves) for b in leaves[i + 1:]],
+                                      int(mink), hi, pair_exp)
         for i, a in enumerate(leaves):
             for b in leaves[i + 1:]:
                 pair = SubSpider([a, b], self.speciesinfo, pair_exp)

@@ -42,6 +42,17 @@ def test_cli_rows_match_reference_on_gpu(host, tmp_path, torch_cuda):
     got = hostcheck.run_scenarios(str(tmp_path), gold["registers"])
     diffs = hostcheck.compare(got, gold["scenarios"])
     assert not diffs, "\n".join(diffs[:40])
+    # progressive prefixes and kij pairs went through the batched GPU schedules: their 2-way union
+    # sketches were never materialised as files, yet their cardinalities are in the cache
+    import glob
+    import pickle
+    sk = os.path.join(str(tmp_path), "t1", "sketchdb")
+    assert glob.glob(os.path.join(sk, "ngen5", "k*", "*.hll"))          # tree root: file-based
+    for k in range(8, 13):                                              # pairs in the prefetched k range
+        assert not glob.glob(os.path.join(sk, "ngen2", f"k{k}", "*.hll")), k
+    with open(os.path.join(sk, "gold_dashing_cardinalities.pickle"), "rb") as f:
+        cards = pickle.load(f)
+    assert sum(1 for p in cards if os.sep + "ngen2" + os.sep in p) >= 10 * 5
 
 
 @pytest.mark.gpu
