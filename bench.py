@@ -174,6 +174,19 @@ def main():
             "what": "genome 0, exact = GPU sort+distinct of canonical k-mers (dd_exact_count_device)",
         }
 
+    # HBM-side traffic of K1 per step: PMC counters cannot be read from inside this process, so the
+    # number comes from the committed rocprofv3 passes (profiles/traffic.json, made by
+    # scripts/make_traffic.py) and is only reported when this run's workload is the profiled one.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            tj = json.load(f)
+        w = tj["workload"]
+        if (w["genomes"], w["mbp"], w["kmin"], w["kmax"], w["log2m"]) == (args.genomes, args.mbp, args.kmin, args.kmax, args.log2m):
+            traffic = tj["k1_bytes_per_step"]["total"]
+    except (OSError, KeyError, ValueError):
+        pass
+
     if rank == 0:
         steps = args.steps
         total_bases = world * ng * nb * steps
@@ -208,7 +221,10 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_note": "K1 bytes per step from profiles/traffic.json (2 x FETCH_SIZE + WRITE_SIZE, separate PMC passes); "
+                                "above the algorithmic bytes because each k-group re-reads the 3-bit token stream and every job "
+                                "merges its LDS registers into the slab -- irrelevant to a VALU-bound kernel (220 GB/s)",
                 "algorithmic_bytes_per_step": alg_bytes,
                 "kernel_ms_per_step": sweep_ms / steps,
                 "launches_per_step": sweep_n / steps,

@@ -240,6 +240,38 @@ def test_sketch_files_gz_and_plain(engine_factory, orc, tmp_path):
     assert eng.sketch_files([], 9, 14).shape == (0, 6, 1 << 12)
 
 
+def test_full_size_properties_cfg2(engine_factory, torch_cuda, orc):
+    """BASELINE cfg 2 genome size (50 Mbp, k 4..40, log2m 14): too big for the oracle sweep, so check
+    size-independent properties instead: sketch(whole) == max(sketch(records 0-1), sketch(records 2-4)),
+    device-generated FASTA == host-generated, exact-count(whole) == exact-count(two parts as a union),
+    run-to-run determinism, and HLL estimate within 4 sigma of the exact count."""
+    torch = torch_cuda
+    from dandd_amd.engine import synth_size
+    eng = engine_factory(14, True)
+    nb, nrec = 50_000_000, 5
+    fa = orc.synth_fasta(SEED, 0, nb, nrec)
+    starts = [i for i in np.flatnonzero(fa == ord(">"))]
+    assert len(starts) == nrec
+    cut = starts[2]
+    dev = torch.empty(synth_size(nb, nrec) + 16, dtype=torch.uint8, device="cuda")
+    eng.synth_fasta_device(SEED, 0, nb, nrec, dev.data_ptr())
+    eng.synchronize()
+    assert np.array_equal(dev[: fa.size].cpu().numpy(), fa)
+    whole = eng.sketch_buffer(fa, 4, 40)
+    assert np.array_equal(whole, eng.sketch_buffer(fa, 4, 40))
+    a, b = eng.sketch_buffer(fa[:cut], 4, 40), eng.sketch_buffer(fa[cut:], 4, 40)
+    assert np.array_equal(np.maximum(a, b), whole)
+    assert np.array_equal(eng.union([a, b]), whole)
+    pa = torch.from_numpy(fa[:cut].copy()).cuda()
+    pb = torch.from_numpy(fa[cut:].copy()).cuda()
+    for k in (12, 31):
+        exact_whole = eng.exact_count_device([dev.data_ptr()], [fa.size], k)
+        exact_parts = eng.exact_count_device([pa.data_ptr(), pb.data_ptr()], [pa.numel(), pb.numel()], k)
+        assert exact_whole == exact_parts
+        est = eng.card(whole[k - 4])
+        assert abs(est - exact_whole) / exact_whole < 4 * 1.04 / np.sqrt(eng.m)
+
+
 @pytest.mark.parametrize("canonical", [True, False])
 def test_exact_count_matches_oracle(engine_factory, orc, tmp_path, canonical):
     """GPU exact distinct-k-mer counter (KMC stand-in) == the oracle's sort+unique, single files and
