@@ -10,6 +10,7 @@ integer addresses (e.g. `torch.Tensor.data_ptr()`), so no torch type crosses the
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -42,6 +43,16 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (same SONAME as
+    # /opt/rocm's).  If this library were loaded first it would pull in the system copy, a later
+    # `import torch` would add the bundled one, and the second runtime to initialise reports "no
+    # ROCm-capable device".  Importing torch first (when it is installed) makes the dynamic loader
+    # resolve our NEEDED libamdhip64.so.7 to the copy torch already mapped.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     if not os.path.exists(p):
         raise EngineError(
             f"{p} not found: build it with `python -m dandd_amd.build` (hipcc, gfx950). "
