@@ -120,6 +120,14 @@ class HipBackend:
         for k, out in zip(ks, out_paths):
             write_sketch_file(out, regs[k - kmin], self.log2m, k, self.canonical)
 
+    def leaf_many(self, fastas, kmin, kmax, path_of):
+        """Sketch MANY FASTAs over [kmin, kmax] through the ingestion pipeline (loader threads read and
+        inflate ahead of the GPU) and store every (fasta, k) sketch at path_of(fasta_index, k)."""
+        regs = self.engine.sketch_files(list(fastas), kmin, kmax)
+        for i in range(len(fastas)):
+            for k in range(kmin, kmax + 1):
+                write_sketch_file(path_of(i, k), regs[i, k - kmin], self.log2m, k, self.canonical)
+
     def union(self, in_paths, out_path):
         parts = [read_sketch_file(p) for p in in_paths]
         k = parts[0][2]

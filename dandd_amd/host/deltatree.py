@@ -352,12 +352,42 @@ class DeltaTree:
         else:
             node.node_ksweep(mink=self.mink, maxk=self.maxk)
 
+    def _presketch_leaves(self, leaves, radius=3):
+        """Leaf sketches for the ks the per-leaf searches are about to ask for -- the whole ksweep
+        range, or kstart +- radius for the hill-climb -- made for ALL leaves by one pipelined batch
+        (files are read/inflated ahead while the GPU sketches) instead of genome by genome
+        (the reference's loop, lib/huffman_dandd.py:402-407, is strictly sequential).  Purely a cache
+        warm-up: a search that leaves the window falls back to the per-leaf path."""
+        be = backend_for(self.experiment)
+        if not hasattr(be, "leaf_many") or len(leaves) < 2 or os.environ.get("DD_NO_PREFETCH"):
+            return
+        if self.experiment["ksweep"] is not None:
+            lo, hi = (int(v) for v in self.experiment["ksweep"])
+        else:
+            lo, hi = max(1, int(self.speciesinfo.kstart) - radius), int(self.speciesinfo.kstart) + radius
+            if self.experiment["tool"] == "dashing":
+                hi = min(hi, 32)
+        lo = max(lo, 1)
+        if hi < lo:
+            return
+        todo, templates = [], []
+        for leaf in leaves:
+            tmpl = SketchPath(leaf.fastas, 0, self.speciesinfo, self.experiment)
+            if any(not sketch_exists(tmpl.with_k(k)) for k in range(lo, hi + 1)):
+                for k in range(lo, hi + 1):
+                    os.makedirs(tmpl.dir.replace("{}", str(k)), exist_ok=True)
+                todo.append(leaf.fastas[0])
+                templates.append(tmpl)
+        if len(todo) > 1:
+            be.leaf_many(todo, lo, hi, lambda i, k: templates[i].with_k(k))
+
     def _build_tree(self, symbol, nchildren, leafnodes=()):
         """Leaves first (in the order given; the sort by ngen is stable), then unions of `nchildren`
         consecutive nodes, each new union inserted behind the nodes that are not larger than it
         (lib/huffman_dandd.py:377-438, including its end-of-list widening of the last union)."""
         nodes = list(leafnodes) or [DeltaTreeNode(s, [], self.speciesinfo, self.experiment) for s in symbol]
         nodes.sort()
+        self._presketch_leaves(nodes)
         for leaf in nodes:
             self._solve(leaf)
         self._dt = nodes
