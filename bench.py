@@ -69,6 +69,26 @@ def cpu_baseline(nbases, nrec, kmin, kmax, log2m):
     }
 
 
+def valu_bound(kmin, kmax, updates_per_s):
+    """The bound that actually binds K1: VALU issue.  Instructions per (token, k) are the PMC counts of
+    profiles/r01_v3_pmc.txt (SQ_INSTS_VALU / wave-steps) per k class; a wave64 instruction occupies a
+    SIMD-32 for 2 cycles at best, so the chip retires at most 256 CU x 4 SIMD x 2.4 GHz / 2 wave
+    instructions per second (= 78.6 T lane-ops/s)."""
+    per_class = [(1, 9, 10.8), (10, 16, 31.7), (17, 32, 37.6), (33, 64, 56.7)]
+    tot = n = 0
+    for lo, hi, instr in per_class:
+        ks = max(0, min(hi, kmax) - max(lo, kmin) + 1)
+        tot += ks * instr
+        n += ks
+    ipu = tot / max(1, n)
+    achieved = updates_per_s * ipu  # lane-instructions per second
+    return {"valu_instr_per_update": ipu, "achieved_lane_instr_per_s": achieved,
+            "peak_lane_instr_per_s": VALU_PEAK_LANEOPS, "frac": achieved / VALU_PEAK_LANEOPS,
+            "note": "peak assumes every instruction is in the 2-cycle class; two thirds of K1's are in the "
+                    "4-cycle class on gfx950 (64-bit shifts/adds, v_mad_u64_u32, v_mul_lo, v_cmp, v_ffbh), "
+                    "against that mix the kernel runs at ~98 % of issue (DESIGN.md section 4)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -231,6 +251,7 @@ def main():
                 "avg_launch_ms": sweep_ms / max(1, sweep_n),
                 "register_updates_per_s": updates_per_s,
                 "valu_lane_ops_peak": VALU_PEAK_LANEOPS,
+                "valu_bound": valu_bound(kmin, kmax, updates_per_s),
                 "note": "integer-VALU bound (hash per (base,k)); see DESIGN.md for ops/update and the VALU fraction",
             },
             "other_kernels_ms_per_step": {"pack_K0": pack_ms / steps, "union_hist_K2": union_ms / steps},
