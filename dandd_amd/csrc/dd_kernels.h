@@ -20,7 +20,8 @@ struct TokenStream {
 };
 
 constexpr int kPackThreads = 256;
-constexpr int kPackChunk = kPackThreads * 16;  // bytes of FASTA per K0 workgroup
+constexpr int kPackBytesPerThread = 64;
+constexpr int kPackChunk = kPackThreads * kPackBytesPerThread;  // 16 KiB of FASTA per K0 workgroup
 constexpr int kSegTokens = 64;                 // tokens per K1 thread segment
 
 // scratch for one K0 run over n bytes: 4 x int64 per chunk

@@ -6,22 +6,31 @@
 // every record boundary becomes a BREAK that resets the k-mer windows.  The oracle's
 // statement of the same rules is oracle/dd_oracle.c:orc_tokenize.
 //
-// HBM-bound: reads each FASTA byte twice (stats pass + write pass; the second pass of a
-// <=256 MiB genome is served by the Infinity Cache) and writes 3 bits per token.  Three launches:
-//   pack_stats  : per 4 KiB chunk -> last newline position, token counts under both
-//                 possible incoming line states (inside a header line / inside sequence)
-//   pack_scan   : one workgroup; running max of newline positions + exclusive sum of token
-//                 counts over chunks (decides each chunk's incoming state by looking at the
-//                 byte after the last newline before it)
-//   pack_write  : per chunk -> tokens staged in LDS, packed 16/32 per word, partial boundary
-//                 words merged with atomicOr (pack_scan zeroed them)
+// The only state that crosses a byte is "am I inside a header line" (1 bit).  A span of bytes
+// acts on that bit as IDENTITY (no newline and no line start in it), or as a CONSTANT (it contains a
+// newline, or starts at a line start: its end state is then decided locally).  Spans compose like
+// that at every level: 64-byte thread spans inside a wave (two ballots and a find-first-set),
+// waves inside a 16 KiB chunk (LDS), chunks inside a genome (pack_scan).  Three launches, batched
+// over all genomes of a call (gridDim.y = genome):
+//   pack_stats : per chunk -> its IDENTITY/CONSTANT summary and its token count under both
+//                possible incoming states
+//   pack_scan  : one workgroup per genome: incoming state and exclusive token offset of every chunk
+//   pack_write : per chunk -> each thread assembles its tokens in registers (32-bit code pieces,
+//                16-bit BREAK pieces), ORs them into the chunk's LDS image at their final bit
+//                positions, the image is copied out; only the first and last word of a chunk can be
+//                shared with a neighbour and go out through atomicOr (pack_scan zeroed them)
+// HBM-bound by design (1 B read twice + 0.375 B written per base); see DESIGN.md for the measured rate.
 #include "dd_common.h"
 #include "dd_kernels.h"
 
 namespace dd {
 namespace {
 
-constexpr int T = kPackThreads;
+constexpr int T = kPackThreads;        // 256 threads = 4 waves
+constexpr int SUB = kPackBytesPerThread / 16;  // 16-byte pieces per thread
+constexpr int NW = T / 64;
+
+enum : int { KIND_ID = 0, KIND_C0 = 1, KIND_C1 = 2 };  // action of a span on the "in header" bit
 
 DD_D uint32_t base_code(uint32_t c) {
     uint32_t x = c | 0x20u;
@@ -33,7 +42,7 @@ struct Bytes16 {
     DD_D uint32_t at(int i) const { return (w[i >> 2] >> ((i & 3) * 8)) & 0xFFu; }
 };
 
-// 16 bytes of this thread; bytes at or beyond n read as '\r' (emits nothing, changes nothing)
+// 16 bytes; bytes at or beyond n read as '\r' (emits nothing, changes nothing)
 DD_D Bytes16 load16(const uint8_t* fa, size_t n, size_t pos) {
     Bytes16 b;
     if (pos + 16 <= n) {
@@ -55,28 +64,47 @@ DD_D Bytes16 load16(const uint8_t* fa, size_t n, size_t pos) {
     return b;
 }
 
-// Line state machine over the thread's 16 bytes (same rules as orc_tokenize).
-//   prev_nl : the byte before this thread's first byte is '\n' (or there is none)
-//   hdr_in  : this thread starts inside a header line (ignored when prev_nl)
-template <bool EMIT>
-DD_D int scan16(const Bytes16& b, bool prev_nl, bool hdr_in, uint8_t* out) {
+// Line state carried through a thread's bytes (same rules as orc_tokenize), plus the two tallies
+// that make one pass enough: tokens emitted before the first newline (they exist only if the span was
+// entered OUTSIDE a header) and tokens emitted from the first newline on (independent of how it was entered).
+struct LineState {
+    bool hdr;      // inside a header line
+    bool ls;       // next byte is the first of a line
+    bool seen_nl;  // a newline has been consumed
+    int pre, rest;
+};
+
+// Tokens of 16 bytes.  PACK: also assemble them (codes: token j at bits 2j..2j+1, bad: bit j).
+template <bool PACK>
+DD_D int scan16(const Bytes16& b, LineState& s, uint32_t& codes, uint32_t& bad) {
     int cnt = 0;
-    bool hdr = hdr_in, ls = prev_nl;
+    if (PACK) {
+        codes = 0;
+        bad = 0;
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        uint32_t c = b.at(i);
-        if (ls) hdr = (c == '>');
+        const uint32_t c = b.at(i);
+        if (s.ls) s.hdr = (c == '>');
         if (c == '\n') {
-            if (hdr) {
-                if (EMIT) out[cnt] = 4;
+            if (s.hdr) {  // one BREAK per header line
+                if (PACK) bad |= 1u << cnt;
                 ++cnt;
+                if (!PACK) ++s.rest;
             }
-            hdr = false;
-            ls = true;
+            s.hdr = false;
+            s.ls = true;
+            s.seen_nl = true;
         } else {
-            ls = false;
-            if (!(hdr || c == '\r')) {
-                if (EMIT) out[cnt] = (uint8_t)base_code(c);
+            s.ls = false;
+            if (!(s.hdr || c == '\r')) {
+                if (PACK) {
+                    const uint32_t code = base_code(c);
+                    codes |= (code & 3u) << (2 * cnt);
+                    bad |= (code >> 2) << cnt;
+                } else {
+                    if (s.seen_nl) ++s.rest; else ++s.pre;
+                }
                 ++cnt;
             }
         }
@@ -84,190 +112,188 @@ DD_D int scan16(const Bytes16& b, bool prev_nl, bool hdr_in, uint8_t* out) {
     return cnt;
 }
 
-// Same state machine, but the thread's tokens are assembled in registers: 2-bit codes in `codes`
-// (token j at bits 2j..2j+1) and BREAK flags in `bad` (bit j).  Returns the token count (<= 16).
-DD_D int scan16_pack(const Bytes16& b, bool prev_nl, bool hdr_in, uint32_t& codes, uint32_t& bad) {
-    int cnt = 0;
-    bool hdr = hdr_in, ls = prev_nl;
-    codes = 0;
-    bad = 0;
+// What a thread's 64 bytes look like from outside: ONE pass of the machine (entered as "not in a
+// header") yields the span's action on the header bit and its token count under either incoming bit,
+// because the two cases differ only before the first newline: entered inside a header, the bytes up
+// to that newline emit nothing and the newline itself emits the record BREAK.
+struct ThreadSpan {
+    Bytes16 b[SUB];
+    bool line_start;  // first byte is the first of a line (the incoming bit is then irrelevant)
+    int kind;         // action on the header bit
+    int t0, t1;       // tokens if entered outside / inside a header line
+};
+
+DD_D ThreadSpan load_span(const uint8_t* fa, size_t n, size_t pos) {
+    ThreadSpan t;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        uint32_t c = b.at(i);
-        if (ls) hdr = (c == '>');
-        if (c == '\n') {
-            if (hdr) {
-                bad |= 1u << cnt;
-                ++cnt;
-            }
-            hdr = false;
-            ls = true;
-        } else {
-            ls = false;
-            if (!(hdr || c == '\r')) {
-                const uint32_t code = base_code(c);
-                codes |= (code & 3u) << (2 * cnt);
-                bad |= (code >> 2) << cnt;
-                ++cnt;
+    for (int j = 0; j < SUB; ++j) t.b[j] = load16(fa, n, pos + 16 * j);
+    t.line_start = (pos == 0) || (pos - 1 < n ? fa[pos - 1] == '\n' : false);
+    LineState s{false, t.line_start, false, 0, 0};
+    uint32_t d0, d1;
+#pragma unroll
+    for (int j = 0; j < SUB; ++j) (void)scan16<false>(t.b[j], s, d0, d1);
+    if (pos >= n) {  // tail of the last chunk
+        t.kind = KIND_ID;
+        t.t0 = t.t1 = 0;
+    } else {
+        t.kind = (s.seen_nl || t.line_start) ? (s.hdr ? KIND_C1 : KIND_C0) : KIND_ID;
+        t.t0 = s.pre + s.rest;
+        t.t1 = t.line_start ? t.t0 : s.rest + (s.seen_nl ? 1 : 0);
+    }
+    return t;
+}
+
+// Header bit entering each thread of the workgroup, given the bit entering the chunk, and the
+// chunk's own summary.  determined = false for threads whose incoming bit is the chunk's.
+struct Incoming {
+    bool hdr;
+    bool determined;
+    int chunk_kind;
+};
+DD_D Incoming propagate(int kind, bool chunk_in, int* sm /*[NW]*/) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long cm = __ballot(kind != KIND_ID), vm = __ballot(kind == KIND_C1);
+    const unsigned long long below = cm & ((1ull << lane) - 1ull);
+    Incoming r;
+    bool from_wave = below != 0;
+    bool val = false;
+    if (from_wave) val = (vm >> (63 - __builtin_clzll(below))) & 1ull;
+    if (lane == 0) sm[wv] = cm ? (((vm >> (63 - __builtin_clzll(cm))) & 1ull) ? KIND_C1 : KIND_C0) : KIND_ID;
+    __syncthreads();
+    bool wave_in = chunk_in, wave_det = false;
+    int ck = KIND_ID;
+    for (int w = 0; w < NW; ++w) {
+        const int k = sm[w];
+        if (k != KIND_ID) {
+            ck = k;
+            if (w < wv) {
+                wave_in = (k == KIND_C1);
+                wave_det = true;
             }
         }
     }
-    return cnt;
-}
-
-DD_D long long last_newline(const Bytes16& b, size_t pos) {
-    long long r = -1;
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-        if (b.at(i) == '\n') r = (long long)(pos + i);
+    r.hdr = from_wave ? val : wave_in;
+    r.determined = from_wave || wave_det;
+    r.chunk_kind = ck;
+    __syncthreads();
     return r;
 }
 
-// ---- workgroup scans over T=256 threads (4 waves) ------------------------------------
-template <typename V, typename Op>
-DD_D V wave_incl(V v, Op op) {
-    const int lane = threadIdx.x & 63;
+// inclusive sum over the workgroup (32-bit); *total = workgroup sum
+DD_D int block_incl_sum(int v, int* sm /*[NW]*/, int* total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        V o = __shfl_up(v, d);
-        if (lane >= d) v = op(v, o);
+        const int o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
     }
-    return v;
-}
-
-struct MaxLL { DD_D long long operator()(long long a, long long b) const { return a > b ? a : b; } };
-struct SumLL { DD_D long long operator()(long long a, long long b) const { return a + b; } };
-
-// inclusive scan across the block; *total receives the block-wide reduction.
-// sm must hold blockDim.x/64 elements.  ident is the identity of op.
-template <typename Op>
-DD_D long long block_incl(long long v, Op op, long long ident, long long* sm, long long* total) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    long long inc = wave_incl(v, op);
-    __syncthreads();
     if (lane == 63) sm[wv] = inc;
     __syncthreads();
-    long long pre = ident, tot = ident;
-    for (int i = 0; i < nw; ++i) {
-        long long x = sm[i];
-        if (i < wv) pre = op(pre, x);
-        tot = op(tot, x);
+    int pre = 0, tot = 0;
+    for (int w = 0; w < NW; ++w) {
+        if (w < wv) pre += sm[w];
+        tot += sm[w];
     }
     *total = tot;
-    return op(pre, inc);
+    __syncthreads();
+    return pre + inc;
 }
 
-// Is position `pos` (not at a line start) inside a header line, given N = position of the last
-// '\n' before pos (or -1)?  The line starts at N+1; it is a header iff it starts with '>'.
-DD_D bool line_is_header(const uint8_t* fa, long long N) { return fa[N + 1] == '>'; }
-
-// ---------------------------------------------------------------------------------------
 // scratch layout of one genome: four arrays of (nchunks + 1) int64
 struct Scratch {
-    long long *lastnl, *cntH, *cntS, *slot;
+    long long *kind_in, *cnt0, *cnt1, *slot;
     DD_D explicit Scratch(const PackGenome& g)
-        : lastnl(g.scratch), cntH(g.scratch + (g.nchunks + 1)), cntS(g.scratch + 2 * (g.nchunks + 1)),
+        : kind_in(g.scratch), cnt0(g.scratch + (g.nchunks + 1)), cnt1(g.scratch + 2 * (g.nchunks + 1)),
           slot(g.scratch + 3 * (g.nchunks + 1)) {}
 };
 
+// ---------------------------------------------------------------------------------------
 // grid = (max chunks over the batch, genomes)
 __global__ __launch_bounds__(T) void pack_stats(const PackGenome* __restrict__ tab) {
-    __shared__ long long sm[T / 64];
+    __shared__ int sm[NW];
     const PackGenome G = tab[blockIdx.y];
     const size_t c = blockIdx.x;
     if (c >= G.nchunks) return;
-    const uint8_t* __restrict__ fa = G.fa;
-    const size_t n = G.n;
-    const Scratch S(G);
-    long long* lastnl = S.lastnl;
-    long long* cntH = S.cntH;
-    long long* cntS = S.cntS;
-    const size_t pos = c * (size_t)kPackChunk + (size_t)threadIdx.x * 16;
-    Bytes16 b = load16(fa, n, pos);
-    const bool prev_nl = (pos == 0) || (pos - 1 < n ? fa[pos - 1] == '\n' : false);
-    long long ln = last_newline(b, pos);
-    long long tot;
-    long long inc = block_incl(ln, MaxLL(), -1, sm, &tot);
-    long long before = __shfl_up(inc, 1);  // exclusive: previous thread's inclusive value
-    if ((threadIdx.x & 63) == 0) before = -1;
-    // cross-wave part of the exclusive value
-    {
-        long long pre = -1;
-        for (int i = 0; i < (int)(threadIdx.x >> 6); ++i) pre = pre > sm[i] ? pre : sm[i];
-        before = before > pre ? before : pre;
+    const size_t pos = c * (size_t)kPackChunk + (size_t)threadIdx.x * kPackBytesPerThread;
+    const ThreadSpan t = load_span(G.fa, G.n, pos);
+    const Incoming in = propagate(t.kind, false, sm);
+    int t0, t1;  // tokens if the CHUNK is entered outside / inside a header
+    if (in.determined || t.line_start) {
+        t0 = t1 = in.hdr ? t.t1 : t.t0;
+    } else {
+        t0 = t.t0;
+        t1 = t.t1;
     }
-    int tH, tS;
-    if (pos >= n) {  // tail of the last chunk: nothing to tokenise
-        tH = tS = 0;
-    } else if (prev_nl) {
-        tH = tS = scan16<false>(b, true, false, nullptr);
-    } else if (before >= 0) {  // a newline earlier in this chunk decides the state
-        bool h = line_is_header(fa, before);
-        tH = tS = scan16<false>(b, false, h, nullptr);
-    } else {  // depends on the chunk's incoming state
-        tH = scan16<false>(b, false, true, nullptr);
-        tS = scan16<false>(b, false, false, nullptr);
-    }
-    long long sH, sS;
-    block_incl((long long)tH, SumLL(), 0, sm, &sH);
-    block_incl((long long)tS, SumLL(), 0, sm, &sS);
+    int s0, s1;
+    block_incl_sum(t0, sm, &s0);
+    block_incl_sum(t1, sm, &s1);
     if (threadIdx.x == 0) {
-        lastnl[c] = tot;
-        cntH[c] = sH;
-        cntS[c] = sS;
+        const Scratch S(G);
+        S.kind_in[c] = in.chunk_kind;
+        S.cnt0[c] = s0;
+        S.cnt1[c] = s1;
     }
 }
 
-// one workgroup of 1024 threads per genome
+// one workgroup of 1024 threads per genome: incoming header bit and token offset of every chunk
 __global__ __launch_bounds__(1024) void pack_scan(const PackGenome* __restrict__ tab) {
-    __shared__ long long sm[16];
+    __shared__ int smk[16];
+    __shared__ long long sms[16];
     const PackGenome G = tab[blockIdx.x];
-    const uint8_t* __restrict__ fa = G.fa;
     const size_t nchunks = G.nchunks;
-    const Scratch SC(G);
-    long long* lastnl_Nin = SC.lastnl;
-    const long long* cntH = SC.cntH;
-    const long long* cntS = SC.cntS;
-    long long* slot_base = SC.slot;
+    const Scratch S(G);
     const TokenStream out = G.out;
-    long long carryN = -1, carryS = 0;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    bool carry_hdr = false;  // header bit entering the next block of 1024 chunks
+    long long carry_sum = 0;
     for (size_t blk = 0; blk < nchunks; blk += 1024) {
         const size_t c = blk + threadIdx.x;
         const bool live = c < nchunks;
-        long long ln = live ? lastnl_Nin[c] : -1;
-        long long totN;
-        long long incN = block_incl(ln, MaxLL(), -1, sm, &totN);
-        // exclusive = max over threads before me (and carry)
+        const int kind = live ? (int)S.kind_in[c] : KIND_ID;
+        // incoming header bit of chunk c = value of the nearest constant chunk before it
+        const unsigned long long cm = __ballot(kind != KIND_ID), vm = __ballot(kind == KIND_C1);
+        const unsigned long long below = cm & ((1ull << lane) - 1ull);
+        if (lane == 0) smk[wv] = cm ? (((vm >> (63 - __builtin_clzll(cm))) & 1ull) ? KIND_C1 : KIND_C0) : KIND_ID;
         __syncthreads();
-        __shared__ long long tmp[1024];
-        tmp[threadIdx.x] = incN;
+        bool hdr_in = carry_hdr, next_carry = carry_hdr;
+        for (int w = 0; w < 16; ++w) {
+            const int k = smk[w];
+            if (k != KIND_ID) {
+                next_carry = (k == KIND_C1);
+                if (w < wv) hdr_in = (k == KIND_C1);
+            }
+        }
+        if (below) hdr_in = (vm >> (63 - __builtin_clzll(below))) & 1ull;
+        const long long cnt = live ? (hdr_in ? S.cnt1[c] : S.cnt0[c]) : 0;
+        // exclusive 64-bit sum
+        long long inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const long long o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) sms[wv] = inc;
         __syncthreads();
-        long long Nin = threadIdx.x ? tmp[threadIdx.x - 1] : -1;
-        Nin = Nin > carryN ? Nin : carryN;
-        long long cnt = 0;
-        if (live) {
-            const size_t pos = c * (size_t)kPackChunk;
-            bool hdr = false;
-            if (pos > 0 && fa[pos - 1] != '\n') hdr = line_is_header(fa, Nin);
-            cnt = hdr ? cntH[c] : cntS[c];
-            lastnl_Nin[c] = Nin;
+        long long pre = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wv) pre += sms[w];
+            tot += sms[w];
         }
-        long long totS;
-        long long incS = block_incl(cnt, SumLL(), 0, sm, &totS);
         if (live) {
-            long long S = carryS + incS - cnt;
-            slot_base[c] = S;
-            out.codes[S >> 4] = 0;
-            out.bad[S >> 5] = 0;
+            const long long s = carry_sum + pre + inc - cnt;
+            S.kind_in[c] = hdr_in ? 1 : 0;
+            S.slot[c] = s;
+            out.codes[s >> 4] = 0;
+            out.bad[s >> 5] = 0;
         }
-        carryN = carryN > totN ? carryN : totN;
-        carryS += totS;
+        carry_hdr = next_carry;
+        carry_sum += tot;
         __syncthreads();
     }
-    __syncthreads();
     if (threadIdx.x == 0) {
-        const long long total = carryS;
-        slot_base[nchunks] = total;
+        const long long total = carry_sum;
+        S.slot[nchunks] = total;
         *out.ntok = (unsigned long long)total;
         const long long pad_end = (total + kSegTokens - 1) / kSegTokens * kSegTokens;
         // the word holding `total` is a partial boundary word of the last chunk: zero it,
@@ -281,65 +307,57 @@ __global__ __launch_bounds__(1024) void pack_scan(const PackGenome* __restrict__
 }
 
 __global__ __launch_bounds__(T) void pack_write(const PackGenome* __restrict__ tab) {
-    __shared__ long long sm[T / 64];
-    __shared__ uint32_t lcodes[kPackChunk / 16 + 2];  // <= 4096 tokens -> <= 257 code words (+1 spill)
-    __shared__ uint32_t lbad[kPackChunk / 32 + 2];
+    __shared__ int sm[NW];
+    // LDS image of the chunk's words, swizzled: a thread's 64 tokens cover ~4 consecutive code words
+    // (~2 BREAK words), so in every LDS instruction lane i touches word ~4i+j; storing word w at
+    // (w mod 4) * ROW + w / 4 makes those addresses consecutive across lanes instead of 8-way bank conflicts
+    constexpr int ROW = kPackChunk / 64 + 4;  // 260
+    __shared__ uint32_t lcodes[4 * ROW];  // <= 16384 tokens -> <= 1025 code words (+1 spill)
+    __shared__ uint32_t lbad[2 * ROW];
+    auto cidx = [](int w) { return (w & 3) * ROW + (w >> 2); };
+    auto bidx = [](int w) { return (w & 1) * ROW + (w >> 1); };
     const PackGenome G = tab[blockIdx.y];
     const size_t c = blockIdx.x;
     if (c >= G.nchunks) return;
-    const uint8_t* __restrict__ fa = G.fa;
-    const size_t n = G.n;
     const Scratch SC(G);
-    const long long* Nin = SC.lastnl;
-    const long long* slot_base = SC.slot;
     const TokenStream out = G.out;
-    const size_t pos = c * (size_t)kPackChunk + (size_t)threadIdx.x * 16;
-    Bytes16 b = load16(fa, n, pos);
-    const bool prev_nl = (pos == 0) || (pos - 1 < n ? fa[pos - 1] == '\n' : false);
-    long long ln = last_newline(b, pos);
-    long long tot;
-    long long inc = block_incl(ln, MaxLL(), -1, sm, &tot);
-    long long before = __shfl_up(inc, 1);
-    if ((threadIdx.x & 63) == 0) before = -1;
-    {
-        long long pre = -1;
-        for (int i = 0; i < (int)(threadIdx.x >> 6); ++i) pre = pre > sm[i] ? pre : sm[i];
-        before = before > pre ? before : pre;
-    }
-    if (before < 0) before = Nin[c];
-    bool h = false;
-    if (!prev_nl && pos < n) h = line_is_header(fa, before);
-    uint32_t my_codes, my_bad;
-    const int cnt = scan16_pack(b, prev_nl, h, my_codes, my_bad);
-    long long total;
-    const long long incS = block_incl((long long)cnt, SumLL(), 0, sm, &total);
-    const long long S = slot_base[c], E = S + total;  // global token range of this chunk
+    const size_t pos = c * (size_t)kPackChunk + (size_t)threadIdx.x * kPackBytesPerThread;
+    const ThreadSpan t = load_span(G.fa, G.n, pos);
+    const Incoming in = propagate(t.kind, SC.kind_in[c] != 0, sm);
+    const int cnt = in.hdr ? t.t1 : t.t0;
+    int total;
+    const int inc = block_incl_sum(cnt, sm, &total);
     if (total == 0) return;
-
-    // The chunk's words are built in LDS at their final bit positions: a thread ORs its <=16
-    // tokens (one 32-bit code piece, one 16-bit BREAK piece, each possibly straddling two words),
-    // then the words are copied out; only the chunk's first and last word can be shared with a
-    // neighbouring chunk and go out through atomicOr (pack_scan zeroed them).
+    const long long S = SC.slot[c], E = S + total;  // global token range of this chunk
     const long long cw0 = S >> 4, bw0 = S >> 5;
     const int ncw = (int)(((E - 1) >> 4) - cw0) + 1, nbw = (int)(((E - 1) >> 5) - bw0) + 1;
-    for (int i = threadIdx.x; i < ncw + 1; i += T) lcodes[i] = 0;
-    for (int i = threadIdx.x; i < nbw + 1; i += T) lbad[i] = 0;
+    for (int i = threadIdx.x; i < 4 * ROW; i += T) lcodes[i] = 0;
+    for (int i = threadIdx.x; i < 2 * ROW; i += T) lbad[i] = 0;
     __syncthreads();
     if (cnt) {
-        const long long t0 = S + (incS - cnt);  // global index of this thread's first token
-        const int wi = (int)((t0 >> 4) - cw0), sh = (int)(t0 & 15) * 2;
-        atomicOr(&lcodes[wi], my_codes << sh);
-        if (sh && (my_codes >> (32 - sh))) atomicOr(&lcodes[wi + 1], my_codes >> (32 - sh));
-        const int bi = (int)((t0 >> 5) - bw0), bs = (int)(t0 & 31);
-        if (my_bad) {
-            atomicOr(&lbad[bi], my_bad << bs);
-            if (bs > 16 && (my_bad >> (32 - bs))) atomicOr(&lbad[bi + 1], my_bad >> (32 - bs));
+        long long tk = S + (inc - cnt);  // global index of this thread's next token
+        LineState s{in.hdr, t.line_start, false, 0, 0};
+#pragma unroll
+        for (int j = 0; j < SUB; ++j) {
+            uint32_t pc, pb;
+            const int n16 = scan16<true>(t.b[j], s, pc, pb);
+            if (n16) {
+                const int wi = (int)((tk >> 4) - cw0), sh = (int)(tk & 15) * 2;
+                if (pc << sh) atomicOr(&lcodes[cidx(wi)], pc << sh);
+                if (sh && (pc >> (32 - sh))) atomicOr(&lcodes[cidx(wi + 1)], pc >> (32 - sh));
+                if (pb) {
+                    const int bi = (int)((tk >> 5) - bw0), bs = (int)(tk & 31);
+                    atomicOr(&lbad[bidx(bi)], pb << bs);
+                    if (bs > 16 && (pb >> (32 - bs))) atomicOr(&lbad[bidx(bi + 1)], pb >> (32 - bs));
+                }
+                tk += n16;
+            }
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < ncw; i += T) {
         const long long w = cw0 + i;
-        const uint32_t v = lcodes[i];
+        const uint32_t v = lcodes[cidx(i)];
         if ((w << 4) >= S && (w << 4) + 16 <= E)
             out.codes[w] = v;
         else if (v)
@@ -347,7 +365,7 @@ __global__ __launch_bounds__(T) void pack_write(const PackGenome* __restrict__ t
     }
     for (int i = threadIdx.x; i < nbw; i += T) {
         const long long w = bw0 + i;
-        const uint32_t v = lbad[i];
+        const uint32_t v = lbad[bidx(i)];
         if ((w << 5) >= S && (w << 5) + 32 <= E)
             out.bad[w] = v;
         else if (v)
