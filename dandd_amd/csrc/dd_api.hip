@@ -402,6 +402,46 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         size_t tiles_per_job = std::max<size_t>(1, (total_tiles * ngroups + target_jobs - 1) / target_jobs);
         ClassJobs cj;
         cj.kclass = kc;
+        if (global_regs && kc != 3 && !getenv("DD_NO_XCD_AFFINITY")) {
+            // Registers live in HBM (log2m >= 18).  Every update reads one random byte of a 2^p-byte
+            // array, so the arrays a workgroup touches should sit in ITS XCD's 4 MiB L2: k-groups are
+            // cut to <= 3 MiB of arrays, each (genome, k-group) pair is given to one XCD, and because
+            // workgroups are dealt round-robin over the 8 XCDs in blockIdx order, job 8*i + x is the
+            // i-th job of XCD x.  Placement is a speed assumption only: every register update is an
+            // agent-scope atomic, correct wherever the workgroup lands.
+            const int g_l2 = (int)std::max<size_t>(1, ((size_t)3 << 20) / m);
+            const int ngr = (nks + g_l2 - 1) / g_l2;
+            std::vector<std::vector<dd::SweepJob>> per_xcd(8);
+            int pair = 0;
+            for (int g = 0; g < ngenomes; ++g) {
+                const size_t ntiles = (nbytes[g] + tile_tokens - 1) / tile_tokens;
+                const size_t tpj = std::max<size_t>(1, ntiles / 128);  // >= 64 resident workgroups share a pair
+                int kcur = ka;
+                for (int q = 0; q < ngr; ++q, ++pair) {
+                    const int nk = nks / ngr + (q < nks % ngr ? 1 : 0);
+                    for (size_t t0 = 0; t0 < ntiles; t0 += tpj) {
+                        dd::SweepJob j;
+                        j.genome = g;
+                        j.kfirst = kcur;
+                        j.nk = nk;
+                        j.krow = kcur - kmin;
+                        j.tile_begin = (unsigned)t0;
+                        j.tile_end = (unsigned)std::min(ntiles, t0 + tpj);
+                        per_xcd[pair % 8].push_back(j);
+                    }
+                    cj.max_nk = std::max(cj.max_nk, nk);
+                    kcur += nk;
+                }
+            }
+            size_t longest = 0;
+            for (auto& v : per_xcd) longest = std::max(longest, v.size());
+            dd::SweepJob idle{};  // empty tile range: the workgroup exits at once
+            idle.kfirst = ka;
+            for (size_t i = 0; i < longest; ++i)
+                for (int x = 0; x < 8; ++x) cj.jobs.push_back(i < per_xcd[x].size() ? per_xcd[x][i] : idle);
+            if (!cj.jobs.empty()) classes.push_back(std::move(cj));
+            continue;
+        }
         // Tile-major order: workgroups that run concurrently work on different (genome, k-group)
         // slabs, so each slab has been warmed by its earlier tiles when its later jobs start.
         size_t max_tiles = 0;
