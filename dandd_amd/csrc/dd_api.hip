@@ -466,6 +466,21 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
                 }
             }
         }
+        // The k-groups of one (genome, tile range) read the same token bytes.  Workgroups are dealt
+        // round-robin over the 8 XCDs in blockIdx order, so within every block of 8 units x ngroups
+        // jobs emit group-major: the groups of unit i then sit at indices i, i+8, i+16, ... = one
+        // XCD, back to back, and the re-reads hit that XCD's L2 instead of HBM (speed only).
+        if (ngroups > 1 && !getenv("DD_NO_XCD_AFFINITY")) {
+            const size_t nunits = cj.jobs.size() / ngroups;
+            std::vector<dd::SweepJob> re;
+            re.reserve(cj.jobs.size());
+            for (size_t u0 = 0; u0 < nunits; u0 += 8) {
+                const size_t nu = std::min<size_t>(8, nunits - u0);
+                for (int q = 0; q < ngroups; ++q)
+                    for (size_t u = 0; u < nu; ++u) re.push_back(cj.jobs[(u0 + u) * ngroups + q]);
+            }
+            cj.jobs.swap(re);
+        }
         if (!cj.jobs.empty()) classes.push_back(std::move(cj));
     }
 
