@@ -95,6 +95,18 @@ struct RegsGlobal {
     }
 };
 
+// 16 bytes of global memory as other agents' atomics left them (two relaxed agent-scope 8-byte
+// loads: they bypass this XCD's non-coherent L2).
+DD_D uint4 load16_fresh(const uint8_t* p) {
+    const unsigned long long* q = static_cast<const unsigned long long*>(__builtin_assume_aligned(p, 16));
+    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+}
+DD_D uint32_t load4_fresh(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Exact byte-max into register idx.
 template <typename R>
 DD_D void reg_raise(const R& regs, uint32_t idx, uint32_t rho) {
@@ -243,10 +255,12 @@ __global__ __launch_bounds__(1024) void sweep_kernel(const SweepGenome* __restri
         // (possibly stale) snapshot is a valid lower bound of the final registers, and a warm
         // array makes the "register rises" path rare: after T tokens have been absorbed only
         // ~m/T of the updates still raise a register.
+        // The snapshot is read with agent-scope loads: other XCDs merge into the slab with
+        // memory-side atomics, which a plain load served by THIS XCD's L2 would not see (it kept
+        // returning the zeroed lines: every flush then CAS-ed every word and jobs started cold).
         uint4* z = reinterpret_cast<uint4*>(g_lds);
-        const uint4* src = reinterpret_cast<const uint4*>(slab);
         const uint32_t n16 = (uint32_t)nk * (m >> 4);
-        for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) z[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) z[i] = load16_fresh(slab + (size_t)i * 16);
     }
     __syncthreads();
 
@@ -309,7 +323,7 @@ __global__ __launch_bounds__(1024) void sweep_kernel(const SweepGenome* __restri
         const uint32_t n16 = (uint32_t)nk * (m >> 4);
         for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) {
             const uint4 lv = l4[i];
-            const uint4 gv = reinterpret_cast<const uint4*>(gw)[i];
+            const uint4 gv = load16_fresh(slab + (size_t)i * 16);
             const uint32_t l[4] = {lv.x, lv.y, lv.z, lv.w};
             const uint32_t o[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
@@ -350,7 +364,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void bit
     const int w0 = c_bitmap_off[kfirst], w1 = c_bitmap_off[klast + 1];
     const uint32_t kmask = __builtin_amdgcn_readfirstlane(((2u << klast) - 1u) & ~((1u << kfirst) - 1u));  // bit k set: k in the job
     // warm start from what earlier jobs recorded (any snapshot is a subset of the final set)
-    for (int i = w0 + (int)threadIdx.x; i < w1; i += blockDim.x) bits[i] = g.bitmap[i];
+    for (int i = w0 + (int)threadIdx.x; i < w1; i += blockDim.x) bits[i] = load4_fresh(&g.bitmap[i]);
     __syncthreads();
 
     const int prime = klast - 1;
@@ -418,7 +432,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void bit
     __syncthreads();
     for (int i = w0 + (int)threadIdx.x; i < w1; i += blockDim.x) {
         const uint32_t mine = bits[i];
-        if (mine & ~g.bitmap[i]) atomicOr(&g.bitmap[i], mine);
+        if (mine & ~load4_fresh(&g.bitmap[i])) atomicOr(&g.bitmap[i], mine);
     }
 }
 
