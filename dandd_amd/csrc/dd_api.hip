@@ -388,13 +388,18 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         int max_nk = 0;
     };
     std::vector<ClassJobs> classes;
-    for (int kc = 0; kc < 4; ++kc) {  // 3 = small-k bitmap class, 0..2 = hashed classes
-        const int lo0 = use_bitmaps ? dd::kBitmapMaxK + 1 : 1;
-        const int ka = std::max(kmin, kc == 3 ? 1 : (kc == 0 ? lo0 : (kc == 1 ? 17 : 33)));
-        const int kb = std::min(kmax, kc == 3 ? (use_bitmaps ? dd::kBitmapMaxK : 0) : (kc == 0 ? 16 : (kc == 1 ? 32 : 64)));
+    // k classes: kBitmapClass = small-k presence bitmaps; the others name the sweep_kernel window
+    // class (dd_sweep.hip): 0: k <= 16, 1: k <= 32, 3: 33 <= k <= 48, 2: k <= 64
+    constexpr int kBitmapClass = -1;
+    const int lo0 = use_bitmaps ? dd::kBitmapMaxK + 1 : 1;
+    const struct { int kc, ka, kb; } class_tab[5] = {
+        {kBitmapClass, 1, use_bitmaps ? dd::kBitmapMaxK : 0}, {0, lo0, 16}, {1, 17, 32}, {3, 33, 48}, {2, 49, 64}};
+    for (const auto& ct : class_tab) {
+        const int kc = ct.kc;
+        const int ka = std::max(kmin, ct.ka), kb = std::min(kmax, ct.kb);
         if (ka > kb) continue;
         const int nks = kb - ka + 1;
-        const int ngroups = kc == 3 ? 1 : (nks + slots - 1) / slots;
+        const int ngroups = kc == kBitmapClass ? 1 : (nks + slots - 1) / slots;
         // aim for ~8 jobs per CU over the whole class so the dispatcher can balance the tail
         size_t total_tiles = 0;
         for (int g = 0; g < ngenomes; ++g) total_tiles += (nbytes[g] + tile_tokens - 1) / tile_tokens;
@@ -402,7 +407,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         size_t tiles_per_job = std::max<size_t>(1, (total_tiles * ngroups + target_jobs - 1) / target_jobs);
         ClassJobs cj;
         cj.kclass = kc;
-        if (global_regs && kc != 3 && !getenv("DD_NO_XCD_AFFINITY")) {
+        if (global_regs && kc != kBitmapClass && !getenv("DD_NO_XCD_AFFINITY")) {
             // Registers live in HBM (log2m >= 18).  Every update reads one random byte of a 2^p-byte
             // array, so the arrays a workgroup touches should sit in ITS XCD's 4 MiB L2: k-groups are
             // cut to <= 3 MiB of arrays, each (genome, k-group) pair is given to one XCD, and because
@@ -522,7 +527,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         plan.threads = threads;
         plan.lds_bytes = global_regs ? 0 : (int)((size_t)classes[i].max_nk * m);
         Span sp(c, DD_KERNEL_SWEEP);
-        if (classes[i].kclass == 3) {
+        if (classes[i].kclass < 0) {
             dd::launch_bitmap(reinterpret_cast<const dd::SweepGenome*>(tdev),
                               reinterpret_cast<const dd::SweepJob*>(tdev + job_off[i]),
                               (int)classes[i].jobs.size(), c->canonical, st);

@@ -163,6 +163,7 @@ DD_D void hll_update2(const R& r0, uint64_t h0, const R& r1, uint64_t h1, int p)
 
 // ---- rolling windows, one set per thread, shared by every k of the group ------------------------
 //   KC 0: k <= 16 (32-bit windows)   KC 1: k <= 32 (64-bit)   KC 2: k <= 64 (128-bit)
+//   KC 3: 33 <= k <= 48 (96-bit: 64 + 32)
 template <int KC>
 struct Windows;
 
@@ -216,8 +217,43 @@ struct Windows<2> {
         const int s = 128 - 2 * k;  // 0..62
         const uint64_t bh = s ? (rh >> s) : rh;
         const uint64_t bl = s ? ((rl >> s) | (rh << (64 - s))) : rl;
-        const bool f_lt = (ah < bh) || (ah == bh && al < bl);
+        const bool f_lt = (ah < bh) | ((ah == bh) & (al < bl));  // bitwise: no exec-mask short circuit
         return wang64_fast<false>(fold128(f_lt ? ah : bh, f_lt ? al : bl));
+    }
+};
+
+// 33 <= k <= 48: the k-mer is 66..96 bits, so the high part fits one 32-bit register and every
+// step on it (mask, funnel shift of the reverse complement, compare, select, fold multiply) is a
+// 32-bit instruction instead of a 64-bit pair.  Same values as Windows<2> for these ks.
+template <>
+struct Windows<3> {
+    uint64_t fl = 0, rt = 0;  // forward: low 64 bits;  reverse complement, top-aligned: bits 95..32
+    uint32_t fh = 0, rb = 0;  // forward: bits 95..64;  reverse complement: bits 31..0
+    DD_D void push(uint32_t c) {
+        fh = __builtin_amdgcn_alignbit(fh, (uint32_t)(fl >> 32), 30);  // (fh << 2) | (fl >> 62)
+        fl = (fl << 2) | c;
+        rb = __builtin_amdgcn_alignbit((uint32_t)rt, rb, 2);           // (rb >> 2) | (rt << 30)
+        rt = (rt >> 2) | ((uint64_t)(3u - c) << 62);
+    }
+    template <bool CANON>
+    DD_D uint64_t hash(int k) const {
+        const int hb = 2 * k - 64;  // 2..32 bits of the k-mer above bit 63
+        const uint32_t ah = (hb == 32) ? fh : (fh & ((1u << hb) - 1u));
+        uint32_t hi = ah;
+        uint64_t lo = fl;
+        if (CANON) {
+            const uint32_t s = 96u - 2u * (uint32_t)k;  // 0..30
+            const uint32_t r3 = (uint32_t)(rt >> 32), r2 = (uint32_t)rt;
+            const uint32_t bh = r3 >> s;
+            const uint64_t bl = ((uint64_t)__builtin_amdgcn_alignbit(r3, r2, s) << 32) |
+                                __builtin_amdgcn_alignbit(r2, rb, s);
+            const bool f_lt = (ah < bh) | ((ah == bh) & (fl < bl));  // bitwise: no exec-mask short circuit
+            hi = f_lt ? ah : bh;
+            lo = f_lt ? fl : bl;
+        }
+        // fold128(hi, lo) with hi < 2^32: hi * G = hi * G_lo + ((hi * G_hi) << 32)   (mod 2^64)
+        const uint64_t hg = (uint64_t)hi * 0x7F4A7C15u + ((uint64_t)(hi * 0x9E3779B9u) << 32);
+        return wang64_fast<false>(lo ^ hg);
     }
 };
 
@@ -519,6 +555,7 @@ void launch_sweep(const SweepGenome* genomes, const SweepJob* jobs, int njobs, i
     do {                                              \
         if (kclass == 0) DD_DISPATCH(0, CN, GL);      \
         else if (kclass == 1) DD_DISPATCH(1, CN, GL); \
+        else if (kclass == 3) DD_DISPATCH(3, CN, GL); \
         else DD_DISPATCH(2, CN, GL);                  \
     } while (0)
     const bool gl = plan.lds_bytes == 0;
