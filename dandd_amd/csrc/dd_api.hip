@@ -451,7 +451,12 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         // slabs, so each slab has been warmed by its earlier tiles when its later jobs start.
         size_t max_tiles = 0;
         for (int g = 0; g < ngenomes; ++g) max_tiles = std::max(max_tiles, (nbytes[g] + tile_tokens - 1) / tile_tokens);
+        // Jobs are handed out in table order; the last quarter of the tiles goes out in jobs a
+        // quarter the size, so the launch does not end waiting on a few full-size stragglers.
+        const size_t taper_from = getenv("DD_NO_TAPER") ? max_tiles : max_tiles - max_tiles / 4;
+        const size_t full_tiles_per_job = tiles_per_job;
         for (size_t t0 = 0; t0 < max_tiles; t0 += tiles_per_job) {
+            if (t0 >= taper_from) tiles_per_job = std::max<size_t>(1, full_tiles_per_job / 4);
             for (int g = 0; g < ngenomes; ++g) {
                 const size_t ntiles = (nbytes[g] + tile_tokens - 1) / tile_tokens;
                 if (t0 >= ntiles) continue;

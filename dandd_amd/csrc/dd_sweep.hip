@@ -161,7 +161,18 @@ DD_D void hll_update2(const R& r0, uint64_t h0, const R& r1, uint64_t h1, int p)
     }
 }
 
+// Reverse the order of the 16 2-bit fields of a code word: the token stream stores token j at bits
+// [2j, 2j+1] (oldest lowest), the forward window wants the newest token lowest.
+DD_D uint32_t pairrev32(uint32_t x) {
+    x = __builtin_bitreverse32(x);  // v_bfrev_b32: fields reversed, but so are the two bits inside each
+    return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+}
+DD_D uint64_t pack64(uint32_t hi, uint32_t lo) { return ((uint64_t)hi << 32) | lo; }
+
 // ---- rolling windows, one set per thread, shared by every k of the group ------------------------
+// prime(hc): the state after pushing the 64 tokens of the previous segment (hc = its four code
+// words), computed with a handful of bit operations instead of 64 pushes.  The reverse-complement
+// window holds tokens in stream order, newest on top, so it is simply the complement of the words.
 //   KC 0: k <= 16 (32-bit windows)   KC 1: k <= 32 (64-bit)   KC 2: k <= 64 (128-bit)
 //   KC 3: 33 <= k <= 48 (96-bit: 64 + 32)
 template <int KC>
@@ -170,6 +181,10 @@ struct Windows;
 template <>
 struct Windows<0> {
     uint32_t fw = 0, rc = 0;
+    DD_D void prime(const uint4& hc) {
+        fw = pairrev32(hc.w);
+        rc = ~hc.w;
+    }
     DD_D void push(uint32_t c) {
         fw = (fw << 2) | c;
         rc = (rc >> 2) | ((3u - c) << 30);
@@ -186,6 +201,10 @@ struct Windows<0> {
 template <>
 struct Windows<1> {
     uint64_t fw = 0, rc = 0;
+    DD_D void prime(const uint4& hc) {
+        fw = pack64(pairrev32(hc.z), pairrev32(hc.w));
+        rc = ~pack64(hc.w, hc.z);
+    }
     DD_D void push(uint32_t c) {
         fw = (fw << 2) | c;
         rc = (rc >> 2) | ((uint64_t)(3u - c) << 62);
@@ -202,6 +221,12 @@ struct Windows<1> {
 template <>
 struct Windows<2> {
     uint64_t fh = 0, fl = 0, rh = 0, rl = 0;
+    DD_D void prime(const uint4& hc) {
+        fl = pack64(pairrev32(hc.z), pairrev32(hc.w));
+        fh = pack64(pairrev32(hc.x), pairrev32(hc.y));
+        rh = ~pack64(hc.w, hc.z);
+        rl = ~pack64(hc.y, hc.x);
+    }
     DD_D void push(uint32_t c) {
         fh = (fh << 2) | (fl >> 62);
         fl = (fl << 2) | c;
@@ -229,6 +254,12 @@ template <>
 struct Windows<3> {
     uint64_t fl = 0, rt = 0;  // forward: low 64 bits;  reverse complement, top-aligned: bits 95..32
     uint32_t fh = 0, rb = 0;  // forward: bits 95..64;  reverse complement: bits 31..0
+    DD_D void prime(const uint4& hc) {
+        fl = pack64(pairrev32(hc.z), pairrev32(hc.w));
+        fh = pairrev32(hc.y);
+        rt = ~pack64(hc.w, hc.z);
+        rb = ~hc.y;
+    }
     DD_D void push(uint32_t c) {
         fh = __builtin_amdgcn_alignbit(fh, (uint32_t)(fl >> 32), 30);  // (fh << 2) | (fl >> 62)
         fl = (fl << 2) | c;
@@ -301,7 +332,6 @@ __global__ __launch_bounds__(1024) void sweep_kernel(const SweepGenome* __restri
     __syncthreads();
 
     const int kmaxg = kfirst + nk - 1;
-    const int prime = kmaxg - 1;  // halo tokens that prime the windows
     const uint4* codes4 = reinterpret_cast<const uint4*>(g.codes);
     const uint2* bad2 = reinterpret_cast<const uint2*>(g.bad);
     auto lds_slot = [p](int j) { return RegsLds{(uint32_t)j << p}; };
@@ -310,27 +340,34 @@ __global__ __launch_bounds__(1024) void sweep_kernel(const SweepGenome* __restri
     for (unsigned tile = job.tile_begin; tile < job.tile_end; ++tile) {
         const unsigned long long seg = (unsigned long long)tile * blockDim.x + threadIdx.x;
         if (seg * kSegTokens >= ntok) continue;
-        Windows<KC> win;
-        int run = 0;
+        // the previous segment (halo) primes the windows; segment 0 starts behind a BREAK
+        uint4 hc = make_uint4(0, 0, 0, 0);
+        uint2 hb = make_uint2(~0u, ~0u);
         if (seg > 0) {
-            const uint4 hc = codes4[seg - 1];
-            const uint2 hb = bad2[seg - 1];
-            const uint32_t cw[4] = {hc.x, hc.y, hc.z, hc.w};
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const uint32_t bw = ((w & 2) ? hb.y : hb.x) >> ((w & 1) * 16);
-#pragma unroll 1
-                for (int i = 0; i < 16; ++i) {
-                    if (w * 16 + i < kSegTokens - prime) continue;
-                    const uint32_t c = (cw[w] >> (2 * i)) & 3u;
-                    run = ((bw >> i) & 1u) ? 0 : run + 1;
-                    win.push(c);
-                }
-            }
+            hc = codes4[seg - 1];
+            hb = bad2[seg - 1];
         }
         const uint4 sc = codes4[seg];
         const uint2 sb = bad2[seg];
         const uint32_t cw[4] = {sc.x, sc.y, sc.z, sc.w};
+        Windows<KC> win;
+        win.prime(hc);
+        if (__all((hb.x | hb.y | sb.x | sb.y) == 0u)) {
+            // No BREAK within 128 tokens of any lane of the wave (the common case away from
+            // record boundaries and N runs): every window of every k <= 64 is valid.
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+#pragma unroll 1
+                for (int i = 0; i < 16; ++i) {
+                    win.push((cw[w] >> (2 * i)) & 3u);
+                    if (GLOBAL) sweep_token<KC, CANON, false>(win, 0, kfirst, nk, p, glb_slot);
+                    else sweep_token<KC, CANON, false>(win, 0, kfirst, nk, p, lds_slot);
+                }
+            }
+            continue;
+        }
+        // run = clean tokens ending at the current one; enters as the clean tail of the halo
+        int run = hb.y ? __builtin_clz(hb.y) : 32 + (hb.x ? __builtin_clz(hb.x) : 32);
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const uint32_t bw = ((w & 2) ? sb.y : sb.x) >> ((w & 1) * 16);
