@@ -399,7 +399,11 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         const int ka = std::max(kmin, ct.ka), kb = std::min(kmax, ct.kb);
         if (ka > kb) continue;
         const int nks = kb - ka + 1;
-        const int ngroups = kc == kBitmapClass ? 1 : (nks + slots - 1) / slots;
+        // The 32-bit class needs few enough VGPRs for 12 waves per SIMD, and measures ~7 % faster
+        // with three 48 KiB workgroups per CU than with two of 80 KiB; the wider classes do not.
+        int slots_c = slots;
+        if (kc == 0 && !global_regs && !getenv("DD_LDS_KB")) slots_c = (int)std::max<size_t>(1, std::min<size_t>(slots, (48 * 1024) / m));
+        const int ngroups = kc == kBitmapClass ? 1 : (nks + slots_c - 1) / slots_c;
         // aim for ~8 jobs per CU over the whole class so the dispatcher can balance the tail
         size_t total_tiles = 0;
         for (int g = 0; g < ngenomes; ++g) total_tiles += (nbytes[g] + tile_tokens - 1) / tile_tokens;

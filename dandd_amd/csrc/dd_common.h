@@ -14,6 +14,55 @@
 
 namespace dd {
 
+// ---- explicit global-address-space accesses ------------------------------------------------------
+// Pointers that reach a kernel inside a table entry (SweepGenome, PackGenome ...) are generic to the
+// compiler, which then emits FLAT instructions: those count against lgkmcnt as well as vmcnt, so
+// every wait for an LDS result also waits for outstanding HBM loads (no prefetch across LDS work),
+// and they cannot use the SGPR-base addressing form.  These helpers state what the host guarantees:
+// the pointer is device global memory.
+#define DD_GLOBAL __attribute__((address_space(1)))
+typedef uint32_t dd_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t dd_u32x2 __attribute__((ext_vector_type(2)));
+DD_D uint4 gload16(const void* p) {
+    const dd_u32x4 v = *(const DD_GLOBAL dd_u32x4*)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+DD_D uint2 gload8(const void* p) {
+    const dd_u32x2 v = *(const DD_GLOBAL dd_u32x2*)p;
+    return make_uint2(v.x, v.y);
+}
+DD_D uint32_t gload4(const void* p) { return *(const DD_GLOBAL uint32_t*)p; }
+DD_D unsigned long long gload8u(const void* p) { return *(const DD_GLOBAL unsigned long long*)p; }
+DD_D void gstore16(void* p, const uint4& v) {
+    dd_u32x4 t;
+    t.x = v.x, t.y = v.y, t.z = v.z, t.w = v.w;
+    *(DD_GLOBAL dd_u32x4*)p = t;
+}
+DD_D void gstore8(void* p, const uint2& v) {
+    dd_u32x2 t;
+    t.x = v.x, t.y = v.y;
+    *(DD_GLOBAL dd_u32x2*)p = t;
+}
+DD_D void gstore4(void* p, uint32_t v) { *(DD_GLOBAL uint32_t*)p = v; }
+// relaxed agent-scope accesses: served by memory / the coherent level, not this XCD's L2
+DD_D uint32_t gload1_fresh(const void* p) {
+    return __hip_atomic_load((const DD_GLOBAL uint8_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+DD_D uint32_t gload4_fresh(const void* p) {
+    return __hip_atomic_load((const DD_GLOBAL uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+DD_D unsigned long long gload8_fresh(const void* p) {
+    return __hip_atomic_load((const DD_GLOBAL unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+DD_D uint32_t gcas32(void* p, uint32_t expect, uint32_t desired) {  // returns the value found
+    __hip_atomic_compare_exchange_strong((DD_GLOBAL uint32_t*)p, &expect, desired, __ATOMIC_RELAXED,
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return expect;
+}
+DD_D void gor32(void* p, uint32_t bits) {
+    (void)__hip_atomic_fetch_or((DD_GLOBAL uint32_t*)p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Thomas Wang 64-bit integer mix.
 DD_HD uint64_t wang64(uint64_t key) {
     key = (~key) + (key << 21);

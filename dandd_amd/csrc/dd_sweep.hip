@@ -83,29 +83,21 @@ struct RegsLds {
 // HBM/L2: same protocol on the genome's slab (p >= 18: one array no longer fits LDS).
 struct RegsGlobal {
     uint8_t* base;
-    DD_D uint32_t load8(uint32_t i) const {
-        return __hip_atomic_load(base + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    DD_D uint32_t load32(uint32_t i) const {
-        return __hip_atomic_load(static_cast<uint32_t*>(__builtin_assume_aligned(base + i, 4)),
-                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    DD_D uint32_t load8(uint32_t i) const { return gload1_fresh(base + i); }
+    DD_D uint32_t load32(uint32_t i) const { return gload4_fresh(__builtin_assume_aligned(base + i, 4)); }
     DD_D uint32_t cas32(uint32_t i, uint32_t expect, uint32_t desired) const {
-        return atomicCAS(reinterpret_cast<uint32_t*>(base + i), expect, desired);
+        return gcas32(__builtin_assume_aligned(base + i, 4), expect, desired);
     }
 };
 
 // 16 bytes of global memory as other agents' atomics left them (two relaxed agent-scope 8-byte
 // loads: they bypass this XCD's non-coherent L2).
 DD_D uint4 load16_fresh(const uint8_t* p) {
-    const unsigned long long* q = static_cast<const unsigned long long*>(__builtin_assume_aligned(p, 16));
-    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint8_t* q = static_cast<const uint8_t*>(__builtin_assume_aligned(p, 16));
+    const unsigned long long a = gload8_fresh(q), b = gload8_fresh(q + 8);
     return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
 }
-DD_D uint32_t load4_fresh(const uint32_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+DD_D uint32_t load4_fresh(const uint32_t* p) { return gload4_fresh(p); }
 
 // Exact byte-max into register idx.
 template <typename R>
@@ -314,8 +306,32 @@ __global__ __launch_bounds__(1024) void sweep_kernel(const SweepGenome* __restri
     const SweepGenome g = genomes[job.genome];
     const int nk = job.nk, kfirst = job.kfirst;
     const uint32_t m = 1u << p;
-    const unsigned long long ntok = *g.ntok;
+    const unsigned long long ntok = gload8u(g.ntok);
     uint8_t* const slab = g.regs + ((size_t)job.krow << p);
+
+    // A thread's input for one tile: its segment (sc, sb) and the previous one (hc, hb: the halo
+    // that primes the windows; segment 0 starts behind a BREAK).  The loads of tile t+1 are issued
+    // before tile t is processed, and those of the first tile before the warm start below.
+    struct TileIn {
+        uint4 hc, sc;
+        uint2 hb, sb;
+        bool live;  // the segment lies inside the token stream
+    };
+    auto fetch = [&](unsigned tile, TileIn& t) {
+        const unsigned long long seg = (unsigned long long)tile * blockDim.x + threadIdx.x;
+        t.live = tile < job.tile_end && seg * kSegTokens < ntok;
+        t.hc = make_uint4(0, 0, 0, 0);
+        t.hb = make_uint2(~0u, ~0u);
+        if (!t.live) return;
+        if (seg > 0) {
+            t.hc = gload16(g.codes + (seg - 1) * 4);
+            t.hb = gload8(g.bad + (seg - 1) * 2);
+        }
+        t.sc = gload16(g.codes + seg * 4);
+        t.sb = gload8(g.bad + seg * 2);
+    };
+    TileIn next;
+    fetch(job.tile_begin, next);
 
     if (!GLOBAL) {
         // Warm start: begin from whatever earlier jobs have already merged into the slab.  Any
@@ -332,23 +348,15 @@ __global__ __launch_bounds__(1024) void sweep_kernel(const SweepGenome* __restri
     __syncthreads();
 
     const int kmaxg = kfirst + nk - 1;
-    const uint4* codes4 = reinterpret_cast<const uint4*>(g.codes);
-    const uint2* bad2 = reinterpret_cast<const uint2*>(g.bad);
     auto lds_slot = [p](int j) { return RegsLds{(uint32_t)j << p}; };
     auto glb_slot = [slab, p](int j) { return RegsGlobal{slab + ((size_t)j << p)}; };
 
     for (unsigned tile = job.tile_begin; tile < job.tile_end; ++tile) {
-        const unsigned long long seg = (unsigned long long)tile * blockDim.x + threadIdx.x;
-        if (seg * kSegTokens >= ntok) continue;
-        // the previous segment (halo) primes the windows; segment 0 starts behind a BREAK
-        uint4 hc = make_uint4(0, 0, 0, 0);
-        uint2 hb = make_uint2(~0u, ~0u);
-        if (seg > 0) {
-            hc = codes4[seg - 1];
-            hb = bad2[seg - 1];
-        }
-        const uint4 sc = codes4[seg];
-        const uint2 sb = bad2[seg];
+        const TileIn cur = next;
+        fetch(tile + 1, next);
+        if (!cur.live) continue;
+        const uint4 hc = cur.hc, sc = cur.sc;
+        const uint2 hb = cur.hb, sb = cur.sb;
         const uint32_t cw[4] = {sc.x, sc.y, sc.z, sc.w};
         Windows<KC> win;
         win.prime(hc);
@@ -404,7 +412,7 @@ __global__ __launch_bounds__(1024) void sweep_kernel(const SweepGenome* __restri
                 uint32_t old = o[q];
                 uint32_t mx = bmax4(old, l[q]);
                 while (mx != old) {
-                    uint32_t prev = atomicCAS(&gw[4 * i + q], old, mx);
+                    uint32_t prev = gcas32(&gw[4 * i + q], old, mx);
                     if (prev == old) break;
                     old = prev;
                     mx = bmax4(old, l[q]);
@@ -433,7 +441,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void bit
     const SweepJob job = jobs[blockIdx.x];
     const SweepGenome g = genomes[job.genome];
     const int kfirst = job.kfirst, klast = job.kfirst + job.nk - 1;
-    const unsigned long long ntok = *g.ntok;
+    const unsigned long long ntok = gload8u(g.ntok);
     const int w0 = c_bitmap_off[kfirst], w1 = c_bitmap_off[klast + 1];
     const uint32_t kmask = __builtin_amdgcn_readfirstlane(((2u << klast) - 1u) & ~((1u << kfirst) - 1u));  // bit k set: k in the job
     // warm start from what earlier jobs recorded (any snapshot is a subset of the final set)
@@ -441,16 +449,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void bit
     __syncthreads();
 
     const int prime = klast - 1;
-    const uint4* codes4 = reinterpret_cast<const uint4*>(g.codes);
-    const uint2* bad2 = reinterpret_cast<const uint2*>(g.bad);
     for (unsigned tile = job.tile_begin; tile < job.tile_end; ++tile) {
         const unsigned long long seg = (unsigned long long)tile * blockDim.x + threadIdx.x;
         if (seg * kSegTokens >= ntok) continue;
         uint32_t fw = 0, rc = 0;
         int run = 0;
         if (seg > 0) {
-            const uint4 hc = codes4[seg - 1];
-            const uint2 hb = bad2[seg - 1];
+            const uint4 hc = gload16(g.codes + (seg - 1) * 4);
+            const uint2 hb = gload8(g.bad + (seg - 1) * 2);
             const uint32_t cw = hc.w, bw = hb.y >> 16;  // last 16 tokens of the halo (prime <= 8)
 #pragma unroll 1
             for (int i = 16 - prime; i < 16; ++i) {
@@ -460,8 +466,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void bit
                 rc = (rc >> 2) | ((3u - c) << 30);
             }
         }
-        const uint4 sc = codes4[seg];
-        const uint2 sb = bad2[seg];
+        const uint4 sc = gload16(g.codes + seg * 4);
+        const uint2 sb = gload8(g.bad + seg * 2);
         const uint32_t cws[4] = {sc.x, sc.y, sc.z, sc.w};
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
@@ -505,7 +511,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void bit
     __syncthreads();
     for (int i = w0 + (int)threadIdx.x; i < w1; i += blockDim.x) {
         const uint32_t mine = bits[i];
-        if (mine & ~load4_fresh(&g.bitmap[i])) atomicOr(&g.bitmap[i], mine);
+        if (mine & ~load4_fresh(&g.bitmap[i])) gor32(&g.bitmap[i], mine);
     }
 }
 
@@ -525,7 +531,7 @@ __global__ __launch_bounds__(1024) void bitmap_finish_kernel(const SweepGenome* 
     const uint32_t* bm = g.bitmap + c_bitmap_off[k];
     const int nw = c_bitmap_off[k + 1] - c_bitmap_off[k];
     for (int w = threadIdx.x; w < nw; w += blockDim.x) {
-        uint32_t v = bm[w];
+        uint32_t v = gload4(bm + w);
         while (v) {
             const uint32_t b = (uint32_t)__builtin_ctz(v);
             v &= v - 1;
@@ -537,7 +543,7 @@ __global__ __launch_bounds__(1024) void bitmap_finish_kernel(const SweepGenome* 
     __syncthreads();
     if (in_lds) {
         const uint4* l4 = reinterpret_cast<const uint4*>(g_lds);
-        for (uint32_t i = threadIdx.x; i < (m >> 4); i += blockDim.x) reinterpret_cast<uint4*>(row)[i] = l4[i];
+        for (uint32_t i = threadIdx.x; i < (m >> 4); i += blockDim.x) gstore16(row + (size_t)i * 16, l4[i]);
     }
 }
 

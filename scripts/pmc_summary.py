@@ -13,7 +13,7 @@ for r in rows:
         key = 'sweep' + name.split('sweep_kernel<')[1][0]
     agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
     dur[key].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6)
-upd = {'sweep0': nb * 7, 'sweep1': nb * 16, 'sweep2': nb * 8, 'bitmap_kernel': nb * 6}
+upd = {'sweep0': nb * 7, 'sweep1': nb * 16, 'sweep3': nb * 8, 'sweep2': nb * 8, 'bitmap_kernel': nb * 6}
 for kc in sorted(agg):
     d = {k: sum(v) / len(v) for k, v in agg[kc].items()}
     print(kc, "avg ms (pmc run) %.3f" % (sum(dur[kc]) / len(dur[kc])))
