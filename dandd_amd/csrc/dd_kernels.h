@@ -8,7 +8,8 @@ namespace dd {
 
 // ---------------------------------------------------------------------------------------
 // Token stream of one genome in HBM (output of K0, input of K1).
-//   codes : 2 bits per token, token j of word w at bits [2j, 2j+1]   (16 tokens / u32)
+//   codes : 2 bits per token, token j of word w at bits [2j, 2j+1]   (16 tokens / u32);
+//           unspecified for BREAK tokens (no window that contains one is ever used)
 //   bad   : 1 bit per token, 1 = BREAK (non-ACGT byte or record boundary) (32 tokens / u32)
 //   ntok  : device scalar, number of tokens; the stream is padded with BREAKs to a
 //           multiple of 64 tokens (one K1 thread segment).

@@ -37,6 +37,8 @@ DD_D uint32_t base_code(uint32_t c) {
     return x == 'a' ? 0u : x == 'c' ? 1u : x == 'g' ? 2u : x == 't' ? 3u : 4u;
 }
 
+DD_D uint64_t pack_u64(uint32_t hi, uint32_t lo) { return ((uint64_t)hi << 32) | lo; }
+
 struct Bytes16 {
     uint32_t w[4];
     DD_D uint32_t at(int i) const { return (w[i >> 2] >> ((i & 3) * 8)) & 0xFFu; }
@@ -46,7 +48,7 @@ struct Bytes16 {
 DD_D Bytes16 load16(const uint8_t* fa, size_t n, size_t pos) {
     Bytes16 b;
     if (pos + 16 <= n) {
-        uint4 v = *reinterpret_cast<const uint4*>(fa + pos);
+        const uint4 v = gload16(fa + pos);
         b.w[0] = v.x; b.w[1] = v.y; b.w[2] = v.z; b.w[3] = v.w;
     } else {
 #pragma unroll
@@ -112,13 +114,54 @@ DD_D int scan16(const Bytes16& b, LineState& s, uint32_t& codes, uint32_t& bad) 
     return cnt;
 }
 
-// What a thread's 64 bytes look like from outside: ONE pass of the machine (entered as "not in a
-// header") yields the span's action on the header bit and its token count under either incoming bit,
-// because the two cases differ only before the first newline: entered inside a header, the bytes up
-// to that newline emit nothing and the newline itself emits the record BREAK.
+// Bit-parallel view of a thread's 64 bytes (SWAR over the 16 words, no per-byte loop).
+struct SpanBits {
+    uint32_t codes[4];  // 2 bits per byte: A/a 0, C/c 1, G/g 2, T/t 3 (meaningless where bad)
+    uint32_t bad[2];    // 1 bit per byte: not one of A C G T a c g t
+    uint32_t nl[2];     // 1 bit per byte: '\n'
+    bool plain;         // every byte is '\n' or lies in 0x40..0x7F: no '>', no '\r', nothing that
+                        // needs the line machine -- each byte is a base, a BREAK, or a dropped newline
+};
+DD_D SpanBits span_bits(const Bytes16 (&b)[SUB]) {
+    SpanBits r;
+    uint32_t other = 0;
+    r.bad[0] = r.bad[1] = r.nl[0] = r.nl[1] = 0;
+#pragma unroll
+    for (int j = 0; j < SUB; ++j) {
+        uint32_t cj = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t w = b[j].w[i];
+            const uint32_t x = w | 0x20202020u;
+            const uint32_t c2 = ((x >> 1) ^ (x >> 2)) & 0x03030303u;        // a c g t -> 0 1 2 3
+            const uint32_t expect = __builtin_amdgcn_perm(0u, 0x74676361u, c2);  // "acgt"[c2] per byte
+            const uint32_t d = x ^ expect;                                   // zero byte: A/C/G/T
+            const uint32_t nz = (((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d) & 0x80808080u;
+            const uint32_t v = w ^ 0x0A0A0A0Au;                              // zero byte: newline
+            const uint32_t nlm = ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;
+            other |= ((((~w) & 0x40404040u) << 1) | (w & 0x80808080u)) & ~nlm;  // outside 0x40..0x7F
+            // gather the four 2-bit codes / four flag bits of the word with one multiply each
+            cj |= ((c2 * 0x01041040u) >> 24) << (8 * i);
+            const int word = 4 * j + i;  // bytes 4*word .. 4*word+3 of the span
+            r.bad[word >> 3] |= ((nz * 0x00204081u) >> 28) << (4 * (word & 7));
+            r.nl[word >> 3] |= ((nlm * 0x00204081u) >> 28) << (4 * (word & 7));
+        }
+        r.codes[j] = cj;
+    }
+    r.plain = other == 0;
+    return r;
+}
+
+// What a thread's 64 bytes look like from outside: the span's action on the header bit and its
+// token count under either incoming bit.  The two cases differ only before the first newline:
+// entered inside a header, the bytes up to that newline emit nothing and the newline itself emits the
+// record BREAK.  Plain spans (almost all of a genome) get this from the newline mask; the others
+// run ONE pass of the byte machine (entered as "not in a header").
 struct ThreadSpan {
     Bytes16 b[SUB];
+    SpanBits bits;
     bool line_start;  // first byte is the first of a line (the incoming bit is then irrelevant)
+    bool plain;       // bits.plain and the whole span lies inside the file
     int kind;         // action on the header bit
     int t0, t1;       // tokens if entered outside / inside a header line
 };
@@ -127,15 +170,27 @@ DD_D ThreadSpan load_span(const uint8_t* fa, size_t n, size_t pos) {
     ThreadSpan t;
 #pragma unroll
     for (int j = 0; j < SUB; ++j) t.b[j] = load16(fa, n, pos + 16 * j);
-    t.line_start = (pos == 0) || (pos - 1 < n ? fa[pos - 1] == '\n' : false);
-    LineState s{false, t.line_start, false, 0, 0};
-    uint32_t d0, d1;
-#pragma unroll
-    for (int j = 0; j < SUB; ++j) (void)scan16<false>(t.b[j], s, d0, d1);
+    t.line_start = (pos == 0) || (pos - 1 < n ? *(const DD_GLOBAL uint8_t*)(fa + pos - 1) == '\n' : false);
+    t.bits = span_bits(t.b);
+    t.plain = t.bits.plain && pos + kPackBytesPerThread <= n;
     if (pos >= n) {  // tail of the last chunk
         t.kind = KIND_ID;
         t.t0 = t.t1 = 0;
+    } else if (t.plain) {
+        const int nnl = __builtin_popcount(t.bits.nl[0]) + __builtin_popcount(t.bits.nl[1]);
+        t.kind = (nnl || t.line_start) ? KIND_C0 : KIND_ID;  // no '>' in the span: it ends outside a header
+        t.t0 = kPackBytesPerThread - nnl;
+        if (t.line_start) t.t1 = t.t0;
+        else if (nnl == 0) t.t1 = 0;
+        else {
+            const int q1 = t.bits.nl[0] ? __builtin_ctz(t.bits.nl[0]) : 32 + __builtin_ctz(t.bits.nl[1]);
+            t.t1 = (kPackBytesPerThread - 1 - q1) - (nnl - 1) + 1;  // bytes after the first newline, less newlines, + BREAK
+        }
     } else {
+        LineState s{false, t.line_start, false, 0, 0};
+        uint32_t d0, d1;
+#pragma unroll
+        for (int j = 0; j < SUB; ++j) (void)scan16<false>(t.b[j], s, d0, d1);
         t.kind = (s.seen_nl || t.line_start) ? (s.hdr ? KIND_C1 : KIND_C0) : KIND_ID;
         t.t0 = s.pre + s.rest;
         t.t1 = t.line_start ? t.t0 : s.rest + (s.seen_nl ? 1 : 0);
@@ -336,21 +391,65 @@ __global__ __launch_bounds__(T) void pack_write(const PackGenome* __restrict__ t
     __syncthreads();
     if (cnt) {
         long long tk = S + (inc - cnt);  // global index of this thread's next token
-        LineState s{in.hdr, t.line_start, false, 0, 0};
-#pragma unroll
-        for (int j = 0; j < SUB; ++j) {
-            uint32_t pc, pb;
-            const int n16 = scan16<true>(t.b[j], s, pc, pb);
-            if (n16) {
-                const int wi = (int)((tk >> 4) - cw0), sh = (int)(tk & 15) * 2;
-                if (pc << sh) atomicOr(&lcodes[cidx(wi)], pc << sh);
-                if (sh && (pc >> (32 - sh))) atomicOr(&lcodes[cidx(wi + 1)], pc >> (32 - sh));
-                if (pb) {
-                    const int bi = (int)((tk >> 5) - bw0), bs = (int)(tk & 31);
-                    atomicOr(&lbad[bidx(bi)], pb << bs);
-                    if (bs > 16 && (pb >> (32 - bs))) atomicOr(&lbad[bidx(bi + 1)], pb >> (32 - bs));
+        if (t.plain && !in.hdr) {
+            // Every byte but the newlines is a token: squeeze the newline fields out of the 128-bit
+            // code string and the 64-bit BREAK string (highest first, so lower positions stay put),
+            // then OR the dense strings into the image at the thread's bit offset.
+            uint64_t clo = pack_u64(t.bits.codes[1], t.bits.codes[0]), chi = pack_u64(t.bits.codes[3], t.bits.codes[2]);
+            uint64_t bad = pack_u64(t.bits.bad[1], t.bits.bad[0]);
+            uint64_t nl = pack_u64(t.bits.nl[1], t.bits.nl[0]);
+            while (nl) {
+                const int q = 63 - __builtin_clzll(nl);
+                nl &= ~(1ull << q);
+                const uint64_t keep = (1ull << q) - 1ull;
+                bad = (bad & keep) | ((bad >> 1) & ~keep);
+                if (q < 32) {
+                    const uint64_t k2 = (1ull << (2 * q)) - 1ull;
+                    clo = (clo & k2) | (((clo >> 2) | (chi << 62)) & ~k2);
+                    chi >>= 2;
+                } else {
+                    const uint64_t k2 = (1ull << (2 * (q - 32))) - 1ull;
+                    chi = (chi & k2) | ((chi >> 2) & ~k2);
                 }
-                tk += n16;
+            }
+            // (the shifts fill the vacated top fields with zeros: exactly cnt fields remain)
+            const int wi = (int)((tk >> 4) - cw0), sh = (int)(tk & 15) * 2;
+            const uint32_t c[5] = {(uint32_t)clo, (uint32_t)(clo >> 32), (uint32_t)chi, (uint32_t)(chi >> 32), 0u};
+            uint32_t prev = 0;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const uint32_t v = (uint32_t)((((uint64_t)c[i] << 32) | prev) >> (32 - sh));  // funnel shift left by sh
+                prev = c[i];
+                if (v) atomicOr(&lcodes[cidx(wi + i)], v);
+            }
+            if (bad) {
+                const int bi = (int)((tk >> 5) - bw0), bs = (int)(tk & 31);
+                const uint32_t bb[3] = {(uint32_t)bad, (uint32_t)(bad >> 32), 0u};
+                uint32_t pb = 0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const uint32_t v = (uint32_t)((((uint64_t)bb[i] << 32) | pb) >> (32 - bs));
+                    pb = bb[i];
+                    if (v) atomicOr(&lbad[bidx(bi + i)], v);
+                }
+            }
+        } else {
+            LineState s{in.hdr, t.line_start, false, 0, 0};
+#pragma unroll
+            for (int j = 0; j < SUB; ++j) {
+                uint32_t pc, pb;
+                const int n16 = scan16<true>(t.b[j], s, pc, pb);
+                if (n16) {
+                    const int wi = (int)((tk >> 4) - cw0), sh = (int)(tk & 15) * 2;
+                    if (pc << sh) atomicOr(&lcodes[cidx(wi)], pc << sh);
+                    if (sh && (pc >> (32 - sh))) atomicOr(&lcodes[cidx(wi + 1)], pc >> (32 - sh));
+                    if (pb) {
+                        const int bi = (int)((tk >> 5) - bw0), bs = (int)(tk & 31);
+                        atomicOr(&lbad[bidx(bi)], pb << bs);
+                        if (bs > 16 && (pb >> (32 - bs))) atomicOr(&lbad[bidx(bi + 1)], pb >> (32 - bs));
+                    }
+                    tk += n16;
+                }
             }
         }
     }
