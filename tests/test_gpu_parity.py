@@ -85,6 +85,31 @@ def test_sweep_parity_long_lines_and_headers(engine_factory, orc):
     _sweep_check(eng, orc, np.frombuffer(fa, dtype=np.uint8), 2, 36, True)
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_sweep_parity_line_width_fuzz(engine_factory, orc, seed):
+    """Random line widths (0..150, so 64-byte spans hold 0, 1, 2 or many newlines at every offset),
+    letters that are not bases, lower case, and -- in some records -- blanks, digits, CRLF and '>'
+    inside lines, which send a span from the bit-parallel tokenizer to the byte machine."""
+    rng = np.random.default_rng(seed)
+    plain = np.frombuffer(b"ACGTACGTACGTACGTacgtNnRY@[_~", dtype=np.uint8)
+    messy = np.frombuffer(b"ACGTACGTACGTacgtN *-0>\r", dtype=np.uint8)
+    parts = []
+    for rec in range(40):
+        parts.append(b">rec%d some description\n" % rec if rec % 5 else b">r\n")
+        alphabet = messy if rec % 7 == 3 else plain
+        width_hi = [3, 20, 61, 64, 65, 150][rec % 6]
+        for _ in range(int(rng.integers(1, 60))):
+            w = int(rng.integers(0, width_hi + 1))
+            parts.append(rng.choice(alphabet, size=w).tobytes() + (b"\r\n" if rec % 11 == 5 else b"\n"))
+    fa = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    eng = engine_factory(10, True)
+    _sweep_check(eng, orc, fa, 1, 40, True)
+    # the same bytes shifted by 1..3 put every newline at a different offset inside its span
+    for shift in (1, 2, 3):
+        shifted = np.concatenate([np.frombuffer(b"\n" * shift, dtype=np.uint8), fa])
+        _sweep_check(eng, orc, shifted, 15, 17, True)
+
+
 def test_sweep_parity_many_tiles(engine_factory, orc):
     """5 Mbp: 77 tiles of 64 Ki tokens -> exercises multi-tile jobs, halos and the HBM merge."""
     eng = engine_factory(14, True)
