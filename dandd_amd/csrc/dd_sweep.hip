@@ -71,23 +71,28 @@ DD_D uint64_t wang64_fast(uint64_t x) {
 // ---- register stores -------------------------------------------------------------------------
 // LDS: byte registers, 32-bit compare-and-swap on the containing word when a register must rise.
 struct RegsLds {
-    uint32_t base;  // byte offset of the slot in g_lds
-    DD_D uint32_t load8(uint32_t i) const { return g_lds[base + i]; }
-    DD_D uint32_t load32(uint32_t i) const {
-        return reinterpret_cast<const uint32_t*>(g_lds)[(base + i) >> 2];  // plain ds_read_b32
-    }
-    DD_D uint32_t cas32(uint32_t i, uint32_t expect, uint32_t desired) const {
-        return atomicCAS(reinterpret_cast<uint32_t*>(g_lds + base + i), expect, desired);
+    uint32_t base;  // byte offset of the slot in g_lds (a multiple of 16)
+    using Addr = uint32_t;
+    DD_D Addr at(uint32_t i) const { return base + i; }
+    DD_D static uint32_t shift(Addr a) { return (a & 3u) * 8u; }
+    DD_D static uint32_t load8(Addr a) { return g_lds[a]; }
+    DD_D static uint32_t load32(Addr a) { return *reinterpret_cast<const uint32_t*>(g_lds + (a & ~3u)); }
+    DD_D static uint32_t cas32(Addr a, uint32_t expect, uint32_t desired) {
+        return atomicCAS(reinterpret_cast<uint32_t*>(g_lds + (a & ~3u)), expect, desired);
     }
 };
 // HBM/L2: same protocol on the genome's slab (p >= 18: one array no longer fits LDS).
 struct RegsGlobal {
-    uint8_t* base;
-    DD_D uint32_t load8(uint32_t i) const { return gload1_fresh(base + i); }
-    DD_D uint32_t load32(uint32_t i) const { return gload4_fresh(__builtin_assume_aligned(base + i, 4)); }
-    DD_D uint32_t cas32(uint32_t i, uint32_t expect, uint32_t desired) const {
-        return gcas32(__builtin_assume_aligned(base + i, 4), expect, desired);
+    uint8_t* base;  // 16-byte aligned
+    using Addr = uint8_t*;
+    DD_D Addr at(uint32_t i) const { return base + i; }
+    DD_D static uint32_t shift(Addr a) { return ((uint32_t)(uintptr_t)a & 3u) * 8u; }
+    DD_D static uint8_t* word(Addr a) {
+        return static_cast<uint8_t*>(__builtin_assume_aligned(a - ((uintptr_t)a & 3u), 4));
     }
+    DD_D static uint32_t load8(Addr a) { return gload1_fresh(a); }
+    DD_D static uint32_t load32(Addr a) { return gload4_fresh(word(a)); }
+    DD_D static uint32_t cas32(Addr a, uint32_t expect, uint32_t desired) { return gcas32(word(a), expect, desired); }
 };
 
 // 16 bytes of global memory as other agents' atomics left them (two relaxed agent-scope 8-byte
@@ -98,21 +103,6 @@ DD_D uint4 load16_fresh(const uint8_t* p) {
     return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
 }
 DD_D uint32_t load4_fresh(const uint32_t* p) { return gload4_fresh(p); }
-
-// Exact byte-max into register idx.
-template <typename R>
-DD_D void reg_raise(const R& regs, uint32_t idx, uint32_t rho) {
-    const uint32_t wi = idx & ~3u, sh = (idx & 3u) * 8u;
-    uint32_t old = regs.load32(wi);
-    while (true) {
-        const uint32_t cur = (old >> sh) & 0xFFu;
-        if (rho <= cur) break;
-        const uint32_t nw = (old & ~(0xFFu << sh)) | (rho << sh);
-        const uint32_t prev = regs.cas32(wi, old, nw);
-        if (prev == old) break;
-        old = prev;
-    }
-}
 
 // idx = h >> (64-p) and lz = rho(h) - 1 (0xFFFFFFFF when the top 32 bits of h << p are all zero)
 struct Probe {
@@ -127,29 +117,43 @@ DD_D Probe probe(uint64_t h, int p) {
     r.lo = lo;
     return r;
 }
-// the rare path: the register (last seen as cur) may have to rise
+// The rare path: the register at `a` was seen below rho.  Exact byte-max through a 32-bit CAS on
+// the containing word; every instruction here is paid by the whole wave for (typically) one lane,
+// so it is kept short: the byte is raised by ADDING (rho - cur) << shift (no carry can leave the
+// byte), and rho needs its long form only when the 32 bits after the index are all zero.
 template <typename R>
-DD_D void raise_checked(const R& regs, const Probe& q, uint32_t cur, int p) {
-    uint32_t rho = q.lz + 1;
-    if (q.hiw == 0) rho = 33u + (uint32_t)__builtin_clz((q.lo << p) | (1u << (p - 1)));
-    if (rho > cur) reg_raise(regs, q.idx, rho);
+DD_D void raise(typename R::Addr a, const Probe& q, int p) {
+    uint32_t rho = q.lz + 1;  // 0 where hiw == 0
+    if (__builtin_expect(__any(q.hiw == 0), 0)) {
+        if (q.hiw == 0) rho = 33u + (uint32_t)__builtin_clz((q.lo << p) | (1u << (p - 1)));
+    }
+    const uint32_t sh = R::shift(a);
+    uint32_t old = R::load32(a);
+    while (true) {
+        const uint32_t cur = (old >> sh) & 0xFFu;
+        if (rho <= cur) break;
+        const uint32_t prev = R::cas32(a, old, old + ((rho - cur) << sh));
+        if (prev == old) break;
+        old = prev;
+    }
 }
 // reg[h >> (64-p)] = max(., rho(h)); the common case (no change) is one byte read + compare.
 template <typename R>
 DD_D void hll_update(const R& regs, uint64_t h, int p) {
     const Probe q = probe(h, p);
-    const uint32_t cur = regs.load8(q.idx);
-    if (q.lz >= cur) raise_checked(regs, q, cur, p);  // rho > cur, or hiw == 0 (resolved there)
+    const typename R::Addr a = regs.at(q.idx);
+    if (q.lz >= R::load8(a)) raise<R>(a, q, p);  // rho > register, or hiw == 0 (resolved there)
 }
 // two independent updates interleaved: both hash chains and both LDS reads are in flight
 // together, one wave-level branch covers the common no-change case of both
 template <typename R>
 DD_D void hll_update2(const R& r0, uint64_t h0, const R& r1, uint64_t h1, int p) {
-    const Probe a = probe(h0, p), b = probe(h1, p);
-    const uint32_t c0 = r0.load8(a.idx), c1 = r1.load8(b.idx);
-    if ((a.lz >= c0) | (b.lz >= c1)) {
-        if (a.lz >= c0) raise_checked(r0, a, c0, p);
-        if (b.lz >= c1) raise_checked(r1, b, c1, p);
+    const Probe qa = probe(h0, p), qb = probe(h1, p);
+    const typename R::Addr a = r0.at(qa.idx), b = r1.at(qb.idx);
+    const uint32_t c0 = R::load8(a), c1 = R::load8(b);
+    if ((qa.lz >= c0) | (qb.lz >= c1)) {
+        if (qa.lz >= c0) raise<R>(a, qa, p);
+        if (qb.lz >= c1) raise<R>(b, qb, p);
     }
 }
 
