@@ -15,7 +15,7 @@ fetch_dir, write_dir = sys.argv[1], sys.argv[2]
 
 
 def per_kernel(d, counter):
-    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
@@ -40,6 +40,7 @@ for k in sorted(set(fetch) | set(write)):
         sweep_fetch += 2 * sum(fetch.get(k, [0])) / steps
         sweep_write += sum(write.get(k, [0])) / steps
 out["k1_bytes_per_step"] = {"fetch": sweep_fetch, "write": sweep_write, "total": sweep_fetch + sweep_write}
-with open(os.path.join(ROOT, "profiles", "traffic.json"), "w") as fh:
+dest = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "traffic.json")
+with open(dest, "w") as fh:
     json.dump(out, fh, indent=1)
 print(json.dumps(out["k1_bytes_per_step"]))
