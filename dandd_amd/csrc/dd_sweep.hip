@@ -71,9 +71,10 @@ DD_D uint64_t wang64_fast(uint64_t x) {
 // ---- register stores -------------------------------------------------------------------------
 // LDS: byte registers, 32-bit compare-and-swap on the containing word when a register must rise.
 struct RegsLds {
-    uint32_t base;  // byte offset of the slot in g_lds (a multiple of 16)
+    uint32_t slot;  // the slot's registers start at byte slot << p of g_lds
     using Addr = uint32_t;
-    DD_D Addr at(uint32_t i) const { return base + i; }
+    // address of register  hi >> (32-p)  (the top p bits of the hash): one v_alignbit of slot:hi
+    DD_D Addr at(uint32_t hi, int p) const { return __builtin_amdgcn_alignbit(slot, hi, 32 - p); }
     DD_D static uint32_t shift(Addr a) { return (a & 3u) * 8u; }
     DD_D static uint32_t load8(Addr a) { return g_lds[a]; }
     DD_D static uint32_t load32(Addr a) { return *reinterpret_cast<const uint32_t*>(g_lds + (a & ~3u)); }
@@ -85,7 +86,7 @@ struct RegsLds {
 struct RegsGlobal {
     uint8_t* base;  // 16-byte aligned
     using Addr = uint8_t*;
-    DD_D Addr at(uint32_t i) const { return base + i; }
+    DD_D Addr at(uint32_t hi, int p) const { return base + (hi >> (32 - p)); }
     DD_D static uint32_t shift(Addr a) { return ((uint32_t)(uintptr_t)a & 3u) * 8u; }
     DD_D static uint8_t* word(Addr a) {
         return static_cast<uint8_t*>(__builtin_assume_aligned(a - ((uintptr_t)a & 3u), 4));
@@ -104,14 +105,15 @@ DD_D uint4 load16_fresh(const uint8_t* p) {
 }
 DD_D uint32_t load4_fresh(const uint32_t* p) { return gload4_fresh(p); }
 
-// idx = h >> (64-p) and lz = rho(h) - 1 (0xFFFFFFFF when the top 32 bits of h << p are all zero)
+// hi = top word of h (its top p bits index the register) and lz = rho(h) - 1 (0xFFFFFFFF when the
+// top 32 bits of h << p are all zero)
 struct Probe {
-    uint32_t idx, lz, hiw, lo;
+    uint32_t hi, lz, hiw, lo;
 };
 DD_D Probe probe(uint64_t h, int p) {
     const uint32_t hi = (uint32_t)(h >> 32), lo = (uint32_t)h;
     Probe r;
-    r.idx = hi >> (32 - p);
+    r.hi = hi;
     r.hiw = __builtin_amdgcn_alignbit(hi, lo, 32 - p);  // bits 63..32 of (h << p)
     r.lz = ffbh(r.hiw);
     r.lo = lo;
@@ -141,7 +143,7 @@ DD_D void raise(typename R::Addr a, const Probe& q, int p) {
 template <typename R>
 DD_D void hll_update(const R& regs, uint64_t h, int p) {
     const Probe q = probe(h, p);
-    const typename R::Addr a = regs.at(q.idx);
+    const typename R::Addr a = regs.at(q.hi, p);
     if (q.lz >= R::load8(a)) raise<R>(a, q, p);  // rho > register, or hiw == 0 (resolved there)
 }
 // two independent updates interleaved: both hash chains and both LDS reads are in flight
@@ -149,7 +151,7 @@ DD_D void hll_update(const R& regs, uint64_t h, int p) {
 template <typename R>
 DD_D void hll_update2(const R& r0, uint64_t h0, const R& r1, uint64_t h1, int p) {
     const Probe qa = probe(h0, p), qb = probe(h1, p);
-    const typename R::Addr a = r0.at(qa.idx), b = r1.at(qb.idx);
+    const typename R::Addr a = r0.at(qa.hi, p), b = r1.at(qb.hi, p);
     const uint32_t c0 = R::load8(a), c1 = R::load8(b);
     if ((qa.lz >= c0) | (qb.lz >= c1)) {
         if (qa.lz >= c0) raise<R>(a, qa, p);
@@ -207,7 +209,9 @@ struct Windows<1> {
     }
     template <bool CANON>
     DD_D uint64_t hash(int k) const {
-        const uint64_t f = (k == 32) ? fw : (fw & ((1ull << (2 * k)) - 1ull));
+        // 16 <= k <= 32: the low word of the window belongs to the k-mer whole, only the high word is masked
+        const uint32_t mhi = (k == 32) ? ~0u : ((1u << (2 * k - 32)) - 1u);
+        const uint64_t f = pack64((uint32_t)(fw >> 32) & mhi, (uint32_t)fw);
         if (!CANON) return wang64_fast<false>(f);
         const uint64_t r = rc >> (64 - 2 * k);
         return wang64_fast<false>(f < r ? f : r);
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(1024) void sweep_kernel(const SweepGenome* __restri
     __syncthreads();
 
     const int kmaxg = kfirst + nk - 1;
-    auto lds_slot = [p](int j) { return RegsLds{(uint32_t)j << p}; };
+    auto lds_slot = [](int j) { return RegsLds{(uint32_t)j}; };
     auto glb_slot = [slab, p](int j) { return RegsGlobal{slab + ((size_t)j << p)}; };
 
     for (unsigned tile = job.tile_begin; tile < job.tile_end; ++tile) {

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(1024) void k1_model(uint32_t* out, int nk, int kfir
     Windows<KC> win;
     uint32_t s = seed ^ ((blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u);
     uint64_t acc = 0;
-    auto lds_slot = [p](int j) { return RegsLds{(uint32_t)j << p}; };
+    auto lds_slot = [](int j) { return RegsLds{(uint32_t)j}; };
     for (int it = 0; it < iters; ++it) {
         s = s * 1664525u + 1013904223u;
         const uint32_t cw = s ^ (s >> 15);
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(1024) void k1_model(uint32_t* out, int nk, int kfir
                     if (MODE == 1) acc ^= h;
                     else {
                         const Probe q = probe(h, p);
-                        acc += q.idx ^ q.lz;
+                        acc += q.hi ^ q.lz;
                     }
                 }
             }
