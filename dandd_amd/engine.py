@@ -48,7 +48,9 @@ def load_library(path=None):
     # `import torch` would add the bundled one, and the second runtime to initialise reports "no
     # ROCm-capable device".  Importing torch first (when it is installed) makes the dynamic loader
     # resolve our NEEDED libamdhip64.so.7 to the copy torch already mapped.
-    if "torch" not in sys.modules:
+    # A process that will never import torch (the `dandd` CLI) sets DANDD_NO_TORCH=1 and saves the
+    # ~1 s import; the library then binds to the system HIP runtime.
+    if "torch" not in sys.modules and os.environ.get("DANDD_NO_TORCH") != "1":
         try:
             import torch  # noqa: F401
         except Exception:

@@ -137,6 +137,8 @@ def build_parser():
 
 
 def main(argv=None):
+    if "torch" not in sys.modules:  # stand-alone process: no torch anywhere on this path (engine.load_library)
+        os.environ.setdefault("DANDD_NO_TORCH", "1")
     args = build_parser().parse_args(sys.argv[1:] if argv is None else argv)
     args.func(args)
     return 0

@@ -22,7 +22,7 @@ from itertools import permutations
 from math import factorial
 from random import sample, shuffle
 
-from .store import Catalog, SketchPath, sketch_exists
+from .store import Catalog, SketchPath, ensure_dir, sketch_exists
 
 # ---------------------------------------------------------------------------------------------
 # backend plumbing: objects of this module are pickled, the GPU context is not
@@ -221,7 +221,7 @@ class DeltaTreeNode:
             self.ksketches[0] = Sketch(0, template, self.speciesinfo, self.experiment)
         ks = [k for k in range(max(1, mink), maxk + 1)]
         for k in ks:
-            os.makedirs(template.dir.replace("{}", str(k)), exist_ok=True)
+            ensure_dir(template.dir.replace("{}", str(k)))
             self.experiment["baseset"].add(template.base.replace("{}", str(k)))
         for child in (self.children if self.ngen > 1 else []):
             child.ksweep_update_node(mink, maxk)
@@ -229,10 +229,12 @@ class DeltaTreeNode:
         todo = []
         for k in ks:
             path = template.with_k(k)
-            if sketch_exists(path):
-                continue
+            # (dictionary first: a prefetched union has a cardinality and no file, and asking the
+            # file system about every such path dominated `progressive`)
             if (self.experiment["lowmem"] or self.experiment.get("prefetched")) and self.ngen > 1 \
                     and float(cards.get(path) or 0) > 0:
+                continue
+            if sketch_exists(path):
                 continue
             todo.append(k)
         if not todo:

@@ -106,7 +106,7 @@ class SketchPath:
         self.relative = os.path.join(f"ngen{self.ngen}", f"k{kval}", self.base) + ext
         self.full = os.path.join(self.dir, self.base) + ext
         if kval != 0:
-            os.makedirs(self.dir, exist_ok=True)
+            ensure_dir(self.dir)
 
     def __repr__(self):
         return f"SketchPath[{self.base}, ngen={self.ngen}, {self.full}]"
@@ -148,5 +148,27 @@ class SketchPath:
         return base
 
 
+_made_dirs = set()
+_seen_sketches = set()
+
+
+def ensure_dir(path):
+    """os.makedirs(path, exist_ok=True), once per path and process: the tree code asks for the same
+    ngen*/k* directories for every node and every k (a million times in a 32-genome `progressive`)."""
+    if path not in _made_dirs:
+        os.makedirs(path, exist_ok=True)
+        _made_dirs.add(path)
+
+
 def sketch_exists(path):
-    return os.path.exists(path) and os.stat(path).st_size != 0
+    """A non-empty sketch file is there.  Sketch files are only ever created, never removed or
+    truncated, within a run, so a positive answer is remembered; a negative one is asked again."""
+    if path in _seen_sketches:
+        return True
+    try:
+        ok = os.stat(path).st_size != 0
+    except OSError:
+        return False
+    if ok:
+        _seen_sketches.add(path)
+    return ok
