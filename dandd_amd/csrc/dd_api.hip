@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -17,6 +18,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <string>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -164,25 +166,54 @@ int upload(dd_ctx* c, void* dst_dev, const void* src, size_t bytes, size_t stage
     return DD_OK;
 }
 
+// Host bytes of one file: malloc/realloc storage that is reused from file to file (no zero fill, no
+// fresh mappings per file -- with 16 loader threads the page-fault traffic of per-file vectors slowed
+// the GPU-driving thread's own copies 20x through the shared address-space lock).
+struct FileBuf {
+    uint8_t* p = nullptr;
+    size_t len = 0, cap = 0;
+    FileBuf() = default;
+    FileBuf(const FileBuf&) = delete;
+    FileBuf& operator=(const FileBuf&) = delete;
+    ~FileBuf() { free(p); }
+    bool reserve(size_t n) {
+        if (n <= cap) return true;
+        void* q = realloc(p, n);
+        if (!q) return false;
+        p = static_cast<uint8_t*>(q);
+        cap = n;
+        return true;
+    }
+    const uint8_t* data() const { return p; }
+    size_t size() const { return len; }
+};
+
 // Whole FASTA file into memory; gzip (any number of members) or plain, decided by zlib itself.
-bool read_fasta_file(const char* path, std::vector<uint8_t>& out, std::string& err) {
+bool read_fasta_file(const char* path, FileBuf& out, std::string& err) {
     gzFile f = gzopen(path, "rb");
     if (!f) {
         err = std::string("cannot open ") + path;
         return false;
     }
     gzbuffer(f, 1u << 20);
-    out.clear();
-    size_t cap = 1u << 22;
-    out.resize(cap);
-    size_t len = 0;
+    // size hint: a plain file is read in one piece; a compressed one usually inflates ~4x
+    size_t hint = 1u << 22;
+    struct stat sb;
+    if (stat(path, &sb) == 0 && sb.st_size > 0) hint = (size_t)sb.st_size + 1;
+    out.len = 0;
+    if (!out.reserve(std::max(out.cap, hint))) {
+        err = std::string("out of host memory reading ") + path;
+        gzclose(f);
+        return false;
+    }
     for (;;) {
-        if (len == cap) {
-            cap *= 2;
-            out.resize(cap);
+        if (out.len == out.cap && !out.reserve(out.cap * 2)) {
+            err = std::string("out of host memory reading ") + path;
+            gzclose(f);
+            return false;
         }
-        const unsigned want = (unsigned)std::min<size_t>(cap - len, 1u << 30);
-        const int got = gzread(f, out.data() + len, want);
+        const unsigned want = (unsigned)std::min<size_t>(out.cap - out.len, 1u << 30);
+        const int got = gzread(f, out.p + out.len, want);
         if (got < 0) {
             int code = 0;
             err = std::string("read error on ") + path + ": " + gzerror(f, &code);
@@ -190,10 +221,9 @@ bool read_fasta_file(const char* path, std::vector<uint8_t>& out, std::string& e
             return false;
         }
         if (got == 0) break;
-        len += (size_t)got;
+        out.len += (size_t)got;
     }
     gzclose(f);
-    out.resize(len);
     return true;
 }
 
@@ -577,7 +607,7 @@ int dd_sketch_buffer(dd_ctx* c, const uint8_t* fasta, size_t nbytes, int kmin, i
 int dd_sketch_fasta(dd_ctx* c, const char* path, int kmin, int kmax, uint8_t* regs) {
     if (check_ctx(c)) return DD_EINVAL;
     if (!path) return fail(DD_EINVAL, "null path");
-    std::vector<uint8_t> buf;
+    FileBuf buf;
     std::string err;
     if (!read_fasta_file(path, buf, err)) return fail(DD_EIO, "%s", err.c_str());
     return dd_sketch_buffer(c, buf.data(), buf.size(), kmin, kmax, regs);
@@ -594,12 +624,19 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
     for (int i = 0; i < nfiles; ++i)
         if (!paths[i]) return fail(DD_EINVAL, "null path at index %d", i);
     if (!nfiles) return DD_OK;
-    if (nthreads <= 0) nthreads = (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+    if (nthreads <= 0) nthreads = (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
     nthreads = std::min(nthreads, nfiles);
     const size_t slab = (size_t)(kmax - kmin + 1) << c->p;
 
+    // Read-ahead is bounded by a pool of `window` host buffers that are reused from file to file:
+    // a directory of whole genomes cannot exhaust host memory, and after the first few files the
+    // loaders touch no fresh pages.
+    const int window = nthreads + 2;
+    std::vector<FileBuf> pool_bufs(window);
+    std::vector<int> free_bufs;
+    for (int b = 0; b < window; ++b) free_bufs.push_back(b);
     struct Slot {
-        std::vector<uint8_t> data;
+        int buf = -1;
         std::string err;
         bool ok = false, done = false;
     };
@@ -607,24 +644,27 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
     std::mutex mu;
     std::condition_variable cv;
     std::atomic<int> next{0};
-    // bound the read-ahead so a directory of whole genomes cannot exhaust host memory
-    const int window = std::max(2 * nthreads, 4);
-    std::atomic<int> consumed{0};
+    int consumed = 0;  // files handed to the GPU so far (guarded by mu)
     auto loader = [&]() {
         for (;;) {
             const int i = next.fetch_add(1);
             if (i >= nfiles) return;
+            int b;
             {
+                // Only files consumed .. consumed+window-1 may hold a buffer: they are consumed in
+                // order, so a later file must never take the buffer an earlier one is waiting for.
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return i < consumed.load() + window; });
+                cv.wait(lk, [&] { return i < consumed + window && !free_bufs.empty(); });
+                b = free_bufs.back();
+                free_bufs.pop_back();
             }
-            Slot local;
-            local.ok = read_fasta_file(paths[i], local.data, local.err);
+            std::string err;
+            const bool ok = read_fasta_file(paths[i], pool_bufs[b], err);
             {
                 std::lock_guard<std::mutex> lk(mu);
-                slots[i].data.swap(local.data);
-                slots[i].err.swap(local.err);
-                slots[i].ok = local.ok;
+                slots[i].buf = b;
+                slots[i].err.swap(err);
+                slots[i].ok = ok;
                 slots[i].done = true;
             }
             cv.notify_all();
@@ -635,25 +675,38 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
 
     int rc = DD_OK;
     std::string first_err;
+    const bool trace = getenv("DD_TRACE_FILES") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_wait = 0, t_sketch = 0;
     for (int i = 0; i < nfiles; ++i) {
+        const double ta = now();
         {
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return slots[i].done; });
         }
+        const double tb = now();
+        t_wait += tb - ta;
         if (rc == DD_OK) {
             if (!slots[i].ok) {
                 rc = DD_EIO;
                 first_err = slots[i].err;
             } else {
-                rc = dd_sketch_buffer(c, slots[i].data.data(), slots[i].data.size(), kmin, kmax,
-                                      regs + (size_t)i * slab);
+                const FileBuf& hb = pool_bufs[slots[i].buf];
+                rc = dd_sketch_buffer(c, hb.data(), hb.size(), kmin, kmax, regs + (size_t)i * slab);
                 if (rc != DD_OK) first_err = g_err;
             }
         }
-        std::vector<uint8_t>().swap(slots[i].data);
-        consumed.store(i + 1);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            free_bufs.push_back(slots[i].buf);
+            consumed = i + 1;
+        }
         cv.notify_all();
+        t_sketch += now() - tb;
+        if (trace && (i < 4 || i == nfiles - 1))
+            fprintf(stderr, "[dd_sketch_files] file %d: waited %.2f ms for the loader, sketched in %.2f ms\n", i, tb - ta, now() - tb);
     }
+    if (trace) fprintf(stderr, "[dd_sketch_files] %d files: %.1f ms waiting for loaders, %.1f ms sketching\n", nfiles, t_wait, t_sketch);
     for (auto& t : pool) t.join();
     if (rc != DD_OK) return fail(rc, "%s", first_err.c_str());
     return DD_OK;
@@ -757,7 +810,7 @@ int dd_exact_count(dd_ctx* c, const char* const* paths, int n, int k, uint64_t* 
     if (n < 0 || !distinct || (n && !paths)) return fail(DD_EINVAL, "null argument");
     DeviceGuard guard(c->device);
     std::vector<size_t> sizes(n), offs(n);
-    std::vector<std::vector<uint8_t>> bufs(n);
+    std::vector<FileBuf> bufs(n);
     size_t tot = 0;
     for (int i = 0; i < n; ++i) {
         std::string err;
@@ -774,8 +827,8 @@ int dd_exact_count(dd_ctx* c, const char* const* paths, int n, int k, uint64_t* 
         if (sizes[i])
             DD_HIP(hipMemcpyAsync(const_cast<uint8_t*>(ptrs[i]), bufs[i].data(), sizes[i], hipMemcpyHostToDevice, c->stream));
     }
-    DD_HIP(hipStreamSynchronize(c->stream));  // host vectors are pageable; release them before the sort
-    bufs.clear();
+    DD_HIP(hipStreamSynchronize(c->stream));  // host buffers are pageable; release them before the sort
+    std::vector<FileBuf>().swap(bufs);
     return dd_exact_count_device(c, ptrs.data(), sizes.data(), n, k, distinct);
 }
 
