@@ -115,6 +115,26 @@ class SketchPath:
         """Concrete path of the k-placeholder ('{}') form."""
         return self.full.replace("{}", str(k))
 
+    def at_k(self, k, catalog, experiment):
+        """The SketchPath the constructor would build for the same files at k, derived from this
+        k-placeholder form (kval 0) by substitution: same names, same catalog registration, without
+        re-deriving the file-set digest name (a `kij` over 64 genomes asks for 150 000 of these)."""
+        if experiment.get("safety"):
+            return SketchPath(self.ffiles, k, catalog, experiment)
+        ktxt = str(k)
+        new = object.__new__(SketchPath)
+        new.ffiles, new.files, new.ngen = self.ffiles, self.files, self.ngen
+        new.dir = self.dir.replace("{}", ktxt)
+        new.base = self.base.replace("{}", ktxt)
+        ext = ".hll" if experiment["tool"] != "kmc" else ""
+        new.relative = os.path.join(f"ngen{self.ngen}", f"k{k}", new.base) + ext
+        new.full = self.full.replace("{}", ktxt)
+        ensure_dir(new.dir)
+        if new.base not in catalog.sketchinfo:
+            catalog.sketchinfo[new.base] = {"sketchbase": new.base, "files": self.files, "ngen": self.ngen,
+                                            "kval": k, "registers": experiment["registers"]}
+        return new
+
     def _digest_sum(self, catalog):
         if self.ngen == 1:
             return file_digest(self.ffiles[0])
