@@ -33,6 +33,23 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_LANEOPS = 78.6e12    # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
 
 
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (the GPU
+    boxes show 256 logical CPUs behind a 16-CPU quota; counting 256 would oversubscribe 16x)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(nbases, nrec, kmin, kmax, log2m):
     """Oracle stand-in for `parallel -j 95% 'dashing sketch -k{} ...' ::: kmin..kmax` on this host."""
     from concurrent.futures import ThreadPoolExecutor
@@ -44,7 +61,7 @@ def cpu_baseline(nbases, nrec, kmin, kmax, log2m):
     except Exception:
         lib = orc.lib()
     fa = orc.synth_fasta(SEED, 0, nbases, nrec)
-    ncpu = os.cpu_count() or 1
+    ncpu = usable_cpus()
     jobs = max(1, int(0.95 * ncpu))
     ks = list(range(kmin, kmax + 1))
     regs = np.zeros((len(ks), 1 << log2m), dtype=np.uint8)
@@ -65,7 +82,8 @@ def cpu_baseline(nbases, nrec, kmin, kmax, log2m):
         "cores": min(jobs, len(ks)),
         "kind": "port",
         "sample": f"1 synthetic genome x {nbases/1e6:g} Mbp, k {kmin}-{kmax}, log2m={log2m}: one single-threaded "
-                  f"oracle job per k (each re-parses the FASTA), {jobs} jobs in flight on {ncpu} host CPUs, {dt:.1f} s wall",
+                  f"oracle job per k (each re-parses the FASTA), {jobs} jobs in flight on {ncpu} usable host CPUs "
+                  f"({os.cpu_count()} logical, cgroup quota applied), {dt:.1f} s wall",
     }
 
 
@@ -102,7 +120,7 @@ def main():
     ap.add_argument("--nrec", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-accuracy", action="store_true")
-    ap.add_argument("--cpu-sample-mbp", type=float, default=16.0)
+    ap.add_argument("--cpu-sample-mbp", type=float, default=32.0)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
