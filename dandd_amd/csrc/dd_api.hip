@@ -398,7 +398,12 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     (void)max_n;
 
     // ---- K1 job tables -----------------------------------------------------------------
-    const bool global_regs = m > (size_t)dd::sweep_max_lds_bytes();
+    // registers in HBM: when one array does not fit LDS (log2m >= 18; DD_GLOBAL_FROM_P lowers that for
+    // experiments), behind a 64 KiB LDS filter unless DD_NO_FILTER is set
+    int global_from_p = 18;
+    if (const char* e = getenv("DD_GLOBAL_FROM_P")) global_from_p = std::max(16, std::min(18, atoi(e)));
+    const bool global_regs = m > (size_t)dd::sweep_max_lds_bytes() || p >= global_from_p;
+    const int filter_logg = (global_regs && !getenv("DD_NO_FILTER")) ? std::max(2, p - 16) : 0;
     // development knobs (environment, read per call): LDS budget per workgroup and jobs per CU
     // 80 KiB per workgroup = two 1024-thread workgroups (8 waves per SIMD) per CU: measured
     // 1.35x faster than one 160 KiB workgroup (4 waves per SIMD cannot cover the LDS latency of
@@ -441,20 +446,30 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         size_t tiles_per_job = std::max<size_t>(1, (total_tiles * ngroups + target_jobs - 1) / target_jobs);
         ClassJobs cj;
         cj.kclass = kc;
-        if (global_regs && kc != kBitmapClass && !getenv("DD_NO_XCD_AFFINITY")) {
+        if (global_regs && kc != kBitmapClass && (filter_logg || !getenv("DD_NO_XCD_AFFINITY"))) {
             // Registers live in HBM (log2m >= 18).  Every update reads one random byte of a 2^p-byte
             // array, so the arrays a workgroup touches should sit in ITS XCD's 4 MiB L2: k-groups are
             // cut to <= 3 MiB of arrays, each (genome, k-group) pair is given to one XCD, and because
             // workgroups are dealt round-robin over the 8 XCDs in blockIdx order, job 8*i + x is the
             // i-th job of XCD x.  Placement is a speed assumption only: every register update is an
             // agent-scope atomic, correct wherever the workgroup lands.
-            const int g_l2 = (int)std::max<size_t>(1, ((size_t)3 << 20) / m);
+            const int g_l2 = filter_logg ? 1 : (int)std::max<size_t>(1, ((size_t)3 << 20) / m);  // filter: one k per job
             const int ngr = (nks + g_l2 - 1) / g_l2;
             std::vector<std::vector<dd::SweepJob>> per_xcd(8);
             int pair = 0;
             for (int g = 0; g < ngenomes; ++g) {
                 const size_t ntiles = (nbytes[g] + tile_tokens - 1) / tile_tokens;
-                const size_t tpj = std::max<size_t>(1, ntiles / 128);  // >= 64 resident workgroups share a pair
+                // >= 64 resident workgroups share a pair; a filtered job first reads its whole row to
+                // build the filter, so those are made four times longer
+                size_t jobs_per_pair = 128;
+                if (filter_logg) {
+                    // a filtered job learns its filter as it goes (bounds rise only where it probes), so
+                    // jobs are as long as ~4096 jobs over the whole launch allow, 4..16 per row (measured best: 16)
+                    const size_t npairs = (size_t)ngenomes * ngr;
+                    jobs_per_pair = std::min<size_t>(16, std::max<size_t>(4, 4096 / std::max<size_t>(1, npairs)));
+                    if (const char* e = getenv("DD_JOBS_PER_ROW")) jobs_per_pair = std::max(1, atoi(e));
+                }
+                const size_t tpj = std::max<size_t>(1, ntiles / jobs_per_pair);
                 int kcur = ka;
                 for (int q = 0; q < ngr; ++q, ++pair) {
                     const int nk = nks / ngr + (q < nks % ngr ? 1 : 0);
@@ -564,7 +579,10 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         plan.log2m = p;
         plan.canonical = c->canonical;
         plan.threads = threads;
-        plan.lds_bytes = global_regs ? 0 : (int)((size_t)classes[i].max_nk * m);
+        // filtered mode: the filter, then a 128-entry candidate queue per wave (dd_sweep.hip)
+        plan.lds_bytes = filter_logg ? (int)(m >> filter_logg) + (threads / 64) * 128 * 4
+                                     : global_regs ? 0 : (int)((size_t)classes[i].max_nk * m);
+        plan.mode = filter_logg ? filter_logg : (global_regs ? 1 : 0);
         Span sp(c, DD_KERNEL_SWEEP);
         if (classes[i].kclass < 0) {
             dd::launch_bitmap(reinterpret_cast<const dd::SweepGenome*>(tdev),

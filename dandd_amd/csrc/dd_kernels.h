@@ -77,6 +77,8 @@ struct SweepPlan {
     int canonical;
     int threads;                // workgroup size
     int lds_bytes;              // dynamic LDS per workgroup
+    int mode;                   // 0: registers in LDS; 1: in HBM, every update checked there;
+                                // 2..4: in HBM behind an LDS filter byte per 2^mode registers (one k per job)
 };
 void launch_sweep(const SweepGenome* genomes_dev, const SweepJob* jobs_dev, int njobs, int kclass,
                   const SweepPlan& plan, hipStream_t st);

@@ -76,7 +76,7 @@ struct RegsLds {
     // address of register  hi >> (32-p)  (the top p bits of the hash): one v_alignbit of slot:hi
     DD_D Addr at(uint32_t hi, int p) const { return __builtin_amdgcn_alignbit(slot, hi, 32 - p); }
     DD_D static uint32_t shift(Addr a) { return (a & 3u) * 8u; }
-    DD_D static uint32_t load8(Addr a) { return g_lds[a]; }
+    DD_D uint32_t bound(Addr a) const { return g_lds[a]; }  // the register itself
     DD_D static uint32_t load32(Addr a) { return *reinterpret_cast<const uint32_t*>(g_lds + (a & ~3u)); }
     DD_D static uint32_t cas32(Addr a, uint32_t expect, uint32_t desired) {
         return atomicCAS(reinterpret_cast<uint32_t*>(g_lds + (a & ~3u)), expect, desired);
@@ -91,7 +91,7 @@ struct RegsGlobal {
     DD_D static uint8_t* word(Addr a) {
         return static_cast<uint8_t*>(__builtin_assume_aligned(a - ((uintptr_t)a & 3u), 4));
     }
-    DD_D static uint32_t load8(Addr a) { return gload1_fresh(a); }
+    DD_D uint32_t bound(Addr a) const { return gload1_fresh(a); }
     DD_D static uint32_t load32(Addr a) { return gload4_fresh(word(a)); }
     DD_D static uint32_t cas32(Addr a, uint32_t expect, uint32_t desired) { return gcas32(word(a), expect, desired); }
 };
@@ -119,32 +119,130 @@ DD_D Probe probe(uint64_t h, int p) {
     r.lo = lo;
     return r;
 }
-// The rare path: the register at `a` was seen below rho.  Exact byte-max through a 32-bit CAS on
-// the containing word; every instruction here is paid by the whole wave for (typically) one lane,
-// so it is kept short: the byte is raised by ADDING (rho - cur) << shift (no carry can leave the
-// byte), and rho needs its long form only when the 32 bits after the index are all zero.
-template <typename R>
-DD_D void raise(typename R::Addr a, const Probe& q, int p) {
+// rho(h) from a probe: lz + 1, in its long form only when the 32 bits after the index are all zero
+// (p = 2^-32: behind a wave-level branch)
+DD_D uint32_t rho_of(const Probe& q, int p) {
     uint32_t rho = q.lz + 1;  // 0 where hiw == 0
     if (__builtin_expect(__any(q.hiw == 0), 0)) {
         if (q.hiw == 0) rho = 33u + (uint32_t)__builtin_clz((q.lo << p) | (1u << (p - 1)));
     }
+    return rho;
+}
+// Exact byte-max of rho into the register at `a` through a 32-bit CAS on the containing word,
+// starting from the word value `old`; returns the register's value afterwards.  The byte is raised by
+// ADDING (rho - cur) << shift: no carry can leave the byte.
+template <typename R>
+DD_D uint32_t cas_raise(typename R::Addr a, uint32_t old, uint32_t rho) {
     const uint32_t sh = R::shift(a);
-    uint32_t old = R::load32(a);
     while (true) {
         const uint32_t cur = (old >> sh) & 0xFFu;
-        if (rho <= cur) break;
+        if (rho <= cur) return cur;
         const uint32_t prev = R::cas32(a, old, old + ((rho - cur) << sh));
-        if (prev == old) break;
+        if (prev == old) return rho;
         old = prev;
     }
 }
+// The rare path: the register at `a` was seen below rho.  Every instruction here is paid by the
+// whole wave for (typically) one lane, so it is kept short.
+template <typename R>
+DD_D void raise(const R&, typename R::Addr a, const Probe& q, int p) {
+    (void)cas_raise<R>(a, R::load32(a), rho_of(q, p));
+}
+
+// ---- log2m >= 18: registers in HBM behind an LDS filter and a candidate queue -----------------------
+// One array (256 KiB .. 1 MiB) no longer fits LDS, and checking every update against HBM/L2 costs one
+// L2 request per LANE (a wave's 64 registers are 64 different lines): measured 243 cycles per
+// wave-update per CU, 7x the VALU time.  Registers only ever rise, so ANY value a register group was
+// once seen to have is a lower bound for ever: LDS keeps, per group of G = 2^LOGG adjacent registers
+// (4..16: one aligned 4..16-byte load), the minimum the group was last seen with.  rho <= that bound
+// proves the update changes nothing -- the common case touches LDS only.
+// The few updates that pass the filter are not applied on the spot (a 2 us memory round trip for one
+// or two lanes of the wave, once per token: measured latency-bound at 600 cycles per update) but
+// queued per wave in LDS as (register, rho); whenever 64 are waiting the whole wave applies them at
+// once: each lane loads its group (one request), raises its register by CAS if needed, and stores the
+// group's new minimum.  A stale or racing bound is merely lower than it could be, never wrong.
+constexpr uint32_t kQueueEntries = 128;  // per wave; a push adds <= 64 to < 64 waiting
+DD_D uint32_t min4(uint32_t w) {  // smallest byte
+    const uint32_t a = w & 0xFFu, b = (w >> 8) & 0xFFu, c = (w >> 16) & 0xFFu, d = w >> 24;
+    const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+template <int LOGG>
+struct RegsFiltered {
+    uint8_t* base;    // the k's register row in HBM, 16-byte aligned; filter byte i covers registers i<<LOGG ..
+    uint32_t queue;   // byte offset of this wave's candidate queue in g_lds
+};
+// apply one (register, rho): exact byte-max in HBM, then raise the group's bound
+template <int LOGG>
+DD_D void filtered_apply(const RegsFiltered<LOGG>& regs, uint32_t idx, uint32_t rho) {
+    constexpr uint32_t G = 1u << LOGG, NW = G / 4;
+    uint8_t* const grp = regs.base + (idx & ~(G - 1u));
+    uint32_t w[NW];
+    // Plain loads, served by this XCD's L2 (the job order gives every row to one XCD): a quarter of the
+    // latency of a memory-side read.  Should the line be stale the values are only LOWER than the truth:
+    // the CAS then fails once and returns the real word, and the bound stored below is still a bound.
+    if (NW == 1) {
+        w[0] = gload4(grp);
+    } else if (NW == 2) {
+        const uint2 v = gload8(grp);
+        w[0] = v.x, w[1] = v.y;
+    } else {
+        const uint4 v = gload16(grp);
+        w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
+    }
+    const uint32_t wi = (idx & (G - 1u)) >> 2;  // this lane's word inside the group
+    uint32_t mine = w[0];
+#pragma unroll
+    for (uint32_t i = 1; i < NW; ++i) mine = (wi == i) ? w[i] : mine;
+    const uint32_t fin = cas_raise<RegsGlobal>(regs.base + idx, mine, rho);  // the register afterwards, >= rho
+    // group minimum with this register at its new value (the others as just seen: still lower bounds)
+    const uint32_t sh = (idx & 3u) * 8u;
+    const uint32_t upd = (mine & ~(0xFFu << sh)) | (fin << sh);
+    uint32_t lo = 0xFFu;
+#pragma unroll
+    for (uint32_t i = 0; i < NW; ++i) {
+        const uint32_t m = min4(wi == i ? upd : w[i]);
+        lo = m < lo ? m : lo;
+    }
+    if (lo > g_lds[idx >> LOGG]) g_lds[idx >> LOGG] = (uint8_t)lo;
+}
+// lanes 0..n-1 apply queue entries first..first+n-1 (called with the whole wave converged)
+template <int LOGG>
+DD_D void filtered_drain(const RegsFiltered<LOGG>& regs, uint32_t first, uint32_t n) {
+    const uint32_t lane = threadIdx.x & 63u;
+    if (lane < n) {
+        const uint32_t e = *reinterpret_cast<const uint32_t*>(g_lds + regs.queue + 4u * (first + lane));
+        const uint32_t idx = e & 0xFFFFFFu, rho = e >> 24;
+        if (rho > g_lds[idx >> LOGG]) filtered_apply(regs, idx, rho);  // the bound may have risen since
+    }
+}
+// One update; must be reached by every lane of the wave (`valid` says whether the lane has a k-mer):
+// `waiting` (entries in this wave's queue) has to stay wave-uniform.
+template <int LOGG>
+DD_D void filtered_update(const RegsFiltered<LOGG>& regs, uint32_t& waiting, uint64_t h, int p, bool valid) {
+    const Probe q = probe(h, p);
+    const uint32_t idx = q.hi >> (32 - p);
+    const bool cand = valid && q.lz >= g_lds[idx >> LOGG];  // rho > bound, or hiw == 0
+    const unsigned long long mask = __ballot(cand);
+    if (mask) {
+        if (cand) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            *reinterpret_cast<uint32_t*>(g_lds + regs.queue + 4u * (waiting + rank)) = idx | (rho_of(q, p) << 24);
+        }
+        waiting += (uint32_t)__builtin_popcountll(mask);
+        if (waiting >= 64u) {
+            waiting -= 64u;
+            filtered_drain(regs, waiting, 64u);
+        }
+    }
+}
+
 // reg[h >> (64-p)] = max(., rho(h)); the common case (no change) is one byte read + compare.
 template <typename R>
 DD_D void hll_update(const R& regs, uint64_t h, int p) {
     const Probe q = probe(h, p);
     const typename R::Addr a = regs.at(q.hi, p);
-    if (q.lz >= R::load8(a)) raise<R>(a, q, p);  // rho > register, or hiw == 0 (resolved there)
+    if (q.lz >= regs.bound(a)) raise(regs, a, q, p);  // rho > bound, or hiw == 0 (resolved there)
 }
 // two independent updates interleaved: both hash chains and both LDS reads are in flight
 // together, one wave-level branch covers the common no-change case of both
@@ -152,10 +250,10 @@ template <typename R>
 DD_D void hll_update2(const R& r0, uint64_t h0, const R& r1, uint64_t h1, int p) {
     const Probe qa = probe(h0, p), qb = probe(h1, p);
     const typename R::Addr a = r0.at(qa.hi, p), b = r1.at(qb.hi, p);
-    const uint32_t c0 = R::load8(a), c1 = R::load8(b);
+    const uint32_t c0 = r0.bound(a), c1 = r1.bound(b);
     if ((qa.lz >= c0) | (qb.lz >= c1)) {
-        if (qa.lz >= c0) raise<R>(a, qa, p);
-        if (qb.lz >= c1) raise<R>(b, qb, p);
+        if (qa.lz >= c0) raise(r0, a, qa, p);
+        if (qb.lz >= c1) raise(r1, b, qb, p);
     }
 }
 
@@ -305,9 +403,11 @@ DD_D void sweep_token(const Windows<KC>& win, int run, int kfirst, int nk, int p
     if (j < nk && (!CHECK || run >= kfirst + j)) hll_update(slot(j), win.template hash<CANON>(kfirst + j), p);
 }
 
-// GLOBAL = false: registers of the group live in LDS (2^p * nk bytes <= 160 KiB).
-// GLOBAL = true : registers are updated in place in the genome's HBM slab.
-template <int KC, bool CANON, bool GLOBAL>
+// MODE 0      : registers of the group live in LDS (2^p * nk bytes <= 160 KiB).
+// MODE 1      : registers are updated in place in the genome's HBM slab, every update checked there.
+// MODE 2, 3, 4: in place behind an LDS filter of one byte per 2^MODE registers (RegsFiltered), one k
+//               per workgroup.
+template <int KC, bool CANON, int MODE>
 __global__ __launch_bounds__(1024) void sweep_kernel(const SweepGenome* __restrict__ genomes,
                                                     const SweepJob* __restrict__ jobs, int p) {
     const SweepJob job = jobs[blockIdx.x];
@@ -330,6 +430,8 @@ __global__ __launch_bounds__(1024) void sweep_kernel(const SweepGenome* __restri
         t.live = tile < job.tile_end && seg * kSegTokens < ntok;
         t.hc = make_uint4(0, 0, 0, 0);
         t.hb = make_uint2(~0u, ~0u);
+        t.sc = make_uint4(0, 0, 0, 0);  // a segment outside the stream is all BREAKs
+        t.sb = make_uint2(~0u, ~0u);
         if (!t.live) return;
         if (seg > 0) {
             t.hc = gload16(g.codes + (seg - 1) * 4);
@@ -341,7 +443,23 @@ __global__ __launch_bounds__(1024) void sweep_kernel(const SweepGenome* __restri
     TileIn next;
     fetch(job.tile_begin, next);
 
-    if (!GLOBAL) {
+    if (MODE >= 2) {
+        // filter = per-group minimum of the row as it stands (any snapshot is a valid lower bound)
+        constexpr int LOGG = MODE >= 2 ? MODE : 2;
+        for (uint32_t i = threadIdx.x; i < (m >> 4); i += blockDim.x) {
+            const uint4 v = load16_fresh(slab + (size_t)i * 16);
+            const uint32_t m0 = min4(v.x), m1 = min4(v.y), m2 = min4(v.z), m3 = min4(v.w);
+            if (LOGG == 2) {
+                reinterpret_cast<uint32_t*>(g_lds)[i] = m0 | (m1 << 8) | (m2 << 16) | (m3 << 24);
+            } else if (LOGG == 3) {
+                reinterpret_cast<uint16_t*>(g_lds)[i] = (uint16_t)((m0 < m1 ? m0 : m1) | ((m2 < m3 ? m2 : m3) << 8));
+            } else {
+                const uint32_t a = m0 < m1 ? m0 : m1, b = m2 < m3 ? m2 : m3;
+                g_lds[i] = (uint8_t)(a < b ? a : b);
+            }
+        }
+    }
+    if (MODE == 0) {
         // Warm start: begin from whatever earlier jobs have already merged into the slab.  Any
         // (possibly stale) snapshot is a valid lower bound of the final registers, and a warm
         // array makes the "register rises" path rare: after T tokens have been absorbed only
@@ -358,11 +476,17 @@ __global__ __launch_bounds__(1024) void sweep_kernel(const SweepGenome* __restri
     const int kmaxg = kfirst + nk - 1;
     auto lds_slot = [](int j) { return RegsLds{(uint32_t)j}; };
     auto glb_slot = [slab, p](int j) { return RegsGlobal{slab + ((size_t)j << p)}; };
+    // filtered mode: one k per job; LDS = filter (m >> LOGG bytes) then one candidate queue per wave
+    constexpr int LOGG = MODE >= 2 ? MODE : 2;
+    const RegsFiltered<LOGG> flt{slab, (m >> LOGG) + (threadIdx.x >> 6) * (kQueueEntries * 4u)};
+    uint32_t waiting = 0;
 
     for (unsigned tile = job.tile_begin; tile < job.tile_end; ++tile) {
         const TileIn cur = next;
         fetch(tile + 1, next);
-        if (!cur.live) continue;
+        // (filtered mode keeps dead lanes in the loop, as all-BREAK segments: its queue counter must
+        // stay wave-uniform)
+        if (!cur.live && MODE < 2) continue;
         const uint4 hc = cur.hc, sc = cur.sc;
         const uint2 hb = cur.hb, sb = cur.sb;
         const uint32_t cw[4] = {sc.x, sc.y, sc.z, sc.w};
@@ -376,7 +500,8 @@ __global__ __launch_bounds__(1024) void sweep_kernel(const SweepGenome* __restri
 #pragma unroll 1
                 for (int i = 0; i < 16; ++i) {
                     win.push((cw[w] >> (2 * i)) & 3u);
-                    if (GLOBAL) sweep_token<KC, CANON, false>(win, 0, kfirst, nk, p, glb_slot);
+                    if (MODE >= 2) filtered_update(flt, waiting, win.template hash<CANON>(kfirst), p, true);
+                    else if (MODE == 1) sweep_token<KC, CANON, false>(win, 0, kfirst, nk, p, glb_slot);
                     else sweep_token<KC, CANON, false>(win, 0, kfirst, nk, p, lds_slot);
                 }
             }
@@ -394,19 +519,22 @@ __global__ __launch_bounds__(1024) void sweep_kernel(const SweepGenome* __restri
                 win.push(c);
                 // wave-uniform fast path: no lane of the wave is within kmaxg tokens of a BREAK
                 if (__all(run >= kmaxg)) {
-                    if (GLOBAL) sweep_token<KC, CANON, false>(win, run, kfirst, nk, p, glb_slot);
+                    if (MODE >= 2) filtered_update(flt, waiting, win.template hash<CANON>(kfirst), p, true);
+                    else if (MODE == 1) sweep_token<KC, CANON, false>(win, run, kfirst, nk, p, glb_slot);
                     else sweep_token<KC, CANON, false>(win, run, kfirst, nk, p, lds_slot);
                 } else {
-                    if (GLOBAL) sweep_token<KC, CANON, true>(win, run, kfirst, nk, p, glb_slot);
+                    if (MODE >= 2) filtered_update(flt, waiting, win.template hash<CANON>(kfirst), p, run >= kfirst);
+                    else if (MODE == 1) sweep_token<KC, CANON, true>(win, run, kfirst, nk, p, glb_slot);
                     else sweep_token<KC, CANON, true>(win, run, kfirst, nk, p, lds_slot);
                 }
             }
         }
     }
+    if (MODE >= 2) filtered_drain(flt, 0u, waiting);  // what is still queued (< 64 entries)
     __syncthreads();
 
     // merge the group's registers into the genome's slab (rows krow .. krow+nk-1 are contiguous)
-    if (!GLOBAL) {
+    if (MODE == 0) {
         const uint4* l4 = reinterpret_cast<const uint4*>(g_lds);
         uint32_t* gw = reinterpret_cast<uint32_t*>(slab);
         const uint32_t n16 = (uint32_t)nk * (m >> 4);
@@ -555,10 +683,10 @@ __global__ __launch_bounds__(1024) void bitmap_finish_kernel(const SweepGenome* 
     }
 }
 
-template <int KC, bool CANON, bool GLOBAL>
+template <int KC, bool CANON, int MODE>
 void launch_one(const SweepGenome* genomes, const SweepJob* jobs, int njobs, const SweepPlan& plan,
                 hipStream_t st) {
-    auto kern = sweep_kernel<KC, CANON, GLOBAL>;
+    auto kern = sweep_kernel<KC, CANON, MODE>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -601,20 +729,26 @@ void launch_bitmap_finish(const SweepGenome* genomes, int ngenomes, int kfirst, 
 void launch_sweep(const SweepGenome* genomes, const SweepJob* jobs, int njobs, int kclass,
                   const SweepPlan& plan, hipStream_t st) {
     if (njobs <= 0) return;
-#define DD_DISPATCH(KC, CN, GL) launch_one<KC, CN, GL>(genomes, jobs, njobs, plan, st)
-#define DD_DISPATCH_KC(CN, GL)                        \
+#define DD_DISPATCH(KC, CN, MD) launch_one<KC, CN, MD>(genomes, jobs, njobs, plan, st)
+#define DD_DISPATCH_KC(CN, MD)                        \
     do {                                              \
-        if (kclass == 0) DD_DISPATCH(0, CN, GL);      \
-        else if (kclass == 1) DD_DISPATCH(1, CN, GL); \
-        else if (kclass == 3) DD_DISPATCH(3, CN, GL); \
-        else DD_DISPATCH(2, CN, GL);                  \
+        if (kclass == 0) DD_DISPATCH(0, CN, MD);      \
+        else if (kclass == 1) DD_DISPATCH(1, CN, MD); \
+        else if (kclass == 3) DD_DISPATCH(3, CN, MD); \
+        else DD_DISPATCH(2, CN, MD);                  \
     } while (0)
-    const bool gl = plan.lds_bytes == 0;
-    if (plan.canonical) {
-        if (gl) DD_DISPATCH_KC(true, true); else DD_DISPATCH_KC(true, false);
-    } else {
-        if (gl) DD_DISPATCH_KC(false, true); else DD_DISPATCH_KC(false, false);
-    }
+#define DD_DISPATCH_MODE(CN)                          \
+    do {                                              \
+        switch (plan.mode) {                          \
+            case 0: DD_DISPATCH_KC(CN, 0); break;     \
+            case 1: DD_DISPATCH_KC(CN, 1); break;     \
+            case 2: DD_DISPATCH_KC(CN, 2); break;     \
+            case 3: DD_DISPATCH_KC(CN, 3); break;     \
+            default: DD_DISPATCH_KC(CN, 4); break;    \
+        }                                             \
+    } while (0)
+    if (plan.canonical) DD_DISPATCH_MODE(true);
+    else DD_DISPATCH_MODE(false);
 }
 
 }  // namespace dd

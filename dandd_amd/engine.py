@@ -42,7 +42,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("DANDD_LIB") or LIB_PATH  # DANDD_LIB: an alternative build (development)
     # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (same SONAME as
     # /opt/rocm's).  If this library were loaded first it would pull in the system copy, a later
     # `import torch` would add the bundled one, and the second runtime to initialise reports "no
