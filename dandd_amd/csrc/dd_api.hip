@@ -464,9 +464,9 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
                 size_t jobs_per_pair = 128;
                 if (filter_logg) {
                     // a filtered job learns its filter as it goes (bounds rise only where it probes), so
-                    // jobs are as long as ~4096 jobs over the whole launch allow, 4..16 per row (measured best: 16)
+                    // jobs are long: >= 48 tiles (3 M tokens) each, ~4096 jobs over the launch, >= 4 per row
                     const size_t npairs = (size_t)ngenomes * ngr;
-                    jobs_per_pair = std::min<size_t>(16, std::max<size_t>(4, 4096 / std::max<size_t>(1, npairs)));
+                    jobs_per_pair = std::max<size_t>(4, std::min<size_t>(4096 / std::max<size_t>(1, npairs), ntiles / 48));
                     if (const char* e = getenv("DD_JOBS_PER_ROW")) jobs_per_pair = std::max(1, atoi(e));
                 }
                 const size_t tpj = std::max<size_t>(1, ntiles / jobs_per_pair);

@@ -13,7 +13,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dandd_amd.engine import Engine, synth_size
 
 nb = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000_000
-nrec, kmin, kmax, p = 5, 4, 40, 14
+nrec, kmin, kmax = 5, 4, 40
+p = int(sys.argv[2]) if len(sys.argv) > 2 else 14
 K, m = kmax - kmin + 1, 1 << p
 eng = Engine(0, p, True)
 n = synth_size(nb, nrec)
@@ -31,13 +32,16 @@ t0 = time.time()
 eng.sketch_device([buf.data_ptr()], [n], kmin, kmax, regs[0].data_ptr())
 eng.synchronize()
 dt = time.time() - t0
+t1 = time.time()
 eng.sketch_device([buf.data_ptr()], [n], kmin, kmax, regs[1].data_ptr())
+eng.synchronize()
+dt2 = time.time() - t1
 eng.sketch_device([part_a.data_ptr(), part_b.data_ptr()], [cut, n - cut], kmin, kmax, regs[2].data_ptr())
 eng.synchronize()
 whole, again = regs[0].cpu().numpy(), regs[1].cpu().numpy()
 parts = np.maximum(regs[2].cpu().numpy(), regs[3].cpu().numpy())
 card = eng.card_batch_device(regs[0].data_ptr(), K)
-print(f"{nb/1e9:.2f} Gbp in {dt*1e3:.1f} ms = {nb/dt/1e9:.2f} Gbp/s (first call, includes workspace allocation)")
+print(f"log2m {p}: {nb/1e9:.2f} Gbp in {dt*1e3:.1f} ms = {nb/dt/1e9:.2f} Gbp/s (first call, includes workspace allocation); second call {dt2*1e3:.1f} ms = {nb/dt2/1e9:.2f} Gbp/s")
 print("deterministic:", np.array_equal(whole, again))
 print("union of parts == whole:", np.array_equal(parts, whole))
 ks = np.arange(kmin, kmax + 1)

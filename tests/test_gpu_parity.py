@@ -74,6 +74,13 @@ def test_sweep_parity_ragged(engine_factory, orc, name):
     _sweep_check(eng, orc, np.frombuffer(fa, dtype=np.uint8), 1, 40, True)
 
 
+@pytest.mark.parametrize("name", ["crlf", "lower_and_n", "short_records", "no_trailing_newline", "empty"])
+def test_sweep_parity_ragged_registers_in_hbm(engine_factory, orc, name):
+    """The same ragged inputs through the log2m 18 path (filter + queue, partial waves, final drain)."""
+    eng = engine_factory(18, True)
+    _sweep_check(eng, orc, np.frombuffer(RAGGED[name], dtype=np.uint8), 1, 40, True)
+
+
 def test_sweep_parity_long_lines_and_headers(engine_factory, orc):
     """A 20 kB header and a 50 kB single sequence line cross several 4 KiB pack chunks."""
     rng = np.random.default_rng(5)
@@ -196,10 +203,13 @@ def test_pairwise_matches_oracle(engine_factory, orc):
                 assert got[i, j, kk] == orc.card(u[kk])
 
 
-def test_batched_device_sketch(engine_factory, torch_cuda, orc):
-    """dd_sketch_device over several HBM-resident genomes of different sizes."""
+@pytest.mark.parametrize("p", [14, 18, 19])
+def test_batched_device_sketch(engine_factory, torch_cuda, orc, p):
+    """dd_sketch_device over several HBM-resident genomes of different sizes (log2m 18, 19: registers in
+    HBM behind the LDS filter + candidate queues; the 1000-base and empty genomes leave most lanes of
+    their only wave outside the stream)."""
     torch = torch_cuda
-    eng = engine_factory(14, True)
+    eng = engine_factory(p, True)
     sizes = [(0, 70000, 2), (1, 250000, 3), (2, 1000, 1), (3, 0, 1)]
     fas = [orc.synth_fasta(SEED, g, nb, nr) for g, nb, nr in sizes]
     bufs = [torch.from_numpy(f.copy()).cuda() if f.size else torch.empty(16, dtype=torch.uint8, device="cuda") for f in fas]
@@ -209,7 +219,7 @@ def test_batched_device_sketch(engine_factory, torch_cuda, orc):
     eng.synchronize()
     got = regs.cpu().numpy()
     for g, f in enumerate(fas):
-        assert np.array_equal(got[g], orc.sketch_sweep(f, 15, 20, 14))
+        assert np.array_equal(got[g], orc.sketch_sweep(f, 15, 20, p))
 
 
 def test_sketch_is_deterministic(engine_factory, orc):
