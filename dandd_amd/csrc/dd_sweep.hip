@@ -269,8 +269,8 @@ DD_D uint64_t pack64(uint32_t hi, uint32_t lo) { return ((uint64_t)hi << 32) | l
 // prime(hc): the state after pushing the 64 tokens of the previous segment (hc = its four code
 // words), computed with a handful of bit operations instead of 64 pushes.  The reverse-complement
 // window holds tokens in stream order, newest on top, so it is simply the complement of the words.
-//   KC 0: k <= 16 (32-bit windows)   KC 1: k <= 32 (64-bit)   KC 2: k <= 64 (128-bit)
-//   KC 3: 33 <= k <= 48 (96-bit: 64 + 32)
+//   KC 0: k <= 16 (32-bit windows)   KC 1: 16 <= k <= 32 (64-bit)   KC 3: 33 <= k <= 48 (96-bit: 64 + 32)
+//   KC 2: 49 <= k <= 64 (128-bit)
 template <int KC>
 struct Windows;
 
@@ -332,14 +332,18 @@ struct Windows<2> {
         rh = (rh >> 2) | ((uint64_t)(3u - c) << 62);
     }
     template <bool CANON>
-    DD_D uint64_t hash(int k) const {  // 33 <= k <= 64
-        const int hb = 2 * k - 64;    // bits of the k-mer in the high word, 2..64
-        const uint64_t ah = (hb == 64) ? fh : (fh & ((1ull << hb) - 1ull));
+    DD_D uint64_t hash(int k) const {  // 49 <= k <= 64 (33..48 is Windows<3>)
+        // the k-mer covers all of fl and the low word of fh: only the top word is masked, and the
+        // reverse complement comes down by 128 - 2k <= 30 bits: one 32-bit funnel shift per word
+        const int hb = 2 * k - 96;  // bits of the k-mer in the top word, 2..32
+        const uint32_t mh = (hb == 32) ? ~0u : ((1u << hb) - 1u);
+        const uint64_t ah = pack64((uint32_t)(fh >> 32) & mh, (uint32_t)fh);
         const uint64_t al = fl;
         if (!CANON) return wang64_fast<false>(fold128(ah, al));
-        const int s = 128 - 2 * k;  // 0..62
-        const uint64_t bh = s ? (rh >> s) : rh;
-        const uint64_t bl = s ? ((rl >> s) | (rh << (64 - s))) : rl;
+        const uint32_t s = 128u - 2u * (uint32_t)k;  // 0..30
+        const uint32_t r3 = (uint32_t)(rh >> 32), r2 = (uint32_t)rh, r1 = (uint32_t)(rl >> 32), r0 = (uint32_t)rl;
+        const uint64_t bh = pack64(r3 >> s, __builtin_amdgcn_alignbit(r3, r2, s));
+        const uint64_t bl = pack64(__builtin_amdgcn_alignbit(r2, r1, s), __builtin_amdgcn_alignbit(r1, r0, s));
         const bool f_lt = (ah < bh) | ((ah == bh) & (al < bl));  // bitwise: no exec-mask short circuit
         return wang64_fast<false>(fold128(f_lt ? ah : bh, f_lt ? al : bl));
     }
@@ -347,7 +351,7 @@ struct Windows<2> {
 
 // 33 <= k <= 48: the k-mer is 66..96 bits, so the high part fits one 32-bit register and every
 // step on it (mask, funnel shift of the reverse complement, compare, select, fold multiply) is a
-// 32-bit instruction instead of a 64-bit pair.  Same values as Windows<2> for these ks.
+// 32-bit instruction instead of a 64-bit pair.
 template <>
 struct Windows<3> {
     uint64_t fl = 0, rt = 0;  // forward: low 64 bits;  reverse complement, top-aligned: bits 95..32

@@ -95,13 +95,13 @@ int main(int argc, char** argv) {
     ROW("class1 k21..24 unpaired, never raises", 1, 3, 4, 21, 0xFFFFFFFFu)
     ROW("class1 k21..24 hash+probe only", 1, 2, 4, 21, 0u)
     ROW("class1 k21..24 hash only", 1, 1, 4, 21, 0u)
-    ROW("class2 k33..36 full, never raises", 2, 0, 4, 33, 0xFFFFFFFFu)
-    ROW("class2 k33..36 full, from cold", 2, 0, 4, 33, 0u)
-    ROW("class2 k33..36 hash only", 2, 1, 4, 33, 0u)
+    ROW("class2 k49..52 full, from cold", 2, 0, 4, 49, 0u)
+    ROW("class2 k49..52 hash only", 2, 1, 4, 49, 0u)
     ROW("class3 k33..36 full, never raises", 3, 0, 4, 33, 0xFFFFFFFFu)
     ROW("class3 k33..36 hash only", 3, 1, 4, 33, 0u)
     ROW("class3 k45..48 full, never raises", 3, 0, 4, 45, 0xFFFFFFFFu)
     ROW("class2 k49..52 full, never raises", 2, 0, 4, 49, 0xFFFFFFFFu)
+    ROW("class2 k61..64 full, never raises", 2, 0, 4, 61, 0xFFFFFFFFu)
     hipFree(out);
     return 0;
 }
