@@ -24,6 +24,8 @@
 #include "dd_common.h"
 #include "dd_kernels.h"
 
+#include <atomic>
+
 namespace dd {
 namespace {
 
@@ -687,16 +689,24 @@ __global__ __launch_bounds__(1024) void bitmap_finish_kernel(const SweepGenome* 
     }
 }
 
+// Dynamic LDS above 64 KiB must be allowed per kernel AND per device (a process may hold contexts on
+// several GPUs); remembered in one bit per device id.
+void allow_full_lds(const void* kern, std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_relaxed) & bit)) {
+        (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        done.fetch_or(bit, std::memory_order_relaxed);
+    }
+}
+
 template <int KC, bool CANON, int MODE>
 void launch_one(const SweepGenome* genomes, const SweepJob* jobs, int njobs, const SweepPlan& plan,
                 hipStream_t st) {
     auto kern = sweep_kernel<KC, CANON, MODE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, sweep_max_lds_bytes());
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};  // one bit per device: the attribute is per device
+    allow_full_lds(reinterpret_cast<const void*>(kern), attr_done);
     hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3((unsigned)plan.threads),
                        (size_t)plan.lds_bytes, st, genomes, jobs, plan.log2m);
 }
@@ -720,12 +730,8 @@ void launch_bitmap_finish(const SweepGenome* genomes, int ngenomes, int kfirst, 
     const size_t m = (size_t)1 << log2m;
     const int in_lds = m <= (size_t)sweep_max_lds_bytes() ? 1 : 0;
     auto kern = bitmap_finish_kernel<true>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, sweep_max_lds_bytes());
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    allow_full_lds(reinterpret_cast<const void*>(kern), attr_done);
     hipLaunchKernelGGL(kern, dim3((unsigned)(klast - kfirst + 1), (unsigned)ngenomes), dim3(1024),
                        in_lds ? m : 0, st, genomes, kfirst, kmin, log2m, in_lds);
 }
