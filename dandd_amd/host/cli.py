@@ -24,11 +24,14 @@ def tree_command(args):
         args.registers = 20
     ksweep = (int(args.mink), int(args.maxk)) if args.ksweep else None
     os.makedirs(args.outdir, exist_ok=True)
-    tree = deltatree.create_delta_tree(
-        tag=args.tag, genomedir=args.genomedir, sketchdir=args.sketchdir, kstart=args.kstart,
-        nchildren=args.nchildren, registers=int(args.registers), flist_loc=args.flist_loc,
-        canonicalize=args.canonicalize, tool=tool, debug=args.debug, nthreads=int(args.nthreads),
-        safety=args.safety, fast=args.fast, verbose=args.verbose, ksweep=ksweep, lowmem=args.lowmem)
+    try:
+        tree = deltatree.create_delta_tree(
+            tag=args.tag, genomedir=args.genomedir, sketchdir=args.sketchdir, kstart=args.kstart,
+            nchildren=args.nchildren, registers=int(args.registers), flist_loc=args.flist_loc,
+            canonicalize=args.canonicalize, tool=tool, debug=args.debug, nthreads=int(args.nthreads),
+            safety=args.safety, fast=args.fast, verbose=args.verbose, ksweep=ksweep, lowmem=args.lowmem)
+    except deltatree.WorkerDone:  # rank > 0 of a multi-GPU run: its leaf sketches are on disk
+        return
     prefix = tree.make_prefix(outdir=args.outdir, tag=args.tag, label=args.label)
     tree.save(fileprefix=prefix, fast=args.fast)
 
@@ -137,10 +140,22 @@ def build_parser():
 
 
 def main(argv=None):
-    if "torch" not in sys.modules:  # stand-alone process: no torch anywhere on this path (engine.load_library)
+    rank, world = deltatree.dist_ranks()
+    dist = None
+    if world > 1:
+        # one process per GPU (torch.distributed.run): `tree` shards the leaf sketches over the ranks and
+        # hands them over through the shared sketch directory; the process group is only a barrier
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif "torch" not in sys.modules:  # stand-alone process: no torch anywhere on this path (engine.load_library)
         os.environ.setdefault("DANDD_NO_TORCH", "1")
     args = build_parser().parse_args(sys.argv[1:] if argv is None else argv)
-    args.func(args)
+    if world == 1 or rank == 0 or args.func is tree_command:
+        args.func(args)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
     return 0
 
 

@@ -45,11 +45,33 @@ def backend_for(experiment):
         if _backend_factory is not None:
             _backends[key] = _backend_factory(key[0], key[1])
         else:
-            # both fail loudly without libdandd_hip.so / a gfx950 GPU
+            # both fail loudly without libdandd_hip.so / a gfx950 GPU; under torch.distributed.run
+            # every rank drives its own GPU
             from .backend import HipBackend, HipExactBackend
             cls = HipExactBackend if exact else HipBackend
-            _backends[key] = cls(log2m=key[0], canonical=key[1])
+            _backends[key] = cls(log2m=key[0], canonical=key[1], device=int(os.environ.get("LOCAL_RANK", "0")))
     return _backends[key]
+
+
+# ---- one process per GPU (python -m torch.distributed.run ... -m dandd_amd.host.cli tree ...) ----------
+# Leaf sketching -- the only heavy step -- is sharded over the ranks by file size; the sketches travel
+# the way they always do in DandD, as files in the shared sketch directory; after a barrier rank 0
+# carries on alone with every leaf sketch cached and the other ranks are done.
+class WorkerDone(Exception):
+    """Raised on ranks > 0 once their share of the leaf sketches is on disk."""
+
+
+def dist_ranks():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def dist_barrier():
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
 
 
 def write_listdict_to_csv(outfile, listdict, suffix="", last_col=None):
@@ -405,7 +427,13 @@ class DeltaTree:
                     os.makedirs(tmpl.dir.replace("{}", str(k)), exist_ok=True)
                 todo.append(leaf.fastas[0])
                 templates.append(tmpl)
-        if len(todo) > 1:
+        rank, world = dist_ranks()
+        if world > 1:
+            from ..dist import shard_by_weight
+            mine = shard_by_weight([os.path.getsize(f) for f in todo], world)[rank]
+            if mine:
+                be.leaf_many([todo[i] for i in mine], lo, hi, lambda i, k: templates[mine[i]].with_k(k))
+        elif len(todo) > 1:
             be.leaf_many(todo, lo, hi, lambda i, k: templates[i].with_k(k))
 
     def _build_tree(self, symbol, nchildren, leafnodes=()):
@@ -415,6 +443,10 @@ class DeltaTree:
         nodes = list(leafnodes) or [DeltaTreeNode(s, [], self.speciesinfo, self.experiment) for s in symbol]
         nodes.sort()
         self._presketch_leaves(nodes)
+        if not leafnodes and dist_ranks()[1] > 1:  # the main tree of a multi-rank `tree` run
+            dist_barrier()
+            if dist_ranks()[0] != 0:
+                raise WorkerDone()
         for leaf in nodes:
             self._solve(leaf)
         self._dt = nodes

@@ -60,3 +60,42 @@ def test_two_rank_gloo_sweep_matches_single_process(orc, tmp_path):
         assert rr["leaf_card"] == want_leaf
         assert rr["root_card"] == want_root
         assert rr["root_sha"] == int(root.astype(np.uint64).sum())
+
+
+def test_two_rank_cli_tree_matches_single_process(orc, tmp_path):
+    """`torch.distributed.run --nproc-per-node 2 ... cli tree`: the leaf sketches are sharded over the
+    ranks and exchanged through the sketch directory; rank 0's outputs equal a single-process run."""
+    import csv
+    data = tmp_path / "genomes"
+    data.mkdir()
+    for g, nb in enumerate([30000, 8000, 22000, 15000, 4000, 26000]):
+        (data / f"g{g}.fasta").write_bytes(orc.synth_fasta(0xD4ADD, g, nb, 2).tobytes())
+    args = ["tree", "-d", str(data), "-s", "dist", "-r", "10", "--ksweep", "--mink", "9", "--maxk", "13"]
+    worker = os.path.join(HERE, "cli_dist_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+
+    out1, log1 = str(tmp_path / "single"), str(tmp_path / "log1")
+    r = subprocess.run([sys.executable, worker, log1] + args + ["-o", out1], env=env, capture_output=True, text=True,
+                       timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+    out2, log2 = str(tmp_path / "two"), str(tmp_path / "log2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), worker, log2] + args + ["-o", out2]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+    touched = [json.load(open(f"{log2}.{rank}"))["touched"] for rank in range(2)]
+    assert touched[0] and touched[1], touched                      # both ranks sketched something
+    assert sorted(touched[0] + touched[1]) == [f"g{g}.fasta" for g in range(6)]  # each leaf exactly once
+
+    def rows(out):
+        with open(os.path.join(out, "dist_6_dashing_deltas.csv")) as f:
+            return [{k: v for k, v in r.items() if k != "command"} for r in csv.DictReader(f)]
+    one, two = rows(out1), rows(out2)
+    assert len(one) > 0 and len(one) == len(two)
+    for a, b in zip(one, two):
+        for key in a:
+            va = a[key].replace(out1, "") if isinstance(a[key], str) else a[key]
+            vb = b[key].replace(out2, "") if isinstance(b[key], str) else b[key]
+            assert va == vb, (key, a[key], b[key])
