@@ -252,7 +252,15 @@ class DeltaTreeNode:
         template = self._template()
         if self.ksketches[0] is None:
             self.ksketches[0] = Sketch(0, template, self.speciesinfo, self.experiment)
-        ks = [k for k in range(max(1, mink), maxk + 1)]
+        # ks this node (and therefore its whole subtree) was already brought up to date for, in this
+        # process: leaves are shared by hundreds of spiders and would otherwise be re-checked every time
+        memo = self.__dict__.get("_swept")
+        if memo is None or memo[0] != os.getpid():
+            memo = self._swept = (os.getpid(), set())
+        swept = memo[1]
+        ks = [k for k in range(max(1, mink), maxk + 1) if k not in swept]
+        if not ks:
+            return
         for k in ks:
             ensure_dir(template.dir.replace("{}", str(k)))
             self.experiment["baseset"].add(template.base.replace("{}", str(k)))
@@ -270,15 +278,15 @@ class DeltaTreeNode:
             if sketch_exists(path):
                 continue
             todo.append(k)
-        if not todo:
-            return
-        be = backend_for(self.experiment)
-        if self.ngen == 1:
-            be.leaf(self.fastas[0], todo, [template.with_k(k) for k in todo])  # one fused GPU pass
-        else:
-            for k in todo:
-                ins = [c.ksketches[0].sfp.with_k(k) for c in self.children]
-                be.union(ins, template.with_k(k))
+        if todo:
+            be = backend_for(self.experiment)
+            if self.ngen == 1:
+                be.leaf(self.fastas[0], todo, [template.with_k(k) for k in todo])  # one fused GPU pass
+            else:
+                for k in todo:
+                    ins = [c.ksketches[0].sfp.with_k(k) for c in self.children]
+                    be.union(ins, template.with_k(k))
+        swept.update(ks)
 
     def update_node(self, kval):
         """Sketch object (file + cardinality) for k at this node and, first, at every descendant."""
