@@ -89,10 +89,11 @@ def cpu_baseline(nbases, nrec, kmin, kmax, log2m):
 
 def valu_bound(kmin, kmax, updates_per_s):
     """The bound that actually binds K1: VALU issue.  Instructions per (token, k) are the PMC counts of
-    profiles/r01_v5_pmc.txt (SQ_INSTS_VALU / wave-steps) per k class (k 49..64: r01_v3); a wave64 instruction occupies a
+    profiles/r01_v6_pmc.txt (SQ_INSTS_VALU / wave-steps) per k class (k 49..64: estimated from the
+    33..48 class plus its 9 extra instructions); a wave64 instruction occupies a
     SIMD-32 for 2 cycles at best, so the chip retires at most 256 CU x 4 SIMD x 2.4 GHz / 2 wave
     instructions per second (= 78.6 T lane-ops/s)."""
-    per_class = [(1, 9, 11.2), (10, 16, 30.4), (17, 32, 35.1), (33, 48, 43.8), (49, 64, 56.7)]
+    per_class = [(1, 9, 11.2), (10, 16, 30.0), (17, 32, 33.9), (33, 48, 43.4), (49, 64, 52.0)]
     tot = n = 0
     for lo, hi, instr in per_class:
         ks = max(0, min(hi, kmax) - max(lo, kmin) + 1)
