@@ -274,6 +274,13 @@ def main():
                 "note": "integer-VALU bound (hash per (base,k)); see DESIGN.md for ops/update and the VALU fraction",
             },
             "other_kernels_ms_per_step": {"pack_K0": pack_ms / steps, "union_hist_K2": union_ms / steps},
+            # the HBM-bound kernel of the path: FASTA bytes read once + 3 bits per base written
+            # (algorithmic; K0 actually reads the FASTA twice)
+            "roofline_k0": {"bound": "hbm", "kernel": "pack_stats + pack_scan + pack_write (K0)",
+                            "achieved": (ng * nbytes + ng * nb * 0.375) / (pack_ms / 1e3 / steps) / 1e9 if pack_ms > 0 else None,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": (ng * nbytes + ng * nb * 0.375) / (pack_ms / 1e3 / steps) / 1e9 / HBM_PEAK_GBS if pack_ms > 0 else None,
+                            "kernel_ms_per_step": pack_ms / steps},
             "delta_genome0": float(delta[0]), "argmax_k_genome0": int(bestk[0]),
             "delta_root": float(delta[ng]), "argmax_k_root": int(bestk[ng]),
         }
