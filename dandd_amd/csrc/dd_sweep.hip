@@ -585,10 +585,31 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void bit
     const int kfirst = job.kfirst, klast = job.kfirst + job.nk - 1;
     const unsigned long long ntok = gload8u(g.ntok);
     const int w0 = c_bitmap_off[kfirst], w1 = c_bitmap_off[klast + 1];
-    const uint32_t kmask = __builtin_amdgcn_readfirstlane(((2u << klast) - 1u) & ~((1u << kfirst) - 1u));  // bit k set: k in the job
-    // warm start from what earlier jobs recorded (any snapshot is a subset of the final set)
-    for (int i = w0 + (int)threadIdx.x; i < w1; i += blockDim.x) bits[i] = load4_fresh(&g.bitmap[i]);
+    uint32_t kmask = __builtin_amdgcn_readfirstlane(((2u << klast) - 1u) & ~((1u << kfirst) - 1u));  // bit k set: k in the job
+    // warm start from what earlier jobs recorded (any snapshot is a subset of the final set), counting
+    // the k-mers each k already has
+    __shared__ uint32_t have[kBitmapMaxK + 2];
+    if (threadIdx.x <= kBitmapMaxK) have[threadIdx.x] = 0;
     __syncthreads();
+    for (int i = w0 + (int)threadIdx.x; i < w1; i += blockDim.x) {
+        const uint32_t v = load4_fresh(&g.bitmap[i]);
+        bits[i] = v;
+        if (v) {
+            int k = kfirst;
+            for (int j = kfirst + 1; j <= klast; ++j) k = (i >= c_bitmap_off[j]) ? j : k;
+            atomicAdd(&have[k], (uint32_t)__builtin_popcount(v));
+        }
+    }
+    __syncthreads();
+    // A k whose set is COMPLETE -- every possible (canonical) k-mer already recorded, which small k
+    // reach within the first few hundred thousand tokens of any genome -- can gain nothing from more
+    // tokens: drop it from this job; if that empties the job, there is nothing to do at all.
+    for (int k = kfirst; k <= klast; ++k) {
+        const uint32_t all = CANON ? (1u << (2 * k - 1)) + ((k & 1) ? 0u : (1u << (k - 1))) : (1u << (2 * k));
+        if (have[k] == all) kmask &= ~(1u << k);
+    }
+    kmask = __builtin_amdgcn_readfirstlane(kmask);
+    if (kmask == 0u) return;
 
     const int prime = klast - 1;
     for (unsigned tile = job.tile_begin; tile < job.tile_end; ++tile) {
