@@ -378,7 +378,6 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
 
     // presence bitmaps for the small-k class (k <= 9), zeroed per call
     const bool use_bitmaps = kmin <= dd::kBitmapMaxK && !getenv("DD_NO_BITMAP");
-    const int kb_last = std::min(kmax, dd::kBitmapMaxK);
     uint32_t* bitmap_base = nullptr;
     if (use_bitmaps) {
         const size_t bbytes = (size_t)ngenomes * dd::kBitmapStride * sizeof(uint32_t);
@@ -593,11 +592,11 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         plan.mode = filter_logg ? filter_logg : (global_regs ? 1 : 0);
         Span sp(c, DD_KERNEL_SWEEP);
         if (classes[i].kclass < 0) {
+            const int ka = classes[i].jobs[0].kfirst, kb = ka + classes[i].jobs[0].nk - 1;
             dd::launch_bitmap(reinterpret_cast<const dd::SweepGenome*>(tdev),
                               reinterpret_cast<const dd::SweepJob*>(tdev + job_off[i]),
-                              (int)classes[i].jobs.size(), c->canonical, st);
-            dd::launch_bitmap_finish(reinterpret_cast<const dd::SweepGenome*>(tdev), ngenomes, kmin, kb_last,
-                                     kmin, p, st);
+                              (int)classes[i].jobs.size(), ka, kb, c->canonical, st);
+            dd::launch_bitmap_finish(reinterpret_cast<const dd::SweepGenome*>(tdev), ngenomes, ka, kb, kmin, p, st);
         } else {
             dd::launch_sweep(reinterpret_cast<const dd::SweepGenome*>(tdev),
                              reinterpret_cast<const dd::SweepJob*>(tdev + job_off[i]),

@@ -55,9 +55,9 @@ struct SweepGenome {            // one per genome, device-resident table
 
 // Small-k path: for k <= kBitmapMaxK there are at most 4^k <= 262144 distinct k-mers, so K1 only
 // records WHICH k-mers occur (one LDS bit each) and hashes every distinct one once afterwards.
-constexpr int kBitmapMaxK = 9;
+constexpr int kBitmapMaxK = 9;           // (k = 10 was tried as a 128 KiB class of its own: its set completes too late to pay)
 constexpr int kBitmapWords = 10924;      // sum over k = 1..9 of max(1, 4^k / 32)
-constexpr int kBitmapStride = 11008;     // words per genome (256-byte multiple)
+constexpr int kBitmapStride = 11008;     // words per genome (256-byte multiple); the slack holds one "complete" flag per k
 // first word of k's bitmap inside a genome's block
 inline constexpr int bitmap_offset(int k) {
     int off = 0;
@@ -84,8 +84,9 @@ void launch_sweep(const SweepGenome* genomes_dev, const SweepJob* jobs_dev, int 
                   const SweepPlan& plan, hipStream_t st);
 int sweep_max_lds_bytes();
 // small-k class: jobs carry ks <= kBitmapMaxK; records k-mer presence in genome.bitmap
-void launch_bitmap(const SweepGenome* genomes_dev, const SweepJob* jobs_dev, int njobs, int canonical,
-                   hipStream_t st);
+// (kfirst..klast: the ks of the class; the LDS image covers exactly their bitmaps)
+void launch_bitmap(const SweepGenome* genomes_dev, const SweepJob* jobs_dev, int njobs, int kfirst, int klast,
+                   int canonical, hipStream_t st);
 // one workgroup per (genome, k in [kfirst, klast]): hash every recorded k-mer once into slab row k-kmin
 void launch_bitmap_finish(const SweepGenome* genomes_dev, int ngenomes, int kfirst, int klast, int kmin,
                           int log2m, hipStream_t st);

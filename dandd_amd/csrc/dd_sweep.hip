@@ -573,19 +573,31 @@ __constant__ int c_bitmap_off[kBitmapMaxK + 2] = {0, bitmap_offset(1), bitmap_of
                                                  bitmap_offset(4), bitmap_offset(5), bitmap_offset(6),
                                                  bitmap_offset(7), bitmap_offset(8), bitmap_offset(9),
                                                  kBitmapWords};
+static_assert(kBitmapMaxK == 9 && bitmap_offset(9) + bitmap_words(9) == kBitmapWords &&
+              kBitmapWords + kBitmapMaxK < kBitmapStride, "bitmap layout");
 
 // amdgpu_num_sgpr: above 80 SGPRs only 7 waves per SIMD are admitted, i.e. ONE 1024-thread
 // workgroup per CU instead of two (MI355X_MICROARCH.md, residency) -- measured 2x on this kernel.
 template <bool CANON>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void bitmap_kernel(const SweepGenome* __restrict__ genomes,
                                                      const SweepJob* __restrict__ jobs) {
-    uint32_t* const bits = reinterpret_cast<uint32_t*>(g_lds);
     const SweepJob job = jobs[blockIdx.x];
     const SweepGenome g = genomes[job.genome];
     const int kfirst = job.kfirst, klast = job.kfirst + job.nk - 1;
     const unsigned long long ntok = gload8u(g.ntok);
     const int w0 = c_bitmap_off[kfirst], w1 = c_bitmap_off[klast + 1];
+    // the LDS image holds words w0..w1-1 of the genome's bitmap block, addressed by their global index
+    uint32_t* const bits = reinterpret_cast<uint32_t*>(g_lds) - w0;
     uint32_t kmask = __builtin_amdgcn_readfirstlane(((2u << klast) - 1u) & ~((1u << kfirst) - 1u));  // bit k set: k in the job
+    // A k whose set is COMPLETE -- every possible (canonical) k-mer already recorded, which small k
+    // reach within the first few hundred thousand tokens of any genome -- can gain nothing from more
+    // tokens.  The job that first sees a complete set (below, and again after its merge) raises a flag
+    // behind the genome's bitmaps; a job that finds all its ks flagged returns before loading anything.
+    uint32_t* const complete = g.bitmap + kBitmapWords;  // one word per k (the block's slack, zeroed per call)
+    for (int k = kfirst; k <= klast; ++k)
+        if (load4_fresh(complete + k)) kmask &= ~(1u << k);
+    kmask = __builtin_amdgcn_readfirstlane(kmask);
+    if (kmask == 0u) return;
     // warm start from what earlier jobs recorded (any snapshot is a subset of the final set), counting
     // the k-mers each k already has
     __shared__ uint32_t have[kBitmapMaxK + 2];
@@ -601,12 +613,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void bit
         }
     }
     __syncthreads();
-    // A k whose set is COMPLETE -- every possible (canonical) k-mer already recorded, which small k
-    // reach within the first few hundred thousand tokens of any genome -- can gain nothing from more
-    // tokens: drop it from this job; if that empties the job, there is nothing to do at all.
+    auto all_of = [](int k) { return CANON ? (1u << (2 * k - 1)) + ((k & 1) ? 0u : (1u << (k - 1))) : (1u << (2 * k)); };
     for (int k = kfirst; k <= klast; ++k) {
-        const uint32_t all = CANON ? (1u << (2 * k - 1)) + ((k & 1) ? 0u : (1u << (k - 1))) : (1u << (2 * k));
-        if (have[k] == all) kmask &= ~(1u << k);
+        if (have[k] == all_of(k)) {
+            kmask &= ~(1u << k);
+            if (threadIdx.x == 0) gstore4(complete + k, 1u);
+        }
     }
     kmask = __builtin_amdgcn_readfirstlane(kmask);
     if (kmask == 0u) return;
@@ -672,10 +684,18 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void bit
         }
     }
     __syncthreads();
+    if (threadIdx.x <= kBitmapMaxK) have[threadIdx.x] = 0;
+    __syncthreads();
     for (int i = w0 + (int)threadIdx.x; i < w1; i += blockDim.x) {
-        const uint32_t mine = bits[i];
-        if (mine & ~load4_fresh(&g.bitmap[i])) gor32(&g.bitmap[i], mine);
+        const uint32_t mine = bits[i], theirs = load4_fresh(&g.bitmap[i]);
+        if (mine & ~theirs) gor32(&g.bitmap[i], mine);
+        int k = kfirst;
+        for (int j = kfirst + 1; j <= klast; ++j) k = (i >= c_bitmap_off[j]) ? j : k;
+        if (mine | theirs) atomicAdd(&have[k], (uint32_t)__builtin_popcount(mine | theirs));
     }
+    __syncthreads();
+    if (threadIdx.x >= (unsigned)kfirst && threadIdx.x <= (unsigned)klast && have[threadIdx.x] == all_of((int)threadIdx.x))
+        gstore4(complete + threadIdx.x, 1u);
 }
 
 // grid = (ks, genomes); registers of the row are built in LDS (or in place when they do not fit)
@@ -712,12 +732,14 @@ __global__ __launch_bounds__(1024) void bitmap_finish_kernel(const SweepGenome* 
 
 // Dynamic LDS above 64 KiB must be allowed per kernel AND per device (a process may hold contexts on
 // several GPUs); remembered in one bit per device id.
-void allow_full_lds(const void* kern, std::atomic<unsigned long long>& done) {
+void allow_full_lds(const void* kern, std::atomic<unsigned long long>& done, int static_lds_bytes = 0) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done.load(std::memory_order_relaxed) & bit)) {
-        (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        // dynamic + the kernel's static LDS must stay within the CU's 160 KiB or the call is refused
+        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - static_lds_bytes) != hipSuccess)
+            (void)hipGetLastError();  // not sticky: a launch that needs the room will report it
         done.fetch_or(bit, std::memory_order_relaxed);
     }
 }
@@ -736,13 +758,18 @@ void launch_one(const SweepGenome* genomes, const SweepJob* jobs, int njobs, con
 
 int sweep_max_lds_bytes() { return 160 * 1024; }
 
-void launch_bitmap(const SweepGenome* genomes, const SweepJob* jobs, int njobs, int canonical, hipStream_t st) {
-    if (njobs <= 0) return;
-    const size_t lds = (size_t)kBitmapWords * 4;
-    if (canonical)
+void launch_bitmap(const SweepGenome* genomes, const SweepJob* jobs, int njobs, int kfirst, int klast,
+                   int canonical, hipStream_t st) {
+    if (njobs <= 0 || kfirst < 1 || klast > kBitmapMaxK || klast < kfirst) return;
+    const size_t lds = (size_t)(bitmap_offset(klast) + bitmap_words(klast) - bitmap_offset(kfirst)) * 4;
+    static std::atomic<unsigned long long> attr_done[2] = {{0}, {0}};
+    if (canonical) {
+        allow_full_lds(reinterpret_cast<const void*>(bitmap_kernel<true>), attr_done[0], 256);
         hipLaunchKernelGGL(bitmap_kernel<true>, dim3((unsigned)njobs), dim3(1024), lds, st, genomes, jobs);
-    else
+    } else {
+        allow_full_lds(reinterpret_cast<const void*>(bitmap_kernel<false>), attr_done[1], 256);
         hipLaunchKernelGGL(bitmap_kernel<false>, dim3((unsigned)njobs), dim3(1024), lds, st, genomes, jobs);
+    }
 }
 
 void launch_bitmap_finish(const SweepGenome* genomes, int ngenomes, int kfirst, int klast, int kmin, int log2m,
