@@ -25,6 +25,7 @@
 
 #include "dd_common.h"
 #include "dd_kernels.h"
+#include "dd_plan.h"
 
 namespace {
 
@@ -377,7 +378,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     char* sb = static_cast<char*>(c->scratch.p);
 
     // presence bitmaps for the small-k class (k <= 9), zeroed per call
-    const bool use_bitmaps = kmin <= dd::kBitmapMaxK && !getenv("DD_NO_BITMAP");
+    const bool use_bitmaps = kmin <= dd::kBitmapMaxK && dd::PlanKnobs::from_env().use_bitmaps;
     uint32_t* bitmap_base = nullptr;
     if (use_bitmaps) {
         const size_t bbytes = (size_t)ngenomes * dd::kBitmapStride * sizeof(uint32_t);
@@ -404,151 +405,9 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     }
     (void)max_n;
 
-    // ---- K1 job tables -----------------------------------------------------------------
-    // registers in HBM: when one array does not fit LDS (log2m >= 18; DD_GLOBAL_FROM_P lowers that for
-    // experiments), behind a 64 KiB LDS filter unless DD_NO_FILTER is set
-    int global_from_p = 18;
-    if (const char* e = getenv("DD_GLOBAL_FROM_P")) global_from_p = std::max(16, std::min(18, atoi(e)));
-    const bool global_regs = m > (size_t)dd::sweep_max_lds_bytes() || p >= global_from_p;
-    const int filter_logg = (global_regs && !getenv("DD_NO_FILTER")) ? std::max(2, p - 16) : 0;
-    // development knobs (environment, read per call): LDS budget per workgroup and jobs per CU
-    // 80 KiB per workgroup = two 1024-thread workgroups (8 waves per SIMD) per CU: measured
-    // 1.35x faster than one 160 KiB workgroup (4 waves per SIMD cannot cover the LDS latency of
-    // the dependent hash -> read -> compare chain); a single array larger than that takes what it needs.
-    size_t lds_budget = 80 * 1024;
-    if (const char* e = getenv("DD_LDS_KB")) lds_budget = std::min<size_t>((size_t)dd::sweep_max_lds_bytes(), (size_t)atoi(e) * 1024);
-    if (lds_budget < m) lds_budget = m;
-    size_t jobs_per_cu = 32;
-    if (const char* e = getenv("DD_JOBS_PER_CU")) jobs_per_cu = std::max(1, atoi(e));
-    const int slots = global_regs ? 64 : (int)std::min<size_t>(64, lds_budget / m);
-    const int threads = 1024;
-    const size_t tile_tokens = (size_t)threads * dd::kSegTokens;
-
-    struct ClassJobs {
-        int kclass;
-        std::vector<dd::SweepJob> jobs;
-        int max_nk = 0;
-    };
-    std::vector<ClassJobs> classes;
-    // k classes: kBitmapClass = small-k presence bitmaps; the others name the sweep_kernel window
-    // class (dd_sweep.hip): 0: k <= 16, 1: k <= 32, 3: 33 <= k <= 48, 2: k <= 64
-    constexpr int kBitmapClass = -1;
-    const int lo0 = use_bitmaps ? dd::kBitmapMaxK + 1 : 1;
-    const struct { int kc, ka, kb; } class_tab[5] = {
-        {kBitmapClass, 1, use_bitmaps ? dd::kBitmapMaxK : 0}, {0, lo0, 16}, {1, 17, 32}, {3, 33, 48}, {2, 49, 64}};
-    for (const auto& ct : class_tab) {
-        const int kc = ct.kc;
-        const int ka = std::max(kmin, ct.ka), kb = std::min(kmax, ct.kb);
-        if (ka > kb) continue;
-        const int nks = kb - ka + 1;
-        // The 32-bit class needs few enough VGPRs for 12 waves per SIMD, and measures ~7 % faster
-        // with three 48 KiB workgroups per CU than with two of 80 KiB; the wider classes do not.
-        int slots_c = slots;
-        if (kc == 0 && !global_regs && !getenv("DD_LDS_KB")) slots_c = (int)std::max<size_t>(1, std::min<size_t>(slots, (48 * 1024) / m));
-        const int ngroups = kc == kBitmapClass ? 1 : (nks + slots_c - 1) / slots_c;
-        // aim for ~8 jobs per CU over the whole class so the dispatcher can balance the tail
-        size_t total_tiles = 0;
-        for (int g = 0; g < ngenomes; ++g) total_tiles += (nbytes[g] + tile_tokens - 1) / tile_tokens;
-        const size_t target_jobs = 256 * jobs_per_cu;
-        size_t tiles_per_job = std::max<size_t>(1, (total_tiles * ngroups + target_jobs - 1) / target_jobs);
-        ClassJobs cj;
-        cj.kclass = kc;
-        if (global_regs && kc != kBitmapClass && (filter_logg || !getenv("DD_NO_XCD_AFFINITY"))) {
-            // Registers live in HBM (log2m >= 18).  Every update reads one random byte of a 2^p-byte
-            // array, so the arrays a workgroup touches should sit in ITS XCD's 4 MiB L2: k-groups are
-            // cut to <= 3 MiB of arrays, each (genome, k-group) pair is given to one XCD, and because
-            // workgroups are dealt round-robin over the 8 XCDs in blockIdx order, job 8*i + x is the
-            // i-th job of XCD x.  Placement is a speed assumption only: every register update is an
-            // agent-scope atomic, correct wherever the workgroup lands.
-            const int g_l2 = filter_logg ? 1 : (int)std::max<size_t>(1, ((size_t)3 << 20) / m);  // filter: one k per job
-            const int ngr = (nks + g_l2 - 1) / g_l2;
-            std::vector<std::vector<dd::SweepJob>> per_xcd(8);
-            int pair = 0;
-            for (int g = 0; g < ngenomes; ++g) {
-                const size_t ntiles = (nbytes[g] + tile_tokens - 1) / tile_tokens;
-                // >= 64 resident workgroups share a pair; a filtered job first reads its whole row to
-                // build the filter, so those are made four times longer
-                size_t jobs_per_pair = 128;
-                if (filter_logg) {
-                    // a filtered job learns its filter as it goes (bounds rise only where it probes), so
-                    // jobs are long: >= 48 tiles (3 M tokens) each, ~4096 jobs over the launch, >= 4 per row
-                    const size_t npairs = (size_t)ngenomes * ngr;
-                    jobs_per_pair = std::max<size_t>(4, std::min<size_t>(4096 / std::max<size_t>(1, npairs), ntiles / 48));
-                    if (const char* e = getenv("DD_JOBS_PER_ROW")) jobs_per_pair = std::max(1, atoi(e));
-                }
-                const size_t tpj = std::max<size_t>(1, ntiles / jobs_per_pair);
-                int kcur = ka;
-                for (int q = 0; q < ngr; ++q, ++pair) {
-                    const int nk = nks / ngr + (q < nks % ngr ? 1 : 0);
-                    for (size_t t0 = 0; t0 < ntiles; t0 += tpj) {
-                        dd::SweepJob j;
-                        j.genome = g;
-                        j.kfirst = kcur;
-                        j.nk = nk;
-                        j.krow = kcur - kmin;
-                        j.tile_begin = (unsigned)t0;
-                        j.tile_end = (unsigned)std::min(ntiles, t0 + tpj);
-                        per_xcd[pair % 8].push_back(j);
-                    }
-                    cj.max_nk = std::max(cj.max_nk, nk);
-                    kcur += nk;
-                }
-            }
-            size_t longest = 0;
-            for (auto& v : per_xcd) longest = std::max(longest, v.size());
-            dd::SweepJob idle{};  // empty tile range: the workgroup exits at once
-            idle.kfirst = ka;
-            for (size_t i = 0; i < longest; ++i)
-                for (int x = 0; x < 8; ++x) cj.jobs.push_back(i < per_xcd[x].size() ? per_xcd[x][i] : idle);
-            if (!cj.jobs.empty()) classes.push_back(std::move(cj));
-            continue;
-        }
-        // Tile-major order: workgroups that run concurrently work on different (genome, k-group)
-        // slabs, so each slab has been warmed by its earlier tiles when its later jobs start.
-        size_t max_tiles = 0;
-        for (int g = 0; g < ngenomes; ++g) max_tiles = std::max(max_tiles, (nbytes[g] + tile_tokens - 1) / tile_tokens);
-        // Jobs are handed out in table order; the last quarter of the tiles goes out in jobs a
-        // quarter the size, so the launch does not end waiting on a few full-size stragglers.
-        const size_t taper_from = getenv("DD_NO_TAPER") ? max_tiles : max_tiles - max_tiles / 4;
-        const size_t full_tiles_per_job = tiles_per_job;
-        for (size_t t0 = 0; t0 < max_tiles; t0 += tiles_per_job) {
-            if (t0 >= taper_from) tiles_per_job = std::max<size_t>(1, full_tiles_per_job / 4);
-            for (int g = 0; g < ngenomes; ++g) {
-                const size_t ntiles = (nbytes[g] + tile_tokens - 1) / tile_tokens;
-                if (t0 >= ntiles) continue;
-                int kcur = ka;
-                for (int q = 0; q < ngroups; ++q) {
-                    const int nk = nks / ngroups + (q < nks % ngroups ? 1 : 0);
-                    dd::SweepJob j;
-                    j.genome = g;
-                    j.kfirst = kcur;
-                    j.nk = nk;
-                    j.krow = kcur - kmin;
-                    j.tile_begin = (unsigned)t0;
-                    j.tile_end = (unsigned)std::min(ntiles, t0 + tiles_per_job);
-                    cj.jobs.push_back(j);
-                    cj.max_nk = std::max(cj.max_nk, nk);
-                    kcur += nk;
-                }
-            }
-        }
-        // The k-groups of one (genome, tile range) read the same token bytes.  Workgroups are dealt
-        // round-robin over the 8 XCDs in blockIdx order, so within every block of 8 units x ngroups
-        // jobs emit group-major: the groups of unit i then sit at indices i, i+8, i+16, ... = one
-        // XCD, back to back, and the re-reads hit that XCD's L2 instead of HBM (speed only).
-        if (ngroups > 1 && !getenv("DD_NO_XCD_AFFINITY")) {
-            const size_t nunits = cj.jobs.size() / ngroups;
-            std::vector<dd::SweepJob> re;
-            re.reserve(cj.jobs.size());
-            for (size_t u0 = 0; u0 < nunits; u0 += 8) {
-                const size_t nu = std::min<size_t>(8, nunits - u0);
-                for (int q = 0; q < ngroups; ++q)
-                    for (size_t u = 0; u < nu; ++u) re.push_back(cj.jobs[(u0 + u) * ngroups + q]);
-            }
-            cj.jobs.swap(re);
-        }
-        if (!cj.jobs.empty()) classes.push_back(std::move(cj));
-    }
+    // ---- K1 job tables (dd_plan.hip) -------------------------------------------------------
+    const std::vector<dd::SweepClass> classes =
+        dd::plan_sweep(p, c->canonical, nbytes, ngenomes, kmin, kmax, dd::PlanKnobs::from_env());
 
     size_t table_bytes = align_up(sizeof(dd::SweepGenome) * ngenomes, 256);
     const size_t pack_off = table_bytes;
@@ -582,27 +441,20 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     // ---- K1 launches -------------------------------------------------------------------
     int blocks = 0;
     for (size_t i = 0; i < classes.size(); ++i) {
-        dd::SweepPlan plan;
-        plan.log2m = p;
-        plan.canonical = c->canonical;
-        plan.threads = threads;
-        // filtered mode: the filter, then a 128-entry candidate queue per wave (dd_sweep.hip)
-        plan.lds_bytes = filter_logg ? (int)(m >> filter_logg) + (threads / 64) * 128 * 4
-                                     : global_regs ? 0 : (int)((size_t)classes[i].max_nk * m);
-        plan.mode = filter_logg ? filter_logg : (global_regs ? 1 : 0);
+        const dd::SweepClass& sc = classes[i];
         Span sp(c, DD_KERNEL_SWEEP);
-        if (classes[i].kclass < 0) {
-            const int ka = classes[i].jobs[0].kfirst, kb = ka + classes[i].jobs[0].nk - 1;
+        if (sc.kclass == dd::kBitmapClass) {
             dd::launch_bitmap(reinterpret_cast<const dd::SweepGenome*>(tdev),
                               reinterpret_cast<const dd::SweepJob*>(tdev + job_off[i]),
-                              (int)classes[i].jobs.size(), ka, kb, c->canonical, st);
-            dd::launch_bitmap_finish(reinterpret_cast<const dd::SweepGenome*>(tdev), ngenomes, ka, kb, kmin, p, st);
+                              (int)sc.jobs.size(), sc.kfirst, sc.klast, c->canonical, st);
+            dd::launch_bitmap_finish(reinterpret_cast<const dd::SweepGenome*>(tdev), ngenomes, sc.kfirst, sc.klast,
+                                     kmin, p, st);
         } else {
             dd::launch_sweep(reinterpret_cast<const dd::SweepGenome*>(tdev),
                              reinterpret_cast<const dd::SweepJob*>(tdev + job_off[i]),
-                             (int)classes[i].jobs.size(), classes[i].kclass, plan, st);
+                             (int)sc.jobs.size(), sc.kclass, sc.plan, st);
         }
-        blocks += (int)classes[i].jobs.size();
+        blocks += (int)sc.jobs.size();
     }
     DD_HIP(hipGetLastError());
     c->st_tokens = tokens_ub;
@@ -1074,6 +926,25 @@ int dd_last_sketch_stats(dd_ctx* c, uint64_t* tokens, uint64_t* updates, int* sw
 }
 
 // --------------------------------------------------------------------------- synthetic
+long dd_plan_sweep(int log2m, const size_t* nbytes, int ngenomes, int kmin, int kmax, dd_plan_job* out,
+                   long cap) {
+    if (log2m < 4 || log2m > 20) return fail(DD_EINVAL, "log2m %d outside 4..20", log2m);
+    if (ngenomes < 0 || (ngenomes && !nbytes) || cap < 0 || (cap && !out)) return fail(DD_EINVAL, "null argument");
+    if (kmin < 1 || kmax > 64 || kmin > kmax) return fail(DD_EINVAL, "k range %d..%d outside 1..64", kmin, kmax);
+    const std::vector<dd::SweepClass> classes =
+        dd::plan_sweep(log2m, 1, nbytes, ngenomes, kmin, kmax, dd::PlanKnobs::from_env());
+    long n = 0;
+    for (const dd::SweepClass& sc : classes) {
+        for (const dd::SweepJob& j : sc.jobs) {
+            if (n < cap)
+                out[n] = dd_plan_job{sc.kclass, sc.plan.mode, sc.plan.lds_bytes, j.genome, j.kfirst, j.nk,
+                                     j.tile_begin, j.tile_end};
+            ++n;
+        }
+    }
+    return n;
+}
+
 size_t dd_synth_size(uint64_t nbases, int nrec) {
     if (nrec < 1) return 0;
     return dd::synth_size(nbases, nrec);

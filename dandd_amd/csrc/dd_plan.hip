@@ -1,0 +1,190 @@
+// dd_plan.hip -- K1 job tables (host code only; see dd_plan.h).
+//
+// What the reference leaves to `parallel -j 95%` (one process per k, /root/reference/lib/
+// huffman_dandd.py:214-218) is decided here: how the (genome x k x token-tile) space of one sketch call
+// is cut into workgroup jobs, in which order they are handed out, and with how much LDS.
+#include "dd_plan.h"
+
+#include <stdlib.h>
+
+#include <algorithm>
+
+namespace dd {
+
+PlanKnobs PlanKnobs::from_env() {
+    PlanKnobs k;
+    if (const char* e = getenv("DD_LDS_KB")) {
+        k.lds_budget = std::min<size_t>((size_t)sweep_max_lds_bytes(), (size_t)std::max(1, atoi(e)) * 1024);
+        k.lds_budget_forced = true;
+    }
+    if (const char* e = getenv("DD_JOBS_PER_CU")) k.jobs_per_cu = (size_t)std::max(1, atoi(e));
+    if (const char* e = getenv("DD_JOBS_PER_ROW")) k.jobs_per_row = (size_t)std::max(1, atoi(e));
+    if (const char* e = getenv("DD_GLOBAL_FROM_P")) k.global_from_p = std::max(16, std::min(18, atoi(e)));
+    k.use_bitmaps = !getenv("DD_NO_BITMAP");
+    k.filter = !getenv("DD_NO_FILTER");
+    k.xcd_affinity = !getenv("DD_NO_XCD_AFFINITY");
+    k.taper = !getenv("DD_NO_TAPER");
+    return k;
+}
+
+namespace {
+
+constexpr int kThreads = 1024;
+constexpr size_t kTileTokens = (size_t)kThreads * kSegTokens;
+
+size_t tiles_of(size_t nbytes) { return (nbytes + kTileTokens - 1) / kTileTokens; }  // tokens <= bytes
+
+SweepJob make_job(int genome, int kfirst, int nk, int kmin, size_t t0, size_t t1) {
+    SweepJob j;
+    j.genome = genome;
+    j.kfirst = kfirst;
+    j.nk = nk;
+    j.krow = kfirst - kmin;
+    j.tile_begin = (unsigned)t0;
+    j.tile_end = (unsigned)t1;
+    return j;
+}
+
+}  // namespace
+
+std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbytes, int ngenomes, int kmin,
+                                   int kmax, const PlanKnobs& knobs) {
+    std::vector<SweepClass> classes;
+    if (ngenomes <= 0 || kmin < 1 || kmax > 64 || kmin > kmax) return classes;
+    const int p = log2m;
+    const size_t m = (size_t)1 << p;
+    // Registers stay in HBM when one array does not fit LDS (log2m >= 18), behind a 64 KiB LDS filter
+    // (one byte per 4 / 8 / 16 registers) unless that is switched off.
+    const bool global_regs = m > (size_t)sweep_max_lds_bytes() || p >= knobs.global_from_p;
+    const int filter_logg = (global_regs && knobs.filter) ? std::max(2, p - 16) : 0;
+    // 80 KiB per workgroup = two 1024-thread workgroups (8 waves per SIMD) per CU: measured 1.35x faster
+    // than one 160 KiB workgroup (4 waves per SIMD cannot cover the LDS latency of the dependent
+    // hash -> read -> compare chain); a single array larger than that takes what it needs.
+    const size_t lds_budget = std::max(knobs.lds_budget, m);
+    const int slots = global_regs ? 64 : (int)std::min<size_t>(64, lds_budget / m);
+    const bool use_bitmaps = knobs.use_bitmaps && kmin <= kBitmapMaxK;
+
+    size_t total_tiles = 0, max_tiles = 0;
+    for (int g = 0; g < ngenomes; ++g) {
+        total_tiles += tiles_of(nbytes[g]);
+        max_tiles = std::max(max_tiles, tiles_of(nbytes[g]));
+    }
+
+    const int lo0 = use_bitmaps ? kBitmapMaxK + 1 : 1;
+    const struct { int kc, ka, kb; } class_tab[5] = {
+        {kBitmapClass, 1, use_bitmaps ? kBitmapMaxK : 0}, {0, lo0, 16}, {1, 17, 32}, {3, 33, 48}, {2, 49, 64}};
+    for (const auto& ct : class_tab) {
+        const int kc = ct.kc;
+        const int ka = std::max(kmin, ct.ka), kb = std::min(kmax, ct.kb);
+        if (ka > kb) continue;
+        const int nks = kb - ka + 1;
+        SweepClass sc;
+        sc.kclass = kc;
+        sc.kfirst = ka;
+        sc.klast = kb;
+        sc.plan.log2m = p;
+        sc.plan.canonical = canonical;
+        sc.plan.threads = kThreads;
+        int max_nk = 0;
+
+        if (global_regs && kc != kBitmapClass && (filter_logg || knobs.xcd_affinity)) {
+            // Registers in HBM.  The arrays a workgroup touches should sit in ITS XCD's 4 MiB L2: k-groups
+            // are cut to <= 3 MiB of arrays (one k with the filter), each (genome, k-group) row is given to
+            // one XCD, and because workgroups are dealt round-robin over the 8 XCDs in blockIdx order, job
+            // 8*i + x is the i-th job of XCD x.  Placement is a speed assumption only: every register update
+            // is an agent-scope atomic, correct wherever the workgroup lands.
+            const int g_l2 = filter_logg ? 1 : (int)std::max<size_t>(1, ((size_t)3 << 20) / m);
+            const int ngr = (nks + g_l2 - 1) / g_l2;
+            std::vector<std::vector<SweepJob>> per_xcd(8);
+            int row = 0;
+            for (int g = 0; g < ngenomes; ++g) {
+                const size_t ntiles = tiles_of(nbytes[g]);
+                size_t jobs_per_row = 128;  // >= 64 resident workgroups share a row
+                if (filter_logg) {
+                    // a filtered job learns its filter as it goes (bounds rise only where it probes), so
+                    // jobs are long: >= 48 tiles (3 M tokens) each, ~4096 jobs over the launch, >= 4 per row
+                    const size_t nrows = (size_t)ngenomes * ngr;
+                    jobs_per_row = std::max<size_t>(4, std::min<size_t>(4096 / std::max<size_t>(1, nrows), ntiles / 48));
+                    if (knobs.jobs_per_row) jobs_per_row = knobs.jobs_per_row;
+                }
+                const size_t tpj = std::max<size_t>(1, ntiles / jobs_per_row);
+                int kcur = ka;
+                for (int q = 0; q < ngr; ++q, ++row) {
+                    const int nk = nks / ngr + (q < nks % ngr ? 1 : 0);
+                    for (size_t t0 = 0; t0 < ntiles; t0 += tpj)
+                        per_xcd[row % 8].push_back(make_job(g, kcur, nk, kmin, t0, std::min(ntiles, t0 + tpj)));
+                    max_nk = std::max(max_nk, nk);
+                    kcur += nk;
+                }
+            }
+            size_t longest = 0;
+            for (auto& v : per_xcd) longest = std::max(longest, v.size());
+            const SweepJob idle = make_job(0, ka, 1, kmin, 0, 0);  // empty tile range: the workgroup exits at once
+            for (size_t i = 0; i < longest; ++i)
+                for (int x = 0; x < 8; ++x) sc.jobs.push_back(i < per_xcd[x].size() ? per_xcd[x][i] : idle);
+        } else {
+            // The 32-bit class needs few enough VGPRs for 12 waves per SIMD, and measures ~7 % faster with
+            // three 48 KiB workgroups per CU than with two of 80 KiB; the wider classes do not.
+            int slots_c = slots;
+            if (kc == 0 && !global_regs && !knobs.lds_budget_forced)
+                slots_c = (int)std::max<size_t>(1, std::min<size_t>(slots, (48 * 1024) / m));
+            const int ngroups = kc == kBitmapClass ? 1 : (nks + slots_c - 1) / slots_c;
+            // ~jobs_per_cu jobs per CU over the whole class so the dispatcher can balance the tail
+            const size_t target_jobs = 256 * knobs.jobs_per_cu;
+            size_t tiles_per_job = std::max<size_t>(1, (total_tiles * ngroups + target_jobs - 1) / target_jobs);
+            // Tile-major order: workgroups that run concurrently work on different (genome, k-group)
+            // slabs, so each slab has been warmed by its earlier tiles when its later jobs start.
+            // Jobs are handed out in table order; the last quarter of the tiles goes out in jobs a
+            // quarter the size, so the launch does not end waiting on a few full-size stragglers.
+            const size_t taper_from = knobs.taper ? max_tiles - max_tiles / 4 : max_tiles;
+            const size_t full_tiles_per_job = tiles_per_job;
+            for (size_t t0 = 0; t0 < max_tiles; t0 += tiles_per_job) {
+                if (t0 >= taper_from) tiles_per_job = std::max<size_t>(1, full_tiles_per_job / 4);
+                for (int g = 0; g < ngenomes; ++g) {
+                    const size_t ntiles = tiles_of(nbytes[g]);
+                    if (t0 >= ntiles) continue;
+                    int kcur = ka;
+                    for (int q = 0; q < ngroups; ++q) {
+                        const int nk = nks / ngroups + (q < nks % ngroups ? 1 : 0);
+                        sc.jobs.push_back(make_job(g, kcur, nk, kmin, t0, std::min(ntiles, t0 + tiles_per_job)));
+                        max_nk = std::max(max_nk, nk);
+                        kcur += nk;
+                    }
+                }
+            }
+            // The k-groups of one (genome, tile range) read the same token bytes.  Workgroups are dealt
+            // round-robin over the 8 XCDs in blockIdx order, so within every block of 8 units x ngroups
+            // jobs emit group-major: the groups of unit i then sit at indices i, i+8, i+16, ... = one
+            // XCD, back to back, and the re-reads hit that XCD's L2 instead of HBM (speed only).
+            if (ngroups > 1 && knobs.xcd_affinity) {
+                const size_t nunits = sc.jobs.size() / ngroups;
+                std::vector<SweepJob> re;
+                re.reserve(sc.jobs.size());
+                for (size_t u0 = 0; u0 < nunits; u0 += 8) {
+                    const size_t nu = std::min<size_t>(8, nunits - u0);
+                    for (int q = 0; q < ngroups; ++q)
+                        for (size_t u = 0; u < nu; ++u) re.push_back(sc.jobs[(u0 + u) * ngroups + q]);
+                }
+                sc.jobs.swap(re);
+            }
+        }
+        if (sc.jobs.empty()) continue;
+        if (kc == kBitmapClass) {
+            sc.plan.mode = 0;
+            sc.plan.lds_bytes = (bitmap_offset(kb) + bitmap_words(kb) - bitmap_offset(ka)) * 4;
+        } else if (filter_logg) {
+            sc.plan.mode = filter_logg;  // the filter, then a 128-entry candidate queue per wave (dd_sweep.hip)
+            sc.plan.lds_bytes = (int)(m >> filter_logg) + (kThreads / 64) * 128 * 4;
+        } else if (global_regs) {
+            sc.plan.mode = 1;
+            sc.plan.lds_bytes = 0;
+        } else {
+            sc.plan.mode = 0;
+            sc.plan.lds_bytes = (int)((size_t)max_nk * m);
+        }
+        classes.push_back(std::move(sc));
+    }
+    return classes;
+}
+
+}  // namespace dd

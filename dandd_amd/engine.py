@@ -26,7 +26,7 @@ EXPORTS = [
     "dd_progressive", "dd_progressive_device", "dd_pairwise", "dd_pairwise_device",
     "dd_exact_count", "dd_exact_count_device",
     "dd_timing_enable", "dd_timing_read", "dd_timing_reset", "dd_last_sketch_stats",
-    "dd_synth_size", "dd_synth_fasta_device",
+    "dd_synth_size", "dd_synth_fasta_device", "dd_plan_sweep",
 ]
 
 
@@ -122,6 +122,8 @@ def load_library(path=None):
     lib.dd_synth_size.argtypes = [u64, i32]
     lib.dd_synth_fasta_device.restype = i32
     lib.dd_synth_fasta_device.argtypes = [vp, u64, i32, u64, i32, vp]
+    lib.dd_plan_sweep.restype = C.c_long
+    lib.dd_plan_sweep.argtypes = [i32, C.POINTER(sz), i32, i32, i32, vp, C.c_long]
     if path is None:
         _lib = lib
     return lib
@@ -137,6 +139,24 @@ def ertl_mle(hist, log2m):
 
 def synth_size(nbases, nrec=1):
     return int(load_library().dd_synth_size(int(nbases), int(nrec)))
+
+
+PLAN_JOB = np.dtype([("kclass", np.int32), ("mode", np.int32), ("lds_bytes", np.int32), ("genome", np.int32),
+                     ("kfirst", np.int32), ("nk", np.int32), ("tile_begin", np.uint32), ("tile_end", np.uint32)])
+
+
+def plan_sweep(log2m, nbytes, kmin, kmax):
+    """The K1 job table dd_sketch_device would use for genomes of `nbytes` bytes (structured array, launch
+    order).  Pure host code in the library: works without a GPU."""
+    lib = load_library()
+    sizes = (C.c_size_t * len(nbytes))(*[int(n) for n in nbytes])
+    n = lib.dd_plan_sweep(int(log2m), sizes, len(nbytes), int(kmin), int(kmax), None, 0)
+    if n < 0:
+        raise EngineError(f"libdandd_hip error {n}: {lib.dd_last_error().decode()}")
+    out = np.zeros(n, dtype=PLAN_JOB)
+    got = lib.dd_plan_sweep(int(log2m), sizes, len(nbytes), int(kmin), int(kmax), out.ctypes.data, n)
+    assert got == n
+    return out
 
 
 def _u8(a):

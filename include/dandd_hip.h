@@ -138,6 +138,21 @@ size_t dd_synth_size(uint64_t nbases, int nrec);
 int dd_synth_fasta_device(dd_ctx *, uint64_t seed, int genome_index, uint64_t nbases, int nrec,
                           uint8_t *out_dev);
 
+/* ---- the K1 job table of a sketch call, without running it (tests; needs no GPU) --------
+ * What stands in for `parallel -j 95%`'s process-per-k scheduling (lib/huffman_dandd.py:214-218):
+ * how dd_sketch_device would cut (genome x k x 65536-token tile) into workgroup jobs for genomes of
+ * these sizes.  Writes at most `cap` jobs in launch order and returns how many there are (or a
+ * negative DD_E* code).  kclass: -1 small-k bitmap class, else the window class of the launch
+ * (0: k <= 16, 1: <= 32, 3: 33..48, 2: 49..64); mode: 0 registers in LDS, 1 in HBM,
+ * 2..4 in HBM behind an LDS filter byte per 2^mode registers. */
+typedef struct {
+    int kclass, mode, lds_bytes;
+    int genome, kfirst, nk;
+    unsigned tile_begin, tile_end;
+} dd_plan_job;
+long dd_plan_sweep(int log2m, const size_t *nbytes, int ngenomes, int kmin, int kmax, dd_plan_job *out,
+                   long cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--dir", default=None)
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--profile", default=None, help="sub-command to run under cProfile (tree|progressive|kij)")
+    ap.add_argument("--hillclimb", action="store_true", help="no --ksweep: DandD's default argmax-k search from -k 12")
     args = ap.parse_args()
 
     work = args.dir or tempfile.mkdtemp(prefix="dandd_e2e_")
@@ -51,7 +52,7 @@ def main():
 
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     cli = [sys.executable, "-m", "dandd_amd.host.cli"]
-    sweep = ["--ksweep", "--mink", str(args.mink), "--maxk", str(args.maxk)]
+    sweep = [] if args.hillclimb else ["--ksweep", "--mink", str(args.mink), "--maxk", str(args.maxk)]
     timings = {}
 
     def run(name, cmd):
@@ -75,7 +76,7 @@ def main():
     dtree = os.path.join(out, sorted(pick)[0])
     run("tree_again_cached", cli + ["tree", "-d", gdir, "-o", out, "-s", "e2e", "-r", str(args.registers)] + sweep)
     run("progressive", cli + ["progressive", "-d", dtree, "-o", out, "-n", str(args.norderings)] + sweep)
-    run("kij", cli + ["kij", "-d", dtree, "-o", out, "--jaccard"] + sweep)
+    run("kij", cli + ["kij", "-d", dtree, "-o", out] + (["--jaccard"] + sweep if sweep else []))
 
     gbp = args.ngenomes * nb / 1e9
     print(json.dumps({

@@ -1,0 +1,91 @@
+"""The K1 job tables (dandd_amd/csrc/dd_plan.hip) checked on the CPU through dd_plan_sweep: every
+(genome, k, token tile) of a sketch call must be covered by exactly one workgroup job, with the window
+class, register mode and LDS footprint the kernels assume.  A hole here would not crash anything -- the
+k-mers of the missing tiles would silently never reach the sketch."""
+import os
+
+import numpy as np
+import pytest
+
+os.environ.setdefault("DANDD_NO_TORCH", "1")
+from dandd_amd.engine import plan_sweep  # noqa: E402
+
+TILE = 1024 * 64  # tokens per tile; tokens <= FASTA bytes
+LDS_MAX = 160 * 1024
+KCLASS_RANGE = {-1: (1, 9), 0: (1, 16), 1: (16, 32), 3: (33, 48), 2: (49, 64)}
+
+SIZES = {
+    "cfg2": [50_600_000] * 10,
+    "ragged": [5_000_000, 0, 1, 63, 64, 65_536, 65_537, 1_000_000, 12_345_678],
+    "single_big": [3_100_000_000],
+    "many_small": [4_000_000 + 1000 * i for i in range(64)],
+}
+
+
+def check(log2m, sizes, kmin, kmax):
+    jobs = plan_sweep(log2m, sizes, kmin, kmax)
+    m = 1 << log2m
+    ntiles = [(n + TILE - 1) // TILE for n in sizes]
+    cover = [np.zeros((kmax - kmin + 1, nt), dtype=np.int32) for nt in ntiles]
+    for j in jobs:
+        lo, hi = KCLASS_RANGE[int(j["kclass"])]
+        if j["tile_end"] <= j["tile_begin"]:
+            continue  # idle filler of the XCD-affine order
+        k0, nk, g = int(j["kfirst"]), int(j["nk"]), int(j["genome"])
+        assert nk >= 1 and lo <= k0 and k0 + nk - 1 <= hi, j
+        assert kmin <= k0 and k0 + nk - 1 <= kmax
+        assert 0 <= g < len(sizes) and j["tile_end"] <= ntiles[g]
+        assert 0 <= j["lds_bytes"] <= LDS_MAX
+        mode = int(j["mode"])
+        if j["kclass"] == -1:
+            assert mode == 0
+        elif log2m >= 18:
+            assert mode == max(2, log2m - 16) and nk == 1          # one k per job behind the filter
+            assert j["lds_bytes"] == (m >> mode) + 16 * 128 * 4    # filter + one queue per wave
+        else:
+            assert mode == 0 and nk * m <= j["lds_bytes"]          # the group's registers fit the LDS asked for
+        cover[g][k0 - kmin:k0 - kmin + nk, j["tile_begin"]:j["tile_end"]] += 1
+    for g, c in enumerate(cover):
+        assert c.size == 0 or (c.min() == 1 and c.max() == 1), f"genome {g}: tiles covered {c.min()}..{c.max()} times"
+    return jobs
+
+
+@pytest.mark.parametrize("name", sorted(SIZES))
+@pytest.mark.parametrize("log2m", [10, 14, 16, 17, 18, 20])
+def test_every_tile_of_every_k_is_covered_once(name, log2m):
+    if name == "single_big" and log2m not in (14, 20):
+        pytest.skip("one large case per register mode is enough")
+    check(log2m, SIZES[name], 4, 40)
+
+
+@pytest.mark.parametrize("krange", [(1, 64), (1, 1), (9, 10), (16, 17), (32, 33), (48, 49), (64, 64), (10, 20)])
+def test_k_ranges_and_class_boundaries(krange):
+    for log2m in (12, 14, 19):
+        check(log2m, SIZES["ragged"], *krange)
+
+
+def test_launch_shape_of_the_headline_config():
+    jobs = check(14, SIZES["cfg2"], 4, 40)
+    by_class = {int(c): jobs[jobs["kclass"] == c] for c in np.unique(jobs["kclass"])}
+    assert sorted(by_class) == [-1, 0, 1, 3]
+    assert set(by_class[-1]["kfirst"]) == {4} and set(by_class[-1]["nk"]) == {6}
+    assert by_class[1]["lds_bytes"].max() <= 80 * 1024     # two workgroups per CU
+    assert by_class[0]["lds_bytes"].max() <= 48 * 1024     # three for the 32-bit class
+    assert all(len(v) >= 2048 for v in by_class.values())  # >> 256 CUs x 2 resident workgroups
+
+
+def test_knobs_change_the_plan_not_the_coverage(monkeypatch):
+    for env in ({"DD_NO_BITMAP": "1"}, {"DD_LDS_KB": "160"}, {"DD_JOBS_PER_CU": "3"}, {"DD_NO_XCD_AFFINITY": "1"},
+                {"DD_NO_TAPER": "1"}, {"DD_NO_FILTER": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for log2m in (14, 18):
+            jobs = plan_sweep(log2m, SIZES["ragged"], 2, 40)
+            ntiles = [(n + TILE - 1) // TILE for n in SIZES["ragged"]]
+            cover = [np.zeros((39, nt), dtype=np.int32) for nt in ntiles]
+            for j in jobs:
+                if j["tile_end"] > j["tile_begin"]:
+                    cover[j["genome"]][j["kfirst"] - 2:j["kfirst"] - 2 + j["nk"], j["tile_begin"]:j["tile_end"]] += 1
+            assert all(c.size == 0 or (c.min() == 1 and c.max() == 1) for c in cover), env
+        for k in env:
+            monkeypatch.delenv(k)
