@@ -108,8 +108,8 @@ struct dd_ctx {
     std::vector<TimedSpan> spans[DD_KERNEL_COUNT];
     std::vector<hipEvent_t> pool;
     // workspaces
-    DevBuf tokens, scratch, tables, fasta, regs, ptrs, hist, est, ord, bitmaps, exact;
-    HostBuf stage;
+    DevBuf tokens, scratch, tables, jobtab, fasta, regs, ptrs, hist, est, ord, bitmaps, exact;
+    HostBuf stage, stage_jobs;  // genome/pack tables and K1 job tables are uploaded in two steps
     hipEvent_t stage_free = nullptr;  // signalled when the last upload from `stage` completed
     // stats of the last sketch call
     uint64_t st_tokens = 0, st_updates = 0;
@@ -161,9 +161,10 @@ struct Span {  // brackets a launch with events when timing is on
 };
 
 // upload a host table through the pinned staging buffer (async on the stream)
-int upload(dd_ctx* c, void* dst_dev, const void* src, size_t bytes, size_t stage_off) {
-    memcpy(static_cast<char*>(c->stage.p) + stage_off, src, bytes);
-    DD_HIP(hipMemcpyAsync(dst_dev, static_cast<char*>(c->stage.p) + stage_off, bytes,
+int upload(dd_ctx* c, HostBuf& stage, void* dst_dev, const void* src, size_t bytes, size_t stage_off) {
+    if (!bytes) return DD_OK;
+    memcpy(static_cast<char*>(stage.p) + stage_off, src, bytes);
+    DD_HIP(hipMemcpyAsync(dst_dev, static_cast<char*>(stage.p) + stage_off, bytes,
                           hipMemcpyHostToDevice, c->stream));
     return DD_OK;
 }
@@ -313,10 +314,11 @@ void dd_destroy(dd_ctx* c) {
         }
     for (auto e : c->pool) (void)hipEventDestroy(e);
     if (c->stage_free) (void)hipEventDestroy(c->stage_free);
-    for (DevBuf* b : {&c->tokens, &c->scratch, &c->tables, &c->fasta, &c->regs, &c->ptrs, &c->hist,
+    for (DevBuf* b : {&c->tokens, &c->scratch, &c->tables, &c->jobtab, &c->fasta, &c->regs, &c->ptrs, &c->hist,
                       &c->est, &c->ord, &c->bitmaps, &c->exact})
         b->release();
     c->stage.release();
+    c->stage_jobs.release();
     delete c;
 }
 
@@ -405,38 +407,40 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     }
     (void)max_n;
 
-    // ---- K1 job tables (dd_plan.hip) -------------------------------------------------------
-    const std::vector<dd::SweepClass> classes =
-        dd::plan_sweep(p, c->canonical, nbytes, ngenomes, kmin, kmax, dd::PlanKnobs::from_env());
-
-    size_t table_bytes = align_up(sizeof(dd::SweepGenome) * ngenomes, 256);
-    const size_t pack_off = table_bytes;
-    table_bytes += align_up(sizeof(dd::PackGenome) * ngenomes, 256);
-    std::vector<size_t> job_off(classes.size());
-    for (size_t i = 0; i < classes.size(); ++i) {
-        job_off[i] = table_bytes;
-        table_bytes += align_up(sizeof(dd::SweepJob) * classes[i].jobs.size(), 256);
-    }
-    if ((rc = c->tables.reserve(table_bytes))) return rc;
-    // the staging buffer may still be feeding a previous call's upload
+    // ---- genome tables up, K0 launched: the K1 job tables are planned on the host meanwhile -------
+    const size_t pack_off = align_up(sizeof(dd::SweepGenome) * ngenomes, 256);
+    const size_t gtab_bytes = pack_off + align_up(sizeof(dd::PackGenome) * ngenomes, 256);
+    if ((rc = c->tables.reserve(gtab_bytes))) return rc;
+    // the staging buffers may still be feeding a previous call's uploads
     DD_HIP(hipEventSynchronize(c->stage_free));
-    if ((rc = c->stage.reserve(table_bytes))) return rc;
+    if ((rc = c->stage.reserve(gtab_bytes))) return rc;
     char* tdev = static_cast<char*>(c->tables.p);
-    if ((rc = upload(c, tdev, gtab.data(), sizeof(dd::SweepGenome) * ngenomes, 0))) return rc;
-    if ((rc = upload(c, tdev + pack_off, ptab.data(), sizeof(dd::PackGenome) * ngenomes, pack_off))) return rc;
-    for (size_t i = 0; i < classes.size(); ++i)
-        if ((rc = upload(c, tdev + job_off[i], classes[i].jobs.data(),
-                         sizeof(dd::SweepJob) * classes[i].jobs.size(), job_off[i])))
-            return rc;
-    DD_HIP(hipEventRecord(c->stage_free, st));
-
-    // ---- K0: pack every genome of the batch (three launches) -------------------------------
+    if ((rc = upload(c, c->stage, tdev, gtab.data(), sizeof(dd::SweepGenome) * ngenomes, 0))) return rc;
+    if ((rc = upload(c, c->stage, tdev + pack_off, ptab.data(), sizeof(dd::PackGenome) * ngenomes, pack_off))) return rc;
     {
-        Span sp(c, DD_KERNEL_PACK);
+        Span sp(c, DD_KERNEL_PACK);  // K0: pack every genome of the batch (three launches)
         dd::launch_pack_batch(reinterpret_cast<const dd::PackGenome*>(tdev + pack_off), ngenomes,
                               max_chunks, st);
     }
     DD_HIP(hipGetLastError());
+
+    // ---- K1 job tables (dd_plan.hip), built while K0 runs -----------------------------------
+    const std::vector<dd::SweepClass> classes =
+        dd::plan_sweep(p, c->canonical, nbytes, ngenomes, kmin, kmax, dd::PlanKnobs::from_env());
+    size_t job_bytes = 0;
+    std::vector<size_t> job_off(classes.size());
+    for (size_t i = 0; i < classes.size(); ++i) {
+        job_off[i] = job_bytes;
+        job_bytes += align_up(sizeof(dd::SweepJob) * classes[i].jobs.size(), 256);
+    }
+    if ((rc = c->jobtab.reserve(job_bytes))) return rc;
+    if ((rc = c->stage_jobs.reserve(job_bytes))) return rc;
+    char* jdev = static_cast<char*>(c->jobtab.p);
+    for (size_t i = 0; i < classes.size(); ++i)
+        if ((rc = upload(c, c->stage_jobs, jdev + job_off[i], classes[i].jobs.data(),
+                         sizeof(dd::SweepJob) * classes[i].jobs.size(), job_off[i])))
+            return rc;
+    DD_HIP(hipEventRecord(c->stage_free, st));
 
     // ---- K1 launches -------------------------------------------------------------------
     int blocks = 0;
@@ -445,13 +449,13 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         Span sp(c, DD_KERNEL_SWEEP);
         if (sc.kclass == dd::kBitmapClass) {
             dd::launch_bitmap(reinterpret_cast<const dd::SweepGenome*>(tdev),
-                              reinterpret_cast<const dd::SweepJob*>(tdev + job_off[i]),
+                              reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]),
                               (int)sc.jobs.size(), sc.kfirst, sc.klast, c->canonical, st);
             dd::launch_bitmap_finish(reinterpret_cast<const dd::SweepGenome*>(tdev), ngenomes, sc.kfirst, sc.klast,
                                      kmin, p, st);
         } else {
             dd::launch_sweep(reinterpret_cast<const dd::SweepGenome*>(tdev),
-                             reinterpret_cast<const dd::SweepJob*>(tdev + job_off[i]),
+                             reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]),
                              (int)sc.jobs.size(), sc.kclass, sc.plan, st);
         }
         blocks += (int)sc.jobs.size();
@@ -658,8 +662,8 @@ int dd_exact_count_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size
     DD_HIP(hipEventSynchronize(c->stage_free));
     if ((rc = c->stage.reserve(pbytes + ebytes))) return rc;
     char* tdev = static_cast<char*>(c->tables.p);
-    if ((rc = upload(c, tdev, ptab.data(), sizeof(dd::PackGenome) * n, 0))) return rc;
-    if ((rc = upload(c, tdev + pbytes, etab.data(), sizeof(dd::ExactGenome) * n, pbytes))) return rc;
+    if ((rc = upload(c, c->stage, tdev, ptab.data(), sizeof(dd::PackGenome) * n, 0))) return rc;
+    if ((rc = upload(c, c->stage, tdev + pbytes, etab.data(), sizeof(dd::ExactGenome) * n, pbytes))) return rc;
     DD_HIP(hipEventRecord(c->stage_free, st));
 
     DD_HIP(hipMemsetAsync(counters, 0, 256, st));
@@ -719,7 +723,7 @@ int dd_union_device(dd_ctx* c, const uint8_t* const* in_dev, int n, size_t len, 
     if ((rc = c->ptrs.reserve(sizeof(void*) * n))) return rc;
     DD_HIP(hipEventSynchronize(c->stage_free));
     if ((rc = c->stage.reserve(sizeof(void*) * n))) return rc;
-    if ((rc = upload(c, c->ptrs.p, in_dev, sizeof(void*) * n, 0))) return rc;
+    if ((rc = upload(c, c->stage, c->ptrs.p, in_dev, sizeof(void*) * n, 0))) return rc;
     DD_HIP(hipEventRecord(c->stage_free, c->stream));
     {
         Span sp(c, DD_KERNEL_UNION);
@@ -815,7 +819,7 @@ int dd_progressive_device(dd_ctx* c, const uint8_t* leaf_dev, int n, int K, cons
     if ((rc = c->ord.reserve(sizeof(int32_t) * norder * n))) return rc;
     DD_HIP(hipEventSynchronize(c->stage_free));
     if ((rc = c->stage.reserve(sizeof(int32_t) * norder * n))) return rc;
-    if ((rc = upload(c, c->ord.p, orderings, sizeof(int32_t) * norder * n, 0))) return rc;
+    if ((rc = upload(c, c->stage, c->ord.p, orderings, sizeof(int32_t) * norder * n, 0))) return rc;
     DD_HIP(hipEventRecord(c->stage_free, c->stream));
     {
         Span sp(c, DD_KERNEL_UNION);
