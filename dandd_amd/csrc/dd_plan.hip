@@ -138,6 +138,7 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
             // quarter the size, so the launch does not end waiting on a few full-size stragglers.
             const size_t taper_from = knobs.taper ? max_tiles - max_tiles / 4 : max_tiles;
             const size_t full_tiles_per_job = tiles_per_job;
+            sc.jobs.reserve((total_tiles / tiles_per_job + (size_t)ngenomes) * ngroups * 2 + 64);
             for (size_t t0 = 0; t0 < max_tiles; t0 += tiles_per_job) {
                 if (t0 >= taper_from) tiles_per_job = std::max<size_t>(1, full_tiles_per_job / 4);
                 for (int g = 0; g < ngenomes; ++g) {
