@@ -110,6 +110,16 @@ struct dd_ctx {
     // workspaces
     DevBuf tokens, scratch, tables, jobtab, fasta, regs, ptrs, hist, est, ord, bitmaps, exact;
     HostBuf stage, stage_jobs;  // genome/pack tables and K1 job tables are uploaded in two steps
+    // the job tables of the last sketch call: a call over genomes of the same sizes and the same k range
+    // (a pipeline sketching fixed-size batches, a benchmark loop) reuses them, on the host and in HBM
+    struct {
+        bool valid = false;
+        int kmin = 0, kmax = 0;
+        std::vector<size_t> sizes;
+        dd::PlanKnobs knobs;
+        std::vector<dd::SweepClass> classes;
+        std::vector<size_t> job_off;
+    } plan;
     hipEvent_t stage_free = nullptr;  // signalled when the last upload from `stage` completed
     // stats of the last sketch call
     uint64_t st_tokens = 0, st_updates = 0;
@@ -425,21 +435,34 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     DD_HIP(hipGetLastError());
 
     // ---- K1 job tables (dd_plan.hip), built while K0 runs -----------------------------------
-    const std::vector<dd::SweepClass> classes =
-        dd::plan_sweep(p, c->canonical, nbytes, ngenomes, kmin, kmax, dd::PlanKnobs::from_env());
-    size_t job_bytes = 0;
-    std::vector<size_t> job_off(classes.size());
-    for (size_t i = 0; i < classes.size(); ++i) {
-        job_off[i] = job_bytes;
-        job_bytes += align_up(sizeof(dd::SweepJob) * classes[i].jobs.size(), 256);
+    const dd::PlanKnobs knobs = dd::PlanKnobs::from_env();
+    auto& pc = c->plan;
+    const bool same_plan = pc.valid && pc.kmin == kmin && pc.kmax == kmax && pc.knobs == knobs &&
+                           pc.sizes.size() == (size_t)ngenomes && std::equal(pc.sizes.begin(), pc.sizes.end(), nbytes);
+    if (!same_plan) {
+        pc.valid = false;
+        pc.classes = dd::plan_sweep(p, c->canonical, nbytes, ngenomes, kmin, kmax, knobs);
+        size_t job_bytes = 0;
+        pc.job_off.assign(pc.classes.size(), 0);
+        for (size_t i = 0; i < pc.classes.size(); ++i) {
+            pc.job_off[i] = job_bytes;
+            job_bytes += align_up(sizeof(dd::SweepJob) * pc.classes[i].jobs.size(), 256);
+        }
+        if ((rc = c->jobtab.reserve(job_bytes))) return rc;
+        if ((rc = c->stage_jobs.reserve(job_bytes))) return rc;
+        for (size_t i = 0; i < pc.classes.size(); ++i)
+            if ((rc = upload(c, c->stage_jobs, static_cast<char*>(c->jobtab.p) + pc.job_off[i], pc.classes[i].jobs.data(),
+                             sizeof(dd::SweepJob) * pc.classes[i].jobs.size(), pc.job_off[i])))
+                return rc;
+        pc.kmin = kmin;
+        pc.kmax = kmax;
+        pc.knobs = knobs;
+        pc.sizes.assign(nbytes, nbytes + ngenomes);
+        pc.valid = true;
     }
-    if ((rc = c->jobtab.reserve(job_bytes))) return rc;
-    if ((rc = c->stage_jobs.reserve(job_bytes))) return rc;
+    const std::vector<dd::SweepClass>& classes = pc.classes;
+    const std::vector<size_t>& job_off = pc.job_off;
     char* jdev = static_cast<char*>(c->jobtab.p);
-    for (size_t i = 0; i < classes.size(); ++i)
-        if ((rc = upload(c, c->stage_jobs, jdev + job_off[i], classes[i].jobs.data(),
-                         sizeof(dd::SweepJob) * classes[i].jobs.size(), job_off[i])))
-            return rc;
     DD_HIP(hipEventRecord(c->stage_free, st));
 
     // ---- K1 launches -------------------------------------------------------------------

@@ -28,6 +28,11 @@ struct PlanKnobs {
     int global_from_p = 18;         // registers stay in HBM from this log2m on
     bool use_bitmaps = true, filter = true, xcd_affinity = true, taper = true;
     static PlanKnobs from_env();
+    bool operator==(const PlanKnobs& o) const {
+        return lds_budget == o.lds_budget && lds_budget_forced == o.lds_budget_forced && jobs_per_cu == o.jobs_per_cu &&
+               jobs_per_row == o.jobs_per_row && global_from_p == o.global_from_p && use_bitmaps == o.use_bitmaps &&
+               filter == o.filter && xcd_affinity == o.xcd_affinity && taper == o.taper;
+    }
 };
 
 std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbytes, int ngenomes, int kmin,
