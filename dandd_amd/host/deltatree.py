@@ -29,6 +29,7 @@ from .store import Catalog, SketchPath, ensure_dir, sketch_exists
 # ---------------------------------------------------------------------------------------------
 _backend_factory = None
 _backends = {}
+_leaf_batch = None  # set while a tree solves its leaves: sketches missing ks for all of them at once
 
 
 def set_backend_factory(factory):
@@ -278,6 +279,9 @@ class DeltaTreeNode:
             if sketch_exists(path):
                 continue
             todo.append(k)
+        if todo and self.ngen == 1 and _leaf_batch is not None:
+            _leaf_batch(todo)  # the same ks (and a margin) for every leaf of the tree in one batch
+            todo = [k for k in todo if not sketch_exists(template.with_k(k))]
         if todo:
             be = backend_for(self.experiment)
             if self.ngen == 1:
@@ -408,31 +412,21 @@ class DeltaTree:
             for path, digest in zip(missing, pool.map(file_digest, missing)):
                 self.speciesinfo.fastahex[os.path.basename(path)] = digest
 
-    def _presketch_leaves(self, leaves, radius=3):
-        """Leaf sketches for the ks the per-leaf searches are about to ask for -- the whole ksweep
-        range, or kstart +- radius for the hill-climb -- made for ALL leaves by one pipelined batch
-        (files are read/inflated ahead while the GPU sketches) instead of genome by genome
-        (the reference's loop, lib/huffman_dandd.py:402-407, is strictly sequential).  Purely a cache
-        warm-up: a search that leaves the window falls back to the per-leaf path."""
+    def _batch_leaf_sketch(self, leaves, lo, hi):
+        """Sketch files of k in [lo, hi] for every leaf that lacks any of them, by ONE pipelined batch
+        (files are read/inflated ahead while the GPU sketches); sharded over the ranks when several."""
         be = backend_for(self.experiment)
-        if not hasattr(be, "leaf_many") or len(leaves) < 2 or os.environ.get("DD_NO_PREFETCH"):
-            return
-        self._predigest(leaves)
-        if self.experiment["ksweep"] is not None:
-            lo, hi = (int(v) for v in self.experiment["ksweep"])
-        else:
-            lo, hi = max(1, int(self.speciesinfo.kstart) - radius), int(self.speciesinfo.kstart) + radius
-            if self.experiment["tool"] == "dashing":
-                hi = min(hi, 32)
-        lo = max(lo, 1)
-        if hi < lo:
-            return
+        lo = max(int(lo), 1)
+        if self.experiment["tool"] == "dashing" and not self.experiment.get("allow_k64"):
+            hi = min(int(hi), 32)
+        if hi < lo or not hasattr(be, "leaf_many"):
+            return 0
         todo, templates = [], []
         for leaf in leaves:
-            tmpl = SketchPath(leaf.fastas, 0, self.speciesinfo, self.experiment)
+            tmpl = leaf._template() if hasattr(leaf, "_template") else SketchPath(leaf.fastas, 0, self.speciesinfo, self.experiment)
             if any(not sketch_exists(tmpl.with_k(k)) for k in range(lo, hi + 1)):
                 for k in range(lo, hi + 1):
-                    os.makedirs(tmpl.dir.replace("{}", str(k)), exist_ok=True)
+                    ensure_dir(tmpl.dir.replace("{}", str(k)))
                 todo.append(leaf.fastas[0])
                 templates.append(tmpl)
         rank, world = dist_ranks()
@@ -443,6 +437,34 @@ class DeltaTree:
                 be.leaf_many([todo[i] for i in mine], lo, hi, lambda i, k: templates[mine[i]].with_k(k))
         elif len(todo) > 1:
             be.leaf_many(todo, lo, hi, lambda i, k: templates[i].with_k(k))
+        return len(todo)
+
+    def _presketch_leaves(self, leaves, radius=3):
+        """Leaf sketches for the ks the per-leaf searches are about to ask for -- the whole ksweep
+        range, or kstart +- radius for the hill-climb -- made for ALL leaves by one pipelined batch
+        instead of genome by genome (the reference's loop, lib/huffman_dandd.py:402-407, is strictly
+        sequential).  Purely a cache warm-up: see _leaf_batch_hook for searches that leave the window."""
+        be = backend_for(self.experiment)
+        if not hasattr(be, "leaf_many") or len(leaves) < 2 or os.environ.get("DD_NO_PREFETCH"):
+            return
+        self._predigest(leaves)
+        if self.experiment["ksweep"] is not None:
+            lo, hi = (int(v) for v in self.experiment["ksweep"])
+        else:
+            lo, hi = max(1, int(self.speciesinfo.kstart) - radius), int(self.speciesinfo.kstart) + radius
+        self._batch_leaf_sketch(leaves, lo, hi)
+
+    def _leaf_batch_hook(self, leaves, margin=2):
+        """While the leaves are being solved: a hill-climb that asks one leaf for ks outside what is on
+        disk gets them -- and `margin` more on either side -- sketched for EVERY
+        leaf in one batch, because the other leaves' searches are about to walk the same way.  One pass
+        over all files per window extension instead of one file read per (leaf, step)."""
+        if len(leaves) < 2 or os.environ.get("DD_NO_PREFETCH") or dist_ranks()[1] > 1:
+            return None
+
+        def hook(ks):
+            return self._batch_leaf_sketch(leaves, min(ks) - margin, max(ks) + margin)
+        return hook
 
     def _build_tree(self, symbol, nchildren, leafnodes=()):
         """Leaves first (in the order given; the sort by ngen is stable), then unions of `nchildren`
@@ -455,8 +477,13 @@ class DeltaTree:
             dist_barrier()
             if dist_ranks()[0] != 0:
                 raise WorkerDone()
-        for leaf in nodes:
-            self._solve(leaf)
+        global _leaf_batch
+        _leaf_batch = self._leaf_batch_hook(nodes) if self.experiment["ksweep"] is None else None
+        try:
+            for leaf in nodes:
+                self._solve(leaf)
+        finally:
+            _leaf_batch = None
         self._dt = nodes
         insert_at = 0
         current = 0

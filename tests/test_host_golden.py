@@ -110,6 +110,50 @@ def test_second_run_is_served_from_cache(host, tmp_path):
     assert not hostcheck.compare({"tree_spider_k10": rows}, {"tree_spider_k10": gold["scenarios"]["tree_spider_k10"]})
 
 
+def test_hill_climb_window_extensions_are_batched_over_leaves(host, tmp_path):
+    """A backend with the batch entry point (the GPU one has it) gets the leaves' hill-climbs served
+    by a few whole-tree batches instead of one call per (leaf, step) -- and the rows do not change."""
+    gold = _golden("ref_hll.json")
+    log = {"single": 0, "batches": []}
+
+    class Batched(hostcheck.OracleBackend):
+        def leaf(self, fasta, ks, outs):
+            log["single"] += 1
+            return super().leaf(fasta, ks, outs)
+
+        def leaf_many(self, fastas, kmin, kmax, path_of):
+            log["batches"].append((len(fastas), kmin, kmax))
+            for i, f in enumerate(fastas):
+                ks = list(range(kmin, kmax + 1))
+                hostcheck.OracleBackend.leaf(self, f, ks, [path_of(i, k) for k in ks])
+
+    from dandd_amd.host import cli
+    import shutil
+
+    def run(factory, name):
+        host.set_backend_factory(factory)
+        data = os.path.join(str(tmp_path), name, "data")
+        shutil.copytree(os.path.join(hostcheck.GOLD, "fasta"), data)
+        out = os.path.join(str(tmp_path), name, "o")
+        # start far below the optimum: every leaf's search leaves the pre-sketched window (kstart +- 3)
+        cli.main(["tree", "-d", data, "-o", out, "-s", "gold", "-k", "2", "-r", str(gold["registers"])])
+        return hostcheck.read_rows(os.path.join(out, "gold_5_dashing_deltas.csv"))
+
+    class Plain(hostcheck.OracleBackend):  # no batch entry point: one backend call per (leaf, step)
+        def leaf(self, fasta, ks, outs):
+            log["plain"] = log.get("plain", 0) + 1
+            return super().leaf(fasta, ks, outs)
+
+    plain = run(lambda r, c: Plain(r, c), "plain")
+    batched = run(lambda r, c: Batched(r, c), "batched")
+    strip = lambda rows: [{k: v for k, v in r.items() if k != "command"} for r in rows]  # noqa: E731
+    assert not hostcheck.compare({"t": strip(batched)}, {"t": strip(plain)})
+    assert len(log["batches"]) >= 2 and all(b[0] >= 2 for b in log["batches"]), log   # window + extensions, many leaves each
+    # climbs ride on the batches: at most one straggler call per leaf (a leaf whose search alone goes
+    # further), against several per leaf without batching
+    assert log["single"] <= 5 and len(log["batches"]) + log["single"] < log["plain"] / 2, log
+
+
 def test_tree_shapes_for_nchildren(host, tmp_path):
     """Shapes the reference builds for (N, nchildren) -- SURVEY.md section 4.3 probe facts."""
     import shutil
