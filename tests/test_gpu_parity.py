@@ -305,6 +305,10 @@ def test_full_size_properties_cfg2(engine_factory, torch_cuda, orc):
         assert exact_whole == exact_parts
         est = eng.card(whole[k - 4])
         assert abs(est - exact_whole) / exact_whole < 4 * 1.04 / np.sqrt(eng.m)
+    # ... and the oracle itself at full size for one k of every kernel class and both sides of every
+    # class boundary (about a second of CPU per k): bit-exact registers at BASELINE scale
+    for k in (4, 9, 10, 16, 17, 32, 33, 40):
+        assert np.array_equal(whole[k - 4], orc.sketch(fa, k, 14, True)), f"k={k} differs from the oracle at 50 Mbp"
 
 
 @pytest.mark.parametrize("canonical", [True, False])
