@@ -333,3 +333,59 @@ def test_exact_count_matches_oracle(engine_factory, orc, tmp_path, canonical):
     empty.write_bytes(b">nothing\n")
     assert eng.exact_count([str(empty)], 5) == 0
     assert eng.exact_count([], 5) == 0
+
+
+def test_device_resident_schedules_and_stream(engine_factory, torch_cuda, orc):
+    """The *_device entry points on HBM-resident slabs, on a caller-owned non-default stream: union,
+    progressive, pairwise, histograms -- all equal to the host-buffer variants and to the oracle."""
+    torch = torch_cuda
+    eng = engine_factory(12, True)
+    stream = torch.cuda.Stream()
+    eng.set_stream(stream.cuda_stream)
+    try:
+        n, kmin, kmax = 6, 11, 14
+        K, m = kmax - kmin + 1, eng.m
+        fas = [orc.synth_fasta(SEED, 20 + g, 40000 + 3000 * g, 2) for g in range(n)]
+        leaf = np.stack([orc.sketch_sweep(f, kmin, kmax, 12) for f in fas])          # [n][K][m]
+        with torch.cuda.stream(stream):
+            dleaf = torch.from_numpy(leaf).cuda()
+            dout = torch.empty((K, m), dtype=torch.uint8, device="cuda")
+        stream.synchronize()
+        eng.union_device([dleaf[g].data_ptr() for g in range(n)], K * m, dout.data_ptr())
+        eng.synchronize()
+        assert np.array_equal(dout.cpu().numpy(), leaf.max(axis=0))
+        ords = [list(range(n)), list(reversed(range(n))), [2, 0, 5, 1, 4, 3]]
+        prog = eng.progressive_device(dleaf.data_ptr(), n, K, ords)
+        assert np.array_equal(prog, eng.progressive(leaf, ords))
+        for o, order in enumerate(ords):
+            run = np.zeros((K, m), dtype=np.uint8)
+            for j, g in enumerate(order):
+                run = np.maximum(run, leaf[g])
+                assert [prog[o, j, kk] for kk in range(K)] == [orc.card(run[kk], 12) for kk in range(K)]
+        pair = eng.pairwise_device(dleaf.data_ptr(), n, K)
+        assert np.array_equal(pair, eng.pairwise(leaf))
+        assert pair[1, 4, 2] == orc.card(np.maximum(leaf[1, 2], leaf[4, 2]), 12)
+        hist = eng.hist_batch_device(dleaf.data_ptr(), n * K).reshape(n, K, 64)
+        assert np.array_equal(hist[3, 1], np.bincount(leaf[3, 1], minlength=64))
+    finally:
+        eng.set_stream(0)
+
+
+def test_timing_spans_and_call_statistics(engine_factory, orc):
+    from dandd_amd.engine import KERNEL_PACK, KERNEL_SWEEP, KERNEL_UNION
+    eng = engine_factory(14, True)
+    fa = orc.synth_fasta(SEED, 9, 200000, 2)
+    eng.timing_enable(True)
+    eng.timing_reset()
+    regs = eng.sketch_buffer(fa, 4, 40)
+    pack_ms, pack_n = eng.timing_read(KERNEL_PACK)
+    sweep_ms, sweep_n = eng.timing_read(KERNEL_SWEEP)
+    assert pack_n == 1 and pack_ms > 0
+    assert sweep_n == 4 and sweep_ms > 0            # small-k class + the 32-, 64- and 96-bit classes
+    eng.card_batch(regs)
+    assert eng.timing_read(KERNEL_UNION)[1] >= 1
+    eng.timing_reset()
+    assert eng.timing_read(KERNEL_SWEEP) == (0.0, 0)
+    eng.timing_enable(False)
+    tokens, updates, blocks = eng.last_sketch_stats()
+    assert tokens == fa.size and updates == fa.size * 37 and blocks > 0
