@@ -32,6 +32,10 @@ __global__ __launch_bounds__(1024) void k1_model(uint32_t* out, int nk, int kfir
             win.push(c);
             if (MODE == 0) {
                 sweep_token<KC, true, false>(win, 64, kfirst, nk, p, lds_slot);
+            } else if (MODE == 4) {
+                // experiment: k loop fully unrolled (nk == 4), so masks/shifts are loop-invariant scalars
+                hll_update2(lds_slot(0), win.template hash<true>(kfirst), lds_slot(1), win.template hash<true>(kfirst + 1), p);
+                hll_update2(lds_slot(2), win.template hash<true>(kfirst + 2), lds_slot(3), win.template hash<true>(kfirst + 3), p);
             } else if (MODE == 3) {
 #pragma unroll 1
                 for (int j = 0; j < nk; ++j) hll_update(lds_slot(j), win.template hash<true>(kfirst + j), p);
@@ -91,6 +95,9 @@ int main(int argc, char** argv) {
     ROW("class0 k13..16 hash+probe only", 0, 2, 4, 13, 0u)
     ROW("class0 k13..16 hash only", 0, 1, 4, 13, 0u)
     ROW("class1 k21..24 full, never raises", 1, 0, 4, 21, 0xFFFFFFFFu)
+    ROW("class1 k21..24 full, k loop unrolled", 1, 4, 4, 21, 0xFFFFFFFFu)
+    ROW("class0 k13..16 full, k loop unrolled", 0, 4, 4, 13, 0xFFFFFFFFu)
+    ROW("class3 k33..36 full, k loop unrolled", 3, 4, 4, 33, 0xFFFFFFFFu)
     ROW("class1 k21..24 full, from cold", 1, 0, 4, 21, 0u)
     ROW("class1 k21..24 unpaired, never raises", 1, 3, 4, 21, 0xFFFFFFFFu)
     ROW("class1 k21..24 hash+probe only", 1, 2, 4, 21, 0u)
