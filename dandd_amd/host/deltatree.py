@@ -22,7 +22,7 @@ from itertools import permutations
 from math import factorial
 from random import sample, shuffle
 
-from .store import Catalog, SketchPath, ensure_dir, sketch_exists
+from .store import Catalog, SketchPath, ensure_dir, forget_sketch, sketch_exists
 
 # ---------------------------------------------------------------------------------------------
 # backend plumbing: objects of this module are pickled, the GPU context is not
@@ -205,6 +205,7 @@ class Sketch:
                 os.remove(f)
             except FileNotFoundError:
                 pass
+            forget_sketch(f)
 
 
 # ---------------------------------------------------------------------------------------------

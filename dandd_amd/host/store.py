@@ -180,6 +180,11 @@ def ensure_dir(path):
         _made_dirs.add(path)
 
 
+def forget_sketch(path):
+    """A sketch file was removed on purpose (Sketch.remove_sketch): drop the remembered answer."""
+    _seen_sketches.discard(path)
+
+
 def sketch_exists(path):
     """A non-empty sketch file is there.  Sketch files are only ever created, never removed or
     truncated, within a run, so a positive answer is remembered; a negative one is asked again."""

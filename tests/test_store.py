@@ -53,7 +53,9 @@ def test_sketch_exists_remembers_only_positive_answers(tmp_path):
         f.write(b"abc")
     assert store.sketch_exists(p)              # appears later: seen
     os.remove(p)
-    assert store.sketch_exists(p)              # remembered (sketches are never removed within a run)
+    assert store.sketch_exists(p)              # remembered (sketches are never removed behind the host layer's back)
+    store.forget_sketch(p)                     # ... and when the host layer removes one itself it says so
+    assert not store.sketch_exists(p)
 
 
 def test_union_name_is_the_hex_sum_rule(tmp_path):
