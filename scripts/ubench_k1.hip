@@ -32,6 +32,17 @@ __global__ __launch_bounds__(1024) void k1_model(uint32_t* out, int nk, int kfir
             win.push(c);
             if (MODE == 0) {
                 sweep_token<KC, true, false>(win, 64, kfirst, nk, p, lds_slot);
+            } else if (MODE == 5) {
+                // experiment: wave-level pre-filter on the hash alone -- skip the LDS probe of a pair when no
+                // lane's rho can exceed the smallest register of its array (here: smallest = 8)
+                const uint32_t thr = (1u << (32 - 8)) - 1u;
+#pragma unroll 1
+                for (int j = 0; j < nk; j += 2) {
+                    const uint64_t h0 = win.template hash<true>(kfirst + j), h1 = win.template hash<true>(kfirst + j + 1);
+                    const uint32_t w0 = __builtin_amdgcn_alignbit((uint32_t)(h0 >> 32), (uint32_t)h0, 32 - p);
+                    const uint32_t w1 = __builtin_amdgcn_alignbit((uint32_t)(h1 >> 32), (uint32_t)h1, 32 - p);
+                    if (__any((w0 <= thr) | (w1 <= thr))) hll_update2(lds_slot(j), h0, lds_slot(j + 1), h1, p);
+                }
             } else if (MODE == 4) {
                 // experiment: k loop fully unrolled (nk == 4), so masks/shifts are loop-invariant scalars
                 hll_update2(lds_slot(0), win.template hash<true>(kfirst), lds_slot(1), win.template hash<true>(kfirst + 1), p);
@@ -96,6 +107,8 @@ int main(int argc, char** argv) {
     ROW("class0 k13..16 hash only", 0, 1, 4, 13, 0u)
     ROW("class1 k21..24 full, never raises", 1, 0, 4, 21, 0xFFFFFFFFu)
     ROW("class1 k21..24 full, k loop unrolled", 1, 4, 4, 21, 0xFFFFFFFFu)
+    ROW("class1 k21..24 hash pre-filter (min reg 8)", 1, 5, 4, 21, 0xFFFFFFFFu)
+    ROW("class0 k13..16 hash pre-filter (min reg 8)", 0, 5, 4, 13, 0xFFFFFFFFu)
     ROW("class0 k13..16 full, k loop unrolled", 0, 4, 4, 13, 0xFFFFFFFFu)
     ROW("class3 k33..36 full, k loop unrolled", 3, 4, 4, 33, 0xFFFFFFFFu)
     ROW("class1 k21..24 full, from cold", 1, 0, 4, 21, 0u)
