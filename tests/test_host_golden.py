@@ -154,6 +154,47 @@ def test_hill_climb_window_extensions_are_batched_over_leaves(host, tmp_path):
     assert log["single"] <= 5 and len(log["batches"]) + log["single"] < log["plain"] / 2, log
 
 
+def test_example_readme_workflow_subset_tree_reuses_leaf_sketches(host, tmp_path):
+    """The walk of /root/reference/example/README.md with its own flag spellings (--datadir, --fastas,
+    --tag, --nchildren, -k, --dtree, --norder as an abbreviation): a later `tree --fastas subset.txt` over
+    the same sketch directory sketches no leaf again -- only the subset's unions are new (README :37)."""
+    calls = {"leaf": 0, "union": 0}
+
+    class Counting(hostcheck.OracleBackend):
+        def leaf(self, *a):
+            calls["leaf"] += 1
+            return super().leaf(*a)
+
+        def union(self, *a):
+            calls["union"] += 1
+            return super().union(*a)
+
+    host.set_backend_factory(lambda r, c: Counting(r, c))
+    from dandd_amd.host import cli
+    import shutil
+    data = os.path.join(str(tmp_path), "fish")
+    shutil.copytree(os.path.join(hostcheck.GOLD, "fasta"), data)
+    out = os.path.join(str(tmp_path), "out")
+    sk = os.path.join(str(tmp_path), "sketchdb")
+    cli.main(["tree", "--datadir", data, "--tag", "fish-mito", "-o", out, "-c", sk, "-r", "12"])
+    assert calls["leaf"] > 0
+    cli.main(["tree", "--datadir", data, "--tag", "fish-mito2", "--nchildren", "2", "-k", "12", "-o", out, "-c", sk, "-r", "12"])
+    listing = os.path.join(str(tmp_path), "fish_subset.txt")
+    with open(listing, "w") as f:
+        for name in sorted(os.listdir(data))[:3]:
+            f.write(os.path.join(data, name) + "\n")
+    before = dict(calls)
+    cli.main(["tree", "--fastas", listing, "--tag", "small_fish", "-k", "12", "-o", out, "-c", sk, "-r", "12"])
+    assert calls["leaf"] == before["leaf"], "leaf sketches of the subset were already in the sketch directory"
+    assert calls["union"] > before["union"]
+    pickle_path = os.path.join(out, "small_fish_3_dashing_dtree.pickle")
+    assert os.path.exists(pickle_path)
+    cli.main(["progressive", "--dtree", pickle_path, "--norder", "4", "-o", out])
+    assert os.path.exists(os.path.join(out, "small_fish_progu4_3_dashing.csv"))
+    cli.main(["kij", "--dtree", pickle_path, "-o", out])
+    assert os.path.exists(os.path.join(out, "small_fish_3_dashing.kij.csv"))
+
+
 def test_tree_shapes_for_nchildren(host, tmp_path):
     """Shapes the reference builds for (N, nchildren) -- SURVEY.md section 4.3 probe facts."""
     import shutil
