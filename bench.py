@@ -142,11 +142,19 @@ def main():
     from dandd_amd import dist as ddist
     from dandd_amd.engine import Engine, synth_size, KERNEL_PACK, KERNEL_SWEEP, KERNEL_UNION
 
+    # Functional test of the N>1 path on a box with fewer GPUs than ranks (never a measurement):
+    # DD_BENCH_BACKEND=gloo DD_BENCH_SHARE_DEVICE=1 puts every rank on cuda:0 and reduces through gloo.
+    backend = os.environ.get("DD_BENCH_BACKEND", "nccl")
+    if os.environ.get("DD_BENCH_SHARE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     ng, nb = args.genomes, int(args.mbp * 1e6)
     kmin, kmax, p = args.kmin, args.kmax, args.log2m
