@@ -67,3 +67,23 @@ def test_union_name_is_the_hex_sum_rule(tmp_path):
     sp = store.SketchPath(files[:2], 12, cat, exp)
     assert sp.base == f"{hex(int(a, 16) + int(b, 16))[:15]}_14n2k12"
     assert store.SketchPath(files[:1], 12, cat, exp).base == "g0.fasta.w.12.spacing.14"
+
+
+def test_dashing_container_round_trip(tmp_path):
+    """The (unverified, recalled) Dashing .hll container: what is written reads back, the header is the
+    32 bytes the module documents, and the native <-> Dashing conversion keeps the registers."""
+    import gzip
+    import numpy as np
+    from dandd_amd.host import backend, dashing_hll
+    rng = np.random.default_rng(3)
+    regs = rng.integers(0, 40, size=1 << 12, dtype=np.uint8)
+    native, exported, back = (str(tmp_path / n) for n in ("a.hll", "a.dashing.hll", "b.hll"))
+    backend.write_sketch_file(native, regs, 12, 21, True)
+    assert dashing_hll.main(["export", native, exported]) == 0
+    raw = gzip.open(exported, "rb").read()
+    assert len(raw) == 32 + (1 << 12) and raw[20:24] == (12).to_bytes(4, "little")
+    got, np_, est = dashing_hll.read_dashing_hll(exported)
+    assert np_ == 12 and est is None and np.array_equal(got, regs)
+    assert dashing_hll.main(["import", exported, back, "21"]) == 0
+    r2, log2m, k, canon = backend.read_sketch_file(back)
+    assert (log2m, k, canon) == (12, 21, True) and np.array_equal(r2, regs)
