@@ -108,8 +108,8 @@ struct dd_ctx {
     std::vector<TimedSpan> spans[DD_KERNEL_COUNT];
     std::vector<hipEvent_t> pool;
     // workspaces
-    DevBuf tokens, scratch, tables, jobtab, fasta, regs, ptrs, hist, est, ord, bitmaps, exact;
-    HostBuf stage, stage_jobs;  // genome/pack tables and K1 job tables are uploaded in two steps
+    DevBuf tokens, scratch, tables, jobtab, fasta, regs, ptrs, hist, est, ord, bitmaps, exact, buckets;
+    HostBuf stage, stage_jobs, stage_rows;  // genome/pack tables and K1 job tables are uploaded in two steps
     // the job tables of the last sketch call: a call over genomes of the same sizes and the same k range
     // (a pipeline sketching fixed-size batches, a benchmark loop) reuses them, on the host and in HBM
     struct {
@@ -325,10 +325,11 @@ void dd_destroy(dd_ctx* c) {
     for (auto e : c->pool) (void)hipEventDestroy(e);
     if (c->stage_free) (void)hipEventDestroy(c->stage_free);
     for (DevBuf* b : {&c->tokens, &c->scratch, &c->tables, &c->jobtab, &c->fasta, &c->regs, &c->ptrs, &c->hist,
-                      &c->est, &c->ord, &c->bitmaps, &c->exact})
+                      &c->est, &c->ord, &c->bitmaps, &c->exact, &c->buckets})
         b->release();
     c->stage.release();
     c->stage_jobs.release();
+    c->stage_rows.release();
     delete c;
 }
 
@@ -465,10 +466,52 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     char* jdev = static_cast<char*>(c->jobtab.p);
     DD_HIP(hipEventRecord(c->stage_free, st));
 
+    // ---- bucket mode (log2m >= 18): row table, cursors, filters and record areas ----------------
+    const dd::SweepPlan* bplan = nullptr;
+    for (const dd::SweepClass& sc : classes)
+        if (sc.plan.mode == dd::kBucketMode) bplan = &sc.plan;
+    const dd::BucketRow* rows_dev = nullptr;
+    const int nrows = ngenomes * K;
+    if (bplan) {
+        const size_t nb = (size_t)1 << bplan->nb_log2;
+        const size_t flt_bytes = m >> bplan->logg, area_bytes = nb * bplan->cap_chunks * 256;
+        int first_hashed = K, hashed_per_genome = 0;  // rows of a genome that belong to a bucket class
+        for (const dd::SweepClass& sc : classes)
+            if (sc.plan.mode == dd::kBucketMode) {
+                first_hashed = std::min(first_hashed, sc.kfirst - kmin);
+                hashed_per_genome += sc.klast - sc.kfirst + 1;
+            }
+        const size_t nhashed = (size_t)ngenomes * hashed_per_genome;
+        const size_t tab_bytes = align_up(sizeof(dd::BucketRow) * nrows, 256);
+        const size_t cur_bytes = align_up((size_t)nrows * nb * 4, 256);
+        const size_t flt_tot = align_up(nhashed * flt_bytes, 256);
+        if ((rc = c->buckets.reserve(tab_bytes + cur_bytes + flt_tot + nhashed * area_bytes))) return rc;
+        if ((rc = c->stage_rows.reserve(tab_bytes))) return rc;
+        char* bb = static_cast<char*>(c->buckets.p);
+        std::vector<dd::BucketRow> rtab(nrows);
+        size_t h = 0;
+        for (int g = 0; g < ngenomes; ++g)
+            for (int kk = 0; kk < K; ++kk) {
+                dd::BucketRow& r = rtab[(size_t)g * K + kk];
+                r.regs = regs_dev + ((size_t)g * K + kk) * m;
+                r.cursor = reinterpret_cast<uint32_t*>(bb + tab_bytes) + ((size_t)g * K + kk) * nb;
+                const bool hashed = kk >= first_hashed && kk < first_hashed + hashed_per_genome;
+                r.filter = hashed ? reinterpret_cast<uint8_t*>(bb + tab_bytes + cur_bytes + h * flt_bytes) : nullptr;
+                r.area = hashed ? reinterpret_cast<uint32_t*>(bb + tab_bytes + cur_bytes + flt_tot + h * area_bytes) : nullptr;
+                h += hashed ? 1 : 0;
+            }
+        // cursors and filters start at zero: nothing handed out, every register's lower bound is 0
+        DD_HIP(hipMemsetAsync(bb + tab_bytes, 0, cur_bytes + flt_tot, st));
+        if ((rc = upload(c, c->stage_rows, bb, rtab.data(), sizeof(dd::BucketRow) * nrows, 0))) return rc;
+        rows_dev = reinterpret_cast<const dd::BucketRow*>(bb);
+        DD_HIP(hipEventRecord(c->stage_free, st));
+    }
+
     // ---- K1 launches -------------------------------------------------------------------
     int blocks = 0;
     for (size_t i = 0; i < classes.size(); ++i) {
         const dd::SweepClass& sc = classes[i];
+        if (sc.plan.mode == dd::kBucketMode) continue;
         Span sp(c, DD_KERNEL_SWEEP);
         if (sc.kclass == dd::kBitmapClass) {
             dd::launch_bitmap(reinterpret_cast<const dd::SweepGenome*>(tdev),
@@ -482,6 +525,29 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
                              (int)sc.jobs.size(), sc.kclass, sc.plan, st);
         }
         blocks += (int)sc.jobs.size();
+    }
+    if (bplan) {
+        // epoch by epoch: scatter launches of every k class, then one replay over all rows
+        const dd::ScatterParams sp{rows_dev, K, bplan->logg, bplan->nb_log2, bplan->cap_chunks};
+        for (int e = 0; e < bplan->nepochs; ++e) {
+            bool any = false;
+            for (size_t i = 0; i < classes.size(); ++i) {
+                const dd::SweepClass& sc = classes[i];
+                if (sc.plan.mode != dd::kBucketMode) continue;
+                const size_t j0 = sc.epoch_begin[e], j1 = sc.epoch_begin[e + 1];
+                if (j1 == j0) continue;
+                Span span(c, DD_KERNEL_SWEEP);
+                dd::launch_scatter(reinterpret_cast<const dd::SweepGenome*>(tdev),
+                                   reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]) + j0, (int)(j1 - j0),
+                                   sc.kclass, sc.plan, sp, st);
+                blocks += (int)(j1 - j0);
+                any = true;
+            }
+            if (any) {
+                Span span(c, DD_KERNEL_SWEEP);
+                dd::launch_replay(rows_dev, nrows, *bplan, st);
+            }
+        }
     }
     DD_HIP(hipGetLastError());
     c->st_tokens = tokens_ub;

@@ -72,16 +72,51 @@ struct SweepJob {               // one per workgroup, device-resident table
     int krow;                   // row of kfirst in the genome's [K][m] slab
     unsigned tile_begin, tile_end;  // tiles of (threads x 64) tokens
 };
+constexpr int kBucketMode = 5;
 struct SweepPlan {
     int log2m;
     int canonical;
     int threads;                // workgroup size
     int lds_bytes;              // dynamic LDS per workgroup
     int mode;                   // 0: registers in LDS; 1: in HBM, every update checked there;
-                                // 2..4: in HBM behind an LDS filter byte per 2^mode registers (one k per job)
+                                // 2..4: in HBM behind an LDS filter byte per 2^mode registers (one k per job);
+                                // 5 (kBucketMode): in HBM, scatter to buckets + replay (below)
+    // kBucketMode only
+    int logg = 0;               // one filter byte per 2^logg registers
+    int nb_log2 = 0;            // 2^nb_log2 buckets (index tiles of 64 KiB) per row
+    unsigned cap_chunks = 0;    // 64-record chunks per bucket
+    int nepochs = 0;
 };
 void launch_sweep(const SweepGenome* genomes_dev, const SweepJob* jobs_dev, int njobs, int kclass,
                   const SweepPlan& plan, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------
+// K1 for log2m >= 18 (one register array no longer fits LDS; DandD's default is -r 20,
+// /root/reference/lib/dandd_cmd.py:187): two phases per EPOCH (a range of token tiles).
+//   scatter: hash every k-mer of the epoch; an update whose rho cannot exceed the filter's lower bound
+//            for its register group is dropped, the others are appended as 4-byte records
+//            (idx | rho << 24) to the bucket of their index tile -- 64-record chunks, one wave-private
+//            chunk per (wave, bucket) at a time, so the only global atomic is one per 64 records.
+//   replay : one workgroup per (row, index tile): tile into LDS, apply the bucket's records with LDS
+//            operations, store the tile back with plain 16-byte stores and refresh the tile's filter.
+// The filter of epoch e is exact knowledge of the registers after epoch e-1, so what scatter drops can
+// never matter; epochs double in length (one token per register first), because bounds rise fast early.
+// ---------------------------------------------------------------------------------------
+struct BucketRow {              // one per (genome, k) row of the call: table[genome * K + (k - kmin)]
+    uint8_t* regs;              // the row's m registers in the caller's slab
+    uint32_t* area;             // record chunks: bucket b, chunk c at area + ((size_t)b * cap_chunks + c) * 64; null = row not bucketed
+    uint32_t* cursor;           // [nb] chunks handed out per bucket this epoch (may run past cap_chunks: overflow)
+    uint8_t* filter;            // [m >> logg] lower bound per register group
+};
+struct ScatterParams {
+    const BucketRow* rows;
+    int K;                      // rows per genome
+    int logg, nb_log2;
+    unsigned cap_chunks;
+};
+void launch_scatter(const SweepGenome* genomes_dev, const SweepJob* jobs_dev, int njobs, int kclass,
+                    const SweepPlan& plan, const ScatterParams& sp, hipStream_t st);
+void launch_replay(const BucketRow* rows_dev, int nrows, const SweepPlan& plan, hipStream_t st);
 int sweep_max_lds_bytes();
 // small-k class: jobs carry ks <= kBitmapMaxK; records k-mer presence in genome.bitmap
 // (kfirst..klast: the ks of the class; the LDS image covers exactly their bitmaps)

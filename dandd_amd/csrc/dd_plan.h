@@ -17,6 +17,9 @@ struct SweepClass {
     int kfirst, klast;
     SweepPlan plan;  // launch shape of the class (mode, LDS bytes, threads)
     std::vector<SweepJob> jobs;
+    // bucket mode (plan.mode == kBucketMode): the jobs of epoch e are jobs[epoch_begin[e] .. epoch_begin[e+1]);
+    // one scatter launch per (class, epoch), one replay launch per epoch over the rows of all classes
+    std::vector<size_t> epoch_begin;
 };
 
 // development knobs, read from the environment by from_env() (README.md lists them)
@@ -27,11 +30,21 @@ struct PlanKnobs {
     size_t jobs_per_row = 0;        // filtered mode; 0 = heuristic
     int global_from_p = 18;         // registers stay in HBM from this log2m on
     bool use_bitmaps = true, filter = true, xcd_affinity = true, taper = true;
+    // registers in HBM, two-phase: scatter (idx, rho) records into per-(row, index tile) buckets, replay
+    // each bucket into an LDS-resident tile (no global atomics); off = the filtered compare-and-swap path
+    bool buckets = true;
+    size_t bucket_e0_tiles = 0;     // tiles in the first epoch; 0 = one token per register (m / 65536, >= 1)
+    size_t bucket_emax_tiles = 0;   // longest epoch; 0 = what the budget below allows, at most 256 tiles
+    size_t bucket_cap_chunks = 0;   // 64-record chunks per bucket; 0 = every token of the longest epoch fits
+    int bucket_logg = 0;            // registers per filter byte (log2); 0 = a 64 KiB filter (at least 4)
+    size_t bucket_budget = (size_t)16 << 30;  // HBM for the record areas of one call
     static PlanKnobs from_env();
     bool operator==(const PlanKnobs& o) const {
         return lds_budget == o.lds_budget && lds_budget_forced == o.lds_budget_forced && jobs_per_cu == o.jobs_per_cu &&
                jobs_per_row == o.jobs_per_row && global_from_p == o.global_from_p && use_bitmaps == o.use_bitmaps &&
-               filter == o.filter && xcd_affinity == o.xcd_affinity && taper == o.taper;
+               filter == o.filter && xcd_affinity == o.xcd_affinity && taper == o.taper && buckets == o.buckets &&
+               bucket_e0_tiles == o.bucket_e0_tiles && bucket_emax_tiles == o.bucket_emax_tiles &&
+               bucket_cap_chunks == o.bucket_cap_chunks && bucket_logg == o.bucket_logg && bucket_budget == o.bucket_budget;
     }
 };
 

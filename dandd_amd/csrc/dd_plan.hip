@@ -24,6 +24,12 @@ PlanKnobs PlanKnobs::from_env() {
     k.filter = !getenv("DD_NO_FILTER");
     k.xcd_affinity = !getenv("DD_NO_XCD_AFFINITY");
     k.taper = !getenv("DD_NO_TAPER");
+    k.buckets = !getenv("DD_NO_BUCKETS");
+    if (const char* e = getenv("DD_BUCKET_E0")) k.bucket_e0_tiles = (size_t)std::max(1, atoi(e));
+    if (const char* e = getenv("DD_BUCKET_EMAX")) k.bucket_emax_tiles = (size_t)std::max(1, atoi(e));
+    if (const char* e = getenv("DD_BUCKET_CAP")) k.bucket_cap_chunks = (size_t)std::max(1, atoi(e));
+    if (const char* e = getenv("DD_BUCKET_LOGG")) k.bucket_logg = std::max(2, std::min(8, atoi(e)));
+    if (const char* e = getenv("DD_BUCKET_GB")) k.bucket_budget = (size_t)std::max(1, atoi(e)) << 30;
     return k;
 }
 
@@ -70,6 +76,32 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
         max_tiles = std::max(max_tiles, tiles_of(nbytes[g]));
     }
 
+    // Bucket mode (scatter + replay, dd_kernels.h): epochs are ranges of token tiles, the same for every row.
+    // The first holds one token per register (nothing can be filtered before the registers have been
+    // seen once), each later one is as long as everything before it -- the filter's bounds rise by about
+    // one per doubling -- up to the length whose worst case (every update survives) fits the HBM budget.
+    const bool bucket_mode = global_regs && knobs.buckets && knobs.filter;
+    const int bucket_logg = knobs.bucket_logg ? knobs.bucket_logg : std::max(2, p - 16);
+    const int nb_log2 = std::max(0, p - 16);  // index tiles of 64 KiB
+    std::vector<size_t> epoch_edge;           // epoch e covers tiles [epoch_edge[e], epoch_edge[e+1])
+    size_t epoch_longest = 0, bucket_row_tokens = 0;
+    if (bucket_mode) {
+        const int first_hashed = use_bitmaps ? std::max(kmin, kBitmapMaxK + 1) : kmin;
+        const size_t nrows = (size_t)ngenomes * (size_t)std::max(0, kmax - first_hashed + 1);
+        const size_t e0 = knobs.bucket_e0_tiles ? knobs.bucket_e0_tiles : std::max<size_t>(1, m / kTileTokens);
+        size_t emax = knobs.bucket_emax_tiles;
+        bucket_row_tokens = knobs.bucket_budget / (std::max<size_t>(1, nrows) * 9 / 2);  // 4 B per record + slack
+        if (!emax) emax = std::min<size_t>(256, bucket_row_tokens / kTileTokens);
+        emax = std::max(emax, e0);
+        epoch_edge.push_back(0);
+        size_t len = e0;
+        while (epoch_edge.back() < max_tiles) {
+            epoch_longest = std::max(epoch_longest, len);
+            epoch_edge.push_back(epoch_edge.back() + len);
+            len = std::min(emax, epoch_edge.back());
+        }
+    }
+
     const int lo0 = use_bitmaps ? kBitmapMaxK + 1 : 1;
     const struct { int kc, ka, kb; } class_tab[5] = {
         {kBitmapClass, 1, use_bitmaps ? kBitmapMaxK : 0}, {0, lo0, 16}, {1, 17, 32}, {3, 33, 48}, {2, 49, 64}};
@@ -87,7 +119,60 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
         sc.plan.threads = kThreads;
         int max_nk = 0;
 
-        if (global_regs && kc != kBitmapClass && (filter_logg || knobs.xcd_affinity)) {
+        if (bucket_mode && kc != kBitmapClass) {
+            // one k per job; row r of the class goes to XCD r % 8 in every epoch (its filter and the token
+            // tiles its ks share stay in that XCD's L2); job 8*i + x is the i-th job of XCD x
+            const size_t nepochs = epoch_edge.size() - 1;
+            size_t max_jobs_row_epoch = 1;
+            const SweepJob idle = make_job(0, ka, 1, kmin, 0, 0);
+            for (size_t e = 0; e < nepochs; ++e) {
+                sc.epoch_begin.push_back(sc.jobs.size());
+                const size_t t_lo = epoch_edge[e], t_hi = epoch_edge[e + 1];
+                size_t tile_rows = 0;
+                for (int g = 0; g < ngenomes; ++g) {
+                    const size_t nt = tiles_of(nbytes[g]);
+                    if (nt > t_lo) tile_rows += (std::min(nt, t_hi) - t_lo) * (size_t)nks;
+                }
+                if (!tile_rows) continue;
+                // ~8 jobs per resident workgroup slot; a job reloads the row's filter, so not below 2 tiles
+                // once the epoch is long enough to allow it
+                const size_t tpj = std::max<size_t>(std::min<size_t>(2, t_hi - t_lo), (tile_rows + 4095) / 4096);
+                std::vector<std::vector<SweepJob>> per_xcd(8);
+                int row = 0;
+                for (int g = 0; g < ngenomes; ++g) {
+                    const size_t nt = std::min(tiles_of(nbytes[g]), t_hi);
+                    for (int q = 0; q < nks; ++q, ++row) {
+                        size_t nj = 0;
+                        for (size_t t0 = t_lo; t0 < nt; t0 += tpj, ++nj)
+                            per_xcd[knobs.xcd_affinity ? row % 8 : 0].push_back(make_job(g, ka + q, 1, kmin, t0, std::min(nt, t0 + tpj)));
+                        max_jobs_row_epoch = std::max(max_jobs_row_epoch, nj);
+                    }
+                }
+                if (!knobs.xcd_affinity) {
+                    sc.jobs.insert(sc.jobs.end(), per_xcd[0].begin(), per_xcd[0].end());
+                } else {
+                    size_t longest = 0;
+                    for (auto& v : per_xcd) longest = std::max(longest, v.size());
+                    for (size_t i = 0; i < longest; ++i)
+                        for (int x = 0; x < 8; ++x) sc.jobs.push_back(i < per_xcd[x].size() ? per_xcd[x][i] : idle);
+                }
+            }
+            sc.epoch_begin.push_back(sc.jobs.size());
+            max_nk = 1;
+            // Every token of the longest epoch may leave a record (nothing is filtered while the registers
+            // are still empty); buckets are hash-uniform, so 1/16 of slack, plus the partly filled chunk
+            // every wave of every job leaves per bucket.  Records beyond the capacity are not lost: they go
+            // straight to the row by compare-and-swap (dd_sweep.hip).
+            const size_t nb = (size_t)1 << nb_log2;
+            // (a call with so many rows that even the first epoch's worst case exceeds the budget gets what
+            // the budget allows; the overflow path keeps it exact)
+            const size_t per_bucket = std::min(epoch_longest * kTileTokens, bucket_row_tokens) / nb;
+            sc.plan.cap_chunks = (unsigned)(knobs.bucket_cap_chunks ? knobs.bucket_cap_chunks
+                                                : (per_bucket + per_bucket / 16) / 64 + max_jobs_row_epoch * (kThreads / 64) + 16);
+            sc.plan.logg = bucket_logg;
+            sc.plan.nb_log2 = nb_log2;
+            sc.plan.nepochs = (int)nepochs;
+        } else if (global_regs && kc != kBitmapClass && (filter_logg || knobs.xcd_affinity)) {
             // Registers in HBM.  The arrays a workgroup touches should sit in ITS XCD's 4 MiB L2: k-groups
             // are cut to <= 3 MiB of arrays (one k with the filter), each (genome, k-group) row is given to
             // one XCD, and because workgroups are dealt round-robin over the 8 XCDs in blockIdx order, job
@@ -173,6 +258,9 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
         if (kc == kBitmapClass) {
             sc.plan.mode = 0;
             sc.plan.lds_bytes = (bitmap_offset(kb) + bitmap_words(kb) - bitmap_offset(ka)) * 4;
+        } else if (bucket_mode) {
+            sc.plan.mode = kBucketMode;  // the filter, then one 8-byte chunk cursor per (wave, bucket)
+            sc.plan.lds_bytes = (int)(m >> bucket_logg) + (kThreads / 64) * (8 << nb_log2);
         } else if (filter_logg) {
             sc.plan.mode = filter_logg;  // the filter, then a 128-entry candidate queue per wave (dd_sweep.hip)
             sc.plan.lds_bytes = (int)(m >> filter_logg) + (kThreads / 64) * 128 * 4;
@@ -185,6 +273,12 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
         }
         classes.push_back(std::move(sc));
     }
+    // one record-area geometry for all rows of the call
+    unsigned cap = 0;
+    for (const SweepClass& sc : classes)
+        if (sc.plan.mode == kBucketMode) cap = std::max(cap, sc.plan.cap_chunks);
+    for (SweepClass& sc : classes)
+        if (sc.plan.mode == kBucketMode) sc.plan.cap_chunks = cap;
     return classes;
 }
 

@@ -730,6 +730,201 @@ __global__ __launch_bounds__(1024) void bitmap_finish_kernel(const SweepGenome* 
     }
 }
 
+
+// ---- log2m >= 18, bucket mode: scatter + replay (dd_kernels.h) --------------------------------------
+// The compare-and-swap path above is bound by the device's scattered-atomic rate (27 G/s measured, any
+// atomic, any footprint: profiles/r01_ubench_atomics.txt).  Here no register is touched by an atomic:
+// scatter only appends records, replay owns its 64 KiB index tile in LDS and stores it back whole.
+constexpr uint32_t kChunkRecords = 64;           // one chunk = 256 B = two 128-byte lines
+constexpr uint32_t kChunkSpent = 64;             // cursor count: chunk used up (also the initial state)
+constexpr uint32_t kBucketFull = 0x40000000u;    // cursor count from here on: the bucket has no chunk left
+
+struct Scatter {
+    uint32_t cur;          // byte offset in g_lds of this wave's cursor table: per bucket (chunk << 32) | count
+    uint32_t* area;
+    uint32_t* cursor;
+    uint8_t* regs;         // the row itself: where records go when their bucket is full
+    uint32_t cap_chunks;
+    int logg, bshift;      // filter granularity; bucket = idx >> bshift
+};
+DD_D unsigned long long lds_add64(uint32_t off, unsigned long long v) {
+    return atomicAdd(reinterpret_cast<unsigned long long*>(g_lds + off), v);
+}
+DD_D uint32_t gadd32(void* p, uint32_t v) {
+    return __hip_atomic_fetch_add((DD_GLOBAL uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// One update.  Reached by whole waves (`valid`: the lane has a k-mer).
+DD_D void scatter_update(const Scatter& s, uint64_t h, int p, bool valid) {
+    const Probe q = probe(h, p);
+    const uint32_t idx = q.hi >> (32 - p);
+    bool pending = valid && q.lz >= g_lds[idx >> s.logg];  // rho > bound (or hiw == 0: rho >= 33)
+    if (!__any(pending)) return;
+    const uint32_t rho = rho_of(q, p);
+    const uint32_t b = idx >> s.bshift;
+    const uint32_t slot = s.cur + b * 8u;
+    for (;;) {
+        if (pending) {
+            const unsigned long long old = lds_add64(slot, 1ull);
+            const uint32_t count = (uint32_t)old, chunk = (uint32_t)(old >> 32);
+            if (count < kChunkRecords) {
+                gstore4(s.area + ((size_t)b * s.cap_chunks + chunk) * kChunkRecords + count, idx | (rho << 24));
+                pending = false;
+            } else if (count == kChunkSpent) {
+                // exactly one lane per (wave, bucket) sees the count pass 64: it fetches the next chunk;
+                // the lanes behind it (65, 66, ...) simply come round again
+                const uint32_t c = gadd32(s.cursor + b, 1u);
+                const unsigned long long fresh = c < s.cap_chunks ? ((unsigned long long)c << 32)
+                                                                  : (((unsigned long long)c << 32) | kBucketFull);
+                *reinterpret_cast<unsigned long long*>(g_lds + slot) = fresh;
+            } else if (count >= kBucketFull) {
+                // no chunk left in this bucket: the record goes to its register directly (exact, slow, rare)
+                uint8_t* a = s.regs + idx;
+                (void)cas_raise<RegsGlobal>(a, RegsGlobal::load32(a), rho);
+                pending = false;
+            }
+        }
+        if (!__any(pending)) break;
+    }
+}
+
+template <int KC, bool CANON>
+__global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __restrict__ genomes,
+                                                      const SweepJob* __restrict__ jobs, int p, ScatterParams sp) {
+    const SweepJob job = jobs[blockIdx.x];
+    if (job.tile_begin >= job.tile_end) return;  // filler of the XCD-affine order
+    const SweepGenome g = genomes[job.genome];
+    const int k = job.kfirst;
+    const uint32_t m = 1u << p;
+    const unsigned long long ntok = gload8u(g.ntok);
+    const BucketRow row = sp.rows[(size_t)job.genome * sp.K + job.krow];
+    const uint32_t nb = 1u << sp.nb_log2, nflt = m >> sp.logg;
+
+    struct TileIn {
+        uint4 hc, sc;
+        uint2 hb, sb;
+        bool live;
+    };
+    auto fetch = [&](unsigned tile, TileIn& t) {
+        const unsigned long long seg = (unsigned long long)tile * blockDim.x + threadIdx.x;
+        t.live = tile < job.tile_end && seg * kSegTokens < ntok;
+        t.hc = make_uint4(0, 0, 0, 0);
+        t.hb = make_uint2(~0u, ~0u);
+        t.sc = make_uint4(0, 0, 0, 0);
+        t.sb = make_uint2(~0u, ~0u);
+        if (!t.live) return;
+        if (seg > 0) {
+            t.hc = gload16(g.codes + (seg - 1) * 4);
+            t.hb = gload8(g.bad + (seg - 1) * 2);
+        }
+        t.sc = gload16(g.codes + seg * 4);
+        t.sb = gload8(g.bad + seg * 2);
+    };
+    TileIn next;
+    fetch(job.tile_begin, next);
+
+    // the row's filter as the previous epoch's replay left it (plain loads: written by an earlier kernel)
+    {
+        uint4* f4 = reinterpret_cast<uint4*>(g_lds);
+        for (uint32_t i = threadIdx.x; i < (nflt >> 4); i += blockDim.x) f4[i] = gload16(row.filter + (size_t)i * 16);
+    }
+    Scatter s;
+    s.cur = nflt + (threadIdx.x >> 6) * (nb * 8u);
+    s.area = row.area;
+    s.cursor = row.cursor;
+    s.regs = row.regs;
+    s.cap_chunks = sp.cap_chunks;
+    s.logg = sp.logg;
+    s.bshift = p - sp.nb_log2;
+    if ((threadIdx.x & 63u) < nb)
+        *reinterpret_cast<unsigned long long*>(g_lds + s.cur + (threadIdx.x & 63u) * 8u) = kChunkSpent;
+    __syncthreads();
+
+    for (unsigned tile = job.tile_begin; tile < job.tile_end; ++tile) {
+        const TileIn cur = next;
+        fetch(tile + 1, next);
+        if (!cur.live) continue;
+        const uint4 hc = cur.hc, sc = cur.sc;
+        const uint2 hb = cur.hb, sb = cur.sb;
+        const uint32_t cw[4] = {sc.x, sc.y, sc.z, sc.w};
+        Windows<KC> win;
+        win.prime(hc);
+        if (__all((hb.x | hb.y | sb.x | sb.y) == 0u)) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+#pragma unroll 1
+                for (int i = 0; i < 16; ++i) {
+                    win.push((cw[w] >> (2 * i)) & 3u);
+                    scatter_update(s, win.template hash<CANON>(k), p, true);
+                }
+            }
+            continue;
+        }
+        int run = hb.y ? __builtin_clz(hb.y) : 32 + (hb.x ? __builtin_clz(hb.x) : 32);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t bw = ((w & 2) ? sb.y : sb.x) >> ((w & 1) * 16);
+#pragma unroll 1
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t c = (cw[w] >> (2 * i)) & 3u;
+                run = ((bw >> i) & 1u) ? 0 : run + 1;
+                win.push(c);
+                scatter_update(s, win.template hash<CANON>(k), p, run >= k);
+            }
+        }
+    }
+    // every chunk this wave still holds is padded with null records (rho 0 raises nothing): replay reads
+    // whole chunks
+    for (uint32_t b = 0; b < nb; ++b) {
+        const unsigned long long st = *reinterpret_cast<const unsigned long long*>(g_lds + s.cur + b * 8u);
+        const uint32_t count = (uint32_t)st, chunk = (uint32_t)(st >> 32), lane = threadIdx.x & 63u;
+        if (count < kChunkRecords && lane >= count)
+            gstore4(s.area + ((size_t)b * s.cap_chunks + chunk) * kChunkRecords + lane, 0u);
+    }
+}
+
+// grid = (buckets, rows).  LDS: the 64 KiB (or m bytes if smaller) index tile.
+__global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restrict__ rows, int p, int logg, int nb_log2,
+                                                     uint32_t cap_chunks) {
+    const BucketRow row = rows[blockIdx.y];
+    if (!row.area) return;
+    const uint32_t b = blockIdx.x;
+    const uint32_t handed = gload4(row.cursor + b);
+    if (handed == 0u) return;  // nothing reached this tile in this epoch: registers and filter stand
+    const uint32_t nchunks = handed < cap_chunks ? handed : cap_chunks;
+    const uint32_t tile = 1u << (p - nb_log2);
+    uint8_t* const tile_g = row.regs + (size_t)b * tile;
+    uint4* l4 = reinterpret_cast<uint4*>(g_lds);
+    for (uint32_t i = threadIdx.x; i < (tile >> 4); i += blockDim.x) l4[i] = gload16(tile_g + (size_t)i * 16);
+    __syncthreads();
+    const uint32_t* rec = row.area + (size_t)b * cap_chunks * kChunkRecords;
+    const uint32_t n4 = nchunks * (kChunkRecords / 4);
+    auto apply = [&](uint32_t e) {
+        const uint32_t rho = e >> 24, a = e & (tile - 1u);
+        if (rho > g_lds[a]) (void)cas_raise<RegsLds>(a, RegsLds::load32(a), rho);
+    };
+    for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) {
+        const uint4 r = gload16(rec + (size_t)i * 4);
+        apply(r.x);
+        apply(r.y);
+        apply(r.z);
+        apply(r.w);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < (tile >> 4); i += blockDim.x) gstore16(tile_g + (size_t)i * 16, l4[i]);
+    // the tile's part of the filter: minimum of every group of 2^logg registers
+    const uint32_t G = 1u << logg;
+    uint8_t* const flt = row.filter + (((size_t)b * tile) >> logg);
+    for (uint32_t f = threadIdx.x; f < (tile >> logg); f += blockDim.x) {
+        uint32_t lo = 0xFFu;
+        for (uint32_t w = 0; w < G; w += 4) {
+            const uint32_t mn = min4(*reinterpret_cast<const uint32_t*>(g_lds + f * G + w));
+            lo = mn < lo ? mn : lo;
+        }
+        flt[f] = (uint8_t)lo;
+    }
+    if (threadIdx.x == 0) gstore4(row.cursor + b, 0u);  // the next epoch starts a fresh bucket
+}
+
 // Dynamic LDS above 64 KiB must be allowed per kernel AND per device (a process may hold contexts on
 // several GPUs); remembered in one bit per device id.
 void allow_full_lds(const void* kern, std::atomic<unsigned long long>& done, int static_lds_bytes = 0) {
@@ -782,6 +977,40 @@ void launch_bitmap_finish(const SweepGenome* genomes, int ngenomes, int kfirst, 
     allow_full_lds(reinterpret_cast<const void*>(kern), attr_done);
     hipLaunchKernelGGL(kern, dim3((unsigned)(klast - kfirst + 1), (unsigned)ngenomes), dim3(1024),
                        in_lds ? m : 0, st, genomes, kfirst, kmin, log2m, in_lds);
+}
+
+
+void launch_scatter(const SweepGenome* genomes, const SweepJob* jobs, int njobs, int kclass, const SweepPlan& plan,
+                    const ScatterParams& sp, hipStream_t st) {
+    if (njobs <= 0) return;
+#define DD_SCATTER(KC, CN)                                                                              \
+    do {                                                                                                \
+        auto kern = scatter_kernel<KC, CN>;                                                             \
+        static std::atomic<unsigned long long> attr_done{0};                                            \
+        allow_full_lds(reinterpret_cast<const void*>(kern), attr_done);                                 \
+        hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3((unsigned)plan.threads), (size_t)plan.lds_bytes, st, \
+                           genomes, jobs, plan.log2m, sp);                                              \
+    } while (0)
+#define DD_SCATTER_KC(CN)                       \
+    do {                                        \
+        if (kclass == 0) DD_SCATTER(0, CN);     \
+        else if (kclass == 1) DD_SCATTER(1, CN); \
+        else if (kclass == 3) DD_SCATTER(3, CN); \
+        else DD_SCATTER(2, CN);                 \
+    } while (0)
+    if (plan.canonical) DD_SCATTER_KC(true);
+    else DD_SCATTER_KC(false);
+#undef DD_SCATTER_KC
+#undef DD_SCATTER
+}
+
+void launch_replay(const BucketRow* rows, int nrows, const SweepPlan& plan, hipStream_t st) {
+    if (nrows <= 0) return;
+    const size_t tile = (size_t)1 << (plan.log2m - plan.nb_log2);
+    static std::atomic<unsigned long long> attr_done{0};
+    allow_full_lds(reinterpret_cast<const void*>(replay_kernel), attr_done);
+    hipLaunchKernelGGL(replay_kernel, dim3(1u << plan.nb_log2, (unsigned)nrows), dim3(1024), tile, st, rows,
+                       plan.log2m, plan.logg, plan.nb_log2, plan.cap_chunks);
 }
 
 void launch_sweep(const SweepGenome* genomes, const SweepJob* jobs, int njobs, int kclass,

@@ -81,6 +81,50 @@ def test_sweep_parity_ragged_registers_in_hbm(engine_factory, orc, name):
     _sweep_check(eng, orc, np.frombuffer(RAGGED[name], dtype=np.uint8), 1, 40, True)
 
 
+BUCKET_KNOBS = {
+    "default": {},
+    "many_epochs": {"DD_BUCKET_E0": "1", "DD_BUCKET_EMAX": "1"},      # every tile its own epoch: filters learned 5 times
+    "overflow": {"DD_BUCKET_CAP": "1", "DD_BUCKET_E0": "2"},          # one chunk per bucket: nearly every record takes the CAS fallback
+    "coarse_filter": {"DD_BUCKET_LOGG": "6", "DD_BUCKET_E0": "1"},    # 64 registers per filter byte
+    "no_xcd_order": {"DD_NO_XCD_AFFINITY": "1", "DD_BUCKET_E0": "1"},
+    "cas_path": {"DD_NO_BUCKETS": "1"},                               # round 1's filtered compare-and-swap path, kept for A/B
+}
+
+
+@pytest.mark.parametrize("knobs", sorted(BUCKET_KNOBS))
+@pytest.mark.parametrize("p", [18, 20])
+def test_bucket_mode_knobs(engine_factory, orc, monkeypatch, knobs, p):
+    """log2m >= 18 (scatter + replay): multi-epoch schedules, bucket overflow, coarse filters and the old
+    path all give the oracle's registers -- ragged records, N runs, k classes 0/1/3 and the bitmap class."""
+    for k, v in BUCKET_KNOBS[knobs].items():
+        monkeypatch.setenv(k, v)
+    eng = engine_factory(p, True)
+    fa = np.concatenate([orc.synth_fasta(SEED, 3, 330_000, 4), np.frombuffer(RAGGED["lower_and_n"] + RAGGED["short_records"], dtype=np.uint8)])
+    _sweep_check(eng, orc, fa, 8, 12, True)
+    _sweep_check(eng, orc, fa, 30, 35, True)
+    if knobs in ("default", "many_epochs"):
+        _sweep_check(eng, orc, fa, 47, 50, True)
+        eng_nc = engine_factory(p, False)
+        _sweep_check(eng_nc, orc, fa, 15, 17, False)
+
+
+def test_bucket_mode_batched_unequal_genomes(engine_factory, torch_cuda, orc, monkeypatch):
+    """Epochs are tile ranges shared by all rows: genomes that end in different epochs, an empty one and a
+    one-tile one in the same call (log2m 19, two tiles per first epoch)."""
+    torch = torch_cuda
+    monkeypatch.setenv("DD_BUCKET_E0", "2")
+    eng = engine_factory(19, True)
+    sizes = [(0, 700_000, 3), (1, 66_000, 1), (2, 0, 1), (3, 140_000, 2), (4, 300_000, 5)]
+    fas = [orc.synth_fasta(SEED, g, nb, nr) for g, nb, nr in sizes]
+    bufs = [torch.from_numpy(f.copy()).cuda() if f.size else torch.empty(16, dtype=torch.uint8, device="cuda") for f in fas]
+    regs = torch.empty((len(fas), 4, eng.m), dtype=torch.uint8, device="cuda")
+    eng.sketch_device([b.data_ptr() for b in bufs], [f.size for f in fas], 15, 18, regs.data_ptr())
+    eng.synchronize()
+    got = regs.cpu().numpy()
+    for g, f in enumerate(fas):
+        assert np.array_equal(got[g], orc.sketch_sweep(f, 15, 18, 19)), g
+
+
 def test_sweep_parity_long_lines_and_headers(engine_factory, orc):
     """A 20 kB header and a 50 kB single sequence line cross several 4 KiB pack chunks."""
     rng = np.random.default_rng(5)

@@ -39,9 +39,15 @@ def check(log2m, sizes, kmin, kmax):
         mode = int(j["mode"])
         if j["kclass"] == -1:
             assert mode == 0
-        elif log2m >= 18:
+        elif log2m >= 18 and os.environ.get("DD_NO_FILTER"):
+            assert mode == 1 and j["lds_bytes"] == 0               # every update checked in HBM
+        elif log2m >= 18 and os.environ.get("DD_NO_BUCKETS"):
             assert mode == max(2, log2m - 16) and nk == 1          # one k per job behind the filter
             assert j["lds_bytes"] == (m >> mode) + 16 * 128 * 4    # filter + one queue per wave
+        elif log2m >= 18:
+            logg = int(os.environ.get("DD_BUCKET_LOGG", max(2, log2m - 16)))
+            assert mode == 5 and nk == 1                           # scatter + replay, one k per job
+            assert j["lds_bytes"] == (m >> logg) + 16 * 8 * (1 << (log2m - 16))  # filter + a chunk cursor per (wave, bucket)
         else:
             assert mode == 0 and nk * m <= j["lds_bytes"]          # the group's registers fit the LDS asked for
         cover[g][k0 - kmin:k0 - kmin + nk, j["tile_begin"]:j["tile_end"]] += 1
@@ -74,9 +80,35 @@ def test_launch_shape_of_the_headline_config():
     assert all(len(v) >= 2048 for v in by_class.values())  # >> 256 CUs x 2 resident workgroups
 
 
+def test_bucket_mode_epochs(monkeypatch):
+    """log2m >= 18: jobs come epoch by epoch (launch order), epochs are the same tile ranges for every row and
+    double in length; DD_NO_BUCKETS brings back the filtered compare-and-swap path, still covering everything."""
+    for env in ({}, {"DD_BUCKET_E0": "1", "DD_BUCKET_EMAX": "3"}, {"DD_BUCKET_LOGG": "6"}, {"DD_BUCKET_GB": "1"},
+                {"DD_NO_BUCKETS": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for log2m in (18, 19, 20):
+            jobs = check(log2m, SIZES["ragged"], 8, 35)
+            real = jobs[(jobs["tile_end"] > jobs["tile_begin"]) & (jobs["kclass"] >= 0)]
+            if "DD_NO_BUCKETS" not in env and "DD_BUCKET_GB" not in env:
+                e0 = int(env.get("DD_BUCKET_E0", max(1, (1 << log2m) // TILE)))
+                emax = max(e0, int(env.get("DD_BUCKET_EMAX", 256)))
+                edges = [0, e0]
+                while edges[-1] < 1000:
+                    edges.append(edges[-1] + min(emax, edges[-1]))
+                for kc in np.unique(real["kclass"]):
+                    sel = real[real["kclass"] == kc]
+                    # launch order never goes back to an earlier epoch, and no job straddles an epoch edge
+                    e_lo = np.searchsorted(edges, sel["tile_begin"].astype(np.int64), side="right")
+                    e_hi = np.searchsorted(edges, sel["tile_end"].astype(np.int64) - 1, side="right")
+                    assert np.all(np.diff(e_lo) >= 0) and np.array_equal(e_lo, e_hi), (env, log2m, kc)
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def test_knobs_change_the_plan_not_the_coverage(monkeypatch):
     for env in ({"DD_NO_BITMAP": "1"}, {"DD_LDS_KB": "160"}, {"DD_JOBS_PER_CU": "3"}, {"DD_NO_XCD_AFFINITY": "1"},
-                {"DD_NO_TAPER": "1"}, {"DD_NO_FILTER": "1"}):
+                {"DD_NO_TAPER": "1"}, {"DD_NO_FILTER": "1"}, {"DD_NO_BUCKETS": "1"}, {"DD_BUCKET_E0": "2"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         for log2m in (14, 18):
