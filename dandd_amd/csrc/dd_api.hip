@@ -474,7 +474,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     const int nrows = ngenomes * K;
     if (bplan) {
         const size_t nb = (size_t)1 << bplan->nb_log2;
-        const size_t flt_bytes = m >> bplan->logg, area_bytes = nb * bplan->cap_chunks * 256;
+        const size_t flt_bytes = m >> bplan->logg, area_bytes = nb * bplan->cap_chunks * 512;  // 128 records per chunk
         int first_hashed = K, hashed_per_genome = 0;  // rows of a genome that belong to a bucket class
         for (const dd::SweepClass& sc : classes)
             if (sc.plan.mode == dd::kBucketMode) {
@@ -528,7 +528,8 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     }
     if (bplan) {
         // epoch by epoch: scatter launches of every k class, then one replay over all rows
-        const dd::ScatterParams sp{rows_dev, K, bplan->logg, bplan->nb_log2, bplan->cap_chunks};
+        const dd::ScatterParams sp{rows_dev, K, bplan->logg, bplan->nb_log2, bplan->cap_chunks,
+                                   getenv("DD_SCATTER_DEBUG") ? atoi(getenv("DD_SCATTER_DEBUG")) : 0};
         for (int e = 0; e < bplan->nepochs; ++e) {
             bool any = false;
             for (size_t i = 0; i < classes.size(); ++i) {

@@ -733,55 +733,87 @@ __global__ __launch_bounds__(1024) void bitmap_finish_kernel(const SweepGenome* 
 
 // ---- log2m >= 18, bucket mode: scatter + replay (dd_kernels.h) --------------------------------------
 // The compare-and-swap path above is bound by the device's scattered-atomic rate (27 G/s measured, any
-// atomic, any footprint: profiles/r01_ubench_atomics.txt).  Here no register is touched by an atomic:
-// scatter only appends records, replay owns its 64 KiB index tile in LDS and stores it back whole.
-constexpr uint32_t kChunkRecords = 64;           // one chunk = 256 B = two 128-byte lines
-constexpr uint32_t kChunkSpent = 64;             // cursor count: chunk used up (also the initial state)
-constexpr uint32_t kBucketFull = 0x40000000u;    // cursor count from here on: the bucket has no chunk left
+// atomic, any footprint: profiles/r01_ubench_atomics.txt), and a first version of this path that stored
+// each record straight to its chunk ran into the same wall: a 4-byte store that is not part of a whole
+// line leaves the L2 as a fabric write of its own (MI355X_MICROARCH.md, stores).  So records are staged
+// per (wave, bucket) in LDS and leave 32 at a time, as one whole 128-byte line written by one store
+// instruction; replay owns its 128 KiB index tile in LDS and stores it back whole.  No register is
+// touched by an atomic unless a bucket overflows.
+constexpr uint32_t kStageRecords = 32;           // one 128-byte line per (wave, bucket)
+constexpr uint32_t kChunkRecords = 128;          // a chunk = 4 lines; one global atomic hands out one chunk
 
 struct Scatter {
-    uint32_t cur;          // byte offset in g_lds of this wave's cursor table: per bucket (chunk << 32) | count
+    uint32_t stage;        // byte offset in g_lds of this wave's staging lines (bucket b at + 128 b)
+    uint32_t state;        // byte offset in g_lds of this wave's {staged count, next record offset} per bucket
     uint32_t* area;
     uint32_t* cursor;
     uint8_t* regs;         // the row itself: where records go when their bucket is full
     uint32_t cap_chunks;
     int logg, bshift;      // filter granularity; bucket = idx >> bshift
+    int debug;
 };
-DD_D unsigned long long lds_add64(uint32_t off, unsigned long long v) {
-    return atomicAdd(reinterpret_cast<unsigned long long*>(g_lds + off), v);
-}
+DD_D uint32_t& lds32(uint32_t off) { return *reinterpret_cast<uint32_t*>(g_lds + off); }
 DD_D uint32_t gadd32(void* p, uint32_t v) {
     return __hip_atomic_fetch_add((DD_GLOBAL uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Bucket b's staging line (n <= 32 records, the rest padded with null records) leaves for its chunk.
+// Called by whole waves with wave-uniform b and n.
+DD_D void scatter_flush(const Scatter& s, uint32_t b, uint32_t n) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t line = s.stage + b * (kStageRecords * 4u);
+    if (lane >= n && lane < kStageRecords) lds32(line + lane * 4u) = 0u;
+    __builtin_amdgcn_wave_barrier();
+    uint32_t dst = __builtin_amdgcn_readfirstlane(lds32(s.state + b * 8u + 4u));
+    if ((dst & (kChunkRecords - 1u)) == 0u) {  // at a chunk boundary (or nothing handed out yet): next chunk
+        uint32_t c = 0;
+        if (lane == 0) c = gadd32(s.cursor + b, 1u);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (c >= s.cap_chunks) {
+            // no chunk left in this bucket: the records go to their registers directly (exact, slow, rare)
+            if (lane < n) {
+                const uint32_t e = lds32(line + lane * 4u);
+                uint8_t* a = s.regs + (e & 0xFFFFFFu);
+                (void)cas_raise<RegsGlobal>(a, RegsGlobal::load32(a), e >> 24);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) lds32(s.state + b * 8u) = 0u;
+            return;
+        }
+        dst = (b * s.cap_chunks + c) * kChunkRecords;
+    }
+    if (lane < kStageRecords / 4u && !(s.debug & 2))         // (debug 2, timing experiment only: lines are not stored)
+        gstore16(s.area + dst + lane * 4u, *reinterpret_cast<const uint4*>(g_lds + line + lane * 16u));
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        lds32(s.state + b * 8u) = 0u;
+        lds32(s.state + b * 8u + 4u) = dst + kStageRecords;
+    }
 }
 // One update.  Reached by whole waves (`valid`: the lane has a k-mer).
 DD_D void scatter_update(const Scatter& s, uint64_t h, int p, bool valid) {
     const Probe q = probe(h, p);
     const uint32_t idx = q.hi >> (32 - p);
     bool pending = valid && q.lz >= g_lds[idx >> s.logg];  // rho > bound (or hiw == 0: rho >= 33)
+    if (s.debug & 1) pending = pending && q.lz >= 40u;       // timing experiment only: (almost) nothing is recorded
     if (!__any(pending)) return;
-    const uint32_t rho = rho_of(q, p);
+    const uint32_t rec = idx | (rho_of(q, p) << 24);
     const uint32_t b = idx >> s.bshift;
-    const uint32_t slot = s.cur + b * 8u;
     for (;;) {
+        uint32_t pos = ~0u;
         if (pending) {
-            const unsigned long long old = lds_add64(slot, 1ull);
-            const uint32_t count = (uint32_t)old, chunk = (uint32_t)(old >> 32);
-            if (count < kChunkRecords) {
-                gstore4(s.area + ((size_t)b * s.cap_chunks + chunk) * kChunkRecords + count, idx | (rho << 24));
-                pending = false;
-            } else if (count == kChunkSpent) {
-                // exactly one lane per (wave, bucket) sees the count pass 64: it fetches the next chunk;
-                // the lanes behind it (65, 66, ...) simply come round again
-                const uint32_t c = gadd32(s.cursor + b, 1u);
-                const unsigned long long fresh = c < s.cap_chunks ? ((unsigned long long)c << 32)
-                                                                  : (((unsigned long long)c << 32) | kBucketFull);
-                *reinterpret_cast<unsigned long long*>(g_lds + slot) = fresh;
-            } else if (count >= kBucketFull) {
-                // no chunk left in this bucket: the record goes to its register directly (exact, slow, rare)
-                uint8_t* a = s.regs + idx;
-                (void)cas_raise<RegsGlobal>(a, RegsGlobal::load32(a), rho);
+            pos = atomicAdd(&lds32(s.state + b * 8u), 1u);
+            if (pos < kStageRecords) {
+                lds32(s.stage + b * (kStageRecords * 4u) + pos * 4u) = rec;
                 pending = false;
             }
+        }
+        // the lane that took a line's last slot is unique per (bucket, line): it names the bucket to flush;
+        // lanes that found the line full (pos >= 32) come round again once it is empty
+        unsigned long long full = __ballot(pos == kStageRecords - 1u);
+        while (full) {
+            const int leader = __builtin_ctzll(full);
+            full &= full - 1ull;
+            scatter_flush(s, (uint32_t)__builtin_amdgcn_readlane((int)b, leader), kStageRecords);
         }
         if (!__any(pending)) break;
     }
@@ -828,21 +860,25 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
         for (uint32_t i = threadIdx.x; i < (nflt >> 4); i += blockDim.x) f4[i] = gload16(row.filter + (size_t)i * 16);
     }
     Scatter s;
-    s.cur = nflt + (threadIdx.x >> 6) * (nb * 8u);
+    s.stage = nflt + (threadIdx.x >> 6) * (nb * kStageRecords * 4u);
+    s.state = nflt + (blockDim.x >> 6) * (nb * kStageRecords * 4u) + (threadIdx.x >> 6) * (nb * 8u);
     s.area = row.area;
     s.cursor = row.cursor;
     s.regs = row.regs;
     s.cap_chunks = sp.cap_chunks;
     s.logg = sp.logg;
     s.bshift = p - sp.nb_log2;
+    s.debug = sp.debug;
     if ((threadIdx.x & 63u) < nb)
-        *reinterpret_cast<unsigned long long*>(g_lds + s.cur + (threadIdx.x & 63u) * 8u) = kChunkSpent;
+        *reinterpret_cast<unsigned long long*>(g_lds + s.state + (threadIdx.x & 63u) * 8u) = 0ull;  // nothing staged, no chunk yet
     __syncthreads();
 
     for (unsigned tile = job.tile_begin; tile < job.tile_end; ++tile) {
         const TileIn cur = next;
         fetch(tile + 1, next);
-        if (!cur.live) continue;
+        // Lanes beyond the stream stay in the loop as all-BREAK segments while any lane of their wave has
+        // tokens: staging and flushing are wave-level operations (a flush stores with lanes 0..7).
+        if (!__any(cur.live)) continue;
         const uint4 hc = cur.hc, sc = cur.sc;
         const uint2 hb = cur.hb, sb = cur.sb;
         const uint32_t cw[4] = {sc.x, sc.y, sc.z, sc.w};
@@ -872,17 +908,19 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
             }
         }
     }
-    // every chunk this wave still holds is padded with null records (rho 0 raises nothing): replay reads
-    // whole chunks
+    // what is still staged leaves as a (padded) line, and the rest of every chunk this wave holds is filled
+    // with null records (rho 0 raises nothing): replay reads whole chunks
     for (uint32_t b = 0; b < nb; ++b) {
-        const unsigned long long st = *reinterpret_cast<const unsigned long long*>(g_lds + s.cur + b * 8u);
-        const uint32_t count = (uint32_t)st, chunk = (uint32_t)(st >> 32), lane = threadIdx.x & 63u;
-        if (count < kChunkRecords && lane >= count)
-            gstore4(s.area + ((size_t)b * s.cap_chunks + chunk) * kChunkRecords + lane, 0u);
+        const uint32_t n = __builtin_amdgcn_readfirstlane(lds32(s.state + b * 8u));
+        if (n) scatter_flush(s, b, n < kStageRecords ? n : kStageRecords);
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds32(s.state + b * 8u + 4u));
+        const uint32_t left = (kChunkRecords - (dst & (kChunkRecords - 1u))) & (kChunkRecords - 1u);  // records to the chunk's end
+        const uint32_t lane = threadIdx.x & 63u;
+        if (lane * 4u < left) gstore16(s.area + dst + lane * 4u, make_uint4(0, 0, 0, 0));
     }
 }
 
-// grid = (buckets, rows).  LDS: the 64 KiB (or m bytes if smaller) index tile.
+// grid = (buckets, rows).  LDS: the 128 KiB (or m bytes if smaller) index tile.
 __global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restrict__ rows, int p, int logg, int nb_log2,
                                                      uint32_t cap_chunks) {
     const BucketRow row = rows[blockIdx.y];
