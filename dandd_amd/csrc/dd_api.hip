@@ -473,8 +473,8 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     const dd::BucketRow* rows_dev = nullptr;
     const int nrows = ngenomes * K;
     if (bplan) {
-        const size_t nb = (size_t)1 << bplan->nb_log2;
-        const size_t flt_bytes = m >> bplan->logg, area_bytes = nb * bplan->cap_chunks * 512;  // 128 records per chunk
+        const size_t flt_bytes = m >> bplan->logg, area_bytes = (size_t)bplan->cap_chunks * 4096;  // 1024 records per chunk
+        const size_t fill_bytes = align_up((size_t)bplan->cap_chunks * 4, 256) + align_up((size_t)bplan->cap_chunks * 16, 256);  // fill + seg
         int first_hashed = K, hashed_per_genome = 0;  // rows of a genome that belong to a bucket class
         for (const dd::SweepClass& sc : classes)
             if (sc.plan.mode == dd::kBucketMode) {
@@ -483,21 +483,25 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
             }
         const size_t nhashed = (size_t)ngenomes * hashed_per_genome;
         const size_t tab_bytes = align_up(sizeof(dd::BucketRow) * nrows, 256);
-        const size_t cur_bytes = align_up((size_t)nrows * nb * 4, 256);
+        const size_t cur_bytes = align_up((size_t)nrows * 4, 256);
         const size_t flt_tot = align_up(nhashed * flt_bytes, 256);
-        if ((rc = c->buckets.reserve(tab_bytes + cur_bytes + flt_tot + nhashed * area_bytes))) return rc;
+        if ((rc = c->buckets.reserve(tab_bytes + cur_bytes + flt_tot + nhashed * (fill_bytes + area_bytes)))) return rc;
         if ((rc = c->stage_rows.reserve(tab_bytes))) return rc;
         char* bb = static_cast<char*>(c->buckets.p);
+        char* fills = bb + tab_bytes + cur_bytes + flt_tot;
+        char* areas = fills + nhashed * fill_bytes;
         std::vector<dd::BucketRow> rtab(nrows);
         size_t h = 0;
         for (int g = 0; g < ngenomes; ++g)
             for (int kk = 0; kk < K; ++kk) {
                 dd::BucketRow& r = rtab[(size_t)g * K + kk];
                 r.regs = regs_dev + ((size_t)g * K + kk) * m;
-                r.cursor = reinterpret_cast<uint32_t*>(bb + tab_bytes) + ((size_t)g * K + kk) * nb;
+                r.cursor = reinterpret_cast<uint32_t*>(bb + tab_bytes) + ((size_t)g * K + kk);
                 const bool hashed = kk >= first_hashed && kk < first_hashed + hashed_per_genome;
                 r.filter = hashed ? reinterpret_cast<uint8_t*>(bb + tab_bytes + cur_bytes + h * flt_bytes) : nullptr;
-                r.area = hashed ? reinterpret_cast<uint32_t*>(bb + tab_bytes + cur_bytes + flt_tot + h * area_bytes) : nullptr;
+                r.fill = hashed ? reinterpret_cast<uint32_t*>(fills + h * fill_bytes) : nullptr;
+                r.seg = hashed ? reinterpret_cast<uint16_t*>(fills + h * fill_bytes + align_up((size_t)bplan->cap_chunks * 4, 256)) : nullptr;
+                r.area = hashed ? reinterpret_cast<uint32_t*>(areas + h * area_bytes) : nullptr;
                 h += hashed ? 1 : 0;
             }
         // cursors and filters start at zero: nothing handed out, every register's lower bound is 0
@@ -528,8 +532,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     }
     if (bplan) {
         // epoch by epoch: scatter launches of every k class, then one replay over all rows
-        const dd::ScatterParams sp{rows_dev, K, bplan->logg, bplan->nb_log2, bplan->cap_chunks,
-                                   getenv("DD_SCATTER_DEBUG") ? atoi(getenv("DD_SCATTER_DEBUG")) : 0};
+        const dd::ScatterParams sp{rows_dev, K, bplan->logg, bplan->cap_chunks};
         for (int e = 0; e < bplan->nepochs; ++e) {
             bool any = false;
             for (size_t i = 0; i < classes.size(); ++i) {

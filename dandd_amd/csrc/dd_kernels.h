@@ -83,8 +83,8 @@ struct SweepPlan {
                                 // 5 (kBucketMode): in HBM, scatter to buckets + replay (below)
     // kBucketMode only
     int logg = 0;               // one filter byte per 2^logg registers
-    int nb_log2 = 0;            // 2^nb_log2 buckets (index tiles of 128 KiB) per row
-    unsigned cap_chunks = 0;    // 128-record chunks per bucket
+    int nb_log2 = 0;            // 2^nb_log2 index tiles of 128 KiB per row (replay)
+    unsigned cap_chunks = 0;    // 1024-record chunks per row and epoch
     int nepochs = 0;
 };
 void launch_sweep(const SweepGenome* genomes_dev, const SweepJob* jobs_dev, int njobs, int kclass,
@@ -95,26 +95,27 @@ void launch_sweep(const SweepGenome* genomes_dev, const SweepJob* jobs_dev, int 
 // /root/reference/lib/dandd_cmd.py:187): two phases per EPOCH (a range of token tiles).
 //   scatter: hash every k-mer of the epoch; an update whose rho cannot exceed the filter's lower bound
 //            for its register group is dropped, the others are appended as 4-byte records
-//            (idx | rho << 24) to the bucket of their index tile: staged per (wave, bucket) in LDS, written
-//            32 at a time as one whole 128-byte line into a wave-private 128-record chunk, so the only
-//            global atomic is the one that hands out a chunk.
-//   replay : one workgroup per (row, index tile): tile into LDS, apply the bucket's records with LDS
-//            operations, store the tile back with plain 16-byte stores and refresh the tile's filter.
+//            (idx | rho << 24) to the ROW's record stream: queued per wave in LDS, stored 64 at a time as
+//            one 256-byte block into a wave-private 1024-record chunk (one global atomic per chunk).
+//   replay : one workgroup per (row, 128 KiB index tile): tile into LDS, stream the row's records and
+//            apply those of this tile with LDS operations, store the tile back with plain 16-byte stores
+//            and refresh the tile's filter.  The tiles of a row run side by side on one XCD.
 // The filter of epoch e is exact knowledge of the registers after epoch e-1, so what scatter drops can
 // never matter; epochs double in length (one token per register first), because bounds rise fast early.
 // ---------------------------------------------------------------------------------------
 struct BucketRow {              // one per (genome, k) row of the call: table[genome * K + (k - kmin)]
     uint8_t* regs;              // the row's m registers in the caller's slab
-    uint32_t* area;             // record chunks: bucket b, chunk c at area + ((size_t)b * cap_chunks + c) * 128; null = row not bucketed
-    uint32_t* cursor;           // [nb] chunks handed out per bucket this epoch (may run past cap_chunks: overflow)
+    uint32_t* area;             // record stream: chunk c at area + c * 1024; null = row not bucketed
+    uint32_t* cursor;           // chunks handed out this epoch (may run past cap_chunks: overflow)
+    uint32_t* fill;             // [cap_chunks] valid records of each chunk
+    uint16_t* seg;              // [cap_chunks][8] where each index tile's records start inside a sorted chunk
     uint8_t* filter;            // [m >> logg] lower bound per register group
 };
 struct ScatterParams {
     const BucketRow* rows;
     int K;                      // rows per genome
-    int logg, nb_log2;
+    int logg;
     unsigned cap_chunks;
-    int debug;                  // DD_SCATTER_DEBUG: timing experiments that break the results (1: record nothing, 2: store nothing)
 };
 void launch_scatter(const SweepGenome* genomes_dev, const SweepJob* jobs_dev, int njobs, int kclass,
                     const SweepPlan& plan, const ScatterParams& sp, hipStream_t st);

@@ -81,7 +81,7 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
     // seen once), each later one is as long as everything before it -- the filter's bounds rise by about
     // one per doubling -- up to the length whose worst case (every update survives) fits the HBM budget.
     const bool bucket_mode = global_regs && knobs.buckets && knobs.filter;
-    const int bucket_logg = knobs.bucket_logg ? knobs.bucket_logg : std::max(2, p - 15);  // a 32 KiB filter
+    const int bucket_logg = knobs.bucket_logg ? knobs.bucket_logg : std::max(2, p - 16);  // a 64 KiB filter
     const int nb_log2 = std::max(0, p - 17);  // index tiles of 128 KiB
     std::vector<size_t> epoch_edge;           // epoch e covers tiles [epoch_edge[e], epoch_edge[e+1])
     size_t epoch_longest = 0, bucket_row_tokens = 0;
@@ -160,15 +160,13 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
             sc.epoch_begin.push_back(sc.jobs.size());
             max_nk = 1;
             // Every token of the longest epoch may leave a record (nothing is filtered while the registers
-            // are still empty); buckets are hash-uniform, so 1/16 of slack, plus the partly filled chunk
-            // every wave of every job leaves per bucket.  Records beyond the capacity are not lost: they go
-            // straight to the row by compare-and-swap (dd_sweep.hip).
-            const size_t nb = (size_t)1 << nb_log2;
+            // are still empty), plus the partly filled chunk every wave of every job leaves.  Records beyond
+            // the capacity are not lost: they go straight to the row by compare-and-swap (dd_sweep.hip).
             // (a call with so many rows that even the first epoch's worst case exceeds the budget gets what
             // the budget allows; the overflow path keeps it exact)
-            const size_t per_bucket = std::min(epoch_longest * kTileTokens, bucket_row_tokens) / nb;
+            const size_t per_row = std::min(epoch_longest * kTileTokens, bucket_row_tokens);
             sc.plan.cap_chunks = (unsigned)(knobs.bucket_cap_chunks ? knobs.bucket_cap_chunks
-                                                : (per_bucket + per_bucket / 16) / 128 + max_jobs_row_epoch * (kThreads / 64) + 16);
+                                                : per_row / 1024 + max_jobs_row_epoch * (kThreads / 64) + 16);
             sc.plan.logg = bucket_logg;
             sc.plan.nb_log2 = nb_log2;
             sc.plan.nepochs = (int)nepochs;
@@ -259,8 +257,8 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
             sc.plan.mode = 0;
             sc.plan.lds_bytes = (bitmap_offset(kb) + bitmap_words(kb) - bitmap_offset(ka)) * 4;
         } else if (bucket_mode) {
-            sc.plan.mode = kBucketMode;  // the filter, then a 128-byte staging line and 8 bytes of state per (wave, bucket)
-            sc.plan.lds_bytes = (int)(m >> bucket_logg) + (kThreads / 64) * (136 << nb_log2);
+            sc.plan.mode = kBucketMode;  // the filter, then a 128-entry record queue per wave
+            sc.plan.lds_bytes = (int)(m >> bucket_logg) + (kThreads / 64) * 128 * 4;
         } else if (filter_logg) {
             sc.plan.mode = filter_logg;  // the filter, then a 128-entry candidate queue per wave (dd_sweep.hip)
             sc.plan.lds_bytes = (int)(m >> filter_logg) + (kThreads / 64) * 128 * 4;

@@ -733,89 +733,68 @@ __global__ __launch_bounds__(1024) void bitmap_finish_kernel(const SweepGenome* 
 
 // ---- log2m >= 18, bucket mode: scatter + replay (dd_kernels.h) --------------------------------------
 // The compare-and-swap path above is bound by the device's scattered-atomic rate (27 G/s measured, any
-// atomic, any footprint: profiles/r01_ubench_atomics.txt), and a first version of this path that stored
-// each record straight to its chunk ran into the same wall: a 4-byte store that is not part of a whole
-// line leaves the L2 as a fabric write of its own (MI355X_MICROARCH.md, stores).  So records are staged
-// per (wave, bucket) in LDS and leave 32 at a time, as one whole 128-byte line written by one store
-// instruction; replay owns its 128 KiB index tile in LDS and stores it back whole.  No register is
-// touched by an atomic unless a bucket overflows.
-constexpr uint32_t kStageRecords = 32;           // one 128-byte line per (wave, bucket)
-constexpr uint32_t kChunkRecords = 128;          // a chunk = 4 lines; one global atomic hands out one chunk
+// atomic, any footprint: profiles/r01_ubench_atomics.txt).  Two earlier forms of this path were measured
+// (profiles/r02_bucket_path.txt): records stored one by one to per-index-tile chunks ran into the same
+// wall (a 4-byte store that is not part of a whole line leaves the L2 as a fabric write of its own);
+// records staged per (wave, index tile) in LDS and flushed as 128-byte lines made the stores cheap but
+// cost 30 VALU + 30 SALU per wave-update for the staging -- the kernel is issue-bound, so that doubled it.
+// Hence: scatter does NO partitioning.  A wave appends its surviving records to one LDS queue (ballot +
+// mbcnt + one ds_write) and, whenever 64 wait, stores them as one 256-byte block to the ROW's record
+// stream; the eight replay workgroups of a row (one per 128 KiB index tile) all read that stream -- they
+// run side by side on one XCD, so the stream comes from HBM once and from that XCD's L2 seven times --
+// and each applies only the records of its own tile.
+constexpr uint32_t kChunkRecords = 1024;         // 4 KiB; one global atomic hands out one chunk of the row's stream
 
 struct Scatter {
-    uint32_t stage;        // byte offset in g_lds of this wave's staging lines (bucket b at + 128 b)
-    uint32_t state;        // byte offset in g_lds of this wave's {staged count, next record offset} per bucket
-    uint32_t* area;
-    uint32_t* cursor;
-    uint8_t* regs;         // the row itself: where records go when their bucket is full
+    uint32_t queue;        // byte offset in g_lds of this wave's record queue (kQueueEntries x 4 B)
+    uint32_t* area;        // the row's record stream, chunk c at area + c * kChunkRecords
+    uint32_t* cursor;      // chunks handed out so far
+    uint32_t* fill;        // valid records per chunk (written by the chunk's owner)
+    uint8_t* regs;         // the row itself: where records go when the stream is full
     uint32_t cap_chunks;
-    int logg, bshift;      // filter granularity; bucket = idx >> bshift
-    int debug;
+    int fshift;            // hash high word >> fshift = index of the register group's filter byte (32 - p + logg)
 };
 DD_D uint32_t& lds32(uint32_t off) { return *reinterpret_cast<uint32_t*>(g_lds + off); }
 DD_D uint32_t gadd32(void* p, uint32_t v) {
     return __hip_atomic_fetch_add((DD_GLOBAL uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// Bucket b's staging line (n <= 32 records, the rest padded with null records) leaves for its chunk.
-// Called by whole waves with wave-uniform b and n.
-DD_D void scatter_flush(const Scatter& s, uint32_t b, uint32_t n) {
+// 64 records (one per lane; null records have rho 0) leave for the row's stream.  `cur` = record offset
+// of the next block; a multiple of kChunkRecords means "no chunk in hand".  Whole waves, uniform state.
+DD_D void scatter_block(const Scatter& s, uint32_t rec, uint32_t& cur) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t line = s.stage + b * (kStageRecords * 4u);
-    if (lane >= n && lane < kStageRecords) lds32(line + lane * 4u) = 0u;
-    __builtin_amdgcn_wave_barrier();
-    uint32_t dst = __builtin_amdgcn_readfirstlane(lds32(s.state + b * 8u + 4u));
-    if ((dst & (kChunkRecords - 1u)) == 0u) {  // at a chunk boundary (or nothing handed out yet): next chunk
+    if ((cur & (kChunkRecords - 1u)) == 0u) {
         uint32_t c = 0;
-        if (lane == 0) c = gadd32(s.cursor + b, 1u);
+        if (lane == 0) c = gadd32(s.cursor, 1u);
         c = __builtin_amdgcn_readfirstlane(c);
         if (c >= s.cap_chunks) {
-            // no chunk left in this bucket: the records go to their registers directly (exact, slow, rare)
-            if (lane < n) {
-                const uint32_t e = lds32(line + lane * 4u);
-                uint8_t* a = s.regs + (e & 0xFFFFFFu);
-                (void)cas_raise<RegsGlobal>(a, RegsGlobal::load32(a), e >> 24);
+            // the stream is full: the records go to their registers directly (exact, slow, rare)
+            if (rec >> 24) {
+                uint8_t* a = s.regs + (rec & 0xFFFFFFu);
+                (void)cas_raise<RegsGlobal>(a, RegsGlobal::load32(a), rec >> 24);
             }
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) lds32(s.state + b * 8u) = 0u;
             return;
         }
-        dst = (b * s.cap_chunks + c) * kChunkRecords;
+        cur = c * kChunkRecords;
     }
-    if (lane < kStageRecords / 4u && !(s.debug & 2))         // (debug 2, timing experiment only: lines are not stored)
-        gstore16(s.area + dst + lane * 4u, *reinterpret_cast<const uint4*>(g_lds + line + lane * 16u));
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
-        lds32(s.state + b * 8u) = 0u;
-        lds32(s.state + b * 8u + 4u) = dst + kStageRecords;
-    }
+    gstore4(s.area + cur + lane, rec);
+    cur += 64u;
+    if ((cur & (kChunkRecords - 1u)) == 0u && lane == 0) gstore4(s.fill + (cur / kChunkRecords - 1u), kChunkRecords);
 }
-// One update.  Reached by whole waves (`valid`: the lane has a k-mer).
-DD_D void scatter_update(const Scatter& s, uint64_t h, int p, bool valid) {
+// One update.  Reached by whole waves (`valid`: the lane has a k-mer); `waiting` and `cur` are wave-uniform.
+DD_D void scatter_update(const Scatter& s, uint32_t& waiting, uint32_t& cur, uint64_t h, int p, bool valid) {
     const Probe q = probe(h, p);
-    const uint32_t idx = q.hi >> (32 - p);
-    bool pending = valid && q.lz >= g_lds[idx >> s.logg];  // rho > bound (or hiw == 0: rho >= 33)
-    if (s.debug & 1) pending = pending && q.lz >= 40u;       // timing experiment only: (almost) nothing is recorded
-    if (!__any(pending)) return;
-    const uint32_t rec = idx | (rho_of(q, p) << 24);
-    const uint32_t b = idx >> s.bshift;
-    for (;;) {
-        uint32_t pos = ~0u;
-        if (pending) {
-            pos = atomicAdd(&lds32(s.state + b * 8u), 1u);
-            if (pos < kStageRecords) {
-                lds32(s.stage + b * (kStageRecords * 4u) + pos * 4u) = rec;
-                pending = false;
-            }
+    const bool cand = valid && q.lz >= g_lds[q.hi >> s.fshift];  // rho > bound (or hiw == 0: rho >= 33)
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(cand);
+    if (mask) {
+        if (cand) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            lds32(s.queue + 4u * (waiting + rank)) = (q.hi >> (32 - p)) | (rho_of(q, p) << 24);
         }
-        // the lane that took a line's last slot is unique per (bucket, line): it names the bucket to flush;
-        // lanes that found the line full (pos >= 32) come round again once it is empty
-        unsigned long long full = __ballot(pos == kStageRecords - 1u);
-        while (full) {
-            const int leader = __builtin_ctzll(full);
-            full &= full - 1ull;
-            scatter_flush(s, (uint32_t)__builtin_amdgcn_readlane((int)b, leader), kStageRecords);
+        waiting += (uint32_t)__builtin_popcountll(mask);
+        if (waiting >= 64u) {
+            waiting -= 64u;
+            scatter_block(s, lds32(s.queue + 4u * (waiting + (threadIdx.x & 63u))), cur);
         }
-        if (!__any(pending)) break;
     }
 }
 
@@ -829,7 +808,7 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
     const uint32_t m = 1u << p;
     const unsigned long long ntok = gload8u(g.ntok);
     const BucketRow row = sp.rows[(size_t)job.genome * sp.K + job.krow];
-    const uint32_t nb = 1u << sp.nb_log2, nflt = m >> sp.logg;
+    const uint32_t nflt = m >> sp.logg;
 
     struct TileIn {
         uint4 hc, sc;
@@ -860,27 +839,24 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
         for (uint32_t i = threadIdx.x; i < (nflt >> 4); i += blockDim.x) f4[i] = gload16(row.filter + (size_t)i * 16);
     }
     Scatter s;
-    s.stage = nflt + (threadIdx.x >> 6) * (nb * kStageRecords * 4u);
-    s.state = nflt + (blockDim.x >> 6) * (nb * kStageRecords * 4u) + (threadIdx.x >> 6) * (nb * 8u);
+    s.queue = nflt + (threadIdx.x >> 6) * (kQueueEntries * 4u);
     s.area = row.area;
     s.cursor = row.cursor;
+    s.fill = row.fill;
     s.regs = row.regs;
     s.cap_chunks = sp.cap_chunks;
-    s.logg = sp.logg;
-    s.bshift = p - sp.nb_log2;
-    s.debug = sp.debug;
-    if ((threadIdx.x & 63u) < nb)
-        *reinterpret_cast<unsigned long long*>(g_lds + s.state + (threadIdx.x & 63u) * 8u) = 0ull;  // nothing staged, no chunk yet
+    s.fshift = 32 - p + sp.logg;
+    uint32_t waiting = 0, cur = 0;
     __syncthreads();
 
     for (unsigned tile = job.tile_begin; tile < job.tile_end; ++tile) {
-        const TileIn cur = next;
+        const TileIn in = next;
         fetch(tile + 1, next);
         // Lanes beyond the stream stay in the loop as all-BREAK segments while any lane of their wave has
-        // tokens: staging and flushing are wave-level operations (a flush stores with lanes 0..7).
-        if (!__any(cur.live)) continue;
-        const uint4 hc = cur.hc, sc = cur.sc;
-        const uint2 hb = cur.hb, sb = cur.sb;
+        // tokens: the queue counter and the stream offset must stay wave-uniform.
+        if (!__any(in.live)) continue;
+        const uint4 hc = in.hc, sc = in.sc;
+        const uint2 hb = in.hb, sb = in.sb;
         const uint32_t cw[4] = {sc.x, sc.y, sc.z, sc.w};
         Windows<KC> win;
         win.prime(hc);
@@ -890,7 +866,7 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
 #pragma unroll 1
                 for (int i = 0; i < 16; ++i) {
                     win.push((cw[w] >> (2 * i)) & 3u);
-                    scatter_update(s, win.template hash<CANON>(k), p, true);
+                    scatter_update(s, waiting, cur, win.template hash<CANON>(k), p, true);
                 }
             }
             continue;
@@ -904,48 +880,186 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
                 const uint32_t c = (cw[w] >> (2 * i)) & 3u;
                 run = ((bw >> i) & 1u) ? 0 : run + 1;
                 win.push(c);
-                scatter_update(s, win.template hash<CANON>(k), p, run >= k);
+                scatter_update(s, waiting, cur, win.template hash<CANON>(k), p, run >= k);
             }
         }
     }
-    // what is still staged leaves as a (padded) line, and the rest of every chunk this wave holds is filled
-    // with null records (rho 0 raises nothing): replay reads whole chunks
-    for (uint32_t b = 0; b < nb; ++b) {
-        const uint32_t n = __builtin_amdgcn_readfirstlane(lds32(s.state + b * 8u));
-        if (n) scatter_flush(s, b, n < kStageRecords ? n : kStageRecords);
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds32(s.state + b * 8u + 4u));
-        const uint32_t left = (kChunkRecords - (dst & (kChunkRecords - 1u))) & (kChunkRecords - 1u);  // records to the chunk's end
+    // what still waits leaves as a block padded with null records; a chunk left partly filled is recorded
+    // as such (replay reads fill[c] records of chunk c)
+    if (waiting) {
         const uint32_t lane = threadIdx.x & 63u;
-        if (lane * 4u < left) gstore16(s.area + dst + lane * 4u, make_uint4(0, 0, 0, 0));
+        scatter_block(s, lane < waiting ? lds32(s.queue + 4u * lane) : 0u, cur);
+    }
+    if ((cur & (kChunkRecords - 1u)) != 0u && (threadIdx.x & 63u) == 0)
+        gstore4(s.fill + cur / kChunkRecords, cur & (kChunkRecords - 1u));
+}
+
+// Between scatter and replay when a row has four or more index tiles (log2m >= 19): every chunk of every
+// stream is sorted by index tile in place (one wave per chunk: LDS counting sort), null records dropped,
+// and the start of each tile's segment is noted in seg[chunk][tile].  A replay workgroup then reads only
+// its own segments; without this every one of the 8 workgroups of a log2m 20 row inspected every record
+// (measured: 42 of 72 ms).  HBM-bound: each record is read and written once more.
+__global__ __launch_bounds__(256) void sort_chunks_kernel(const BucketRow* __restrict__ rows, int p, int nb_log2,
+                                                         uint32_t cap_chunks, int wgs_per_row) {
+    __shared__ uint32_t sorted[4][kChunkRecords];
+    __shared__ uint32_t hist[4][16];
+    const BucketRow row = rows[blockIdx.x / wgs_per_row];
+    if (!row.area) return;
+    const uint32_t handed = gload4(row.cursor);
+    const uint32_t nchunks = handed < cap_chunks ? handed : cap_chunks;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, nb = 1u << nb_log2;
+    const int tshift = p - nb_log2;
+    for (uint32_t c = (blockIdx.x % wgs_per_row) * 4u + wave; c < nchunks; c += (uint32_t)wgs_per_row * 4u) {
+        const uint32_t f = gload4(row.fill + c);
+        uint32_t e[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t pos = (uint32_t)i * 256u + lane * 4u;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (pos < f) v = gload16(row.area + (size_t)c * kChunkRecords + pos);
+            e[4 * i] = v.x, e[4 * i + 1] = v.y, e[4 * i + 2] = v.z, e[4 * i + 3] = v.w;
+        }
+        if (lane < 16) hist[wave][lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (e[i] >> 24) atomicAdd(&hist[wave][(e[i] & 0xFFFFFFu) >> tshift], 1u);
+        __builtin_amdgcn_wave_barrier();
+        // exclusive prefix over the (at most 8) tiles: lanes 0..7
+        const uint32_t mine = lane < nb ? hist[wave][lane] : 0u;
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 8; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= (uint32_t)d) incl += up;
+        }
+        const uint32_t total = __shfl(incl, (int)nb - 1);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nb) {
+            hist[wave][lane] = incl - mine;
+            ((DD_GLOBAL uint16_t*)row.seg)[(size_t)c * 8u + lane] = (uint16_t)(incl - mine);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (e[i] >> 24) sorted[wave][atomicAdd(&hist[wave][(e[i] & 0xFFFFFFu) >> tshift], 1u)] = e[i];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t pos = (uint32_t)i * 256u + lane * 4u;
+            if (pos < total) {
+                const uint4 v = *reinterpret_cast<const uint4*>(&sorted[wave][pos]);  // past `total`: stale, never read
+                gstore16(row.area + (size_t)c * kChunkRecords + pos, v);
+            }
+        }
+        if (lane == 0) gstore4(row.fill + c, total);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
-// grid = (buckets, rows).  LDS: the 128 KiB (or m bytes if smaller) index tile.
-__global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restrict__ rows, int p, int logg, int nb_log2,
-                                                     uint32_t cap_chunks) {
-    const BucketRow row = rows[blockIdx.y];
+// One workgroup per (row, index tile); LDS: the tile (128 KiB, or m bytes if smaller), then one queue per
+// wave.  Block ids are laid out so that the tiles of one row are consecutive workgroups of ONE XCD
+// (workgroups are dealt round robin over the 8 XCDs in id order): with unsorted chunks they stream the
+// same records at about the same time.
+template <bool SORTED>
+__global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restrict__ rows, int nrows, int p, int logg,
+                                                     int nb_log2, uint32_t cap_chunks) {
+    const uint32_t nb = 1u << nb_log2;
+    const uint32_t within = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
+    const uint32_t r = (within >> nb_log2) * 8u + xcd, b = within & (nb - 1u);
+    if (r >= (uint32_t)nrows) return;
+    const BucketRow row = rows[r];
     if (!row.area) return;
-    const uint32_t b = blockIdx.x;
-    const uint32_t handed = gload4(row.cursor + b);
-    if (handed == 0u) return;  // nothing reached this tile in this epoch: registers and filter stand
+    const uint32_t handed = gload4(row.cursor);
+    if (handed == 0u) return;  // nothing was recorded for this row in this epoch: registers and filter stand
     const uint32_t nchunks = handed < cap_chunks ? handed : cap_chunks;
-    const uint32_t tile = 1u << (p - nb_log2);
+    const int tshift = p - nb_log2;
+    const uint32_t tile = 1u << tshift;
     uint8_t* const tile_g = row.regs + (size_t)b * tile;
     uint4* l4 = reinterpret_cast<uint4*>(g_lds);
     for (uint32_t i = threadIdx.x; i < (tile >> 4); i += blockDim.x) l4[i] = gload16(tile_g + (size_t)i * 16);
     __syncthreads();
-    const uint32_t* rec = row.area + (size_t)b * cap_chunks * kChunkRecords;
-    const uint32_t n4 = nchunks * (kChunkRecords / 4);
+    const uint32_t lane = threadIdx.x & 63u;
     auto apply = [&](uint32_t e) {
         const uint32_t rho = e >> 24, a = e & (tile - 1u);
         if (rho > g_lds[a]) (void)cas_raise<RegsLds>(a, RegsLds::load32(a), rho);
     };
-    for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) {
-        const uint4 r = gload16(rec + (size_t)i * 4);
-        apply(r.x);
-        apply(r.y);
-        apply(r.z);
-        apply(r.w);
+    if (SORTED) {
+        // a wave takes every 16th chunk, four at a time: the four segment headers, then the (up to 128)
+        // records of each segment are in flight together
+        constexpr int U = 4;
+        const DD_GLOBAL uint16_t* seg = (const DD_GLOBAL uint16_t*)row.seg;
+        for (uint32_t c = threadIdx.x >> 6; c < nchunks; c += 16u * U) {
+            uint32_t st[U], en[U], r0[U], r1[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t cc = c + 16u * u;
+                st[u] = en[u] = 0;
+                if (cc < nchunks) {
+                    st[u] = seg[(size_t)cc * 8u + b];
+                    en[u] = b + 1u < nb ? (uint32_t)seg[(size_t)cc * 8u + b + 1u] : gload4(row.fill + cc);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t* base = row.area + (size_t)(c + 16u * u) * kChunkRecords;
+                const uint32_t i0 = st[u] + lane, i1 = i0 + 64u;
+                r0[u] = i0 < en[u] ? gload4(base + i0) : 0u;
+                r1[u] = i1 < en[u] ? gload4(base + i1) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                apply(r0[u]);
+                apply(r1[u]);
+                const uint32_t* base = row.area + (size_t)(c + 16u * u) * kChunkRecords;
+                for (uint32_t i = st[u] + 128u + lane; i < en[u]; i += 64u) apply(gload4(base + i));  // a segment twice its expected size
+            }
+        }
+    } else {
+        // Only one record in 2^nb_log2 belongs to this tile, and raising a register is a chain of dependent
+        // LDS operations: records of this tile are first collected in a per-wave queue (behind the tile in
+        // LDS) and applied 64 at a time with every lane busy.
+        const uint32_t queue = tile + (threadIdx.x >> 6) * (kQueueEntries * 4u);
+        uint32_t waiting = 0;
+        auto inspect = [&](uint32_t e) {
+            const bool mine = (e >> 24) != 0u && ((e & 0xFFFFFFu) >> tshift) == b;
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(mine);
+            if (mask) {
+                if (mine) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                    lds32(queue + 4u * (waiting + rank)) = e;
+                }
+                waiting += (uint32_t)__builtin_popcountll(mask);
+                if (waiting >= 64u) {
+                    waiting -= 64u;
+                    apply(lds32(queue + 4u * (waiting + lane)));
+                }
+            }
+        };
+        // every workgroup of the row reads the whole stream: kDepth passes of four chunks (256 threads x 16
+        // bytes per chunk) are kept in flight
+        constexpr int kDepth = 8;
+        const uint32_t sub = threadIdx.x >> 8, off = (threadIdx.x & 255u) * 4u;
+        auto fetch = [&](uint32_t c0, uint4& v) {
+            const uint32_t c = c0 + sub;
+            v = make_uint4(0, 0, 0, 0);
+            if (c < nchunks && off < gload4(row.fill + c)) v = gload16(row.area + (size_t)c * kChunkRecords + off);
+        };
+        uint4 ring[kDepth];
+#pragma unroll
+        for (int d = 0; d < kDepth; ++d) fetch(4u * d, ring[d]);
+        for (uint32_t c0 = 0; c0 < nchunks; c0 += 4u * kDepth) {
+#pragma unroll
+            for (int d = 0; d < kDepth; ++d) {
+                const uint4 v = ring[d];
+                fetch(c0 + 4u * (kDepth + d), ring[d]);
+                inspect(v.x);
+                inspect(v.y);
+                inspect(v.z);
+                inspect(v.w);
+            }
+        }
+        if (lane < waiting) apply(lds32(queue + 4u * lane));
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < (tile >> 4); i += blockDim.x) gstore16(tile_g + (size_t)i * 16, l4[i]);
@@ -960,7 +1074,13 @@ __global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restric
         }
         flt[f] = (uint8_t)lo;
     }
-    if (threadIdx.x == 0) gstore4(row.cursor + b, 0u);  // the next epoch starts a fresh bucket
+}
+
+// the stream cursors of all rows back to zero for the next epoch (replay's workgroups of a row cannot do
+// it themselves: its sibling tiles may still be reading the cursor)
+__global__ void reset_cursors_kernel(const BucketRow* __restrict__ rows, int nrows) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < nrows && rows[r].area) gstore4(rows[r].cursor, 0u);
 }
 
 // Dynamic LDS above 64 KiB must be allowed per kernel AND per device (a process may hold contexts on
@@ -1045,10 +1165,22 @@ void launch_scatter(const SweepGenome* genomes, const SweepJob* jobs, int njobs,
 void launch_replay(const BucketRow* rows, int nrows, const SweepPlan& plan, hipStream_t st) {
     if (nrows <= 0) return;
     const size_t tile = (size_t)1 << (plan.log2m - plan.nb_log2);
-    static std::atomic<unsigned long long> attr_done{0};
-    allow_full_lds(reinterpret_cast<const void*>(replay_kernel), attr_done);
-    hipLaunchKernelGGL(replay_kernel, dim3(1u << plan.nb_log2, (unsigned)nrows), dim3(1024), tile, st, rows,
-                       plan.log2m, plan.logg, plan.nb_log2, plan.cap_chunks);
+    const unsigned blocks = (unsigned)((nrows + 7) / 8) * 8u << plan.nb_log2;
+    static std::atomic<unsigned long long> attr_done[2] = {{0}, {0}};
+    if (plan.nb_log2 >= 2) {
+        // four or more tiles per row: sort every chunk by tile first, replay reads its own segments only
+        const int wgs_per_row = 32;
+        hipLaunchKernelGGL(sort_chunks_kernel, dim3((unsigned)nrows * wgs_per_row), dim3(256), 0, st, rows, plan.log2m,
+                           plan.nb_log2, plan.cap_chunks, wgs_per_row);
+        allow_full_lds(reinterpret_cast<const void*>(replay_kernel<true>), attr_done[0]);
+        hipLaunchKernelGGL(replay_kernel<true>, dim3(blocks), dim3(1024), tile, st, rows, nrows, plan.log2m, plan.logg,
+                           plan.nb_log2, plan.cap_chunks);
+    } else {
+        allow_full_lds(reinterpret_cast<const void*>(replay_kernel<false>), attr_done[1]);
+        hipLaunchKernelGGL(replay_kernel<false>, dim3(blocks), dim3(1024), tile + 16 * kQueueEntries * 4, st, rows, nrows,
+                           plan.log2m, plan.logg, plan.nb_log2, plan.cap_chunks);
+    }
+    hipLaunchKernelGGL(reset_cursors_kernel, dim3((unsigned)(nrows + 255) / 256), dim3(256), 0, st, rows, nrows);
 }
 
 void launch_sweep(const SweepGenome* genomes, const SweepJob* jobs, int njobs, int kclass,
