@@ -474,7 +474,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     const int nrows = ngenomes * K;
     if (bplan) {
         const size_t flt_bytes = m >> bplan->logg, area_bytes = (size_t)bplan->cap_chunks * 4096;  // 1024 records per chunk
-        const size_t fill_bytes = align_up((size_t)bplan->cap_chunks * 4, 256) + align_up((size_t)bplan->cap_chunks * 16, 256);  // fill + seg
+        const size_t fill_bytes = align_up((size_t)bplan->cap_chunks * 4, 256) + align_up((size_t)bplan->cap_chunks * 32, 256);  // fill + seg
         int first_hashed = K, hashed_per_genome = 0;  // rows of a genome that belong to a bucket class
         for (const dd::SweepClass& sc : classes)
             if (sc.plan.mode == dd::kBucketMode) {

@@ -83,7 +83,7 @@ struct SweepPlan {
                                 // 5 (kBucketMode): in HBM, scatter to buckets + replay (below)
     // kBucketMode only
     int logg = 0;               // one filter byte per 2^logg registers
-    int nb_log2 = 0;            // 2^nb_log2 index tiles of 128 KiB per row (replay)
+    int nb_log2 = 0;            // 2^nb_log2 index tiles of 64 KiB per row (replay)
     unsigned cap_chunks = 0;    // 1024-record chunks per row and epoch
     int nepochs = 0;
 };
@@ -97,9 +97,10 @@ void launch_sweep(const SweepGenome* genomes_dev, const SweepJob* jobs_dev, int 
 //            for its register group is dropped, the others are appended as 4-byte records
 //            (idx | rho << 24) to the ROW's record stream: queued per wave in LDS, stored 64 at a time as
 //            one 256-byte block into a wave-private 1024-record chunk (one global atomic per chunk).
-//   replay : one workgroup per (row, 128 KiB index tile): tile into LDS, stream the row's records and
-//            apply those of this tile with LDS operations, store the tile back with plain 16-byte stores
-//            and refresh the tile's filter.  The tiles of a row run side by side on one XCD.
+//   sort   : every 1024-record chunk is sorted by index tile in place (HBM-bound streaming pass).
+//   replay : one workgroup per (row, 64 KiB index tile): tile into LDS, apply the tile's segment of every
+//            chunk with LDS operations, store the tile back with plain 16-byte stores and refresh the
+//            tile's filter.
 // The filter of epoch e is exact knowledge of the registers after epoch e-1, so what scatter drops can
 // never matter; epochs double in length (one token per register first), because bounds rise fast early.
 // ---------------------------------------------------------------------------------------
@@ -108,7 +109,7 @@ struct BucketRow {              // one per (genome, k) row of the call: table[ge
     uint32_t* area;             // record stream: chunk c at area + c * 1024; null = row not bucketed
     uint32_t* cursor;           // chunks handed out this epoch (may run past cap_chunks: overflow)
     uint32_t* fill;             // [cap_chunks] valid records of each chunk
-    uint16_t* seg;              // [cap_chunks][8] where each index tile's records start inside a sorted chunk
+    uint16_t* seg;              // [cap_chunks][16] where each index tile's records start inside a sorted chunk
     uint8_t* filter;            // [m >> logg] lower bound per register group
 };
 struct ScatterParams {

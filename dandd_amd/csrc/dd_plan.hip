@@ -82,7 +82,7 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
     // one per doubling -- up to the length whose worst case (every update survives) fits the HBM budget.
     const bool bucket_mode = global_regs && knobs.buckets && knobs.filter;
     const int bucket_logg = knobs.bucket_logg ? knobs.bucket_logg : std::max(2, p - 16);  // a 64 KiB filter
-    const int nb_log2 = std::max(0, p - 17);  // index tiles of 128 KiB
+    const int nb_log2 = std::max(0, p - 16);  // index tiles of 64 KiB
     std::vector<size_t> epoch_edge;           // epoch e covers tiles [epoch_edge[e], epoch_edge[e+1])
     size_t epoch_longest = 0, bucket_row_tokens = 0;
     if (bucket_mode) {

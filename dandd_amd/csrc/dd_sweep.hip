@@ -894,11 +894,11 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
         gstore4(s.fill + cur / kChunkRecords, cur & (kChunkRecords - 1u));
 }
 
-// Between scatter and replay when a row has four or more index tiles (log2m >= 19): every chunk of every
+// Between scatter and replay when a row has more than one index tile (log2m >= 17): every chunk of every
 // stream is sorted by index tile in place (one wave per chunk: LDS counting sort), null records dropped,
 // and the start of each tile's segment is noted in seg[chunk][tile].  A replay workgroup then reads only
-// its own segments; without this every one of the 8 workgroups of a log2m 20 row inspected every record
-// (measured: 42 of 72 ms).  HBM-bound: each record is read and written once more.
+// its own segments; without this every one of the 8 workgroups of a log2m 20 row (128 KiB tiles then)
+// inspected every record (measured: 42 of 72 ms).  HBM-bound: each record is read and written once more.
 __global__ __launch_bounds__(256) void sort_chunks_kernel(const BucketRow* __restrict__ rows, int p, int nb_log2,
                                                          uint32_t cap_chunks, int wgs_per_row) {
     __shared__ uint32_t sorted[4][kChunkRecords];
@@ -925,11 +925,11 @@ __global__ __launch_bounds__(256) void sort_chunks_kernel(const BucketRow* __res
         for (int i = 0; i < 16; ++i)
             if (e[i] >> 24) atomicAdd(&hist[wave][(e[i] & 0xFFFFFFu) >> tshift], 1u);
         __builtin_amdgcn_wave_barrier();
-        // exclusive prefix over the (at most 8) tiles: lanes 0..7
+        // exclusive prefix over the (at most 16) tiles: lanes 0..15
         const uint32_t mine = lane < nb ? hist[wave][lane] : 0u;
         uint32_t incl = mine;
 #pragma unroll
-        for (int d = 1; d < 8; d <<= 1) {
+        for (int d = 1; d < 16; d <<= 1) {
             const uint32_t up = __shfl_up(incl, d);
             if (lane >= (uint32_t)d) incl += up;
         }
@@ -937,7 +937,7 @@ __global__ __launch_bounds__(256) void sort_chunks_kernel(const BucketRow* __res
         __builtin_amdgcn_wave_barrier();
         if (lane < nb) {
             hist[wave][lane] = incl - mine;
-            ((DD_GLOBAL uint16_t*)row.seg)[(size_t)c * 8u + lane] = (uint16_t)(incl - mine);
+            ((DD_GLOBAL uint16_t*)row.seg)[(size_t)c * 16u + lane] = (uint16_t)(incl - mine);
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -957,11 +957,10 @@ __global__ __launch_bounds__(256) void sort_chunks_kernel(const BucketRow* __res
     }
 }
 
-// One workgroup per (row, index tile); LDS: the tile (128 KiB, or m bytes if smaller), then one queue per
-// wave.  Block ids are laid out so that the tiles of one row are consecutive workgroups of ONE XCD
-// (workgroups are dealt round robin over the 8 XCDs in id order): with unsorted chunks they stream the
-// same records at about the same time.
-template <bool SORTED>
+// One workgroup per (row, index tile); LDS: the tile (64 KiB, or m bytes if smaller); two workgroups per
+// CU.  A wave takes every 16th chunk of the row's stream, U at a time, and reads only the segment of its
+// own tile (all of a chunk when the row is a single tile and nothing was sorted); segment headers, records
+// and the LDS work of three consecutive steps overlap.
 __global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restrict__ rows, int nrows, int p, int logg,
                                                      int nb_log2, uint32_t cap_chunks) {
     const uint32_t nb = 1u << nb_log2;
@@ -973,93 +972,68 @@ __global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restric
     const uint32_t handed = gload4(row.cursor);
     if (handed == 0u) return;  // nothing was recorded for this row in this epoch: registers and filter stand
     const uint32_t nchunks = handed < cap_chunks ? handed : cap_chunks;
-    const int tshift = p - nb_log2;
-    const uint32_t tile = 1u << tshift;
+    const uint32_t tile = 1u << (p - nb_log2);
     uint8_t* const tile_g = row.regs + (size_t)b * tile;
     uint4* l4 = reinterpret_cast<uint4*>(g_lds);
     for (uint32_t i = threadIdx.x; i < (tile >> 4); i += blockDim.x) l4[i] = gload16(tile_g + (size_t)i * 16);
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
-    auto apply = [&](uint32_t e) {
+    auto apply = [&](uint32_t e) {  // null records (rho 0) fall through
         const uint32_t rho = e >> 24, a = e & (tile - 1u);
-        if (rho > g_lds[a]) (void)cas_raise<RegsLds>(a, RegsLds::load32(a), rho);
+        const uint32_t w = RegsLds::load32(a);
+        if (rho > ((w >> RegsLds::shift(a)) & 0xFFu)) (void)cas_raise<RegsLds>(a, w, rho);
     };
-    if (SORTED) {
-        // a wave takes every 16th chunk, four at a time: the four segment headers, then the (up to 128)
-        // records of each segment are in flight together
-        constexpr int U = 4;
-        const DD_GLOBAL uint16_t* seg = (const DD_GLOBAL uint16_t*)row.seg;
-        for (uint32_t c = threadIdx.x >> 6; c < nchunks; c += 16u * U) {
-            uint32_t st[U], en[U], r0[U], r1[U];
+    constexpr int U = 4;
+    const DD_GLOBAL uint16_t* seg = (const DD_GLOBAL uint16_t*)row.seg;
+    struct Head {
+        uint32_t st[U], en[U];
+    };
+    struct Recs {
+        uint32_t r0[U], r1[U];
+    };
+    auto heads = [&](uint32_t c, Head& h) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t cc = c + 16u * u;
-                st[u] = en[u] = 0;
-                if (cc < nchunks) {
-                    st[u] = seg[(size_t)cc * 8u + b];
-                    en[u] = b + 1u < nb ? (uint32_t)seg[(size_t)cc * 8u + b + 1u] : gload4(row.fill + cc);
+        for (int u = 0; u < U; ++u) {
+            const uint32_t cc = c + 16u * u;
+            h.st[u] = h.en[u] = 0;
+            if (cc < nchunks) {
+                if (nb > 1u) {
+                    h.st[u] = seg[(size_t)cc * 16u + b];
+                    h.en[u] = b + 1u < nb ? (uint32_t)seg[(size_t)cc * 16u + b + 1u] : gload4(row.fill + cc);
+                } else {
+                    h.en[u] = gload4(row.fill + cc);
                 }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t* base = row.area + (size_t)(c + 16u * u) * kChunkRecords;
-                const uint32_t i0 = st[u] + lane, i1 = i0 + 64u;
-                r0[u] = i0 < en[u] ? gload4(base + i0) : 0u;
-                r1[u] = i1 < en[u] ? gload4(base + i1) : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                apply(r0[u]);
-                apply(r1[u]);
-                const uint32_t* base = row.area + (size_t)(c + 16u * u) * kChunkRecords;
-                for (uint32_t i = st[u] + 128u + lane; i < en[u]; i += 64u) apply(gload4(base + i));  // a segment twice its expected size
             }
         }
-    } else {
-        // Only one record in 2^nb_log2 belongs to this tile, and raising a register is a chain of dependent
-        // LDS operations: records of this tile are first collected in a per-wave queue (behind the tile in
-        // LDS) and applied 64 at a time with every lane busy.
-        const uint32_t queue = tile + (threadIdx.x >> 6) * (kQueueEntries * 4u);
-        uint32_t waiting = 0;
-        auto inspect = [&](uint32_t e) {
-            const bool mine = (e >> 24) != 0u && ((e & 0xFFFFFFu) >> tshift) == b;
-            const unsigned long long mask = __builtin_amdgcn_ballot_w64(mine);
-            if (mask) {
-                if (mine) {
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                    lds32(queue + 4u * (waiting + rank)) = e;
-                }
-                waiting += (uint32_t)__builtin_popcountll(mask);
-                if (waiting >= 64u) {
-                    waiting -= 64u;
-                    apply(lds32(queue + 4u * (waiting + lane)));
-                }
-            }
-        };
-        // every workgroup of the row reads the whole stream: kDepth passes of four chunks (256 threads x 16
-        // bytes per chunk) are kept in flight
-        constexpr int kDepth = 8;
-        const uint32_t sub = threadIdx.x >> 8, off = (threadIdx.x & 255u) * 4u;
-        auto fetch = [&](uint32_t c0, uint4& v) {
-            const uint32_t c = c0 + sub;
-            v = make_uint4(0, 0, 0, 0);
-            if (c < nchunks && off < gload4(row.fill + c)) v = gload16(row.area + (size_t)c * kChunkRecords + off);
-        };
-        uint4 ring[kDepth];
+    };
+    auto records = [&](uint32_t c, const Head& h, Recs& v) {
 #pragma unroll
-        for (int d = 0; d < kDepth; ++d) fetch(4u * d, ring[d]);
-        for (uint32_t c0 = 0; c0 < nchunks; c0 += 4u * kDepth) {
-#pragma unroll
-            for (int d = 0; d < kDepth; ++d) {
-                const uint4 v = ring[d];
-                fetch(c0 + 4u * (kDepth + d), ring[d]);
-                inspect(v.x);
-                inspect(v.y);
-                inspect(v.z);
-                inspect(v.w);
-            }
+        for (int u = 0; u < U; ++u) {
+            const uint32_t* base = row.area + (size_t)(c + 16u * u) * kChunkRecords;
+            const uint32_t i0 = h.st[u] + lane, i1 = i0 + 64u;
+            v.r0[u] = i0 < h.en[u] ? gload4(base + i0) : 0u;
+            v.r1[u] = i1 < h.en[u] ? gload4(base + i1) : 0u;
         }
-        if (lane < waiting) apply(lds32(queue + 4u * lane));
+    };
+    const uint32_t step = 16u * U, c_first = threadIdx.x >> 6;
+    Head h1, h2;
+    Recs v1;
+    heads(c_first, h1);
+    heads(c_first + step, h2);
+    records(c_first, h1, v1);
+    for (uint32_t c = c_first; c < nchunks; c += step) {
+        const Head h0 = h1;
+        const Recs v0 = v1;
+        h1 = h2;
+        heads(c + 2u * step, h2);      // headers two steps ahead
+        records(c + step, h1, v1);     // records one step ahead
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            apply(v0.r0[u]);
+            apply(v0.r1[u]);
+            const uint32_t* base = row.area + (size_t)(c + 16u * u) * kChunkRecords;
+            for (uint32_t i = h0.st[u] + 128u + lane; i < h0.en[u]; i += 64u) apply(gload4(base + i));  // longer than twice the expected size
+        }
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < (tile >> 4); i += blockDim.x) gstore16(tile_g + (size_t)i * 16, l4[i]);
@@ -1166,20 +1140,15 @@ void launch_replay(const BucketRow* rows, int nrows, const SweepPlan& plan, hipS
     if (nrows <= 0) return;
     const size_t tile = (size_t)1 << (plan.log2m - plan.nb_log2);
     const unsigned blocks = (unsigned)((nrows + 7) / 8) * 8u << plan.nb_log2;
-    static std::atomic<unsigned long long> attr_done[2] = {{0}, {0}};
-    if (plan.nb_log2 >= 2) {
-        // four or more tiles per row: sort every chunk by tile first, replay reads its own segments only
+    if (plan.nb_log2 >= 1) {  // several tiles per row: sort every chunk by tile first
         const int wgs_per_row = 32;
         hipLaunchKernelGGL(sort_chunks_kernel, dim3((unsigned)nrows * wgs_per_row), dim3(256), 0, st, rows, plan.log2m,
                            plan.nb_log2, plan.cap_chunks, wgs_per_row);
-        allow_full_lds(reinterpret_cast<const void*>(replay_kernel<true>), attr_done[0]);
-        hipLaunchKernelGGL(replay_kernel<true>, dim3(blocks), dim3(1024), tile, st, rows, nrows, plan.log2m, plan.logg,
-                           plan.nb_log2, plan.cap_chunks);
-    } else {
-        allow_full_lds(reinterpret_cast<const void*>(replay_kernel<false>), attr_done[1]);
-        hipLaunchKernelGGL(replay_kernel<false>, dim3(blocks), dim3(1024), tile + 16 * kQueueEntries * 4, st, rows, nrows,
-                           plan.log2m, plan.logg, plan.nb_log2, plan.cap_chunks);
     }
+    static std::atomic<unsigned long long> attr_done{0};
+    allow_full_lds(reinterpret_cast<const void*>(replay_kernel), attr_done);
+    hipLaunchKernelGGL(replay_kernel, dim3(blocks), dim3(1024), tile, st, rows, nrows, plan.log2m, plan.logg, plan.nb_log2,
+                       plan.cap_chunks);
     hipLaunchKernelGGL(reset_cursors_kernel, dim3((unsigned)(nrows + 255) / 256), dim3(256), 0, st, rows, nrows);
 }
 
