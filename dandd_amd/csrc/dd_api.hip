@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <zlib.h>
@@ -99,6 +100,8 @@ struct TimedSpan {
     hipEvent_t a, b;
 };
 
+struct FileBuf;  // host bytes of one file (below)
+
 }  // namespace
 
 struct dd_ctx {
@@ -121,6 +124,14 @@ struct dd_ctx {
         std::vector<size_t> job_off;
     } plan;
     hipEvent_t stage_free = nullptr;  // signalled when the last upload from `stage` completed
+    // ingestion pipeline (dd_sketch_files): pinned host buffers for the loader threads, a copy stream, two
+    // device buffer sets (FASTA bytes in, register slabs out) and two pinned bounce buffers for the results
+    std::vector<FileBuf*> file_pool;
+    hipStream_t copy_stream = nullptr, out_stream = nullptr;  // H2D and D2H on streams of their own: an in-order stream would park batch b+1's upload behind batch b's results
+    DevBuf pipe_fasta[2], pipe_regs[2];
+    HostBuf pipe_out[2];
+    hipEvent_t pipe_h2d[2] = {nullptr, nullptr}, pipe_done[2] = {nullptr, nullptr}, pipe_d2h[2] = {nullptr, nullptr};
+    double ingest_ms[4] = {0, 0, 0, 0};  // last dd_sketch_files call: wall, waiting for loaders, batches, bytes (as a double)
     // stats of the last sketch call
     uint64_t st_tokens = 0, st_updates = 0;
     int st_blocks = 0;
@@ -179,26 +190,45 @@ int upload(dd_ctx* c, HostBuf& stage, void* dst_dev, const void* src, size_t byt
     return DD_OK;
 }
 
-// Host bytes of one file: malloc/realloc storage that is reused from file to file (no zero fill, no
-// fresh mappings per file -- with 16 loader threads the page-fault traffic of per-file vectors slowed
-// the GPU-driving thread's own copies 20x through the shared address-space lock).
+// Host bytes of one file.  Pageable flavour: malloc storage in 2 MiB-aligned blocks the kernel may back
+// with huge pages (512x fewer page faults for a 250 MB .. 3 GB buffer).  Pinned flavour (the ingestion
+// pipeline's pool): hipHostMalloc storage, so the H2D copy of a loaded file is a true asynchronous DMA at
+// PCIe speed; pinning is slow, which is why those buffers live in the context and are reused from file
+// to file and from call to call.  Contents are carried over when a buffer grows.
 struct FileBuf {
     uint8_t* p = nullptr;
     size_t len = 0, cap = 0;
+    bool pinned = false;
     FileBuf() = default;
     FileBuf(const FileBuf&) = delete;
     FileBuf& operator=(const FileBuf&) = delete;
-    ~FileBuf() { free(p); }
+    ~FileBuf() { release(); }
+    void release() {
+        if (p) {
+            if (pinned) (void)hipHostFree(p);
+            else free(p);
+        }
+        p = nullptr;
+        len = cap = 0;
+    }
     bool reserve(size_t n) {
         if (n <= cap) return true;
-        // whole files: 2 MiB-aligned blocks the kernel may back with huge pages (512x fewer page
-        // faults to fill and to tear down a 250 MB .. 3 GB buffer); contents are carried over
         const size_t want = (n + kHuge - 1) / kHuge * kHuge;
         void* q = nullptr;
-        if (posix_memalign(&q, kHuge, want) != 0 || !q) return false;
-        (void)madvise(q, want, MADV_HUGEPAGE);
+        if (pinned) {
+            if (hipHostMalloc(&q, want, hipHostMallocDefault) != hipSuccess || !q) {
+                (void)hipGetLastError();
+                return false;
+            }
+        } else {
+            if (posix_memalign(&q, kHuge, want) != 0 || !q) return false;
+            (void)madvise(q, want, MADV_HUGEPAGE);
+        }
         if (len) memcpy(q, p, len);
-        free(p);
+        if (p) {
+            if (pinned) (void)hipHostFree(p);
+            else free(p);
+        }
         p = static_cast<uint8_t*>(q);
         cap = want;
         return true;
@@ -248,6 +278,22 @@ bool read_fasta_file(const char* path, FileBuf& out, std::string& err) {
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// CPUs this process may really use: the affinity mask capped by the cgroup quota (a container that shows
+// 256 logical CPUs behind a 16-CPU quota must not get 256 loader threads)
+int usable_cpus() {
+    int n = (int)std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::max(1, CPU_COUNT(&set));
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32];
+        long period = 0;
+        if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0)
+            n = std::min(n, std::max(1, (int)(atol(quota) / period)));
+        fclose(f);
+    }
+    return n;
+}
 
 int check_ctx(dd_ctx* c) {
     if (!c) return fail(DD_EINVAL, "null context");
@@ -330,6 +376,16 @@ void dd_destroy(dd_ctx* c) {
     c->stage.release();
     c->stage_jobs.release();
     c->stage_rows.release();
+    for (FileBuf* fb : c->file_pool) delete fb;
+    for (int i = 0; i < 2; ++i) {
+        c->pipe_fasta[i].release();
+        c->pipe_regs[i].release();
+        c->pipe_out[i].release();
+        for (hipEvent_t e : {c->pipe_h2d[i], c->pipe_done[i], c->pipe_d2h[i]})
+            if (e) (void)hipEventDestroy(e);
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->out_stream) (void)hipStreamDestroy(c->out_stream);
     delete c;
 }
 
@@ -588,8 +644,16 @@ int dd_sketch_fasta(dd_ctx* c, const char* path, int kmin, int kmax, uint8_t* re
 }
 
 // Many FASTA files (plain or .gz, as DandD's species directories hold them,
-// /root/reference/lib/species_specifics.py:93): loader threads read + inflate ahead while the
-// GPU sketches the files already in memory, in order; regs is [nfiles][K][m] on the host.
+// /root/reference/lib/species_specifics.py:93); regs is [nfiles][K][m] on the host.  A pipeline:
+//   loader threads   read + inflate into pinned host buffers of the context's pool, ahead of the GPU,
+//                    bounded by the pool (a directory of whole genomes cannot exhaust host memory);
+//   copy stream      H2D of batch b+1 while the compute stream sketches batch b, D2H of batch b-1's
+//                    register slabs into a pinned bounce buffer (event-chained, no per-file sync);
+//   compute stream   ONE dd_sketch_device launch per batch -- consecutive small files are coalesced until a
+//                    batch holds ~128 MB, so a directory of 5 Mbp genomes fills the chip instead of
+//                    launching 77 workgroups per file.
+// The reference's loop is one genome at a time, each re-read and re-inflated once per k
+// (lib/huffman_dandd.py:402-407).
 int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, int kmax, uint8_t* regs,
                     int nthreads) {
     if (check_ctx(c)) return DD_EINVAL;
@@ -598,48 +662,138 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
     for (int i = 0; i < nfiles; ++i)
         if (!paths[i]) return fail(DD_EINVAL, "null path at index %d", i);
     if (!nfiles) return DD_OK;
-    if (nthreads <= 0) nthreads = (int)std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
-    nthreads = std::min(nthreads, nfiles);
+    DeviceGuard guard(c->device);
+    if (nthreads <= 0) nthreads = std::min(16, usable_cpus());
     const size_t slab = (size_t)(kmax - kmin + 1) << c->p;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    const bool trace = getenv("DD_TRACE_FILES") != nullptr;
 
-    // Read-ahead is bounded by a pool of `window` host buffers that are reused from file to file:
-    // a directory of whole genomes cannot exhaust host memory, and after the first few files the
-    // loaders touch no fresh pages.
-    const int window = nthreads + 2;
-    std::vector<FileBuf> pool_bufs(window);
+    // batch size in files: ~128 MB of FASTA per launch, judged by what is on disk (a .gz inflates ~4x)
+    size_t disk_bytes = 0;
+    for (int i = 0; i < nfiles; ++i) {
+        struct stat sb;
+        if (stat(paths[i], &sb) == 0 && sb.st_size > 0) {
+            const size_t n = (size_t)sb.st_size, L = strlen(paths[i]);
+            disk_bytes += (L > 3 && strcmp(paths[i] + L - 3, ".gz") == 0) ? 4 * n : n;
+        }
+    }
+    const size_t avg = std::max<size_t>(1, disk_bytes / (size_t)nfiles);
+    const size_t kBatchBytes = (size_t)(getenv("DD_BATCH_MB") ? std::max(1, atoi(getenv("DD_BATCH_MB"))) : 128) << 20;
+    const int batch_files = (int)std::max<size_t>(1, std::min<size_t>(64, kBatchBytes / avg));
+    // loaders may run two batches ahead of the GPU
+    const int window = std::max(nthreads + 2, 2 * batch_files + nthreads);
+    while ((int)c->file_pool.size() < window) {
+        FileBuf* fb = new FileBuf();
+        fb->pinned = true;
+        c->file_pool.push_back(fb);
+    }
+    if (!c->copy_stream) {
+        DD_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        DD_HIP(hipStreamCreateWithFlags(&c->out_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            DD_HIP(hipEventCreateWithFlags(&c->pipe_h2d[i], hipEventDisableTiming));
+            DD_HIP(hipEventCreateWithFlags(&c->pipe_done[i], hipEventDisableTiming));
+            DD_HIP(hipEventCreateWithFlags(&c->pipe_d2h[i], hipEventDisableTiming));
+        }
+    }
+
     std::vector<int> free_bufs;
     for (int b = 0; b < window; ++b) free_bufs.push_back(b);
     struct Slot {
         int buf = -1;
         std::string err;
-        bool ok = false, done = false;
+        bool ok = true, done = false;
+        bool claimed = false, ready = false;  // a loader took the file's buffer / the buffer can be written to
+        int pieces_left = 0;
+        size_t plain_size = 0;                // > 0: not gzip, read in pieces by several loaders
     };
     std::vector<Slot> slots(nfiles);
+    // Work items in file order.  A plain file is cut into 8 MiB pieces that different loaders pread into the
+    // file's pinned buffer -- the first file of a directory is then in memory after one piece-time instead of
+    // one file-time, which is what the GPU waits for at the start; a gzip file is one item (zlib is serial).
+    struct Item {
+        int file;
+        size_t off, len;  // len 0: the whole file through zlib
+    };
+    std::vector<Item> items;
+    const size_t kPiece = (size_t)8 << 20;
+    for (int i = 0; i < nfiles; ++i) {
+        struct stat sb;
+        unsigned char magic[2] = {0, 0};
+        bool plain = false;
+        if (stat(paths[i], &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+            if (FILE* f = fopen(paths[i], "rb")) {
+                plain = fread(magic, 1, 2, f) == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b);
+                fclose(f);
+            }
+        }
+        if (plain) {
+            slots[i].plain_size = (size_t)sb.st_size;
+            for (size_t off = 0; off < slots[i].plain_size; off += kPiece) {
+                items.push_back(Item{i, off, std::min(kPiece, slots[i].plain_size - off)});
+                ++slots[i].pieces_left;
+            }
+        } else {
+            items.push_back(Item{i, 0, 0});
+            slots[i].pieces_left = 1;
+        }
+    }
     std::mutex mu;
     std::condition_variable cv;
-    std::atomic<int> next{0};
-    int consumed = 0;  // files handed to the GPU so far (guarded by mu)
+    std::atomic<size_t> next{0};
+    int consumed = 0;  // files whose host buffer went back to the pool (guarded by mu)
+    const int device = c->device;
     auto loader = [&]() {
+        (void)hipSetDevice(device);  // pinned allocations belong to the context's device
         for (;;) {
-            const int i = next.fetch_add(1);
-            if (i >= nfiles) return;
-            int b;
+            const size_t w = next.fetch_add(1);
+            if (w >= items.size()) return;
+            const Item it = items[w];
+            Slot& sl = slots[it.file];
+            bool mine = false;  // this loader sets the file's buffer up
             {
                 // Only files consumed .. consumed+window-1 may hold a buffer: they are consumed in
                 // order, so a later file must never take the buffer an earlier one is waiting for.
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return i < consumed + window && !free_bufs.empty(); });
-                b = free_bufs.back();
-                free_bufs.pop_back();
+                if (!sl.claimed) {
+                    sl.claimed = mine = true;
+                    cv.wait(lk, [&] { return it.file < consumed + window && !free_bufs.empty(); });
+                    sl.buf = free_bufs.back();
+                    free_bufs.pop_back();
+                } else {
+                    cv.wait(lk, [&] { return sl.ready; });
+                }
             }
+            FileBuf& fb = *c->file_pool[sl.buf];
             std::string err;
-            const bool ok = read_fasta_file(paths[i], pool_bufs[b], err);
+            bool ok = true;
+            if (mine) {
+                fb.len = 0;
+                if (sl.plain_size) {
+                    ok = fb.reserve(sl.plain_size + 16);
+                    if (ok) fb.len = sl.plain_size;
+                    else err = std::string("out of pinned host memory reading ") + paths[it.file];
+                }
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    sl.ready = true;
+                    if (!ok) sl.ok = false, sl.err = err;
+                }
+                cv.notify_all();
+            }
+            if (it.len == 0) {
+                ok = read_fasta_file(paths[it.file], fb, err);
+            } else if (ok && fb.cap >= sl.plain_size) {
+                FILE* f = fopen(paths[it.file], "rb");
+                ok = f && fseeko(f, (off_t)it.off, SEEK_SET) == 0 && fread(fb.p + it.off, 1, it.len, f) == it.len;
+                if (!ok) err = std::string("read error on ") + paths[it.file];
+                if (f) fclose(f);
+            }
             {
                 std::lock_guard<std::mutex> lk(mu);
-                slots[i].buf = b;
-                slots[i].err.swap(err);
-                slots[i].ok = ok;
-                slots[i].done = true;
+                if (!ok && sl.ok) sl.ok = false, sl.err = err;
+                if (--sl.pieces_left == 0) sl.done = true;
             }
             cv.notify_all();
         }
@@ -649,40 +803,159 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
 
     int rc = DD_OK;
     std::string first_err;
-    const bool trace = getenv("DD_TRACE_FILES") != nullptr;
-    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t_wait = 0, t_sketch = 0;
-    for (int i = 0; i < nfiles; ++i) {
+    double t_wait = 0;
+    int nbatches = 0;
+    size_t total_bytes = 0;
+    struct InFlight {
+        int first = 0, count = 0;   // files of the batch
+        bool active = false;
+    };
+    InFlight fly[2];
+    // hand a finished batch's results to the caller and its host buffers back to the pool
+    auto retire = [&](int set) -> int {
+        InFlight& f = fly[set];
+        if (!f.active) return DD_OK;
+        f.active = false;
+        if (hipEventSynchronize(c->pipe_d2h[set]) != hipSuccess) return fail(DD_EHIP, "ingestion pipeline: D2H failed");
+        memcpy(regs + (size_t)f.first * slab, c->pipe_out[set].p, (size_t)f.count * slab);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (int i = f.first; i < f.first + f.count; ++i) free_bufs.push_back(slots[i].buf);
+            consumed = f.first + f.count;
+        }
+        cv.notify_all();
+        return DD_OK;
+    };
+    auto release_unsent = [&](int first, int count) {  // error path: the loaders must never wait for ever
+        std::lock_guard<std::mutex> lk(mu);
+        for (int i = first; i < first + count; ++i)
+            if (slots[i].buf >= 0) free_bufs.push_back(slots[i].buf);
+        consumed = first + count;
+    };
+
+    int i = 0;
+    while (i < nfiles) {
+        // the next batch: consecutive files, as many as are wanted and already loaded (at least one)
+        const int set = nbatches & 1;
         const double ta = now();
+        int count = 0;
         {
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return slots[i].done; });
+            // as many as a batch wants and are already loaded (at least one): the GPU is never kept waiting for a
+            // full batch; equal batches also let dd_sketch_device reuse its job tables and the buffers below
+            while (count < batch_files && i + count < nfiles && slots[i + count].done) ++count;
         }
-        const double tb = now();
-        t_wait += tb - ta;
+        t_wait += now() - ta;
         if (rc == DD_OK) {
-            if (!slots[i].ok) {
-                rc = DD_EIO;
-                first_err = slots[i].err;
-            } else {
-                const FileBuf& hb = pool_bufs[slots[i].buf];
-                rc = dd_sketch_buffer(c, hb.data(), hb.size(), kmin, kmax, regs + (size_t)i * slab);
-                if (rc != DD_OK) first_err = g_err;
-            }
+            for (int j = i; j < i + count; ++j)
+                if (!slots[j].ok) {
+                    rc = DD_EIO;
+                    first_err = slots[j].err;
+                    break;
+                }
         }
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            free_bufs.push_back(slots[i].buf);
-            consumed = i + 1;
+        if (rc != DD_OK) {  // drain: give every buffer back as its file arrives
+            release_unsent(i, count);
+            cv.notify_all();
+            i += count;
+            continue;
         }
-        cv.notify_all();
-        t_sketch += now() - tb;
-        if (trace && (i < 4 || i == nfiles - 1))
-            fprintf(stderr, "[dd_sketch_files] file %d: waited %.2f ms for the loader, sketched in %.2f ms\n", i, tb - ta, now() - tb);
+        // this buffer set was used by batch nbatches-2: finish that one first
+        const double tr = now();
+        if ((rc = retire(set)) != DD_OK) {
+            first_err = g_err;
+            continue;
+        }
+        const double ti = now();
+        std::vector<size_t> sizes(count), offs(count);
+        size_t tot = 0;
+        for (int j = 0; j < count; ++j) {
+            sizes[j] = c->file_pool[slots[i + j].buf]->size();
+            offs[j] = tot;
+            tot += align_up(sizes[j] + 16, 256);
+        }
+        total_bytes += tot;
+        // (growing a device buffer frees the old one: the compute stream may still read it for the batch before
+        // last only if that batch has not been retired -- it has, above)
+        if ((rc = c->pipe_fasta[set].reserve(tot + 16)) != DD_OK || (rc = c->pipe_regs[set].reserve((size_t)count * slab)) != DD_OK ||
+            (rc = c->pipe_out[set].reserve((size_t)count * slab)) != DD_OK) {
+            first_err = g_err;
+            release_unsent(i, count);
+            cv.notify_all();
+            i += count;
+            continue;
+        }
+        hipError_t e = hipSuccess;
+        std::vector<const uint8_t*> ptrs(count);
+        for (int j = 0; j < count && e == hipSuccess; ++j) {
+            ptrs[j] = static_cast<const uint8_t*>(c->pipe_fasta[set].p) + offs[j];
+            if (sizes[j])
+                e = hipMemcpyAsync(const_cast<uint8_t*>(ptrs[j]), c->file_pool[slots[i + j].buf]->data(), sizes[j],
+                                   hipMemcpyHostToDevice, c->copy_stream);
+        }
+        if (e == hipSuccess) e = hipEventRecord(c->pipe_h2d[set], c->copy_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->pipe_h2d[set], 0);
+        if (e == hipSuccess) {
+            rc = dd_sketch_device(c, ptrs.data(), sizes.data(), count, kmin, kmax, static_cast<uint8_t*>(c->pipe_regs[set].p));
+            if (rc != DD_OK) first_err = g_err;
+        }
+        if (e == hipSuccess && rc == DD_OK) e = hipEventRecord(c->pipe_done[set], c->stream);
+        if (e == hipSuccess && rc == DD_OK) e = hipStreamWaitEvent(c->out_stream, c->pipe_done[set], 0);
+        if (e == hipSuccess && rc == DD_OK)
+            e = hipMemcpyAsync(c->pipe_out[set].p, c->pipe_regs[set].p, (size_t)count * slab, hipMemcpyDeviceToHost, c->out_stream);
+        if (e == hipSuccess && rc == DD_OK) e = hipEventRecord(c->pipe_d2h[set], c->out_stream);
+        if (e != hipSuccess && rc == DD_OK) {
+            rc = DD_EHIP;
+            first_err = std::string("ingestion pipeline: ") + hipGetErrorString(e);
+        }
+        if (rc != DD_OK) {
+            (void)hipStreamSynchronize(c->copy_stream);  // nothing may still read the host buffers
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipStreamSynchronize(c->out_stream);
+            release_unsent(i, count);
+            cv.notify_all();
+        } else {
+            fly[set].first = i;
+            fly[set].count = count;
+            fly[set].active = true;
+            ++nbatches;
+        }
+        if (trace)
+            fprintf(stderr, "[dd_sketch_files] t=%.2f batch %d: files %d..%d (%.1f MB): waited %.2f ms for loaders, %.2f ms retiring, %.2f ms issuing\n",
+                    now() - t_begin, nbatches - 1, i, i + count - 1, tot / 1e6, tr - ta, ti - tr, now() - ti);
+        i += count;
     }
-    if (trace) fprintf(stderr, "[dd_sketch_files] %d files: %.1f ms waiting for loaders, %.1f ms sketching\n", nfiles, t_wait, t_sketch);
+    // batches retire in order: the older of the two first
+    for (int k2 = 0; k2 < 2; ++k2) {
+        const int set = (nbatches + k2) & 1;
+        if (rc == DD_OK) {
+            if ((rc = retire(set)) != DD_OK) first_err = g_err;
+        } else if (fly[set].active) {
+            (void)hipStreamSynchronize(c->copy_stream);
+            release_unsent(fly[set].first, fly[set].count);
+            fly[set].active = false;
+            cv.notify_all();
+        }
+    }
     for (auto& t : pool) t.join();
+    c->ingest_ms[0] = now() - t_begin;
+    c->ingest_ms[1] = t_wait;
+    c->ingest_ms[2] = nbatches;
+    c->ingest_ms[3] = (double)total_bytes;
+    if (trace)
+        fprintf(stderr, "[dd_sketch_files] %d files, %d batches of <= %d files, %.1f ms (%.1f ms waiting for loaders), %.1f MB\n",
+                nfiles, nbatches, batch_files, c->ingest_ms[0], t_wait, total_bytes / 1e6);
     if (rc != DD_OK) return fail(rc, "%s", first_err.c_str());
+    return DD_OK;
+}
+
+int dd_last_ingest_stats(dd_ctx* c, double* wall_ms, double* loader_wait_ms, int* batches, uint64_t* bytes) {
+    if (check_ctx(c)) return DD_EINVAL;
+    if (wall_ms) *wall_ms = c->ingest_ms[0];
+    if (loader_wait_ms) *loader_wait_ms = c->ingest_ms[1];
+    if (batches) *batches = (int)c->ingest_ms[2];
+    if (bytes) *bytes = (uint64_t)c->ingest_ms[3];
     return DD_OK;
 }
 

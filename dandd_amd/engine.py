@@ -21,7 +21,7 @@ KERNEL_PACK, KERNEL_SWEEP, KERNEL_UNION = 0, 1, 2
 
 EXPORTS = [
     "dd_abi_version", "dd_last_error", "dd_create", "dd_destroy", "dd_set_stream", "dd_synchronize",
-    "dd_sketch_buffer", "dd_sketch_fasta", "dd_sketch_files", "dd_sketch_device", "dd_union", "dd_union_device",
+    "dd_sketch_buffer", "dd_sketch_fasta", "dd_sketch_files", "dd_last_ingest_stats", "dd_sketch_device", "dd_union", "dd_union_device",
     "dd_card", "dd_card_batch", "dd_card_batch_device", "dd_hist_batch_device", "dd_ertl_mle",
     "dd_progressive", "dd_progressive_device", "dd_pairwise", "dd_pairwise_device",
     "dd_exact_count", "dd_exact_count_device",
@@ -82,6 +82,8 @@ def load_library(path=None):
     lib.dd_sketch_fasta.argtypes = [vp, C.c_char_p, i32, i32, vp]
     lib.dd_sketch_files.restype = i32
     lib.dd_sketch_files.argtypes = [vp, C.POINTER(C.c_char_p), i32, i32, i32, vp, i32]
+    lib.dd_last_ingest_stats.restype = i32
+    lib.dd_last_ingest_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32), C.POINTER(u64)]
     lib.dd_sketch_device.restype = i32
     lib.dd_sketch_device.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), i32, i32, i32, vp]
     lib.dd_union.restype = i32
@@ -224,6 +226,12 @@ class Engine:
         regs = np.empty((n, kmax - kmin + 1, self.m), dtype=np.uint8)
         self._check(self._lib.dd_sketch_files(self._ctx, arr, n, kmin, kmax, regs.ctypes.data, int(nthreads)))
         return regs
+
+    def last_ingest_stats(self):
+        """(wall ms, ms waiting for the loader threads, batched launches, FASTA bytes) of the last sketch_files."""
+        w, l, b, n = C.c_double(), C.c_double(), C.c_int(), C.c_uint64()
+        self._check(self._lib.dd_last_ingest_stats(self._ctx, C.byref(w), C.byref(l), C.byref(b), C.byref(n)))
+        return w.value, l.value, b.value, n.value
 
     def sketch_device(self, fasta_ptrs, nbytes, kmin, kmax, regs_ptr):
         """Batched HBM-resident sketch: device addresses in, regs_ptr[ng][K][m] device address out."""

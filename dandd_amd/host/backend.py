@@ -21,75 +21,154 @@ import numpy as np
 MAGIC = b"DDHLL\x01\x00\x00"
 _HDR = struct.Struct("<8sBBBB")  # magic, log2m, k, canonical, reserved
 
+# Two containers live under the reference's `.hll` names (lib/sketch_classes.py:47-52,100,110):
+#   native  : 12-byte header + 2^log2m register bytes -- what this engine writes by default (no zlib pass
+#             over every sketch of every k);
+#   dashing : Dashing's own container (gzip or plain: `-z` is optional there), so a sketch directory made by
+#             a real DandD + Dashing can be read and, with DANDD_SKETCH_FORMAT=dashing, extended in place.
+# Reading detects the container by its first bytes; writing follows the switch.  Dashing's 32-byte header is
+# taken from the published sketch library as recalled -- no Dashing binary exists here to check it against
+# (DESIGN.md section 6); the register bytes are the part this repo verifies.
+_DASH = struct.Struct("<5IId")  # is_calculated, clamp, estimator, joint estimator, nthreads; np; cached value
+_ERTL_MLE, _ERTL_JOINT_MLE = 2, 3
 
-def write_sketch_file(path, regs, log2m, k, canonical):
-    """One HLL sketch on disk: 12-byte header + 2^log2m register bytes."""
+
+def sketch_format():
+    fmt = os.environ.get("DANDD_SKETCH_FORMAT", "native").lower()
+    if fmt not in ("native", "dashing", "dashing-plain"):
+        raise ValueError(f"DANDD_SKETCH_FORMAT={fmt!r}: expected native, dashing or dashing-plain")
+    return fmt
+
+
+def _name_k(path):
+    """k from a sketch file NAME (Dashing's container does not hold it): `.w.<k>.spacing.` or `k<k>[nc].hll`."""
+    import re
+    base = os.path.basename(path)
+    m = re.search(r"\.w\.(\d+)\.spacing\.", base) or re.search(r"k(\d+)(?:nc)?\.hll$", base)
+    return int(m.group(1)) if m else 0
+
+
+def write_sketch_file(path, regs, log2m, k, canonical, fmt=None):
+    """One HLL sketch on disk, in the container DANDD_SKETCH_FORMAT selects."""
     regs = np.ascontiguousarray(regs, dtype=np.uint8)
     if regs.size != (1 << log2m):
         raise ValueError("register count does not match log2m")
-    tmp = path + ".tmp"
-    with open(tmp, "wb") as f:
-        f.write(_HDR.pack(MAGIC, log2m, k, 1 if canonical else 0, 0))
-        f.write(regs.tobytes())
+    fmt = fmt or sketch_format()
+    tmp = f"{path}.{os.getpid()}.tmp"  # per process: ranks of a multi-GPU run share the sketch directory
+    if fmt == "native":
+        with open(tmp, "wb") as f:
+            f.write(_HDR.pack(MAGIC, log2m, k, 1 if canonical else 0, 0))
+            f.write(regs.tobytes())
+    else:
+        head = _DASH.pack(0, 0, _ERTL_MLE, _ERTL_JOINT_MLE, 1, log2m, 0.0)
+        if fmt == "dashing":
+            import gzip
+            with gzip.open(tmp, "wb", compresslevel=6) as f:
+                f.write(head)
+                f.write(regs.tobytes())
+        else:
+            with open(tmp, "wb") as f:
+                f.write(head)
+                f.write(regs.tobytes())
     os.replace(tmp, path)
 
 
 def read_sketch_file(path):
+    """-> (registers, log2m, k, canonical) from either container."""
     with open(path, "rb") as f:
         raw = f.read()
-    if len(raw) < _HDR.size:
+    if raw[:8] == MAGIC:
+        magic, log2m, k, canonical, _ = _HDR.unpack_from(raw)
+        regs = np.frombuffer(raw, dtype=np.uint8, offset=_HDR.size)
+        if regs.size != (1 << log2m):
+            raise ValueError(f"{path}: expected {1 << log2m} registers, found {regs.size}")
+        return regs, log2m, k, bool(canonical)
+    if raw[:2] == b"\x1f\x8b":
+        import gzip
+        raw = gzip.decompress(raw)
+    if len(raw) < _DASH.size:
         raise ValueError(f"{path}: truncated sketch file")
-    magic, log2m, k, canonical, _ = _HDR.unpack_from(raw)
-    if magic != MAGIC:
-        raise ValueError(f"{path}: not a dandd_amd sketch file")
-    regs = np.frombuffer(raw, dtype=np.uint8, offset=_HDR.size)
-    if regs.size != (1 << log2m):
-        raise ValueError(f"{path}: expected {1 << log2m} registers, found {regs.size}")
-    return regs, log2m, k, bool(canonical)
+    _calc, _clamp, _est, _jest, _nthr, np_, _value = _DASH.unpack_from(raw)
+    regs = np.frombuffer(raw, dtype=np.uint8, offset=_DASH.size)
+    if not 4 <= np_ <= 32 or regs.size != (1 << np_):
+        raise ValueError(f"{path}: neither a dandd_amd nor a Dashing sketch file")
+    # k and the canonical flag are not in Dashing's container: k comes from the file name, and DandD marks
+    # non-canonical unions with an `nc` suffix (leaves carry no marker, SURVEY.md section 9)
+    return regs, int(np_), _name_k(path), not os.path.basename(path).endswith("nc.hll")
 
 
 class HipExactBackend:
     """`--exact`: the KMC branch of the reference (lib/sketch_classes.py:377-465), which counts
     distinct canonical k-mers exactly.  A "database" here is a small JSON file naming the FASTAs it
-    covers; the cardinality is computed on the GPU (sort + distinct, dd_exact_count).  The
-    reference's own KMC branch recurses forever at this commit; this one works."""
+    covers (base names plus the directories they were seen in) and, once it has been asked for, their
+    exact distinct k-mer count -- computed on the GPU (sort + distinct, dd_exact_count).  Like a KMC
+    database it answers `info` on its own afterwards, and it survives a moved genome directory as long as
+    DANDD_GENOMEDIR (or the recorded directory) still holds files of those names.  The reference's own KMC
+    branch recurses forever at this commit; this one works."""
 
     name = "hip-exact"
 
     def __init__(self, log2m=20, canonical=True, device=0):
         from ..engine import Engine
         self.canonical = bool(canonical)
-        self.engine = Engine(device=device, log2m=14, canonical=self.canonical)
+        # the register count plays no part in exact counting; the context only needs a valid one
+        self.engine = Engine(device=device, log2m=max(4, min(20, int(log2m))), canonical=self.canonical)
 
     def describe(self, op, **kw):
         args = " ".join(f"{k}={v}" for k, v in kw.items())
         return f"hip-exact:{op} canonical={int(self.canonical)} {args}".strip()
 
     @staticmethod
-    def _write(path, k, fastas):
+    def _write(path, db):
         import json
-        tmp = path + ".tmp"
+        tmp = f"{path}.{os.getpid()}.tmp"
         with open(tmp, "w") as f:
-            json.dump({"k": int(k), "fastas": sorted(set(fastas))}, f)
+            json.dump(db, f)
         os.replace(tmp, path)
 
     @staticmethod
     def _read(path):
         import json
         with open(path) as f:
-            return json.load(f)
+            db = json.load(f)
+        if "names" not in db:  # round-1 files: absolute paths only
+            db["names"] = [os.path.basename(p) for p in db["fastas"]]
+            db["dirs"] = sorted({os.path.dirname(p) for p in db["fastas"]})
+        return db
+
+    @staticmethod
+    def _locate(db):
+        dirs = [d for d in [os.environ.get("DANDD_GENOMEDIR")] + list(db.get("dirs", [])) if d]
+        found = []
+        for name in db["names"]:
+            for d in dirs:
+                cand = os.path.join(d, name)
+                if os.path.exists(cand):
+                    found.append(cand)
+                    break
+            else:
+                raise FileNotFoundError(f"{name}: not in {dirs} (set DANDD_GENOMEDIR to where the genomes are now)")
+        return found
 
     def leaf(self, fasta, ks, out_paths):
+        full = os.path.abspath(fasta)
         for k, out in zip(ks, out_paths):
-            self._write(out, k, [os.path.abspath(fasta)])
+            self._write(out, {"k": int(k), "canonical": self.canonical, "names": [os.path.basename(full)],
+                              "dirs": [os.path.dirname(full)]})
 
     def union(self, in_paths, out_path):
         parts = [self._read(p) for p in in_paths]
-        self._write(out_path, parts[0]["k"], [f for p in parts for f in p["fastas"]])
+        self._write(out_path, {"k": parts[0]["k"], "canonical": self.canonical,
+                               "names": sorted({n for p in parts for n in p["names"]}),
+                               "dirs": sorted({d for p in parts for d in p.get("dirs", [])})})
 
     def card(self, path):
         db = self._read(path)
-        return float(self.engine.exact_count(db["fastas"], db["k"]))
+        if db.get("distinct") is None:
+            db["distinct"] = int(self.engine.exact_count(self._locate(db), db["k"]))
+            db.pop("fastas", None)
+            self._write(path, db)
+        return float(db["distinct"])
 
     def close(self):
         self.engine.close()

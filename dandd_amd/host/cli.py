@@ -37,8 +37,9 @@ def tree_command(args):
 
 
 def _load_tree(path):
-    with open(path, "rb") as f:
-        return pickle.load(f)
+    """A tree pickle written by this package or by the reference itself (dandd_amd/host/compat.py)."""
+    from .compat import load_tree
+    return load_tree(path)
 
 
 def progressive_command(args):
@@ -50,6 +51,15 @@ def progressive_command(args):
     exp.update(debug=args.debug, safety=args.safety, fast=args.fast, verbose=args.verbose, lowmem=args.lowmem,
                baseset=set(), ksweep=(int(args.mink), int(args.maxk)) if args.ksweep else None)
     tree.speciesinfo.update(tool=exp["tool"])
+    if deltatree.dist_ranks()[0] != 0:
+        # rank > 0 of a multi-GPU run: its share of the leaf sketches the sweep needs, then done.  The spider
+        # over the run's FASTAs is the one rank 0 builds inside progressive_union; both meet at its barrier.
+        try:
+            deltatree.DeltaSpider(fasta_files=tree.progressive_fastas(args.flist_loc), speciesinfo=tree.speciesinfo,
+                                  experiment=exp)
+        except deltatree.WorkerDone:
+            pass
+        return
     results, summary = tree.progressive_wrapper(flist_loc=args.flist_loc, count=args.norderings,
                                                 ordering_file=args.ordering_file, step=args.step)
     write_listdict_to_csv(outfile + ".csv", results)
@@ -71,6 +81,11 @@ def kij_command(args):
         sub = []
     if args.ksweep:
         tree.experiment["ksweep"] = (int(args.mink), int(args.maxk))
+    if deltatree.dist_ranks()[1] > 1:
+        # every rank sketches its share of the leaves for the whole range; rank 0 finishes alone
+        tree.presketch_range(int(args.mink), int(args.maxk))
+        if deltatree.dist_ranks()[0] != 0:
+            return
     tree.ksweep(mink=int(args.mink), maxk=int(args.maxk))
     kij_rows, j_rows = tree.pairwise_spiders(sublist=sub, mink=args.mink, maxk=args.maxk, jaccard=args.jaccard)
     write_listdict_to_csv(outfile + ".kij.csv", kij_rows)
@@ -140,22 +155,27 @@ def build_parser():
 
 
 def main(argv=None):
-    rank, world = deltatree.dist_ranks()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     if world > 1:
-        # one process per GPU (torch.distributed.run): `tree` shards the leaf sketches over the ranks and
-        # hands them over through the shared sketch directory; the process group is only a barrier
+        # one process per GPU (torch.distributed.run): every sub-command shards the leaf sketches it needs
+        # over the ranks and hands them over through the shared sketch directory; the process group is only
+        # a barrier
         import torch.distributed as dist
         if not dist.is_initialized():
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        deltatree.set_dist_active(True)
     elif "torch" not in sys.modules:  # stand-alone process: no torch anywhere on this path (engine.load_library)
         os.environ.setdefault("DANDD_NO_TORCH", "1")
-    args = build_parser().parse_args(sys.argv[1:] if argv is None else argv)
-    if world == 1 or rank == 0 or args.func is tree_command:
+    try:
+        args = build_parser().parse_args(sys.argv[1:] if argv is None else argv)
         args.func(args)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        if dist is not None:
+            dist.barrier()
+    finally:
+        deltatree.set_dist_active(False)
+        if dist is not None:
+            dist.destroy_process_group()
     return 0
 
 

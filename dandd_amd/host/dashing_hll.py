@@ -22,40 +22,20 @@ the file NAME, `<fasta>.w.<k>.spacing.<R>.hll`), so reading one back needs them 
     python -m dandd_amd.host.dashing_hll export <sketch.hll> <out.hll>      (native -> Dashing)
     python -m dandd_amd.host.dashing_hll import <in.hll> <sketch.hll> K [--no-canon]
 """
-import gzip
-import struct
 import sys
-
-import numpy as np
 
 from .backend import read_sketch_file, write_sketch_file
 
-_HEAD = struct.Struct("<5IId")  # is_calculated, clamp, estim, jestim, nthreads; np; value
-ERTL_MLE, ERTL_JOINT_MLE = 2, 3
 
-
-def write_dashing_hll(path, regs, log2m, estimate=None):
-    regs = np.ascontiguousarray(regs, dtype=np.uint8)
-    if regs.size != (1 << log2m):
-        raise ValueError("register count does not match log2m")
-    head = _HEAD.pack(0 if estimate is None else 1, 0, ERTL_MLE, ERTL_JOINT_MLE, 1, log2m,
-                      0.0 if estimate is None else float(estimate))
-    with gzip.open(path, "wb", compresslevel=6) as f:
-        f.write(head)
-        f.write(regs.tobytes())
+def write_dashing_hll(path, regs, log2m, estimate=None, compressed=True):
+    """(the cached estimate slot is left invalid: Dashing recomputes it)"""
+    write_sketch_file(path, regs, log2m, 0, True, fmt="dashing" if compressed else "dashing-plain")
 
 
 def read_dashing_hll(path):
-    """-> (registers uint8[2^np], np, cached estimate or None)"""
-    with gzip.open(path, "rb") as f:
-        raw = f.read()
-    if len(raw) < _HEAD.size:
-        raise ValueError(f"{path}: truncated")
-    is_calc, _clamp, _estim, _jestim, _nthreads, np_, value = _HEAD.unpack_from(raw)
-    regs = np.frombuffer(raw, dtype=np.uint8, offset=_HEAD.size)
-    if not 4 <= np_ <= 32 or regs.size != (1 << np_):
-        raise ValueError(f"{path}: header says 2^{np_} registers, file holds {regs.size}")
-    return regs, int(np_), (float(value) if is_calc else None)
+    """-> (registers uint8[2^np], np, None)"""
+    regs, np_, _k, _canon = read_sketch_file(path)
+    return regs, np_, None
 
 
 def main(argv):
@@ -65,7 +45,7 @@ def main(argv):
         return 0
     if len(argv) >= 4 and argv[0] == "import":
         regs, log2m, _ = read_dashing_hll(argv[1])
-        write_sketch_file(argv[2], regs, log2m, int(argv[3]), "--no-canon" not in argv)
+        write_sketch_file(argv[2], regs, log2m, int(argv[3]), "--no-canon" not in argv, fmt="native")
         return 0
     print(__doc__)
     return 2

@@ -54,19 +54,33 @@ def backend_for(experiment):
     return _backends[key]
 
 
-# ---- one process per GPU (python -m torch.distributed.run ... -m dandd_amd.host.cli tree ...) ----------
+# ---- one process per GPU (python -m torch.distributed.run ... -m dandd_amd.host.cli <subcommand> ...) ---
 # Leaf sketching -- the only heavy step -- is sharded over the ranks by file size; the sketches travel
 # the way they always do in DandD, as files in the shared sketch directory; after a barrier rank 0
-# carries on alone with every leaf sketch cached and the other ranks are done.
+# carries on alone with every leaf sketch cached and the other ranks are done.  The sharding is switched
+# on by the CLI (set_dist_active) for the commands in which EVERY rank takes part, never by the mere
+# presence of WORLD_SIZE in the environment: a barrier needs all its parties.
 class WorkerDone(Exception):
     """Raised on ranks > 0 once their share of the leaf sketches is on disk."""
 
 
+_dist_active = False
+
+
+def set_dist_active(on):
+    global _dist_active
+    _dist_active = bool(on)
+
+
 def dist_ranks():
+    if not _dist_active:
+        return 0, 1
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
 def dist_barrier():
+    if not _dist_active:
+        return
     try:
         import torch.distributed as dist
     except ImportError:
@@ -208,6 +222,18 @@ class Sketch:
             forget_sketch(f)
 
 
+class DashSketchObj(Sketch):
+    """HyperLogLog sketch (the reference's class of this name, lib/sketch_classes.py:302)."""
+
+
+class KMCSketchObj(Sketch):
+    """Exact k-mer database (`--exact`; the reference's class of this name, lib/sketch_classes.py:377)."""
+
+
+def sketch_class(experiment):
+    return KMCSketchObj if experiment.get("tool") == "kmc" else DashSketchObj
+
+
 # ---------------------------------------------------------------------------------------------
 class DeltaTreeNode:
     def __init__(self, node_title, children, speciesinfo, experiment, progeny=None):
@@ -253,7 +279,7 @@ class DeltaTreeNode:
         self._grow(maxk)
         template = self._template()
         if self.ksketches[0] is None:
-            self.ksketches[0] = Sketch(0, template, self.speciesinfo, self.experiment)
+            self.ksketches[0] = sketch_class(self.experiment)(0, template, self.speciesinfo, self.experiment)
         # ks this node (and therefore its whole subtree) was already brought up to date for, in this
         # process: leaves are shared by hundreds of spiders and would otherwise be re-checked every time
         memo = self.__dict__.get("_swept")
@@ -308,7 +334,7 @@ class DeltaTreeNode:
             for child in self.children:
                 child.update_node(kval)
                 inputs.append(child.ksketches[kval].sketch)
-        self.ksketches[kval] = Sketch(kval, sfp, self.speciesinfo, self.experiment, presketches=inputs)
+        self.ksketches[kval] = sketch_class(self.experiment)(kval, sfp, self.speciesinfo, self.experiment, presketches=inputs)
 
     def node_ksweep(self, mink, maxk):
         self.ksweep_update_node(mink, maxk)
@@ -422,23 +448,35 @@ class DeltaTree:
             hi = min(int(hi), 32)
         if hi < lo or not hasattr(be, "leaf_many"):
             return 0
+        rank, world = dist_ranks()
+        if world > 1:
+            # the plan covers ALL leaves and depends on nothing a rank could see differently (file sizes,
+            # not which sketches happen to exist at the moment a rank looks): every rank computes the same
+            # shards, then skips what is already on disk within its own
+            from ..dist import shard_by_weight
+            mine = set(shard_by_weight([os.path.getsize(leaf.fastas[0]) for leaf in leaves], world)[rank])
         todo, templates = [], []
-        for leaf in leaves:
+        for i, leaf in enumerate(leaves):
+            if world > 1 and i not in mine:
+                continue
             tmpl = leaf._template() if hasattr(leaf, "_template") else SketchPath(leaf.fastas, 0, self.speciesinfo, self.experiment)
             if any(not sketch_exists(tmpl.with_k(k)) for k in range(lo, hi + 1)):
                 for k in range(lo, hi + 1):
                     ensure_dir(tmpl.dir.replace("{}", str(k)))
                 todo.append(leaf.fastas[0])
                 templates.append(tmpl)
-        rank, world = dist_ranks()
-        if world > 1:
-            from ..dist import shard_by_weight
-            mine = shard_by_weight([os.path.getsize(f) for f in todo], world)[rank]
-            if mine:
-                be.leaf_many([todo[i] for i in mine], lo, hi, lambda i, k: templates[mine[i]].with_k(k))
-        elif len(todo) > 1:
+        if todo and (world > 1 or len(todo) > 1):
             be.leaf_many(todo, lo, hi, lambda i, k: templates[i].with_k(k))
         return len(todo)
+
+    def presketch_range(self, lo, hi):
+        """Sketch files of k in [lo, hi] for every leaf of this tree in one batch -- sharded over the ranks
+        of a multi-GPU run, which meet at a barrier afterwards (every rank must call this)."""
+        leaves = self.leaf_nodes()
+        self._predigest(leaves)
+        n = self._batch_leaf_sketch(leaves, lo, hi)
+        dist_barrier()
+        return n
 
     def _presketch_leaves(self, leaves, radius=3):
         """Leaf sketches for the ks the per-leaf searches are about to ask for -- the whole ksweep
@@ -474,7 +512,7 @@ class DeltaTree:
         nodes = list(leafnodes) or [DeltaTreeNode(s, [], self.speciesinfo, self.experiment) for s in symbol]
         nodes.sort()
         self._presketch_leaves(nodes)
-        if not leafnodes and dist_ranks()[1] > 1:  # the main tree of a multi-rank `tree` run
+        if not leafnodes and dist_ranks()[1] > 1:  # a tree built from FASTA names in a multi-rank run
             dist_barrier()
             if dist_ranks()[0] != 0:
                 raise WorkerDone()
@@ -531,8 +569,9 @@ class DeltaTree:
     def save(self, fileprefix, fast=False):
         filepath = fileprefix + "_dtree.pickle"
         if not fast:
+            from .compat import dump_tree
             with open(filepath, "wb") as f:
-                pickle.dump(self, f)
+                dump_tree(self, f)  # under the reference's GLOBAL names: its own progressive/kij can load it
             print("Tree Pickle saved to: " + filepath)
             mapping = fileprefix + "_sketchdb.txt"
             write_listdict_to_csv(mapping, [self.speciesinfo.sketchinfo[b] for b in self.experiment["baseset"]])
@@ -630,7 +669,8 @@ class DeltaTree:
         return filled
 
     # ---- progressive unions (lib/huffman_dandd.py:574-663) -------------------------------------------
-    def orderings_list(self, ordering_file=None, flist_loc=None, count=0):
+    def progressive_fastas(self, flist_loc=None):
+        """The FASTAs a `progressive` run covers, in its order (lib/huffman_dandd.py:574-588)."""
         fastas = self.fastas
         fastas.sort()
         if flist_loc:
@@ -638,6 +678,10 @@ class DeltaTree:
                 wanted = [line.strip() for line in f]
             present = set(fastas)
             fastas = [f for f in wanted if f in present]
+        return fastas
+
+    def orderings_list(self, ordering_file=None, flist_loc=None, count=0):
+        fastas = self.progressive_fastas(flist_loc)
         if count == 1:
             return fastas, [tuple(range(len(fastas)))]
         default = os.path.join(self.speciesinfo.sketchdir, f"{self.speciesinfo.tag}_{len(fastas)}_orderings.pickle")

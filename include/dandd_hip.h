@@ -62,11 +62,16 @@ int dd_sketch_buffer(dd_ctx *, const uint8_t *fasta, size_t nbytes, int kmin, in
  * lib/species_specifics.py:93); inflated on the host with zlib. */
 int dd_sketch_fasta(dd_ctx *, const char *path, int kmin, int kmax, uint8_t *regs);
 /* Ingestion pipeline for a whole directory of genomes: `nthreads` loader threads (0 = auto) read
- * and inflate ahead (bounded window) while the GPU sketches the files already in memory, in
- * order.  regs[nfiles][K][m] on the host.  Replaces the reference's sequential per-genome loop
- * (lib/huffman_dandd.py:402-407), each iteration of which re-inflates the file once per k. */
+ * and inflate into pinned host buffers ahead of the GPU (bounded pool); a copy stream moves batch b+1
+ * to the device and batch b-1's registers back while batch b is sketched; consecutive small files
+ * share one launch (~128 MB per batch).  regs[nfiles][K][m] on the host.  Replaces the reference's
+ * sequential per-genome loop (lib/huffman_dandd.py:402-407), each iteration of which re-inflates the
+ * file once per k. */
 int dd_sketch_files(dd_ctx *, const char *const *paths, int nfiles, int kmin, int kmax,
                     uint8_t *regs, int nthreads);
+/* statistics of the last dd_sketch_files call: wall time, time the GPU-driving thread waited for the loader
+ * threads, number of batched launches, FASTA bytes sent to the device */
+int dd_last_ingest_stats(dd_ctx *, double *wall_ms, double *loader_wait_ms, int *batches, uint64_t *bytes);
 /* Batched, HBM-resident form: ngenomes FASTA byte buffers already on the device,
  * regs_dev[ngenomes][K][m] on the device.  Asynchronous on the context's stream. */
 int dd_sketch_device(dd_ctx *, const uint8_t *const *fasta_dev, const size_t *nbytes,

@@ -143,9 +143,20 @@ def run_ref(args, env, cwd):
     return r.stdout
 
 
+FIXTURE_ROOT = "/tmp/dandd_gold_fixture"  # absolute paths end up inside the tree pickle: the test re-creates this place
+
+
+def card_table(sketchdir, tag, tool="dashing"):
+    """{sketch file basename: cardinality} of the reference's cardinality cache (lib/species_specifics.py:78-89)."""
+    with open(os.path.join(sketchdir, f"{tag}_{tool}_cardinalities.pickle"), "rb") as f:
+        return {os.path.basename(k): v for k, v in sorted(pickle.load(f).items())}
+
+
 def scenario(backend, fdir, registers):
     """One full walk through the reference CLI; returns every CSV it wrote as rows."""
-    work = tempfile.mkdtemp(prefix="ddgold_")
+    work = FIXTURE_ROOT + "_" + backend
+    shutil.rmtree(work, ignore_errors=True)
+    os.makedirs(work)
     try:
         bindir = os.path.join(work, "bin")
         os.makedirs(bindir)
@@ -167,6 +178,10 @@ def scenario(backend, fdir, registers):
         run_ref(["tree", "-d", data, "-o", o, "-s", "gold", "-k", "10", "-r", str(registers)], env, work)
         out["tree_spider_k10"] = read_csv(os.path.join(o, "gold_5_dashing_deltas.csv"))
         tree_pickle = os.path.join(o, "gold_5_dashing_dtree.pickle")
+        # the tree pickle the REFERENCE wrote, as a fixture (data: pickled objects, no source text): the host
+        # layer must be able to run `progressive` / `kij` from it (lib/dandd_cmd.py:66,108)
+        if backend == "hll":
+            shutil.copyfile(tree_pickle, os.path.join(HERE, "ref_tree_hll.pickle"))
         # 2. progressive on that tree with fixed orderings (pre-seeded orderings pickle), ksweep 8..14
         sketchdir = os.path.join(o, "sketchdb")
         orderings = {(0, 1, 2, 3, 4), (4, 2, 0, 3, 1), (1, 3, 4, 0, 2)}
@@ -194,6 +209,13 @@ def scenario(backend, fdir, registers):
         run_ref(["tree", "-d", data, "-o", o5, "-s", "gold", "-r", str(registers), "--ksweep", "--mink", "9",
                  "--maxk", "12", "-C"], env, work)
         out["tree_ksweep_9_12_nocanon"] = read_csv(os.path.join(o5, "gold_5_dashing_deltas.csv"))
+        # 6. BASELINE config 1 as stated: `tree --ksweep --mink 10 --maxk 20` (no hill-climb; the deltas rows are
+        #    the k=0 placeholders, the result is the cardinality of every node at every k)
+        o6 = outdir("t4")
+        run_ref(["tree", "-d", data, "-o", o6, "-s", "gold", "-r", str(registers), "--ksweep", "--mink", "10",
+                 "--maxk", "20"], env, work)
+        out["tree_ksweep_10_20"] = read_csv(os.path.join(o6, "gold_5_dashing_deltas.csv"))
+        out["tree_ksweep_10_20_cards"] = card_table(os.path.join(o6, "sketchdb"), "gold")
         with open(os.path.join(work, "trace.log")) as f:
             out["_n_external_commands"] = sum(1 for _ in f)
         return out

@@ -117,7 +117,16 @@ def run_scenarios(work, registers):
     o5 = od("t3")
     cli.main(["tree", "-d", data, "-o", o5, "-s", "gold", "-r", str(registers), "--ksweep", "--mink", "9", "--maxk", "12", "-C"])
     out["tree_ksweep_9_12_nocanon"] = read_rows(os.path.join(o5, "gold_5_dashing_deltas.csv"))
+    o6 = od("t4")  # BASELINE config 1 as stated: k-sweep 10..20, every node's cardinality at every k
+    cli.main(["tree", "-d", data, "-o", o6, "-s", "gold", "-r", str(registers), "--ksweep", "--mink", "10", "--maxk", "20"])
+    out["tree_ksweep_10_20"] = read_rows(os.path.join(o6, "gold_5_dashing_deltas.csv"))
+    out["tree_ksweep_10_20_cards"] = card_table(os.path.join(o6, "sketchdb"), "gold")
     return out
+
+
+def card_table(sketchdir, tag, tool="dashing"):
+    with open(os.path.join(sketchdir, f"{tag}_{tool}_cardinalities.pickle"), "rb") as f:
+        return {os.path.basename(k): v for k, v in pickle.load(f).items()}
 
 
 def same_cell(a, b):
@@ -136,6 +145,11 @@ def compare(got, want):
         if name.startswith("_"):
             continue
         g = got.get(name)
+        if isinstance(rows, dict):  # {sketch basename: cardinality}
+            for key, want_v in rows.items():
+                if g is None or key not in g or float(g[key]) != float(want_v):
+                    diffs.append(f"{name}[{key}]: got {None if g is None else g.get(key)!r}, expected {want_v!r}")
+            continue
         if g is None or len(g) != len(rows):
             diffs.append(f"{name}: {None if g is None else len(g)} rows, expected {len(rows)}")
             continue

@@ -218,3 +218,49 @@ def test_tree_shapes_for_nchildren(host, tmp_path):
     assert s52 == [["g0", "g1"], ["g2", "g3"], ["g4", "g0_g1"], ["g2_g3", "g4_g0_g1"]]
     s73 = shape(7, 3)
     assert s73[0] == ["g0", "g1", "g2"] and s73[-1] == ["g3", "g4", "g5", "g6", "g0_g1_g2"]
+
+
+def test_dashing_container_sketch_directory_is_consumed_and_extended(host, tmp_path, monkeypatch):
+    """a sketch directory whose .hll files are in Dashing's container (as a real DandD + Dashing run
+    leaves them, gzip or plain) is read in place -- no leaf is sketched again -- and with
+    DANDD_SKETCH_FORMAT=dashing new sketches are written in that container too; rows equal the goldens."""
+    import gzip
+    import shutil
+    gold = _golden("ref_hll.json")
+    calls = {"leaf": 0}
+
+    class Counting(hostcheck.OracleBackend):
+        def leaf(self, *a):
+            calls["leaf"] += 1
+            return super().leaf(*a)
+
+    host.set_backend_factory(lambda r, c: Counting(r, c))
+    from dandd_amd.host import cli
+    data = os.path.join(str(tmp_path), "data")
+    shutil.copytree(os.path.join(hostcheck.GOLD, "fasta"), data)
+    out = os.path.join(str(tmp_path), "o")
+    args = ["tree", "-d", data, "-o", out, "-s", "gold", "-k", "10", "-r", str(gold["registers"])]
+    monkeypatch.setenv("DANDD_SKETCH_FORMAT", "dashing")
+    cli.main(args)
+    assert calls["leaf"] > 0
+    sk = os.path.join(out, "sketchdb")
+    leaf_files = [os.path.join(dp, f) for dp, _, fs in os.walk(os.path.join(sk, "ngen1")) for f in fs if f.endswith(".hll")]
+    assert leaf_files and all(open(f, "rb").read(2) == b"\x1f\x8b" for f in leaf_files)
+    raw = gzip.open(leaf_files[0], "rb").read()
+    assert len(raw) == 32 + (1 << gold["registers"])
+    # half of the leaf sketches re-written uncompressed (Dashing without -z), caches dropped: a second run under
+    # the default (native) switch must read both flavours and sketch nothing
+    for f in leaf_files[::2]:
+        plain = gzip.open(f, "rb").read()
+        with open(f, "wb") as g:
+            g.write(plain)
+    monkeypatch.delenv("DANDD_SKETCH_FORMAT")
+    for name in os.listdir(sk):
+        if name.endswith(".pickle") or name.endswith(".bkp"):
+            os.remove(os.path.join(sk, name))
+    before = calls["leaf"]
+    out2 = os.path.join(str(tmp_path), "o2")
+    cli.main(["tree", "-d", data, "-o", out2, "-c", sk, "-s", "gold", "-k", "10", "-r", str(gold["registers"])])
+    assert calls["leaf"] == before, "leaf sketches in Dashing's container were sketched again"
+    rows = hostcheck.read_rows(os.path.join(out2, "gold_5_dashing_deltas.csv"))
+    assert not hostcheck.compare({"tree_spider_k10": rows}, {"tree_spider_k10": gold["scenarios"]["tree_spider_k10"]})
