@@ -4,23 +4,36 @@
     python bench.py --gpus N --steps K --warmup W
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[1], per GPU): 10 synthetic 50-Mbp FASTAs resident in HBM,
+Default workload (BASELINE.json configs[1], per GPU): 10 synthetic 50-Mbp FASTAs resident in HBM,
 HyperLogLog log2m=14, k-sweep 4..40 (K=37).  One STEP = one pass of the whole hot path over that
 batch: K0 pack + K1 fused k-sweep sketch of every genome, K2 N-way root union (+ RCCL max
 all-reduce of the root when N>1), K2/K3 cardinalities of every leaf and of the root, delta =
 max_k card/k on the host.  Metric: Gbp/s = bases sketched over the whole k-sweep / wall time,
-aggregated over all ranks (weak scaling: every rank owns its own 10 genomes).
+aggregated over all ranks.  The step is dandd_amd.dist.sharded_ksweep -- the same function the
+world-size-2 tests run.
 
-Extra objects on the JSON line (see DESIGN.md "Measurement"):
-  roofline     -- dominant kernel (K1 sweep): algorithmic bytes / its HIP-event time vs 8 TB/s,
-                  plus the VALU-issue bound that actually binds it
-  cpu_baseline -- the CPU oracle run the way DandD drives Dashing (one job per (genome, k),
-                  each re-parsing the FASTA, floor(0.95*nproc) jobs in flight) on a bounded sample
+--config selects the other BASELINE.json workloads (never the driver's default line):
+  cfg2       10 x 50 Mbp per GPU, k 4-40 (weak scaling; the default)
+  cfg3       64 x 5 Mbp, k 2-32, all-pairs KIJ matrix in the step (genomes sharded over the ranks)
+  cfg4       30 x 250 Mbp, k 2-32, 10 orderings (strong scaling: the 30 genomes are sharded over the ranks)
+  cfg5       100 x 3 Gbp, k 4-64 (strong scaling; needs >= 4 GPUs for the FASTA bytes to fit)
+  cfg4share / cfg5share   one GPU's share of cfg4 / cfg5 on 8 GPUs (8 x 250 Mbp; 13 x 3 Gbp, k 4-64)
+
+Extra objects on the JSON line (DESIGN.md "Measurement"):
+  roofline      dominant kernel (K1): algorithmic bytes / its HIP-event time vs 8 TB/s, plus the VALU-issue bound
+  cpu_baseline  Dashing itself when a `dashing` binary is on PATH (registers diffed against the oracle), else the
+                CPU oracle run the way DandD drives Dashing (one job per (genome, k), each re-parsing the FASTA)
+  accuracy_vs_exact   cardinality and delta errors of ALL leaves and the root against the GPU exact counter
+  secondary     the same step at log2m 16 (where delta meets the 1 % target) and at DandD's default log2m 20
+  ingest        dd_sketch_files on FASTA files (PCIe and file reads included; never `value`)
 """
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -31,6 +44,17 @@ sys.path.insert(0, ROOT)
 SEED = 0xD4ADD
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_LANEOPS = 78.6e12    # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
+VALU_PROFILE = "profiles/r01_v6_pmc.txt (K1 v6; the k <= 48 hashed classes are unchanged since)"
+
+CONFIGS = {
+    # name: genomes (total or per GPU), Mbp, nrec, kmin, kmax, sharded over ranks?, extra schedule
+    "cfg2": dict(genomes=10, mbp=50.0, nrec=5, kmin=4, kmax=40, strong=False, extra=None),
+    "cfg3": dict(genomes=64, mbp=5.0, nrec=5, kmin=2, kmax=32, strong=True, extra="pairwise"),
+    "cfg4": dict(genomes=30, mbp=250.0, nrec=1, kmin=2, kmax=32, strong=True, extra="progressive"),
+    "cfg5": dict(genomes=100, mbp=3000.0, nrec=24, kmin=4, kmax=64, strong=True, extra=None),
+    "cfg4share": dict(genomes=8, mbp=250.0, nrec=1, kmin=2, kmax=32, strong=False, extra="progressive"),
+    "cfg5share": dict(genomes=13, mbp=3000.0, nrec=24, kmin=4, kmax=64, strong=False, extra=None),
+}
 
 
 def usable_cpus():
@@ -50,20 +74,64 @@ def usable_cpus():
     return n
 
 
+def dashing_baseline(fa, nbases, ks, log2m, jobs, ncpu, exe):
+    """a real Dashing, driven the way DandD drives it (`parallel -j 95%` over k,
+    /root/reference/lib/huffman_dandd.py:214-218), timed, and its registers diffed against the oracle --
+    the only place the "bit-exact vs Dashing" question can be settled (no Dashing exists in the build image)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from dandd_amd.host.backend import read_sketch_file
+    from oracle import dd_oracle as orc
+    work = tempfile.mkdtemp(prefix="dd_dashing_")
+    try:
+        fasta = os.path.join(work, "sample.fasta")
+        fa.tofile(fasta)
+
+        def one(k):
+            d = os.path.join(work, f"k{k}")
+            os.makedirs(d, exist_ok=True)
+            subprocess.run([exe, "sketch", f"-k{k}", "-S", str(log2m), "--prefix", d, fasta], check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            return os.path.join(d, f"sample.fasta.w.{k}.spacing.{log2m}.hll")
+
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=jobs) as ex:
+            outs = list(ex.map(one, ks))
+        dt = time.perf_counter() - t0
+        same, checked = [], [k for k in ks if k <= 32][:: max(1, len(ks) // 6)]
+        for k in checked:
+            regs = read_sketch_file(outs[ks.index(k)])[0]
+            same.append(bool(np.array_equal(regs, orc.sketch(fa, k, log2m, True))))
+        return {"value": nbases / dt / 1e9, "unit": "Gbp/s", "cores": min(jobs, len(ks)), "kind": "dashing",
+                "sample": f"1 synthetic genome x {nbases/1e6:g} Mbp, k {ks[0]}-{ks[-1]}, -S {log2m}: one `{exe} sketch` process per k, "
+                          f"{jobs} in flight on {ncpu} usable host CPUs, {dt:.1f} s wall",
+                "registers_equal_oracle": dict(zip(map(str, checked), same)), "registers_all_equal": all(same)}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def cpu_baseline(nbases, nrec, kmin, kmax, log2m):
-    """Oracle stand-in for `parallel -j 95% 'dashing sketch -k{} ...' ::: kmin..kmax` on this host."""
+    """`parallel -j 95% 'dashing sketch -k{} ...' ::: kmin..kmax` on this host: Dashing itself when it is on PATH,
+    otherwise the oracle as its stand-in."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import dd_oracle as orc
+    ncpu = usable_cpus()
+    jobs = max(1, int(0.95 * ncpu))
+    ks = list(range(kmin, kmax + 1))
+    fa = orc.synth_fasta(SEED, 0, nbases, nrec)
+    exe = shutil.which("dashing")
+    if exe:
+        try:
+            return dashing_baseline(fa, nbases, [k for k in ks if k <= 32] or ks, log2m, jobs, ncpu, exe)
+        except Exception as e:  # a dashing that does not speak the expected CLI: fall back, but say so
+            note = f"`{exe}` found but unusable ({type(e).__name__}: {e}); "
+    else:
+        note = ""
     path = None
     try:  # native-arch build for a fair timing; fall back to the portable build
         path = orc.build(arch="native", out=os.path.join("/tmp", f"liboracle_native_{os.getpid()}.so"))
         lib = orc.lib(path)
     except Exception:
         lib = orc.lib()
-    fa = orc.synth_fasta(SEED, 0, nbases, nrec)
-    ncpu = usable_cpus()
-    jobs = max(1, int(0.95 * ncpu))
-    ks = list(range(kmin, kmax + 1))
     regs = np.zeros((len(ks), 1 << log2m), dtype=np.uint8)
 
     def one(i):
@@ -81,18 +149,17 @@ def cpu_baseline(nbases, nrec, kmin, kmax, log2m):
         "unit": "Gbp/s",
         "cores": min(jobs, len(ks)),
         "kind": "port",
-        "sample": f"1 synthetic genome x {nbases/1e6:g} Mbp, k {kmin}-{kmax}, log2m={log2m}: one single-threaded "
-                  f"oracle job per k (each re-parses the FASTA), {jobs} jobs in flight on {ncpu} usable host CPUs "
-                  f"({os.cpu_count()} logical, cgroup quota applied), {dt:.1f} s wall",
+        "sample": note + f"1 synthetic genome x {nbases/1e6:g} Mbp, k {kmin}-{kmax}, log2m={log2m}: one single-threaded "
+                         f"oracle job per k (each re-parses the FASTA), {jobs} jobs in flight on {ncpu} usable host CPUs "
+                         f"({os.cpu_count()} logical, cgroup quota applied), {dt:.1f} s wall; no `dashing` on PATH",
     }
 
 
 def valu_bound(kmin, kmax, updates_per_s):
-    """The bound that actually binds K1: VALU issue.  Instructions per (token, k) are the PMC counts of
-    profiles/r01_v6_pmc.txt (SQ_INSTS_VALU / wave-steps) per k class (k 49..64: estimated from the
-    33..48 class plus its 9 extra instructions); a wave64 instruction occupies a
-    SIMD-32 for 2 cycles at best, so the chip retires at most 256 CU x 4 SIMD x 2.4 GHz / 2 wave
-    instructions per second (= 78.6 T lane-ops/s)."""
+    """The bound that actually binds K1 at log2m <= 17: VALU issue.  Instructions per (token, k) are PMC counts
+    (VALU_PROFILE) per k class (k 49..64: estimated from the 33..48 class plus its 9 extra instructions); a wave64
+    instruction occupies a SIMD-32 for 2 cycles at best, so the chip retires at most 256 CU x 4 SIMD x 2.4 GHz / 2
+    wave instructions per second (= 78.6 T lane-ops/s)."""
     per_class = [(1, 9, 11.2), (10, 16, 30.0), (17, 32, 33.9), (33, 48, 43.4), (49, 64, 52.0)]
     tot = n = 0
     for lo, hi, instr in per_class:
@@ -103,9 +170,109 @@ def valu_bound(kmin, kmax, updates_per_s):
     achieved = updates_per_s * ipu  # lane-instructions per second
     return {"valu_instr_per_update": ipu, "achieved_lane_instr_per_s": achieved,
             "peak_lane_instr_per_s": VALU_PEAK_LANEOPS, "frac": achieved / VALU_PEAK_LANEOPS,
+            "instr_counts_from": VALU_PROFILE,
             "note": "peak assumes every instruction is in the 2-cycle class; two thirds of K1's are in the "
                     "4-cycle class on gfx950 (64-bit shifts/adds, v_mad_u64_u32, v_mul_lo, v_cmp, v_ffbh), "
                     "against that mix the kernel runs at ~98 % of issue (DESIGN.md section 4)"}
+
+
+class Workload:
+    """The genomes of one rank in HBM and the engine-backed callbacks of dandd_amd.dist.sharded_ksweep."""
+
+    def __init__(self, torch, eng, genome_ids, nb, nrec, kmin, kmax):
+        from dandd_amd.engine import synth_size
+        self.torch, self.eng = torch, eng
+        self.kmin, self.kmax, self.K, self.m = kmin, kmax, kmax - kmin + 1, eng.m
+        self.ids, self.nb, self.ng = list(genome_ids), nb, len(genome_ids)
+        self.nbytes = synth_size(nb, nrec)
+        self.fasta = [torch.empty(self.nbytes + 16, dtype=torch.uint8, device="cuda") for _ in self.ids]
+        for t, gi in zip(self.fasta, self.ids):
+            eng.synth_fasta_device(SEED, gi, nb, nrec, t.data_ptr())
+        eng.synchronize()
+        self.regs = torch.empty((self.ng + 1, self.K, self.m), dtype=torch.uint8, device="cuda")  # leaves + root
+        self.ptrs = [f.data_ptr() for f in self.fasta]
+        self.sizes = [self.nbytes] * self.ng
+        self.ks = np.arange(kmin, kmax + 1, dtype=np.float64)
+
+    def sketch_into(self, indices, leaves):      # K0 + K1: every local genome in one batched call
+        self.eng.sketch_device(self.ptrs, self.sizes, self.kmin, self.kmax, leaves.data_ptr())
+
+    def union_into(self, leaves, root):           # K2 root union of this rank's leaves
+        if leaves.shape[0]:
+            self.eng.union_device([leaves[g].data_ptr() for g in range(leaves.shape[0])], self.K * self.m, root.data_ptr())
+        else:
+            root.zero_()
+
+    def card_of(self, regs):                      # K2 + K3
+        return self.eng.card_batch_device(regs.data_ptr(), regs.shape[0] * self.K)
+
+    def step(self, ddist):
+        _, _, card = ddist.sharded_ksweep(self.sizes, self.K, self.m, self.sketch_into, self.union_into, self.card_of,
+                                          regs=self.regs, mine=list(range(self.ng)))
+        d = card / self.ks
+        return d.max(axis=1), d.argmax(axis=1) + self.kmin, card   # delta, argmax-k per leaf and (last row) root
+
+
+def accuracy_block(wl, card, what):
+    """The "delta rel-err vs KMC --exact" half of the metric, over EVERY leaf and this rank's root: the GPU exact
+    counter (sort + distinct of canonical k-mers) at every k, against the HLL cardinalities of the last step."""
+    eng, K, ks = wl.eng, wl.K, wl.ks
+    exact = np.zeros((wl.ng + 1, K))
+    for g in range(wl.ng):
+        for kk in range(K):
+            exact[g, kk] = eng.exact_count_device([wl.ptrs[g]], [wl.nbytes], wl.kmin + kk)
+    for kk in range(K):
+        exact[wl.ng, kk] = eng.exact_count_device(wl.ptrs, wl.sizes, wl.kmin + kk)
+    rel = (card - exact) / exact
+    d_hll, d_ex = (card / ks).max(axis=1), (exact / ks).max(axis=1)
+    drel = (d_hll - d_ex) / d_ex
+    sigma = 1.04 / float(np.sqrt(wl.m))
+    return {
+        "what": what,
+        "sketches": wl.ng + 1, "ks": K, "hll_sigma": sigma,
+        "delta_rel_err_per_sketch": [float(x) for x in drel],
+        "delta_rel_err_max_abs": float(np.abs(drel).max()), "delta_rel_err_mean_signed": float(drel.mean()),
+        "delta_rel_err_root": float(drel[-1]),
+        "argmax_k_equal": int(((card / ks).argmax(axis=1) == (exact / ks).argmax(axis=1)).sum()),
+        "card_rel_err_mean_signed": float(rel.mean()), "card_rel_err_rms": float(np.sqrt((rel ** 2).mean())),
+        "card_rel_err_max_abs": float(np.abs(rel).max()),
+        # saturated small k (every possible k-mer present) is exact in both; the statistic that can show a hash
+        # bias is the signed mean over the unsaturated ks, in units of its own standard error
+        "card_rel_err_mean_signed_k_ge_14": float(rel[:, ks >= 14].mean()) if (ks >= 14).any() else None,
+        "mean_signed_in_sigma_of_mean": float(rel[:, ks >= 14].mean() / (sigma / np.sqrt(max(1, rel[:, ks >= 14].size))))
+        if (ks >= 14).any() else None,
+        "delta_within_1pct": bool(np.abs(drel).max() <= 0.01),
+    }
+
+
+def ingest_probe(eng, ng, nb, nrec, kmin, kmax, torch):
+    """dd_sketch_files over FASTA files (tmpfs when there is one: a warm page cache), third call."""
+    from dandd_amd.engine import synth_size
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="dd_ingest_", dir=base)
+    try:
+        n = synth_size(nb, nrec)
+        buf = torch.empty(n + 16, dtype=torch.uint8, device="cuda")
+        paths = []
+        for g in range(ng):
+            eng.synth_fasta_device(SEED, g, nb, nrec, buf.data_ptr())
+            eng.synchronize()
+            p = os.path.join(d, f"g{g:03d}.fasta")
+            buf[:n].cpu().numpy().tofile(p)
+            paths.append(p)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            eng.sketch_files(paths, kmin, kmax, 0)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        _, wait, batches, nbytes = eng.last_ingest_stats()
+        return {"value": ng * nb / best / 1e9, "unit": "Gbp/s", "ms": best * 1e3, "launches": batches, "fasta_MB": nbytes / 1e6,
+                "what": f"dd_sketch_files: {ng} x {nb/1e6:g} Mbp plain FASTA files in {base or 'the temp dir'} (warm page cache) -> "
+                        f"pinned host buffers -> H2D on a copy stream overlapped with K0/K1 -> registers back to the host; "
+                        f"k {kmin}-{kmax}; best of 3 calls (PCIe-inclusive: reported beside `value`, never as it)"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def main():
@@ -113,16 +280,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--genomes", type=int, default=10)
-    ap.add_argument("--mbp", type=float, default=50.0)
-    ap.add_argument("--kmin", type=int, default=4)
-    ap.add_argument("--kmax", type=int, default=40)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
+    ap.add_argument("--genomes", type=int, default=None)
+    ap.add_argument("--mbp", type=float, default=None)
+    ap.add_argument("--kmin", type=int, default=None)
+    ap.add_argument("--kmax", type=int, default=None)
     ap.add_argument("--log2m", type=int, default=14)
-    ap.add_argument("--nrec", type=int, default=5)
+    ap.add_argument("--nrec", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-accuracy", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-ingest", action="store_true")
     ap.add_argument("--cpu-sample-mbp", type=float, default=32.0)
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    for key in ("genomes", "mbp", "kmin", "kmax", "nrec"):
+        if getattr(args, key) is not None:
+            cfg[key] = getattr(args, key)
+    headline = args.config == "cfg2"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -135,12 +310,12 @@ def main():
     # CPU baseline first (rank 0, N=1 only), before this process touches the GPU
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(int(args.cpu_sample_mbp * 1e6), args.nrec, args.kmin, args.kmax, args.log2m)
+        cpu = cpu_baseline(int(args.cpu_sample_mbp * 1e6), cfg["nrec"], cfg["kmin"], cfg["kmax"], args.log2m)
 
     import torch
     import torch.distributed as dist
     from dandd_amd import dist as ddist
-    from dandd_amd.engine import Engine, synth_size, KERNEL_PACK, KERNEL_SWEEP, KERNEL_UNION
+    from dandd_amd.engine import Engine, KERNEL_PACK, KERNEL_SWEEP, KERNEL_UNION
 
     # Functional test of the N>1 path on a box with fewer GPUs than ranks (never a measurement):
     # DD_BENCH_BACKEND=gloo DD_BENCH_SHARE_DEVICE=1 puts every rank on cuda:0 and reduces through gloo.
@@ -156,30 +331,34 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    ng, nb = args.genomes, int(args.mbp * 1e6)
-    kmin, kmax, p = args.kmin, args.kmax, args.log2m
+    nb = int(cfg["mbp"] * 1e6)
+    kmin, kmax, p = cfg["kmin"], cfg["kmax"], args.log2m
     K, m = kmax - kmin + 1, 1 << p
+    if cfg["strong"]:   # the job's genomes sharded over the ranks (equal sizes: round robin by weight)
+        ids = ddist.shard_by_weight([nb] * cfg["genomes"], world)[rank]
+        total_genomes = cfg["genomes"]
+    else:               # every rank brings its own genomes
+        ids = list(range(rank * cfg["genomes"], (rank + 1) * cfg["genomes"]))
+        total_genomes = cfg["genomes"] * world
     eng = Engine(device=local_rank, log2m=p, canonical=True)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    wl = Workload(torch, eng, ids, nb, cfg["nrec"], kmin, kmax)
+    ng, nbytes = wl.ng, wl.nbytes
 
-    # synthetic genomes generated on the device (never cross PCIe); rank r owns genomes r*ng..
-    nbytes = synth_size(nb, args.nrec)
-    fasta = [torch.empty(nbytes + 16, dtype=torch.uint8, device="cuda") for _ in range(ng)]
-    for g in range(ng):
-        eng.synth_fasta_device(SEED, rank * ng + g, nb, args.nrec, fasta[g].data_ptr())
-    regs = torch.empty((ng + 1, K, m), dtype=torch.uint8, device="cuda")  # leaves + root
-    ptrs = [f.data_ptr() for f in fasta]
-    sizes = [nbytes] * ng
-    leaf_ptrs = [regs[g].data_ptr() for g in range(ng)]
-    ks = np.arange(kmin, kmax + 1, dtype=np.float64)
+    orderings = None
+    if cfg["extra"] == "progressive":
+        with open(os.path.join(ROOT, "tests", "golden", "cfg4_orderings.json")) as f:
+            orderings = [o for o in json.load(f)["orderings"]]
+        if ng != 8:  # the fixture is for the 8-genome share; other shard sizes use rotations
+            orderings = [list(np.roll(np.arange(ng), s)) for s in range(min(10, max(1, ng)))]
 
     def step():
-        eng.sketch_device(ptrs, sizes, kmin, kmax, regs.data_ptr())                 # K0 + K1
-        eng.union_device(leaf_ptrs, K * m, regs[ng].data_ptr())                      # K2 root union
-        if world > 1:
-            ddist.allreduce_max_u8(regs[ng])                                         # RCCL max over xGMI
-        card = eng.card_batch_device(regs.data_ptr(), (ng + 1) * K).reshape(ng + 1, K)  # K2 + K3
-        return (card / ks).max(axis=1), (card / ks).argmax(axis=1) + kmin            # delta, argmax-k
+        out = wl.step(ddist)
+        if cfg["extra"] == "pairwise" and ng:
+            wl.pair = eng.pairwise_device(wl.regs.data_ptr(), ng, K)           # all local pairs x all k
+        elif cfg["extra"] == "progressive" and ng:
+            wl.prog = eng.progressive_device(wl.regs.data_ptr(), ng, K, orderings)
+        return out
 
     def fence():
         torch.cuda.synchronize()
@@ -194,49 +373,66 @@ def main():
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        delta, bestk = step()
+        delta, bestk, card = step()
     fence()
     dt = time.perf_counter() - t0
     sweep_ms, sweep_n = eng.timing_read(KERNEL_SWEEP)
     pack_ms, pack_n = eng.timing_read(KERNEL_PACK)
     union_ms, union_n = eng.timing_read(KERNEL_UNION)
     eng.timing_enable(False)
-
     dt = ddist.max_over_ranks(dt, device="cuda")
 
-    # accuracy half of the metric (outside the timed region, rank 0): delta of genome 0 from the HLL
-    # sweep vs delta from the GPU exact counter (the KMC --exact stand-in) over the same k range
-    accuracy = None
-    if rank == 0 and not args.no_accuracy:
-        card0 = eng.card_batch_device(regs[0].data_ptr(), K)
-        exact0 = np.array([eng.exact_count_device([ptrs[0]], [nbytes], k) for k in range(kmin, kmax + 1)],
-                          dtype=np.float64)
-        d_hll, d_exact = (card0 / ks).max(), (exact0 / ks).max()
-        accuracy = {
-            "delta_hll": float(d_hll), "delta_exact": float(d_exact),
-            "delta_rel_err": float(abs(d_hll - d_exact) / d_exact),
-            "argmax_k_hll": int((card0 / ks).argmax() + kmin), "argmax_k_exact": int((exact0 / ks).argmax() + kmin),
-            "max_card_rel_err_over_k": float(np.max(np.abs(card0 - exact0) / exact0)),
-            "hll_sigma": 1.04 / float(np.sqrt(m)),
-            "what": "genome 0, exact = GPU sort+distinct of canonical k-mers (dd_exact_count_device)",
-        }
+    extras = {}
+    if rank == 0 and world == 1 and headline:
+        if not args.no_accuracy:
+            extras["accuracy_vs_exact"] = accuracy_block(
+                wl, card, f"log2m {p}: all {ng} leaves + their root, k {kmin}-{kmax}; exact = GPU sort+distinct of canonical "
+                          "k-mers (dd_exact_count_device, the KMC --exact stand-in)")
+        if not args.no_secondary:
+            sec = {}
+            for p2, why in ((16, "the register count at which delta meets the 1 % target"),
+                            (20, "DandD's default -r 20 (/root/reference/lib/dandd_cmd.py:187): registers in HBM, scatter + sort + replay")):
+                if p2 == p:
+                    continue
+                e2 = Engine(device=local_rank, log2m=p2, canonical=True)
+                e2.set_stream(torch.cuda.current_stream().cuda_stream)
+                w2 = Workload(torch, e2, ids, nb, cfg["nrec"], kmin, kmax)
+                for _ in range(2):
+                    w2.step(ddist)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    _, _, card2 = w2.step(ddist)
+                torch.cuda.synchronize()
+                d2 = (time.perf_counter() - t1) / 3
+                entry = {"why": why, "value": ng * nb / d2 / 1e9, "unit": "Gbp/s", "ms_per_step": d2 * 1e3, "steps": 3}
+                if p2 == 16 and not args.no_accuracy:
+                    entry["accuracy_vs_exact"] = accuracy_block(w2, card2, "log2m 16, same genomes and k range")
+                sec[f"log2m{p2}"] = entry
+                del w2
+                e2.close()
+                torch.cuda.empty_cache()
+            extras["secondary"] = sec
+        if not args.no_ingest:
+            extras["ingest"] = ingest_probe(eng, ng, nb, cfg["nrec"], kmin, kmax, torch)
 
     # HBM-side traffic of K1 per step: PMC counters cannot be read from inside this process, so the
     # number comes from the committed rocprofv3 passes (profiles/traffic.json, made by
     # scripts/make_traffic.py) and is only reported when this run's workload is the profiled one.
-    traffic = None
+    traffic, traffic_src = None, None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             tj = json.load(f)
         w = tj["workload"]
-        if (w["genomes"], w["mbp"], w["kmin"], w["kmax"], w["log2m"]) == (args.genomes, args.mbp, args.kmin, args.kmax, args.log2m):
+        if (w["genomes"], w["mbp"], w["kmin"], w["kmax"], w["log2m"]) == (cfg["genomes"], cfg["mbp"], kmin, kmax, p):
             traffic = tj["k1_bytes_per_step"]["total"]
+            traffic_src = "profiles/traffic.json (" + tj.get("kernel_version", "K1 v8, round 1") + ")"
     except (OSError, KeyError, ValueError):
         pass
 
     if rank == 0:
         steps = args.steps
-        total_bases = world * ng * nb * steps
+        total_bases = total_genomes * nb * steps
         # algorithmic bytes of one step on one GPU: FASTA read once + registers written once
         alg_bytes = ng * nbytes + ng * K * m
         sweep_s_per_step = sweep_ms / 1e3 / steps
@@ -251,34 +447,36 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if cfg["strong"] else "weak",
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": f"cfg2: {ng} x {args.mbp:g} Mbp synthetic FASTA per GPU resident in HBM, HLL log2m={p}, "
-                            f"k-sweep {kmin}-{kmax} (K={K}), leaf sketches + root union + all cardinalities + delta",
+                "workload": f"{args.config}: {ng} x {cfg['mbp']:g} Mbp synthetic FASTA on this GPU ({total_genomes} over {world} GPU(s)) resident in HBM, "
+                            f"HLL log2m={p}, k-sweep {kmin}-{kmax} (K={K}), leaf sketches + root union + all cardinalities + delta"
+                            + (f" + {cfg['extra']} schedule" if cfg["extra"] else ""),
                 "genomes_per_gpu": ng, "bases_per_genome": nb, "kmin": kmin, "kmax": kmax, "log2m": p,
                 "parallelism": f"genomes sharded over {world} GPU(s)" + ("; RCCL max all-reduce of the root" if world > 1 else ""),
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "sweep_kernel (K1, all k-class launches of one step)",
+                "kernel": "K1: sweep_kernel launches of one step" + (" (scatter + sort + replay at log2m >= 18)" if p >= 18 else ""),
                 "achieved": achieved_gbs,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_note": "K1 bytes per step from profiles/traffic.json (2 x FETCH_SIZE + WRITE_SIZE, separate PMC passes); "
-                                "above the algorithmic bytes because each k-group re-reads the 3-bit token stream and every job "
-                                "merges its LDS registers into the slab -- irrelevant to a VALU-bound kernel (220 GB/s)",
+                "traffic_from": traffic_src,
+                "traffic_note": "K1 bytes per step = 2 x FETCH_SIZE + WRITE_SIZE of separate PMC passes; above the algorithmic bytes because "
+                                "each k-group re-reads the 3-bit token stream and every job merges its LDS registers into the slab -- "
+                                "243 GB/s, irrelevant to a VALU-bound kernel",
                 "algorithmic_bytes_per_step": alg_bytes,
                 "kernel_ms_per_step": sweep_ms / steps,
                 "launches_per_step": sweep_n / steps,
                 "avg_launch_ms": sweep_ms / max(1, sweep_n),
                 "register_updates_per_s": updates_per_s,
                 "valu_lane_ops_peak": VALU_PEAK_LANEOPS,
-                "valu_bound": valu_bound(kmin, kmax, updates_per_s),
+                "valu_bound": valu_bound(kmin, kmax, updates_per_s) if p < 18 else None,
                 "note": "integer-VALU bound (hash per (base,k)); see DESIGN.md for ops/update and the VALU fraction",
             },
             "other_kernels_ms_per_step": {"pack_K0": pack_ms / steps, "union_hist_K2": union_ms / steps},
@@ -289,11 +487,10 @@ def main():
                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": (ng * nbytes + ng * nb * 0.375) / (pack_ms / 1e3 / steps) / 1e9 / HBM_PEAK_GBS if pack_ms > 0 else None,
                             "kernel_ms_per_step": pack_ms / steps},
-            "delta_genome0": float(delta[0]), "argmax_k_genome0": int(bestk[0]),
+            "delta_genome0": float(delta[0]) if ng else None, "argmax_k_genome0": int(bestk[0]) if ng else None,
             "delta_root": float(delta[ng]), "argmax_k_root": int(bestk[ng]),
         }
-        if accuracy is not None:
-            out["accuracy_vs_exact"] = accuracy
+        out.update(extras)
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

@@ -52,30 +52,45 @@ def max_over_ranks(value, device=None):
     return float(t.item())
 
 
-def distributed_ksweep(fastas, sizes, kmin, kmax, m, sketch_fn, union_fn, card_fn, device=None):
-    """Sketch `fastas` over k in [kmin, kmax], sharded by size over the ranks of the default group.
+def sharded_ksweep(weights, K, m, sketch_into, union_into, card_of, regs=None, mine=None, device=None):
+    """One pass of the sharded k-sweep on this rank -- THE N>1 path: bench.py's step and the multi-GPU tests
+    both run this function (the reference has no counterpart: it parallelises over k only,
+    /root/reference/lib/huffman_dandd.py:217).
 
-    sketch_fn(path) -> uint8 [K][m] (torch tensor on `device`)   this rank's leaf sketch
-    union_fn(list of [K][m]) -> [K][m]                           local N-way byte max
-    card_fn([J][m]) -> float64 ndarray [J]                       cardinalities
-    Returns on every rank: (leaf_card [n][K], root [K][m] tensor, root_card [K]).
-    """
+    weights        sizes of ALL genomes of the job, the same list on every rank; rank r sketches
+                   shard_by_weight(weights, world)[r] -- or `mine` when the caller has fixed the shard (weak
+                   scaling: every rank brings its own genomes)
+    sketch_into(indices, leaves)   leaves: uint8 tensor [n][K][m] <- sketches of genomes `indices`
+    union_into(leaves, root)       root: uint8 tensor [K][m] <- byte-max over this rank's leaves (zeros if none)
+    card_of(regs)                  float64 [(n+1)*K] cardinalities of regs = leaves followed by the root
+    The only exchange is a MAX all-reduce of the root slab (RCCL ncclMax/ncclUint8 over xGMI; gloo on CPU).
+    Returns (mine, regs [n+1][K][m], card [n+1][K]); row n is the root over ALL ranks' genomes."""
     import torch
     import torch.distributed as dist
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    rank = dist.get_rank() if dist.is_initialized() else 0
-    K, n = kmax - kmin + 1, len(fastas)
-    mine = shard_by_weight(list(sizes), world)[rank]
-    slabs = [sketch_fn(fastas[i]) for i in mine]
-    leaf_card = torch.zeros((n, K), dtype=torch.float64, device=device)
-    if slabs:
-        cards = card_fn(torch.stack(slabs).reshape(-1, m)).reshape(len(slabs), K)
-        leaf_card[torch.tensor(mine, device=device)] = torch.as_tensor(cards, dtype=torch.float64, device=device)
-        root = union_fn(slabs)
-    else:
-        root = torch.zeros((K, m), dtype=torch.uint8, device=device)
-    if world > 1:
-        dist.all_reduce(leaf_card, op=dist.ReduceOp.SUM)  # disjoint rows: sum == gather
-        allreduce_max_u8(root)
-    root_card = np.asarray(card_fn(root.reshape(-1, m)), dtype=np.float64)
-    return leaf_card.cpu().numpy(), root, root_card
+    live = dist.is_available() and dist.is_initialized()
+    world, rank = (dist.get_world_size(), dist.get_rank()) if live else (1, 0)
+    if mine is None:
+        mine = shard_by_weight(list(weights), world)[rank]
+    n = len(mine)
+    if regs is None:
+        regs = torch.empty((n + 1, K, m), dtype=torch.uint8, device=device)
+    if n:
+        sketch_into(mine, regs[:n])
+    union_into(regs[:n], regs[n])
+    allreduce_max_u8(regs[n])
+    card = np.asarray(card_of(regs), dtype=np.float64).reshape(n + 1, K)
+    return mine, regs, card
+
+
+def gather_rows(rows, mine, n_total, device=None):
+    """Rows (float64 [len(mine)][K]) owned by the ranks -> the full [n_total][K] table on every rank
+    (disjoint owners: a SUM all-reduce of the zero-padded table is a gather)."""
+    import torch
+    import torch.distributed as dist
+    rows = np.asarray(rows, dtype=np.float64)
+    full = torch.zeros((n_total, rows.shape[1] if rows.ndim == 2 else 0), dtype=torch.float64, device=device)
+    if len(mine):
+        full[torch.tensor(list(mine), device=device)] = torch.as_tensor(rows, dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(full, op=dist.ReduceOp.SUM)
+    return full.cpu().numpy()

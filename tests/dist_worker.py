@@ -1,5 +1,5 @@
 """Worker of tests/test_distributed.py: one rank of a gloo world; the GPU calls of
-dandd_amd.dist.distributed_ksweep are replaced by the CPU oracle (checker) so the sharding +
+dandd_amd.dist.sharded_ksweep (the function bench.py steps through) are replaced by the CPU oracle (checker) so the sharding +
 all-reduce logic runs without a GPU."""
 import json
 import os
@@ -24,18 +24,25 @@ def main():
     sizes = [os.path.getsize(f) for f in fastas]
     touched = []
 
-    def sketch_fn(path):
-        touched.append(os.path.basename(path))
-        return torch.from_numpy(orc.sketch_sweep(np.fromfile(path, dtype=np.uint8), kmin, kmax, p))
+    K = kmax - kmin + 1
 
-    def union_fn(slabs):
-        return torch.from_numpy(orc.union(*[s.numpy() for s in slabs]))
+    def sketch_into(indices, leaves):
+        for j, i in enumerate(indices):
+            touched.append(os.path.basename(fastas[i]))
+            leaves[j] = torch.from_numpy(orc.sketch_sweep(np.fromfile(fastas[i], dtype=np.uint8), kmin, kmax, p))
 
-    def card_fn(regs):
-        r = regs.numpy()
+    def union_into(leaves, root):
+        root.zero_()
+        for j in range(leaves.shape[0]):
+            torch.maximum(root, leaves[j], out=root)
+
+    def card_of(regs):
+        r = regs.reshape(-1, m).numpy()
         return np.array([orc.card(r[i], p) for i in range(r.shape[0])])
 
-    leaf_card, root, root_card = dd.distributed_ksweep(fastas, sizes, kmin, kmax, m, sketch_fn, union_fn, card_fn)
+    mine, regs, card = dd.sharded_ksweep(sizes, K, m, sketch_into, union_into, card_of)
+    leaf_card = dd.gather_rows(card[:len(mine)], mine, len(fastas))
+    root, root_card = regs[len(mine)], card[len(mine)]
     slowest = dd.max_over_ranks(float(rank + 1))
     with open(f"{out_path}.{rank}", "w") as f:
         json.dump({"rank": rank, "world": world, "touched": touched, "leaf_card": leaf_card.tolist(),

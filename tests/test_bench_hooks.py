@@ -1,0 +1,87 @@
+"""bench.py's side legs: the Dashing hook of the CPU baseline and the N>1 path on one GPU."""
+import json
+import os
+import socket
+import stat
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+# `dashing sketch -k<K> -S <p> --prefix <dir> <fasta>` restated with the oracle, writing Dashing's own container
+# (gzip) under Dashing's own output name: what the hook has to cope with if a real binary is ever on PATH
+SHIM = r'''#!/usr/bin/env python3
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from oracle import dd_oracle as orc
+from dandd_amd.host.backend import write_sketch_file
+a = sys.argv[1:]
+assert a[0] == "sketch", a
+k = S = prefix = fasta = None
+i = 1
+while i < len(a):
+    t = a[i]
+    if t.startswith("-k"): k = int(t[2:])
+    elif t == "-S": i += 1; S = int(a[i])
+    elif t == "--prefix": i += 1; prefix = a[i]
+    else: fasta = t
+    i += 1
+regs = orc.sketch(np.fromfile(fasta, dtype=np.uint8), k, S, True)
+if os.environ.get("SHIM_CORRUPT") and k == int(os.environ["SHIM_CORRUPT"]):
+    regs = regs.copy(); regs[5] += 1
+write_sketch_file(os.path.join(prefix, os.path.basename(fasta) + ".w.%%d.spacing.%%d.hll" %% (k, S)), regs, S, k, True, fmt="dashing")
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_cpu_baseline_uses_and_checks_a_dashing_on_path(tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    base = bench.cpu_baseline(120_000, 2, 10, 13, 12)
+    assert base["kind"] == "port" and base["value"] > 0 and "no `dashing` on PATH" in base["sample"]
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    exe = bindir / "dashing"
+    exe.write_text(SHIM % {"root": ROOT})
+    exe.chmod(exe.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(bindir) + os.pathsep + os.environ["PATH"])
+    got = bench.cpu_baseline(120_000, 2, 10, 13, 12)
+    assert got["kind"] == "dashing" and got["value"] > 0
+    assert got["registers_all_equal"] is True and set(got["registers_equal_oracle"]) <= {"10", "11", "12", "13"}
+    monkeypatch.setenv("SHIM_CORRUPT", "10")   # a Dashing whose registers differ must be reported, not hidden
+    bad = bench.cpu_baseline(120_000, 2, 10, 13, 12)
+    assert bad["kind"] == "dashing" and bad["registers_all_equal"] is False and bad["registers_equal_oracle"]["10"] is False
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_matches_single_process(torch_cuda):
+    """The N>1 code path of bench.py (dandd_amd.dist.sharded_ksweep + the MAX all-reduce of the root) on a
+    one-GPU box: two ranks share cuda:0 and reduce through gloo.  The root over both ranks' 2 x 10 genomes must be
+    the root a single process computes over the same 20 genomes."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", DD_BENCH_BACKEND="gloo", DD_BENCH_SHARE_DEVICE="1")
+    common = ["--steps", "2", "--warmup", "1", "--mbp", "5", "--no-cpu-baseline", "--no-accuracy", "--no-secondary", "--no-ingest"]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common,
+                         env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-4000:]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--genomes", "20"] + common,
+                         env=dict(os.environ), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-4000:]
+    j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "weak" and j2["config"]["genomes_per_gpu"] == 10
+    assert j2["delta_root"] == j1["delta_root"] and j2["argmax_k_root"] == j1["argmax_k_root"]
+    assert j2["delta_genome0"] == j1["delta_genome0"]
+    assert np.isfinite(j2["value"]) and j2["value"] > 0

@@ -99,3 +99,49 @@ def test_two_rank_cli_tree_matches_single_process(orc, tmp_path):
             va = a[key].replace(out1, "") if isinstance(a[key], str) else a[key]
             vb = b[key].replace(out2, "") if isinstance(b[key], str) else b[key]
             assert va == vb, (key, a[key], b[key])
+
+
+def test_two_rank_cli_progressive_and_kij_shard_uncached_leaf_sketches(orc, tmp_path):
+    """`progressive --ksweep` and `kij` over a k range the tree never sketched: under torch.distributed.run
+    EVERY rank takes part (its share of the leaf sketches, by file size), the ranks meet at one barrier, rank 0
+    writes the outputs -- equal to a single-process run from an identical tree -- and the launcher exits 0."""
+    import csv
+    import pickle
+    import shutil
+    worker = os.path.join(HERE, "cli_dist_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    data = tmp_path / "genomes"
+    data.mkdir()
+    for g, nb in enumerate([30000, 8000, 22000, 15000, 4000, 26000]):
+        (data / f"g{g}.fasta").write_bytes(orc.synth_fasta(0xD4ADD, g, nb, 2).tobytes())
+    orderings = str(tmp_path / "orderings.pickle")
+    with open(orderings, "wb") as f:
+        pickle.dump({(0, 1, 2, 3, 4, 5), (5, 3, 1, 0, 2, 4)}, f)
+
+    def run(cmd_prefix, log, args):
+        r = subprocess.run(cmd_prefix + [worker, log] + args, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+    def rows(path, strip):
+        with open(path) as f:
+            return [{k: (v.replace(strip, "") if isinstance(v, str) else v) for k, v in r.items() if k != "command"}
+                    for r in csv.DictReader(f)]
+
+    results = {}
+    for name, nproc in (("one", 1), ("two", 2)):
+        out = str(tmp_path / name)
+        run([sys.executable], str(tmp_path / f"{name}_tree"), ["tree", "-d", str(data), "-s", "d", "-r", "10", "-k", "10", "-o", out])
+        tree = os.path.join(out, "d_6_dashing_dtree.pickle")
+        prefix = [sys.executable] if nproc == 1 else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                                                      "--master-addr", "127.0.0.1", "--master-port", str(_free_port())]
+        run(prefix, str(tmp_path / f"{name}_prog"), ["progressive", "-d", tree, "-o", out, "-r", orderings, "-n", "2", "--ksweep", "--mink", "20", "--maxk", "23"])
+        prefix = prefix[:-1] + [str(_free_port())] if nproc == 2 else prefix
+        run(prefix, str(tmp_path / f"{name}_kij"), ["kij", "-d", tree, "-o", out, "--jaccard", "--mink", "26", "--maxk", "28"])
+        results[name] = (rows(os.path.join(out, "d_progu2_6_dashingsummary.csv"), out), rows(os.path.join(out, "d_6_dashing.kij.csv"), out),
+                         rows(os.path.join(out, "d_6_dashing.j.csv"), out))
+    for a, b in zip(results["one"], results["two"]):
+        assert len(a) > 0 and a == b
+    for step in ("prog", "kij"):
+        touched = [json.load(open(str(tmp_path / f"two_{step}.{rank}")))["touched"] for rank in range(2)]
+        assert touched[0] and touched[1], (step, touched)                            # both ranks sketched something
+        assert sorted(touched[0] + touched[1]) == [f"g{g}.fasta" for g in range(6)]  # each leaf exactly once
