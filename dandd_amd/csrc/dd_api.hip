@@ -25,8 +25,12 @@
 #include <vector>
 
 #include "dd_common.h"
+#include "dd_io.h"
 #include "dd_kernels.h"
 #include "dd_plan.h"
+
+using dd::FileBuf;
+using dd::read_fasta_file;
 
 namespace {
 
@@ -99,8 +103,6 @@ struct HostBuf {  // grow-only pinned host staging
 struct TimedSpan {
     hipEvent_t a, b;
 };
-
-struct FileBuf;  // host bytes of one file (below)
 
 }  // namespace
 
@@ -188,93 +190,6 @@ int upload(dd_ctx* c, HostBuf& stage, void* dst_dev, const void* src, size_t byt
     DD_HIP(hipMemcpyAsync(dst_dev, static_cast<char*>(stage.p) + stage_off, bytes,
                           hipMemcpyHostToDevice, c->stream));
     return DD_OK;
-}
-
-// Host bytes of one file.  Pageable flavour: malloc storage in 2 MiB-aligned blocks the kernel may back
-// with huge pages (512x fewer page faults for a 250 MB .. 3 GB buffer).  Pinned flavour (the ingestion
-// pipeline's pool): hipHostMalloc storage, so the H2D copy of a loaded file is a true asynchronous DMA at
-// PCIe speed; pinning is slow, which is why those buffers live in the context and are reused from file
-// to file and from call to call.  Contents are carried over when a buffer grows.
-struct FileBuf {
-    uint8_t* p = nullptr;
-    size_t len = 0, cap = 0;
-    bool pinned = false;
-    FileBuf() = default;
-    FileBuf(const FileBuf&) = delete;
-    FileBuf& operator=(const FileBuf&) = delete;
-    ~FileBuf() { release(); }
-    void release() {
-        if (p) {
-            if (pinned) (void)hipHostFree(p);
-            else free(p);
-        }
-        p = nullptr;
-        len = cap = 0;
-    }
-    bool reserve(size_t n) {
-        if (n <= cap) return true;
-        const size_t want = (n + kHuge - 1) / kHuge * kHuge;
-        void* q = nullptr;
-        if (pinned) {
-            if (hipHostMalloc(&q, want, hipHostMallocDefault) != hipSuccess || !q) {
-                (void)hipGetLastError();
-                return false;
-            }
-        } else {
-            if (posix_memalign(&q, kHuge, want) != 0 || !q) return false;
-            (void)madvise(q, want, MADV_HUGEPAGE);
-        }
-        if (len) memcpy(q, p, len);
-        if (p) {
-            if (pinned) (void)hipHostFree(p);
-            else free(p);
-        }
-        p = static_cast<uint8_t*>(q);
-        cap = want;
-        return true;
-    }
-    static constexpr size_t kHuge = (size_t)2 << 20;
-    const uint8_t* data() const { return p; }
-    size_t size() const { return len; }
-};
-
-// Whole FASTA file into memory; gzip (any number of members) or plain, decided by zlib itself.
-bool read_fasta_file(const char* path, FileBuf& out, std::string& err) {
-    gzFile f = gzopen(path, "rb");
-    if (!f) {
-        err = std::string("cannot open ") + path;
-        return false;
-    }
-    gzbuffer(f, 1u << 20);
-    // size hint: a plain file is read in one piece; a compressed one usually inflates ~4x
-    size_t hint = 1u << 22;
-    struct stat sb;
-    if (stat(path, &sb) == 0 && sb.st_size > 0) hint = (size_t)sb.st_size + 1;
-    out.len = 0;
-    if (!out.reserve(std::max(out.cap, hint))) {
-        err = std::string("out of host memory reading ") + path;
-        gzclose(f);
-        return false;
-    }
-    for (;;) {
-        if (out.len == out.cap && !out.reserve(out.cap * 2)) {
-            err = std::string("out of host memory reading ") + path;
-            gzclose(f);
-            return false;
-        }
-        const unsigned want = (unsigned)std::min<size_t>(out.cap - out.len, 1u << 30);
-        const int got = gzread(f, out.p + out.len, want);
-        if (got < 0) {
-            int code = 0;
-            err = std::string("read error on ") + path + ": " + gzerror(f, &code);
-            gzclose(f);
-            return false;
-        }
-        if (got == 0) break;
-        out.len += (size_t)got;
-    }
-    gzclose(f);
-    return true;
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -391,7 +306,14 @@ void dd_destroy(dd_ctx* c) {
 
 int dd_set_stream(dd_ctx* c, void* hip_stream) {
     if (check_ctx(c)) return DD_EINVAL;
-    c->stream = static_cast<hipStream_t>(hip_stream);
+    hipStream_t next = static_cast<hipStream_t>(hip_stream);
+    if (next != c->stream) {
+        // Work queued on the old stream still uses the context's tables and workspaces (the cached K1 job
+        // tables were uploaded there); nothing orders a new stream behind it, so it is drained first.
+        DeviceGuard g(c->device);
+        DD_HIP(hipStreamSynchronize(c->stream));
+        c->stream = next;
+    }
     return DD_OK;
 }
 
@@ -997,22 +919,18 @@ int dd_exact_count_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size
     }
     if (!slots) return DD_OK;
     const bool wide = k > 32;
-    const size_t key_bytes = slots * sizeof(uint64_t);
-    const size_t temp_bytes = dd::exact_sort_temp_bytes(slots, k);
     const size_t arrays = wide ? 4 : 2;
+    // HBM for the k-mer arrays (keys + the sort's other half): everything at once when that fits the budget,
+    // else in passes over disjoint parts of the k-mer space (below).  KMC unions arbitrarily many databases
+    // (/root/reference/lib/sketch_classes.py:453-465); so must this.
+    size_t budget = (size_t)24 << 30;
+    if (const char* e = getenv("DD_EXACT_MB")) budget = (size_t)std::max(1, atoi(e)) << 20;
+    const bool single = arrays * slots * sizeof(uint64_t) <= budget;
+    const size_t cap = single ? slots : std::max<size_t>(budget / (arrays * sizeof(uint64_t)), 4096);  // k-mers per pass
     if ((rc = c->tokens.reserve(tot))) return rc;
     if ((rc = c->scratch.reserve(scratch_tot))) return rc;
-    if ((rc = c->exact.reserve(arrays * align_up(key_bytes, 256) + temp_bytes + 256))) return rc;
     char* tb = static_cast<char*>(c->tokens.p);
     char* sb = static_cast<char*>(c->scratch.p);
-    char* eb = static_cast<char*>(c->exact.p);
-    unsigned long long* counters = reinterpret_cast<unsigned long long*>(eb);
-    const size_t stride = align_up(key_bytes, 256);
-    uint64_t* lo = reinterpret_cast<uint64_t*>(eb + 256);
-    uint64_t* lo_alt = reinterpret_cast<uint64_t*>(eb + 256 + stride);
-    uint64_t* hi = wide ? reinterpret_cast<uint64_t*>(eb + 256 + 2 * stride) : nullptr;
-    uint64_t* hi_alt = wide ? reinterpret_cast<uint64_t*>(eb + 256 + 3 * stride) : nullptr;
-    void* temp = eb + 256 + arrays * stride;
 
     std::vector<dd::PackGenome> ptab(n);
     std::vector<dd::ExactGenome> etab(n);
@@ -1031,24 +949,98 @@ int dd_exact_count_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size
     if ((rc = upload(c, c->stage, tdev, ptab.data(), sizeof(dd::PackGenome) * n, 0))) return rc;
     if ((rc = upload(c, c->stage, tdev + pbytes, etab.data(), sizeof(dd::ExactGenome) * n, pbytes))) return rc;
     DD_HIP(hipEventRecord(c->stage_free, st));
-
-    DD_HIP(hipMemsetAsync(counters, 0, 256, st));
-    DD_HIP(hipMemsetAsync(lo, 0xFF, key_bytes, st));  // unwritten slots read as the all-ones sentinel
-    if (wide) DD_HIP(hipMemsetAsync(hi, 0xFF, key_bytes, st));
     {
         Span sp(c, DD_KERNEL_PACK);
         dd::launch_pack_batch(reinterpret_cast<const dd::PackGenome*>(tdev), n, max_chunks, st);
     }
-    dd::launch_kmer_extract(reinterpret_cast<const dd::ExactGenome*>(tdev + pbytes), n, max_segments, k,
-                            c->canonical, lo, hi, counters, st);
+    const dd::ExactGenome* etab_dev = reinterpret_cast<const dd::ExactGenome*>(tdev + pbytes);
+
+    // layout of the k-mer workspace for `cap` keys: counters (256 B) | histogram (32 KiB) | lo | lo_alt [| hi | hi_alt] | temp
+    const size_t hist_bytes = (size_t)dd::kExactBins * sizeof(unsigned long long);
+    auto carve = [&](size_t keys, size_t temp_bytes, unsigned long long*& counters, unsigned long long*& hist, uint64_t*& lo,
+                     uint64_t*& lo_alt, uint64_t*& hi, uint64_t*& hi_alt, void*& temp) -> int {
+        const size_t stride = align_up(keys * sizeof(uint64_t), 256);
+        int r = c->exact.reserve(256 + hist_bytes + arrays * stride + temp_bytes + 256);
+        if (r) return r;
+        char* eb = static_cast<char*>(c->exact.p);
+        counters = reinterpret_cast<unsigned long long*>(eb);
+        hist = reinterpret_cast<unsigned long long*>(eb + 256);
+        char* kb = eb + 256 + hist_bytes;
+        lo = reinterpret_cast<uint64_t*>(kb);
+        lo_alt = reinterpret_cast<uint64_t*>(kb + stride);
+        hi = wide ? reinterpret_cast<uint64_t*>(kb + 2 * stride) : nullptr;
+        hi_alt = wide ? reinterpret_cast<uint64_t*>(kb + 3 * stride) : nullptr;
+        temp = kb + arrays * stride;
+        return DD_OK;
+    };
+    unsigned long long *counters = nullptr, *hist = nullptr;
+    uint64_t *lo = nullptr, *lo_alt = nullptr, *hi = nullptr, *hi_alt = nullptr;
+    void* temp = nullptr;
+
+    if (single) {
+        const size_t key_bytes = slots * sizeof(uint64_t);
+        const size_t temp_bytes = dd::exact_sort_temp_bytes(slots, k);
+        if ((rc = carve(slots, temp_bytes, counters, hist, lo, lo_alt, hi, hi_alt, temp))) return rc;
+        DD_HIP(hipMemsetAsync(counters, 0, 256, st));
+        DD_HIP(hipMemsetAsync(lo, 0xFF, key_bytes, st));  // unwritten slots read as the all-ones sentinel
+        if (wide) DD_HIP(hipMemsetAsync(hi, 0xFF, key_bytes, st));
+        dd::launch_kmer_extract(etab_dev, n, max_segments, k, c->canonical, lo, hi, counters, st);
+        DD_HIP(hipGetLastError());
+        DD_HIP(dd::launch_exact_sort_count(lo, hi, lo_alt, hi_alt, slots, k, temp, temp_bytes, counters, st));
+        unsigned long long h[3] = {0, 0, 0};
+        DD_HIP(hipMemcpyAsync(h, counters, sizeof h, hipMemcpyDeviceToHost, st));
+        DD_HIP(hipStreamSynchronize(st));
+        // the all-ones group holds the sentinels of unwritten slots and/or genuine T^k k-mers
+        const bool sentinel_present = h[0] < (unsigned long long)slots, all_t = h[1] != 0;
+        *distinct = h[2] - ((sentinel_present || all_t) ? 1 : 0) + (all_t ? 1 : 0);
+        return DD_OK;
+    }
+
+    // ---- more k-mers than the budget holds: passes over disjoint parts of the k-mer space ------------
+    // The k-mer space is cut into 4096 bins by a mix of the k-mer itself (equal k-mers share a bin), a
+    // counting pass sizes the bins, consecutive bins are grouped into passes of at most `cap` k-mers, and every
+    // pass extracts (densely), sorts and counts only its own bins: distinct = sum over passes.
+    size_t temp_bytes = dd::exact_sort_temp_bytes(cap, k);
+    if ((rc = carve(cap, temp_bytes, counters, hist, lo, lo_alt, hi, hi_alt, temp))) return rc;
+    DD_HIP(hipMemsetAsync(counters, 0, 256 + hist_bytes, st));
+    dd::launch_kmer_extract(etab_dev, n, max_segments, k, c->canonical, lo, hi, counters, st, 1, hist, 0, 0);
     DD_HIP(hipGetLastError());
-    DD_HIP(dd::launch_exact_sort_count(lo, hi, lo_alt, hi_alt, slots, k, temp, temp_bytes, counters, st));
-    unsigned long long h[3] = {0, 0, 0};
-    DD_HIP(hipMemcpyAsync(h, counters, sizeof h, hipMemcpyDeviceToHost, st));
+    std::vector<unsigned long long> bins(dd::kExactBins);
+    DD_HIP(hipMemcpyAsync(bins.data(), hist, hist_bytes, hipMemcpyDeviceToHost, st));
     DD_HIP(hipStreamSynchronize(st));
-    // the all-ones group holds the sentinels of unwritten slots and/or genuine T^k k-mers
-    const bool sentinel_present = h[0] < (unsigned long long)slots, all_t = h[1] != 0;
-    *distinct = h[2] - ((sentinel_present || all_t) ? 1 : 0) + (all_t ? 1 : 0);
+    const unsigned long long biggest = *std::max_element(bins.begin(), bins.end());
+    size_t pass_cap = cap;
+    if (biggest > pass_cap) {
+        // one bin alone is over the budget (one k-mer repeated billions of times lands in one bin): the arrays
+        // grow to hold it if the device has the room, otherwise this input cannot be counted here
+        pass_cap = (size_t)biggest;
+        temp_bytes = dd::exact_sort_temp_bytes(pass_cap, k);
+        if ((rc = carve(pass_cap, temp_bytes, counters, hist, lo, lo_alt, hi, hi_alt, temp)))
+            return fail(DD_ENOMEM, "exact count: one part of the k-mer space holds %llu k-mers, more than fits in HBM", biggest);
+    }
+    unsigned long long total = 0;
+    int npass = 0;
+    for (uint32_t b0 = 0; b0 < (uint32_t)dd::kExactBins;) {
+        unsigned long long in_pass = 0;
+        uint32_t b1 = b0;
+        while (b1 < (uint32_t)dd::kExactBins && in_pass + bins[b1] <= pass_cap) in_pass += bins[b1++];
+        if (in_pass) {
+            DD_HIP(hipMemsetAsync(counters, 0, 256, st));
+            dd::launch_kmer_extract(etab_dev, n, max_segments, k, c->canonical, lo, hi, counters, st, 2, hist, b0, b1);
+            DD_HIP(hipGetLastError());
+            // (every slot below in_pass is written: no sentinel, T^k is an ordinary value here)
+            DD_HIP(dd::launch_exact_sort_count(lo, hi, lo_alt, hi_alt, (size_t)in_pass, k, temp, temp_bytes, counters, st));
+            unsigned long long h[4] = {0, 0, 0, 0};
+            DD_HIP(hipMemcpyAsync(h, counters, sizeof h, hipMemcpyDeviceToHost, st));
+            DD_HIP(hipStreamSynchronize(st));
+            if (h[3] != in_pass) return fail(DD_EHIP, "exact count: pass over bins %u..%u appended %llu k-mers, %llu expected", b0, b1, h[3], in_pass);
+            total += h[2];
+            ++npass;
+        }
+        b0 = b1;
+    }
+    c->st_blocks = npass;  // (visible through dd_last_sketch_stats: how many passes the last exact count took)
+    *distinct = total;
     return DD_OK;
 }
 

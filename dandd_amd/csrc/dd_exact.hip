@@ -19,17 +19,34 @@
 namespace dd {
 namespace {
 
-// one thread per 64-token segment; k-mer ending at token t goes to out[base + t]
-template <bool CANON, bool WIDE>
+// Partition of the k-mer space for inputs whose k-mers do not fit the HBM budget at once: 4096 bins by a mix
+// of the k-mer itself, so equal k-mers always share a bin and the distinct count is the sum over bins.
+constexpr int kExactBinBits = 12;
+DD_D uint32_t exact_bin(uint64_t lo, uint64_t hi) { return (uint32_t)(splitmix64(lo ^ (hi * 0x9E3779B97F4A7C15ull)) >> (64 - kExactBinBits)); }
+
+// one thread per 64-token segment.
+//   MODE 0: the k-mer ending at token t goes to out[base + t] (everything at once; unwritten slots keep a sentinel)
+//   MODE 1: only counts k-mers per bin into hist[4096] (LDS histogram per workgroup, one flush)
+//   MODE 2: k-mers whose bin is in [bin_lo, bin_hi) are appended densely (wave-aggregated atomic on counters[3])
+template <bool CANON, bool WIDE, int MODE>
 __global__ __launch_bounds__(256) void kmer_extract_kernel(const ExactGenome* __restrict__ tab, int k,
                                                           uint64_t* __restrict__ out_lo,
                                                           uint64_t* __restrict__ out_hi,
-                                                          unsigned long long* __restrict__ counters) {
+                                                          unsigned long long* __restrict__ counters,
+                                                          unsigned long long* __restrict__ hist, uint32_t bin_lo,
+                                                          uint32_t bin_hi) {
+    __shared__ uint32_t lhist[MODE == 1 ? (1 << kExactBinBits) : 1];
+    if (MODE == 1) {
+        for (int i = threadIdx.x; i < (1 << kExactBinBits); i += blockDim.x) lhist[i] = 0;
+        __syncthreads();
+    }
     const ExactGenome g = tab[blockIdx.y];
     const unsigned long long ntok = *g.ntok;
     const unsigned long long seg = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned valid = 0, allt = 0;
-    if (seg * kSegTokens < ntok) {
+    // (MODE 2 keeps every lane in the token loop: the append is a wave-level operation)
+    const bool live = seg * kSegTokens < ntok;
+    if (MODE == 2 ? __any(live) : live) {
         const uint4* codes4 = reinterpret_cast<const uint4*>(g.codes);
         const uint2* bad2 = reinterpret_cast<const uint2*>(g.bad);
         // 128-bit windows serve every k <= 64; the sort, not this kernel, is the cost
@@ -40,8 +57,8 @@ __global__ __launch_bounds__(256) void kmer_extract_kernel(const ExactGenome* __
         const int s = 128 - 2 * k;  // right shift that aligns the reverse-complement window
         for (int part = (seg > 0 ? 0 : 1); part < 2; ++part) {
             const unsigned long long sidx = seg - 1 + part;
-            const uint4 c4 = codes4[sidx];
-            const uint2 b2 = bad2[sidx];
+            const uint4 c4 = live ? codes4[sidx] : make_uint4(0, 0, 0, 0);
+            const uint2 b2 = live ? bad2[sidx] : make_uint2(~0u, ~0u);
             const uint32_t cw[4] = {c4.x, c4.y, c4.z, c4.w};
             const uint64_t bw = ((uint64_t)b2.y << 32) | b2.x;
 #pragma unroll
@@ -55,7 +72,8 @@ __global__ __launch_bounds__(256) void kmer_extract_kernel(const ExactGenome* __
                 fl = (fl << 2) | c;
                 rl = (rl >> 2) | (rh << 62);
                 rh = (rh >> 2) | ((uint64_t)(3u - c) << 62);
-                if (part == 0 || run < k) continue;
+                const bool have = part != 0 && run >= k;
+                if (MODE != 2 && !have) continue;
                 uint64_t ah = fh & mhi, al = fl & mlo;
                 if (CANON) {
                     uint64_t bh, bl;
@@ -74,14 +92,40 @@ __global__ __launch_bounds__(256) void kmer_extract_kernel(const ExactGenome* __
                         al = bl;
                     }
                 }
-                const unsigned long long pos = g.base + sidx * kSegTokens + (unsigned)t;
-                out_lo[pos] = al;
-                if (WIDE) out_hi[pos] = ah;
-                ++valid;
-                if (al == mlo && ah == mhi) allt = 1;
+                if (MODE == 0) {
+                    const unsigned long long pos = g.base + sidx * kSegTokens + (unsigned)t;
+                    out_lo[pos] = al;
+                    if (WIDE) out_hi[pos] = ah;
+                    ++valid;
+                    if (al == mlo && ah == mhi) allt = 1;
+                } else if (MODE == 1) {
+                    atomicAdd(&lhist[exact_bin(al, WIDE ? ah : 0ull)], 1u);
+                } else {
+                    const uint32_t bin = exact_bin(al, WIDE ? ah : 0ull);
+                    const bool take = have && bin >= bin_lo && bin < bin_hi;
+                    const unsigned long long mask = __ballot(take);
+                    if (mask) {
+                        const uint32_t lane = threadIdx.x & 63u;
+                        unsigned long long basepos = 0;
+                        if (lane == (uint32_t)__builtin_ctzll(mask)) basepos = atomicAdd(&counters[3], (unsigned long long)__builtin_popcountll(mask));
+                        basepos = __shfl(basepos, __builtin_ctzll(mask));
+                        if (take) {
+                            const unsigned long long pos = basepos + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                            out_lo[pos] = al;
+                            if (WIDE) out_hi[pos] = ah;
+                        }
+                    }
+                }
             }
         }
     }
+    if (MODE == 1) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < (1 << kExactBinBits); i += blockDim.x)
+            if (lhist[i]) atomicAdd(&hist[i], (unsigned long long)lhist[i]);
+        return;
+    }
+    if (MODE == 2) return;
     // wave-level reduction of the two statistics, one atomic per wave
     for (int d = 32; d > 0; d >>= 1) {
         valid += __shfl_down(valid, d);
@@ -114,16 +158,25 @@ __global__ __launch_bounds__(256) void count_unique_kernel(const uint64_t* __res
 }  // namespace
 
 void launch_kmer_extract(const ExactGenome* tab_dev, int ng, size_t max_segments, int k, int canonical,
-                         uint64_t* lo, uint64_t* hi, unsigned long long* counters, hipStream_t st) {
+                         uint64_t* lo, uint64_t* hi, unsigned long long* counters, hipStream_t st, int mode,
+                         unsigned long long* hist, uint32_t bin_lo, uint32_t bin_hi) {
     if (ng <= 0 || !max_segments) return;
     const dim3 grid((unsigned)((max_segments + 255) / 256), (unsigned)ng), block(256);
     const bool wide = k > 32;
-#define DD_EX(CN, WD) hipLaunchKernelGGL((kmer_extract_kernel<CN, WD>), grid, block, 0, st, tab_dev, k, lo, hi, counters)
+#define DD_EX(CN, WD, MD) \
+    hipLaunchKernelGGL((kmer_extract_kernel<CN, WD, MD>), grid, block, 0, st, tab_dev, k, lo, hi, counters, hist, bin_lo, bin_hi)
+#define DD_EX_MODE(CN, WD)             \
+    do {                               \
+        if (mode == 0) DD_EX(CN, WD, 0); \
+        else if (mode == 1) DD_EX(CN, WD, 1); \
+        else DD_EX(CN, WD, 2);         \
+    } while (0)
     if (canonical) {
-        if (wide) DD_EX(true, true); else DD_EX(true, false);
+        if (wide) DD_EX_MODE(true, true); else DD_EX_MODE(true, false);
     } else {
-        if (wide) DD_EX(false, true); else DD_EX(false, false);
+        if (wide) DD_EX_MODE(false, true); else DD_EX_MODE(false, false);
     }
+#undef DD_EX_MODE
 #undef DD_EX
 }
 

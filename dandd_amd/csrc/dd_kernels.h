@@ -152,9 +152,14 @@ struct ExactGenome {
     const unsigned long long* ntok;
     unsigned long long base;    // first slot of this genome in the k-mer arrays
 };
-// counters[0] += valid k-mers written, counters[1] |= 1 if a valid k-mer is all-ones (T^k, non-canonical)
+// mode 0: every k-mer to its token's slot; counters[0] += valid k-mers written, counters[1] |= 1 if a valid
+//         k-mer is all-ones (T^k, non-canonical)
+// mode 1: hist[4096] += k-mers per bin of the k-mer space (kExactBins bins by a mix of the k-mer)
+// mode 2: k-mers of bins [bin_lo, bin_hi) appended densely from slot counters[3] on (counters[3] += their number)
+constexpr int kExactBins = 4096;
 void launch_kmer_extract(const ExactGenome* tab_dev, int ng, size_t max_segments, int k, int canonical,
-                         uint64_t* lo, uint64_t* hi, unsigned long long* counters, hipStream_t st);
+                         uint64_t* lo, uint64_t* hi, unsigned long long* counters, hipStream_t st, int mode = 0,
+                         unsigned long long* hist = nullptr, uint32_t bin_lo = 0, uint32_t bin_hi = 0);
 size_t exact_sort_temp_bytes(size_t n, int k);
 // counters[2] += number of distinct values among the n slots (unwritten slots hold all-ones)
 hipError_t launch_exact_sort_count(uint64_t* lo, uint64_t* hi, uint64_t* lo_alt, uint64_t* hi_alt, size_t n,

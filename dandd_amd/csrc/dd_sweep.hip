@@ -594,15 +594,23 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void bit
     // tokens.  The job that first sees a complete set (below, and again after its merge) raises a flag
     // behind the genome's bitmaps; a job that finds all its ks flagged returns before loading anything.
     uint32_t* const complete = g.bitmap + kBitmapWords;  // one word per k (the block's slack, zeroed per call)
-    for (int k = kfirst; k <= klast; ++k)
-        if (load4_fresh(complete + k)) kmask &= ~(1u << k);
-    kmask = __builtin_amdgcn_readfirstlane(kmask);
-    if (kmask == 0u) return;
     // warm start from what earlier jobs recorded (any snapshot is a subset of the final set), counting
     // the k-mers each k already has
     __shared__ uint32_t have[kBitmapMaxK + 2];
+    __shared__ uint32_t flagged;
+    // ONE thread reads the flags for the workgroup: another workgroup may set a flag at any moment, and waves
+    // that read it at different times would disagree on kmask -- some would return while others go on to read
+    // LDS words the returned waves were meant to load.
+    if (threadIdx.x == 0) {
+        uint32_t f = 0;
+        for (int k = kfirst; k <= klast; ++k)
+            if (load4_fresh(complete + k)) f |= 1u << k;
+        flagged = f;
+    }
     if (threadIdx.x <= kBitmapMaxK) have[threadIdx.x] = 0;
     __syncthreads();
+    kmask = __builtin_amdgcn_readfirstlane(kmask & ~flagged);
+    if (kmask == 0u) return;
     for (int i = w0 + (int)threadIdx.x; i < w1; i += blockDim.x) {
         const uint32_t v = load4_fresh(&g.bitmap[i]);
         bits[i] = v;

@@ -117,7 +117,9 @@ int dd_pairwise_device(dd_ctx *, const uint8_t *leaf_dev, int n, int K, double *
  * Replaces   kmc -ci1 -cs2 -k<K> [-b] -fm <fasta> <db> <tmp>   +   kmc_tools complex (set union)
  * +   kmc_tools info <db> | grep 'total k-mers'   (lib/sketch_classes.py:395,444-448,453-465):
  * number of distinct (canonical, per the context) k-mers over ALL n inputs together, k in 1..64.
- * Uses 16 (k<=32) or 32 (k>32) bytes of HBM per input byte. */
+ * Uses 16 (k<=32) or 32 (k>32) bytes of HBM per input byte up to a budget of 24 GiB (DD_EXACT_MB overrides);
+ * larger inputs are counted in passes over disjoint parts of the k-mer space, so a union of any number of
+ * genomes that fits HBM as FASTA bytes can be counted. */
 int dd_exact_count_device(dd_ctx *, const uint8_t *const *fasta_dev, const size_t *nbytes, int n,
                           int k, uint64_t *distinct);
 int dd_exact_count(dd_ctx *, const char *const *paths, int n, int k, uint64_t *distinct);

@@ -296,7 +296,7 @@ int orc_exact_count(const uint8_t *const *fas, const size_t *ns, int nbuf, int k
     if (k < 1 || k > 64) return -1;
     struct vec128 s = {0, 0, 0};
     for (int i = 0; i < nbuf; ++i) for_each_kmer(fas[i], ns[i], k, canonical, vec_push, &s);
-    qsort(s.v, s.n, sizeof(u128), cmp128);
+    if (s.n) qsort(s.v, s.n, sizeof(u128), cmp128);  /* (an input without a single k-mer leaves s.v NULL: found by the UBSan leg) */
     uint64_t d = 0;
     for (size_t i = 0; i < s.n; ++i)
         if (i == 0 || s.v[i] != s.v[i - 1]) ++d;

@@ -65,7 +65,7 @@ def lib(path=None):
     if path:
         return _bind(C.CDLL(path))
     if _LIB is None:
-        p = os.path.join(_HERE, "liboracle.so")
+        p = os.environ.get("DD_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")  # DD_ORACLE_LIB: the sanitizer build (tests/test_sanitizers.py)
         if not os.path.exists(p):
             build()
         _LIB = _bind(C.CDLL(p))

@@ -243,3 +243,32 @@ def test_cfg5_share_whole_genome(engine_factory, torch_cuda, orc):
     eng.sketch_device([g1.data_ptr()], [s1], 61, 61, one.data_ptr())
     eng.synchronize()
     assert np.array_equal(one[0].cpu().numpy(), orc.sketch(_host(g1, s1), 61, 14, True))
+
+
+def test_exact_count_of_a_union_larger_than_the_key_budget(engine_factory, torch_cuda):
+    """The `--exact` yardstick at scale (/root/reference/lib/sketch_classes.py:453-465 unions any number of KMC
+    databases): 4 x 3 Gbp = 12 GB of FASTA, 12.2 G k-mers = 195 GB of keys at once -- counted in passes under the
+    default 24 GiB budget.  The same number comes out under a different budget (different partition), the union
+    with a repeated input does not change it, and the HLL estimate of the union agrees within 4 sigma."""
+    torch = torch_cuda
+    eng = engine_factory(14, True)
+    bufs, sizes = _device_genomes(torch, eng, [(300 + g, 3_000_000_000, 24) for g in range(4)])
+    ptrs = [b.data_ptr() for b in bufs]
+    k = 31
+    total = eng.exact_count_device(ptrs, sizes, k)
+    passes = eng.last_sketch_stats()[2]
+    assert passes >= 8
+    os.environ["DD_EXACT_MB"] = str(40 * 1024)
+    try:
+        assert eng.exact_count_device(ptrs, sizes, k) == total
+        assert eng.last_sketch_stats()[2] < passes
+        one = eng.exact_count_device(ptrs[:1], sizes[:1], k)
+        assert eng.exact_count_device([ptrs[0], ptrs[0]], [sizes[0], sizes[0]], k) == one   # a repeated input adds nothing
+    finally:
+        del os.environ["DD_EXACT_MB"]
+    assert one < total < 4 * one + 1
+    regs = torch.empty((5, 1, eng.m), dtype=torch.uint8, device="cuda")
+    eng.sketch_device(ptrs, sizes, k, k, regs.data_ptr())
+    eng.union_device([regs[g].data_ptr() for g in range(4)], eng.m, regs[4].data_ptr())
+    est = eng.card_batch_device(regs[4].data_ptr(), 1)[0]
+    assert abs(est - total) / total < 4 * 1.04 / np.sqrt(eng.m), (est, total)

@@ -379,6 +379,29 @@ def test_exact_count_matches_oracle(engine_factory, orc, tmp_path, canonical):
     assert eng.exact_count([], 5) == 0
 
 
+@pytest.mark.parametrize("canonical", [True, False])
+def test_exact_count_in_passes_matches_oracle(engine_factory, orc, tmp_path, monkeypatch, canonical):
+    """More k-mers than the HBM budget holds (here: a 1 MB budget): the count is taken in passes over disjoint
+    parts of the k-mer space and must not change -- unions, both sides of the 64/128-bit boundary, T^k."""
+    eng = engine_factory(12, canonical)
+    fas = [orc.synth_fasta(SEED, 30 + g, 90000 + 20000 * g, 2 + g) for g in range(3)]
+    fas.append(np.frombuffer(b">p\n" + b"T" * 3000 + b"\n" + b"ACGT" * 500 + b"\n", dtype=np.uint8))
+    paths = []
+    for i, fa in enumerate(fas):
+        p = tmp_path / f"x{i}.fasta"
+        p.write_bytes(fa.tobytes())
+        paths.append(str(p))
+    for k in (5, 15, 31, 33, 60):
+        for sel in ([0], [0, 1, 2, 3], [3]):
+            want = orc.exact_count([fas[i] for i in sel], k, canonical)
+            monkeypatch.delenv("DD_EXACT_MB", raising=False)
+            assert eng.exact_count([paths[i] for i in sel], k) == want
+            monkeypatch.setenv("DD_EXACT_MB", "1")
+            assert eng.exact_count([paths[i] for i in sel], k) == want, (k, sel)
+            if len(sel) > 1:
+                assert eng.last_sketch_stats()[2] > 1   # really several passes
+
+
 def test_device_resident_schedules_and_stream(engine_factory, torch_cuda, orc):
     """The *_device entry points on HBM-resident slabs, on a caller-owned non-default stream: union,
     progressive, pairwise, histograms -- all equal to the host-buffer variants and to the oracle."""
