@@ -451,7 +451,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     const dd::BucketRow* rows_dev = nullptr;
     const int nrows = ngenomes * K;
     if (bplan) {
-        const size_t flt_bytes = m >> bplan->logg, area_bytes = (size_t)bplan->cap_chunks * 4096;  // 1024 records per chunk
+        const size_t flt_bytes = align_up((m >> bplan->logg) * bplan->fbits / 8, 16), area_bytes = (size_t)bplan->cap_chunks * 4096;  // 1024 records per chunk
         const size_t fill_bytes = align_up((size_t)bplan->cap_chunks * 4, 256) + align_up((size_t)bplan->cap_chunks * 32, 256);  // fill + seg
         int first_hashed = K, hashed_per_genome = 0;  // rows of a genome that belong to a bucket class
         for (const dd::SweepClass& sc : classes)

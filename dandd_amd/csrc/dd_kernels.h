@@ -82,7 +82,8 @@ struct SweepPlan {
                                 // 2..4: in HBM behind an LDS filter byte per 2^mode registers (one k per job);
                                 // 5 (kBucketMode): in HBM, scatter to buckets + replay (below)
     // kBucketMode only
-    int logg = 0;               // one filter byte per 2^logg registers
+    int logg = 0;               // one filter entry per 2^logg registers
+    int fbits = 8;              // bits per filter entry: 8, or 4 (bounds saturate at 15, two entries per byte)
     int nb_log2 = 0;            // 2^nb_log2 index tiles of 64 KiB per row (replay)
     unsigned cap_chunks = 0;    // 1024-record chunks per row and epoch
     int nepochs = 0;

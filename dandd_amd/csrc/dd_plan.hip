@@ -28,7 +28,8 @@ PlanKnobs PlanKnobs::from_env() {
     if (const char* e = getenv("DD_BUCKET_E0")) k.bucket_e0_tiles = (size_t)std::max(1, atoi(e));
     if (const char* e = getenv("DD_BUCKET_EMAX")) k.bucket_emax_tiles = (size_t)std::max(1, atoi(e));
     if (const char* e = getenv("DD_BUCKET_CAP")) k.bucket_cap_chunks = (size_t)std::max(1, atoi(e));
-    if (const char* e = getenv("DD_BUCKET_LOGG")) k.bucket_logg = std::max(2, std::min(8, atoi(e)));
+    if (const char* e = getenv("DD_BUCKET_LOGG")) k.bucket_logg = std::max(1, std::min(8, atoi(e)));
+    if (const char* e = getenv("DD_BUCKET_FBITS")) k.bucket_fbits = atoi(e) == 4 ? 4 : 8;
     if (const char* e = getenv("DD_BUCKET_GB")) k.bucket_budget = (size_t)std::max(1, atoi(e)) << 30;
     return k;
 }
@@ -81,7 +82,9 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
     // seen once), each later one is as long as everything before it -- the filter's bounds rise by about
     // one per doubling -- up to the length whose worst case (every update survives) fits the HBM budget.
     const bool bucket_mode = global_regs && knobs.buckets && knobs.filter;
-    const int bucket_logg = knobs.bucket_logg ? knobs.bucket_logg : std::max(2, p - 16);  // a 64 KiB filter
+    const int bucket_fbits = knobs.bucket_fbits ? knobs.bucket_fbits : 4;  // measured: 4-bit entries win at log2m 18, 19 and 20
+    // a 64 KiB filter: 2^(p-16) registers per byte-wide entry, half as many per 4-bit entry
+    const int bucket_logg = knobs.bucket_logg ? knobs.bucket_logg : std::max(1, p - 16 - (bucket_fbits == 4 ? 1 : 0));
     const int nb_log2 = std::max(0, p - 16);  // index tiles of 64 KiB
     std::vector<size_t> epoch_edge;           // epoch e covers tiles [epoch_edge[e], epoch_edge[e+1])
     size_t epoch_longest = 0, bucket_row_tokens = 0;
@@ -168,6 +171,7 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
             sc.plan.cap_chunks = (unsigned)(knobs.bucket_cap_chunks ? knobs.bucket_cap_chunks
                                                 : per_row / 1024 + max_jobs_row_epoch * (kThreads / 64) + 16);
             sc.plan.logg = bucket_logg;
+            sc.plan.fbits = bucket_fbits;
             sc.plan.nb_log2 = nb_log2;
             sc.plan.nepochs = (int)nepochs;
         } else if (global_regs && kc != kBitmapClass && (filter_logg || knobs.xcd_affinity)) {
@@ -258,7 +262,7 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
             sc.plan.lds_bytes = (bitmap_offset(kb) + bitmap_words(kb) - bitmap_offset(ka)) * 4;
         } else if (bucket_mode) {
             sc.plan.mode = kBucketMode;  // the filter, then a 128-entry record queue per wave
-            sc.plan.lds_bytes = (int)(m >> bucket_logg) + (kThreads / 64) * 128 * 4;
+            sc.plan.lds_bytes = (int)((m >> bucket_logg) * bucket_fbits / 8) + (kThreads / 64) * 128 * 4;
         } else if (filter_logg) {
             sc.plan.mode = filter_logg;  // the filter, then a 128-entry candidate queue per wave (dd_sweep.hip)
             sc.plan.lds_bytes = (int)(m >> filter_logg) + (kThreads / 64) * 128 * 4;

@@ -789,9 +789,19 @@ DD_D void scatter_block(const Scatter& s, uint32_t rec, uint32_t& cur) {
     if ((cur & (kChunkRecords - 1u)) == 0u && lane == 0) gstore4(s.fill + (cur / kChunkRecords - 1u), kChunkRecords);
 }
 // One update.  Reached by whole waves (`valid`: the lane has a k-mer); `waiting` and `cur` are wave-uniform.
+// NIB: the filter holds 4-bit bounds (saturating at 15), two register groups per byte -- twice the resolution
+// in the same 64 KiB of LDS for three more instructions per update.
+template <bool NIB>
 DD_D void scatter_update(const Scatter& s, uint32_t& waiting, uint32_t& cur, uint64_t h, int p, bool valid) {
     const Probe q = probe(h, p);
-    const bool cand = valid && q.lz >= g_lds[q.hi >> s.fshift];  // rho > bound (or hiw == 0: rho >= 33)
+    uint32_t bound;
+    if (NIB) {
+        const uint32_t e = q.hi >> s.fshift;
+        bound = (g_lds[e >> 1] >> ((e & 1u) * 4u)) & 15u;
+    } else {
+        bound = g_lds[q.hi >> s.fshift];
+    }
+    const bool cand = valid && q.lz >= bound;  // rho > bound (or hiw == 0: rho >= 33)
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(cand);
     if (mask) {
         if (cand) {
@@ -806,7 +816,7 @@ DD_D void scatter_update(const Scatter& s, uint32_t& waiting, uint32_t& cur, uin
     }
 }
 
-template <int KC, bool CANON>
+template <int KC, bool CANON, bool NIB>
 __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __restrict__ genomes,
                                                       const SweepJob* __restrict__ jobs, int p, ScatterParams sp) {
     const SweepJob job = jobs[blockIdx.x];
@@ -816,7 +826,7 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
     const uint32_t m = 1u << p;
     const unsigned long long ntok = gload8u(g.ntok);
     const BucketRow row = sp.rows[(size_t)job.genome * sp.K + job.krow];
-    const uint32_t nflt = m >> sp.logg;
+    const uint32_t nflt = (m >> sp.logg) >> (NIB ? 1 : 0);  // bytes
 
     struct TileIn {
         uint4 hc, sc;
@@ -874,7 +884,7 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
 #pragma unroll 1
                 for (int i = 0; i < 16; ++i) {
                     win.push((cw[w] >> (2 * i)) & 3u);
-                    scatter_update(s, waiting, cur, win.template hash<CANON>(k), p, true);
+                    scatter_update<NIB>(s, waiting, cur, win.template hash<CANON>(k), p, true);
                 }
             }
             continue;
@@ -888,7 +898,7 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
                 const uint32_t c = (cw[w] >> (2 * i)) & 3u;
                 run = ((bw >> i) & 1u) ? 0 : run + 1;
                 win.push(c);
-                scatter_update(s, waiting, cur, win.template hash<CANON>(k), p, run >= k);
+                scatter_update<NIB>(s, waiting, cur, win.template hash<CANON>(k), p, run >= k);
             }
         }
     }
@@ -970,7 +980,7 @@ __global__ __launch_bounds__(256) void sort_chunks_kernel(const BucketRow* __res
 // own tile (all of a chunk when the row is a single tile and nothing was sorted); segment headers, records
 // and the LDS work of three consecutive steps overlap.
 __global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restrict__ rows, int nrows, int p, int logg,
-                                                     int nb_log2, uint32_t cap_chunks) {
+                                                     int nb_log2, uint32_t cap_chunks, int fbits) {
     const uint32_t nb = 1u << nb_log2;
     const uint32_t within = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
     const uint32_t r = (within >> nb_log2) * 8u + xcd, b = within & (nb - 1u);
@@ -1045,16 +1055,31 @@ __global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restric
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < (tile >> 4); i += blockDim.x) gstore16(tile_g + (size_t)i * 16, l4[i]);
-    // the tile's part of the filter: minimum of every group of 2^logg registers
+    // the tile's part of the filter: minimum of every group of 2^logg registers (as a byte, or saturated to 15
+    // and packed two to a byte)
     const uint32_t G = 1u << logg;
-    uint8_t* const flt = row.filter + (((size_t)b * tile) >> logg);
-    for (uint32_t f = threadIdx.x; f < (tile >> logg); f += blockDim.x) {
+    auto group_min = [&](uint32_t f) {
         uint32_t lo = 0xFFu;
-        for (uint32_t w = 0; w < G; w += 4) {
-            const uint32_t mn = min4(*reinterpret_cast<const uint32_t*>(g_lds + f * G + w));
-            lo = mn < lo ? mn : lo;
+        if (G >= 4u) {
+            for (uint32_t w = 0; w < G; w += 4) {
+                const uint32_t mn = min4(*reinterpret_cast<const uint32_t*>(g_lds + f * G + w));
+                lo = mn < lo ? mn : lo;
+            }
+        } else {
+            for (uint32_t w = 0; w < G; ++w) lo = g_lds[f * G + w] < lo ? g_lds[f * G + w] : lo;
         }
-        flt[f] = (uint8_t)lo;
+        return lo;
+    };
+    const uint32_t ngroups = tile >> logg;
+    if (fbits == 4) {
+        uint8_t* const flt = row.filter + ((((size_t)b * tile) >> logg) >> 1);
+        for (uint32_t f = threadIdx.x; f < (ngroups >> 1); f += blockDim.x) {
+            const uint32_t a = group_min(2u * f), c = group_min(2u * f + 1u);
+            flt[f] = (uint8_t)((a < 15u ? a : 15u) | ((c < 15u ? c : 15u) << 4));
+        }
+    } else {
+        uint8_t* const flt = row.filter + (((size_t)b * tile) >> logg);
+        for (uint32_t f = threadIdx.x; f < ngroups; f += blockDim.x) flt[f] = (uint8_t)group_min(f);
     }
 }
 
@@ -1123,13 +1148,18 @@ void launch_bitmap_finish(const SweepGenome* genomes, int ngenomes, int kfirst, 
 void launch_scatter(const SweepGenome* genomes, const SweepJob* jobs, int njobs, int kclass, const SweepPlan& plan,
                     const ScatterParams& sp, hipStream_t st) {
     if (njobs <= 0) return;
-#define DD_SCATTER(KC, CN)                                                                              \
+#define DD_SCATTER_N(KC, CN, NB)                                                                        \
     do {                                                                                                \
-        auto kern = scatter_kernel<KC, CN>;                                                             \
+        auto kern = scatter_kernel<KC, CN, NB>;                                                         \
         static std::atomic<unsigned long long> attr_done{0};                                            \
         allow_full_lds(reinterpret_cast<const void*>(kern), attr_done);                                 \
         hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3((unsigned)plan.threads), (size_t)plan.lds_bytes, st, \
                            genomes, jobs, plan.log2m, sp);                                              \
+    } while (0)
+#define DD_SCATTER(KC, CN)                      \
+    do {                                        \
+        if (plan.fbits == 4) DD_SCATTER_N(KC, CN, true); \
+        else DD_SCATTER_N(KC, CN, false);       \
     } while (0)
 #define DD_SCATTER_KC(CN)                       \
     do {                                        \
@@ -1142,6 +1172,7 @@ void launch_scatter(const SweepGenome* genomes, const SweepJob* jobs, int njobs,
     else DD_SCATTER_KC(false);
 #undef DD_SCATTER_KC
 #undef DD_SCATTER
+#undef DD_SCATTER_N
 }
 
 void launch_replay(const BucketRow* rows, int nrows, const SweepPlan& plan, hipStream_t st) {
@@ -1156,7 +1187,7 @@ void launch_replay(const BucketRow* rows, int nrows, const SweepPlan& plan, hipS
     static std::atomic<unsigned long long> attr_done{0};
     allow_full_lds(reinterpret_cast<const void*>(replay_kernel), attr_done);
     hipLaunchKernelGGL(replay_kernel, dim3(blocks), dim3(1024), tile, st, rows, nrows, plan.log2m, plan.logg, plan.nb_log2,
-                       plan.cap_chunks);
+                       plan.cap_chunks, plan.fbits);
     hipLaunchKernelGGL(reset_cursors_kernel, dim3((unsigned)(nrows + 255) / 256), dim3(256), 0, st, rows, nrows);
 }
 

@@ -85,7 +85,9 @@ BUCKET_KNOBS = {
     "default": {},
     "many_epochs": {"DD_BUCKET_E0": "1", "DD_BUCKET_EMAX": "1"},      # every tile its own epoch: filters learned 5 times
     "overflow": {"DD_BUCKET_CAP": "1", "DD_BUCKET_E0": "2"},          # one chunk per bucket: nearly every record takes the CAS fallback
-    "coarse_filter": {"DD_BUCKET_LOGG": "6", "DD_BUCKET_E0": "1"},    # 64 registers per filter byte
+    "coarse_filter": {"DD_BUCKET_LOGG": "6", "DD_BUCKET_E0": "1"},    # 64 registers per filter entry
+    "nibble_filter": {"DD_BUCKET_FBITS": "4", "DD_BUCKET_E0": "1"},   # 4-bit bounds (saturating), two entries per byte
+    "byte_filter": {"DD_BUCKET_FBITS": "8", "DD_BUCKET_E0": "1"},
     "no_xcd_order": {"DD_NO_XCD_AFFINITY": "1", "DD_BUCKET_E0": "1"},
     "cas_path": {"DD_NO_BUCKETS": "1"},                               # round 1's filtered compare-and-swap path, kept for A/B
 }
