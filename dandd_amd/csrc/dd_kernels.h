@@ -84,6 +84,7 @@ struct SweepPlan {
     // kBucketMode only
     int logg = 0;               // one filter entry per 2^logg registers
     int fbits = 8;              // bits per filter entry: 8, or 4 (bounds saturate at 15, two entries per byte)
+    int nk_job = 1;             // ks per scatter job (1 or 2)
     int nb_log2 = 0;            // 2^nb_log2 index tiles of 64 KiB per row (replay)
     unsigned cap_chunks = 0;    // 1024-record chunks per row and epoch
     int nepochs = 0;

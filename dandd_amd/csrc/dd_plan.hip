@@ -82,6 +82,7 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
     // seen once), each later one is as long as everything before it -- the filter's bounds rise by about
     // one per doubling -- up to the length whose worst case (every update survives) fits the HBM budget.
     const bool bucket_mode = global_regs && knobs.buckets && knobs.filter;
+    const int bucket_nk = 1;  // ks per scatter job (two were measured slower: dd_sweep.hip)
     const int bucket_fbits = knobs.bucket_fbits ? knobs.bucket_fbits : 4;  // measured: 4-bit entries win at log2m 18, 19 and 20
     // a 64 KiB filter: 2^(p-16) registers per byte-wide entry, half as many per 4-bit entry
     const int bucket_logg = knobs.bucket_logg ? knobs.bucket_logg : std::max(1, p - 16 - (bucket_fbits == 4 ? 1 : 0));
@@ -137,17 +138,19 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
                     if (nt > t_lo) tile_rows += (std::min(nt, t_hi) - t_lo) * (size_t)nks;
                 }
                 if (!tile_rows) continue;
-                // ~8 jobs per resident workgroup slot; a job reloads the row's filter, so not below 2 tiles
+                // ~8 jobs per resident workgroup slot; a job reloads its rows' filters, so not below 2 tiles
                 // once the epoch is long enough to allow it
-                const size_t tpj = std::max<size_t>(std::min<size_t>(2, t_hi - t_lo), (tile_rows + 4095) / 4096);
+                const size_t slots = bucket_nk == 2 ? 2048 : 4096;  // two-k jobs: one workgroup per CU, twice the work each
+                const size_t tpj = std::max<size_t>(std::min<size_t>(2, t_hi - t_lo), (tile_rows / bucket_nk + slots - 1) / slots);
                 std::vector<std::vector<SweepJob>> per_xcd(8);
                 int row = 0;
                 for (int g = 0; g < ngenomes; ++g) {
                     const size_t nt = std::min(tiles_of(nbytes[g]), t_hi);
-                    for (int q = 0; q < nks; ++q, ++row) {
+                    for (int q = 0; q < nks; q += bucket_nk, ++row) {  // one or two consecutive ks per job
+                        const int nkj = std::min(bucket_nk, nks - q);
                         size_t nj = 0;
                         for (size_t t0 = t_lo; t0 < nt; t0 += tpj, ++nj)
-                            per_xcd[knobs.xcd_affinity ? row % 8 : 0].push_back(make_job(g, ka + q, 1, kmin, t0, std::min(nt, t0 + tpj)));
+                            per_xcd[knobs.xcd_affinity ? row % 8 : 0].push_back(make_job(g, ka + q, nkj, kmin, t0, std::min(nt, t0 + tpj)));
                         max_jobs_row_epoch = std::max(max_jobs_row_epoch, nj);
                     }
                 }
@@ -161,7 +164,7 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
                 }
             }
             sc.epoch_begin.push_back(sc.jobs.size());
-            max_nk = 1;
+            max_nk = bucket_nk;
             // Every token of the longest epoch may leave a record (nothing is filtered while the registers
             // are still empty), plus the partly filled chunk every wave of every job leaves.  Records beyond
             // the capacity are not lost: they go straight to the row by compare-and-swap (dd_sweep.hip).
@@ -172,6 +175,7 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
                                                 : per_row / 1024 + max_jobs_row_epoch * (kThreads / 64) + 16);
             sc.plan.logg = bucket_logg;
             sc.plan.fbits = bucket_fbits;
+            sc.plan.nk_job = bucket_nk;
             sc.plan.nb_log2 = nb_log2;
             sc.plan.nepochs = (int)nepochs;
         } else if (global_regs && kc != kBitmapClass && (filter_logg || knobs.xcd_affinity)) {
@@ -262,7 +266,7 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
             sc.plan.lds_bytes = (bitmap_offset(kb) + bitmap_words(kb) - bitmap_offset(ka)) * 4;
         } else if (bucket_mode) {
             sc.plan.mode = kBucketMode;  // the filter, then a 128-entry record queue per wave
-            sc.plan.lds_bytes = (int)((m >> bucket_logg) * bucket_fbits / 8) + (kThreads / 64) * 128 * 4;
+            sc.plan.lds_bytes = bucket_nk * ((int)((m >> bucket_logg) * bucket_fbits / 8) + (kThreads / 64) * 128 * 4);
         } else if (filter_logg) {
             sc.plan.mode = filter_logg;  // the filter, then a 128-entry candidate queue per wave (dd_sweep.hip)
             sc.plan.lds_bytes = (int)(m >> filter_logg) + (kThreads / 64) * 128 * 4;

@@ -760,7 +760,8 @@ struct Scatter {
     uint32_t* fill;        // valid records per chunk (written by the chunk's owner)
     uint8_t* regs;         // the row itself: where records go when the stream is full
     uint32_t cap_chunks;
-    int fshift;            // hash high word >> fshift = index of the register group's filter byte (32 - p + logg)
+    int fshift;            // hash high word >> fshift = index of the register group's filter entry (32 - p + logg)
+    uint32_t fbase;        // byte offset in g_lds of this k's filter
 };
 DD_D uint32_t& lds32(uint32_t off) { return *reinterpret_cast<uint32_t*>(g_lds + off); }
 DD_D uint32_t gadd32(void* p, uint32_t v) {
@@ -797,9 +798,9 @@ DD_D void scatter_update(const Scatter& s, uint32_t& waiting, uint32_t& cur, uin
     uint32_t bound;
     if (NIB) {
         const uint32_t e = q.hi >> s.fshift;
-        bound = (g_lds[e >> 1] >> ((e & 1u) * 4u)) & 15u;
+        bound = (g_lds[s.fbase + (e >> 1)] >> ((e & 1u) * 4u)) & 15u;
     } else {
-        bound = g_lds[q.hi >> s.fshift];
+        bound = g_lds[s.fbase + (q.hi >> s.fshift)];
     }
     const bool cand = valid && q.lz >= bound;  // rho > bound (or hiw == 0: rho >= 33)
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(cand);
@@ -816,17 +817,21 @@ DD_D void scatter_update(const Scatter& s, uint32_t& waiting, uint32_t& cur, uin
     }
 }
 
-template <int KC, bool CANON, bool NIB>
+// NK = ks per job.  Only NK = 1 is instantiated: two consecutive ks per job (shared token loads and window
+// push, 7 of the ~50 VALU instructions of an update; two 64 KiB filters = one workgroup per CU) measured
+// SLOWER on MI355X -- 35.1 / 40.7 / 49.4 ms against 28.2 / 33.2 / 43.3 at log2m 18 / 19 / 20
+// (profiles/r02_bucket_path.txt); the code path is kept for the record.
+template <int KC, bool CANON, bool NIB, int NK>
 __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __restrict__ genomes,
                                                       const SweepJob* __restrict__ jobs, int p, ScatterParams sp) {
     const SweepJob job = jobs[blockIdx.x];
     if (job.tile_begin >= job.tile_end) return;  // filler of the XCD-affine order
     const SweepGenome g = genomes[job.genome];
     const int k = job.kfirst;
+    const bool two = NK == 2 && job.nk == 2;
     const uint32_t m = 1u << p;
     const unsigned long long ntok = gload8u(g.ntok);
-    const BucketRow row = sp.rows[(size_t)job.genome * sp.K + job.krow];
-    const uint32_t nflt = (m >> sp.logg) >> (NIB ? 1 : 0);  // bytes
+    const uint32_t nflt = (m >> sp.logg) >> (NIB ? 1 : 0);  // bytes per filter
 
     struct TileIn {
         uint4 hc, sc;
@@ -851,27 +856,34 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
     TileIn next;
     fetch(job.tile_begin, next);
 
-    // the row's filter as the previous epoch's replay left it (plain loads: written by an earlier kernel)
-    {
-        uint4* f4 = reinterpret_cast<uint4*>(g_lds);
-        for (uint32_t i = threadIdx.x; i < (nflt >> 4); i += blockDim.x) f4[i] = gload16(row.filter + (size_t)i * 16);
+    // each row's filter as the previous epoch's replay left it (plain loads: written by an earlier kernel),
+    // then the per-wave queues
+    Scatter s[NK];
+    uint32_t waiting[NK], cur[NK];
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+        const BucketRow row = sp.rows[(size_t)job.genome * sp.K + job.krow + ((j == 0 || two) ? j : 0)];
+        if (j == 0 || two) {
+            uint4* f4 = reinterpret_cast<uint4*>(g_lds + (uint32_t)j * nflt);
+            for (uint32_t i = threadIdx.x; i < (nflt >> 4); i += blockDim.x) f4[i] = gload16(row.filter + (size_t)i * 16);
+        }
+        s[j].fbase = (uint32_t)j * nflt;
+        s[j].queue = (uint32_t)NK * nflt + ((threadIdx.x >> 6) * NK + j) * (kQueueEntries * 4u);
+        s[j].area = row.area;
+        s[j].cursor = row.cursor;
+        s[j].fill = row.fill;
+        s[j].regs = row.regs;
+        s[j].cap_chunks = sp.cap_chunks;
+        s[j].fshift = 32 - p + sp.logg;
+        waiting[j] = cur[j] = 0;
     }
-    Scatter s;
-    s.queue = nflt + (threadIdx.x >> 6) * (kQueueEntries * 4u);
-    s.area = row.area;
-    s.cursor = row.cursor;
-    s.fill = row.fill;
-    s.regs = row.regs;
-    s.cap_chunks = sp.cap_chunks;
-    s.fshift = 32 - p + sp.logg;
-    uint32_t waiting = 0, cur = 0;
     __syncthreads();
 
     for (unsigned tile = job.tile_begin; tile < job.tile_end; ++tile) {
         const TileIn in = next;
         fetch(tile + 1, next);
         // Lanes beyond the stream stay in the loop as all-BREAK segments while any lane of their wave has
-        // tokens: the queue counter and the stream offset must stay wave-uniform.
+        // tokens: the queue counters and the stream offsets must stay wave-uniform.
         if (!__any(in.live)) continue;
         const uint4 hc = in.hc, sc = in.sc;
         const uint2 hb = in.hb, sb = in.sb;
@@ -884,7 +896,8 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
 #pragma unroll 1
                 for (int i = 0; i < 16; ++i) {
                     win.push((cw[w] >> (2 * i)) & 3u);
-                    scatter_update<NIB>(s, waiting, cur, win.template hash<CANON>(k), p, true);
+                    scatter_update<NIB>(s[0], waiting[0], cur[0], win.template hash<CANON>(k), p, true);
+                    if (NK == 2 && two) scatter_update<NIB>(s[NK - 1], waiting[NK - 1], cur[NK - 1], win.template hash<CANON>(k + 1), p, true);
                 }
             }
             continue;
@@ -898,18 +911,23 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
                 const uint32_t c = (cw[w] >> (2 * i)) & 3u;
                 run = ((bw >> i) & 1u) ? 0 : run + 1;
                 win.push(c);
-                scatter_update<NIB>(s, waiting, cur, win.template hash<CANON>(k), p, run >= k);
+                scatter_update<NIB>(s[0], waiting[0], cur[0], win.template hash<CANON>(k), p, run >= k);
+                if (NK == 2 && two) scatter_update<NIB>(s[NK - 1], waiting[NK - 1], cur[NK - 1], win.template hash<CANON>(k + 1), p, run >= k + 1);
             }
         }
     }
     // what still waits leaves as a block padded with null records; a chunk left partly filled is recorded
     // as such (replay reads fill[c] records of chunk c)
-    if (waiting) {
-        const uint32_t lane = threadIdx.x & 63u;
-        scatter_block(s, lane < waiting ? lds32(s.queue + 4u * lane) : 0u, cur);
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+        if (j && !two) break;
+        if (waiting[j]) {
+            const uint32_t lane = threadIdx.x & 63u;
+            scatter_block(s[j], lane < waiting[j] ? lds32(s[j].queue + 4u * lane) : 0u, cur[j]);
+        }
+        if ((cur[j] & (kChunkRecords - 1u)) != 0u && (threadIdx.x & 63u) == 0)
+            gstore4(s[j].fill + cur[j] / kChunkRecords, cur[j] & (kChunkRecords - 1u));
     }
-    if ((cur & (kChunkRecords - 1u)) != 0u && (threadIdx.x & 63u) == 0)
-        gstore4(s.fill + cur / kChunkRecords, cur & (kChunkRecords - 1u));
 }
 
 // Between scatter and replay when a row has more than one index tile (log2m >= 17): every chunk of every
@@ -1148,14 +1166,15 @@ void launch_bitmap_finish(const SweepGenome* genomes, int ngenomes, int kfirst, 
 void launch_scatter(const SweepGenome* genomes, const SweepJob* jobs, int njobs, int kclass, const SweepPlan& plan,
                     const ScatterParams& sp, hipStream_t st) {
     if (njobs <= 0) return;
-#define DD_SCATTER_N(KC, CN, NB)                                                                        \
+#define DD_SCATTER_NN(KC, CN, NB, NKJ)                                                                  \
     do {                                                                                                \
-        auto kern = scatter_kernel<KC, CN, NB>;                                                         \
+        auto kern = scatter_kernel<KC, CN, NB, NKJ>;                                                    \
         static std::atomic<unsigned long long> attr_done{0};                                            \
         allow_full_lds(reinterpret_cast<const void*>(kern), attr_done);                                 \
         hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3((unsigned)plan.threads), (size_t)plan.lds_bytes, st, \
                            genomes, jobs, plan.log2m, sp);                                              \
     } while (0)
+#define DD_SCATTER_N(KC, CN, NB) DD_SCATTER_NN(KC, CN, NB, 1)
 #define DD_SCATTER(KC, CN)                      \
     do {                                        \
         if (plan.fbits == 4) DD_SCATTER_N(KC, CN, true); \
@@ -1173,6 +1192,7 @@ void launch_scatter(const SweepGenome* genomes, const SweepJob* jobs, int njobs,
 #undef DD_SCATTER_KC
 #undef DD_SCATTER
 #undef DD_SCATTER_N
+#undef DD_SCATTER_NN
 }
 
 void launch_replay(const BucketRow* rows, int nrows, const SweepPlan& plan, hipStream_t st) {
