@@ -786,6 +786,27 @@ class DeltaTree:
         return list(out)
 
 
+def write_phylip(tuples, path, k=0):
+    """Lower-triangular PHYLIP distance matrix (distance = 1 - similarity) of the `--afproject` tuples
+    (tool, name1, name2, k, value, k1, k2, k12) at one k -- k = 0 selects the K-independent Jaccard rows.  The
+    format the reference's helper hands to `fneighbor` (helpers/allpairs.py:182-207: count line, then one row per
+    name in sorted order holding the distances to the names before it)."""
+    recs, names = {}, set()
+    for _tool, a, b, kk, value, _k1, _k2, _k12 in tuples:
+        if kk != k:
+            continue
+        names.update((a, b))
+        recs[(a, b)] = recs[(b, a)] = 1 - value
+    if not recs:
+        raise ValueError(f"no pair at k={k}")
+    names = sorted(names)
+    with open(path, "wt") as f:
+        print(len(names), file=f)
+        for i, a in enumerate(names):
+            print(" ".join(map(str, [a] + [recs[(a, b)] for b in names[:i]])), file=f)
+    return names
+
+
 class SubSpider(DeltaTree):
     """Existing leaf nodes under one new union node."""
 

@@ -264,3 +264,37 @@ def test_dashing_container_sketch_directory_is_consumed_and_extended(host, tmp_p
     assert calls["leaf"] == before, "leaf sketches in Dashing's container were sketched again"
     rows = hostcheck.read_rows(os.path.join(out2, "gold_5_dashing_deltas.csv"))
     assert not hostcheck.compare({"tree_spider_k10": rows}, {"tree_spider_k10": gold["scenarios"]["tree_spider_k10"]})
+
+
+def test_afproject_tuples_and_phylip_export(host, tmp_path):
+    """`kij --afproject` (lib/dandd_cmd.py:123-132, lib/huffman_dandd.py:697-718): the pickled tuples are the kij and
+    Jaccard rows in the (tool, A, B, k, value, Ak, Bk, ABk) form of the reference's helpers, and the PHYLIP writer
+    lays the k = 0 (KIJ) distances out the way helpers/allpairs.py:182-207 does."""
+    import pickle
+    import shutil
+    from dandd_amd.host import cli
+    from dandd_amd.host.deltatree import write_phylip
+    gold = _golden("ref_hll.json")
+    host.set_backend_factory(lambda r, c: hostcheck.OracleBackend(r, c))
+    data = os.path.join(str(tmp_path), "data")
+    shutil.copytree(os.path.join(hostcheck.GOLD, "fasta"), data)
+    out = os.path.join(str(tmp_path), "o")
+    cli.main(["tree", "-d", data, "-o", out, "-s", "gold", "-k", "10", "-r", str(gold["registers"])])
+    cli.main(["kij", "-d", os.path.join(out, "gold_5_dashing_dtree.pickle"), "-o", out, "--jaccard", "--mink", "8", "--maxk", "12", "--afproject"])
+    with open(os.path.join(out, "gold_5_dashing_AFtuples.pickle"), "rb") as f:
+        tuples = pickle.load(f)
+    kij = {(t[1], t[2]): t for t in tuples if t[3] == 0}
+    assert len(kij) == 10 and len(tuples) == 10 + 10 * 5
+    for row in gold["scenarios"]["kij"]:
+        t = kij[(row["Atitle"], row["Btitle"])]
+        assert t[0] == "dashing" and t[4] == float(row["KIJ"]) and (t[5], t[6], t[7]) == (int(row["Ak"]), int(row["Bk"]), int(row["ABk"]))
+    for row in gold["scenarios"]["kij_jaccard_8_12"]:
+        assert ("dashing", row["Atitle"], row["Btitle"], int(row["kval"]), float(row["jaccard"]), None, None, None) in tuples
+    names = write_phylip(tuples, os.path.join(out, "kij.phy"))
+    lines = open(os.path.join(out, "kij.phy")).read().splitlines()
+    assert names == ["g0", "g1", "g2", "g3", "g4"] and lines[0] == "5" and lines[1] == "g0"
+    assert lines[3].split()[0] == "g2" and float(lines[3].split()[2]) == 1 - kij[("g1", "g2")][4]
+    assert [len(l.split()) for l in lines[1:]] == [1, 2, 3, 4, 5]
+    write_phylip(tuples, os.path.join(out, "j10.phy"), k=10)
+    with pytest.raises(ValueError):
+        write_phylip(tuples, os.path.join(out, "none.phy"), k=99)
