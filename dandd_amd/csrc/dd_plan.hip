@@ -85,7 +85,10 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
     const int bucket_nk = 1;  // ks per scatter job (two were measured slower: dd_sweep.hip)
     const int bucket_fbits = knobs.bucket_fbits ? knobs.bucket_fbits : 4;  // measured: 4-bit entries win at log2m 18, 19 and 20
     // a 64 KiB filter: 2^(p-16) registers per byte-wide entry, half as many per 4-bit entry
-    const int bucket_logg = knobs.bucket_logg ? knobs.bucket_logg : std::max(1, p - 16 - (bucket_fbits == 4 ? 1 : 0));
+    int bucket_logg = knobs.bucket_logg ? knobs.bucket_logg : std::max(1, p - 16 - (bucket_fbits == 4 ? 1 : 0));
+    // (a knob that asks for more filter than a workgroup can hold gets the finest one that fits; 16 bytes at least)
+    while ((m >> bucket_logg) * bucket_fbits / 8 + (kThreads / 64) * 512 > (size_t)sweep_max_lds_bytes()) ++bucket_logg;
+    while (bucket_logg > 0 && (m >> bucket_logg) * bucket_fbits / 8 < 16) --bucket_logg;
     const int nb_log2 = std::max(0, p - 16);  // index tiles of 64 KiB
     std::vector<size_t> epoch_edge;           // epoch e covers tiles [epoch_edge[e], epoch_edge[e+1])
     size_t epoch_longest = 0, bucket_row_tokens = 0;

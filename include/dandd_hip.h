@@ -150,8 +150,10 @@ int dd_synth_fasta_device(dd_ctx *, uint64_t seed, int genome_index, uint64_t nb
  * how dd_sketch_device would cut (genome x k x 65536-token tile) into workgroup jobs for genomes of
  * these sizes.  Writes at most `cap` jobs in launch order and returns how many there are (or a
  * negative DD_E* code).  kclass: -1 small-k bitmap class, else the window class of the launch
- * (0: k <= 16, 1: <= 32, 3: 33..48, 2: 49..64); mode: 0 registers in LDS, 1 in HBM,
- * 2..4 in HBM behind an LDS filter byte per 2^mode registers. */
+ * (0: k <= 16, 1: <= 32, 3: 33..48, 2: 49..64); mode: 0 registers in LDS; 5 (log2m >= 18) registers in HBM
+ * through scatter + chunk sort + replay, jobs listed epoch by epoch; 1 in HBM with every update checked there
+ * and 2..4 in HBM behind an LDS filter byte per 2^mode registers with compare-and-swap (round 1's paths,
+ * DD_NO_FILTER / DD_NO_BUCKETS). */
 typedef struct {
     int kclass, mode, lds_bytes;
     int genome, kfirst, nk;

@@ -47,6 +47,8 @@ def check(log2m, sizes, kmin, kmax):
         elif log2m >= 18:
             fbits = int(os.environ.get("DD_BUCKET_FBITS", 4))
             logg = int(os.environ.get("DD_BUCKET_LOGG", max(1, log2m - 16 - (1 if fbits == 4 else 0))))
+            while (m >> logg) * fbits // 8 + 16 * 512 > LDS_MAX:
+                logg += 1
             nkj = 1
             assert mode == 5 and nk == 1                           # scatter + replay, one k per job
             assert j["lds_bytes"] == nkj * ((m >> logg) * fbits // 8 + 16 * 128 * 4)    # per k: filter + one record queue per wave
