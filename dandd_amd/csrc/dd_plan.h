@@ -36,7 +36,7 @@ struct PlanKnobs {
     size_t bucket_e0_tiles = 0;     // tiles in the first epoch; 0 = one token per register (m / 65536, >= 1)
     size_t bucket_emax_tiles = 0;   // longest epoch; 0 = what the budget below allows, at most 256 tiles
     size_t bucket_cap_chunks = 0;   // 64-record chunks per bucket; 0 = every token of the longest epoch fits
-    int bucket_logg = 0;            // registers per filter entry (log2); 0 = a 64 KiB filter
+    int bucket_logg = 0;            // registers per filter entry (log2) PLUS ONE; 0 = default (a 64 KiB filter)
     int bucket_fbits = 0;           // bits per filter entry (8 or 4); 0 = 4
     size_t bucket_budget = (size_t)16 << 30;  // HBM for the record areas of one call
     static PlanKnobs from_env();

@@ -28,7 +28,7 @@ PlanKnobs PlanKnobs::from_env() {
     if (const char* e = getenv("DD_BUCKET_E0")) k.bucket_e0_tiles = (size_t)std::max(1, atoi(e));
     if (const char* e = getenv("DD_BUCKET_EMAX")) k.bucket_emax_tiles = (size_t)std::max(1, atoi(e));
     if (const char* e = getenv("DD_BUCKET_CAP")) k.bucket_cap_chunks = (size_t)std::max(1, atoi(e));
-    if (const char* e = getenv("DD_BUCKET_LOGG")) k.bucket_logg = std::max(1, std::min(8, atoi(e)));
+    if (const char* e = getenv("DD_BUCKET_LOGG")) k.bucket_logg = std::max(0, std::min(8, atoi(e))) + 1;  // stored + 1: 0 = not set
     if (const char* e = getenv("DD_BUCKET_FBITS")) k.bucket_fbits = atoi(e) == 4 ? 4 : 8;
     if (const char* e = getenv("DD_BUCKET_GB")) k.bucket_budget = (size_t)std::max(1, atoi(e)) << 30;
     return k;
@@ -85,7 +85,7 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
     const int bucket_nk = 1;  // ks per scatter job (two were measured slower: dd_sweep.hip)
     const int bucket_fbits = knobs.bucket_fbits ? knobs.bucket_fbits : 4;  // measured: 4-bit entries win at log2m 18, 19 and 20
     // a 64 KiB filter: 2^(p-16) registers per byte-wide entry, half as many per 4-bit entry
-    int bucket_logg = knobs.bucket_logg ? knobs.bucket_logg : std::max(1, p - 16 - (bucket_fbits == 4 ? 1 : 0));
+    int bucket_logg = knobs.bucket_logg ? knobs.bucket_logg - 1 : std::max(1, p - 16 - (bucket_fbits == 4 ? 1 : 0));
     // (a knob that asks for more filter than a workgroup can hold gets the finest one that fits; 16 bytes at least)
     while ((m >> bucket_logg) * bucket_fbits / 8 + (kThreads / 64) * 512 > (size_t)sweep_max_lds_bytes()) ++bucket_logg;
     while (bucket_logg > 0 && (m >> bucket_logg) * bucket_fbits / 8 < 16) --bucket_logg;
@@ -226,6 +226,15 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
             // ~jobs_per_cu jobs per CU over the whole class so the dispatcher can balance the tail
             const size_t target_jobs = 256 * knobs.jobs_per_cu;
             size_t tiles_per_job = std::max<size_t>(1, (total_tiles * ngroups + target_jobs - 1) / target_jobs);
+            // A job loads and merges its k-group's registers whatever its length: small calls (one batch of the
+            // ingestion pipeline: 2 x 50 Mbp, 26 x 5 Mbp) keep four tiles per job as long as that still leaves
+            // four jobs per workgroup slot (measured 5-7 % on such calls; large calls are unaffected).
+            if (!knobs.lds_budget_forced)
+                for (size_t want = 4; want > tiles_per_job; want >>= 1)
+                    if (total_tiles * ngroups >= want * 2048) {
+                        tiles_per_job = want;
+                        break;
+                    }
             // Tile-major order: workgroups that run concurrently work on different (genome, k-group)
             // slabs, so each slab has been warmed by its earlier tiles when its later jobs start.
             // Jobs are handed out in table order; the last quarter of the tiles goes out in jobs a

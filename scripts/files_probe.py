@@ -23,7 +23,7 @@ def probe(eng, ng, nb, gz, kmin=4, kmax=40, log=print):
                 f.write(gzip.compress(raw, compresslevel=1) if gz else raw)
             paths.append(pth)
         best = None
-        for it in range(3):
+        for it in range(6):
             t0 = time.perf_counter()
             regs = eng.sketch_files(paths, kmin, kmax, 0)
             dt = time.perf_counter() - t0
