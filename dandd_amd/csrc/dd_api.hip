@@ -522,7 +522,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
                 Span span(c, DD_KERNEL_SWEEP);
                 dd::launch_scatter(reinterpret_cast<const dd::SweepGenome*>(tdev),
                                    reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]) + j0, (int)(j1 - j0),
-                                   sc.kclass, sc.plan, sp, st);
+                                   sc.kclass, sc.plan, sp, st, e == 0 && !getenv("DD_BUCKET_NO_FIRST"));
                 blocks += (int)(j1 - j0);
                 any = true;
             }

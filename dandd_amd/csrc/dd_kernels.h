@@ -84,7 +84,8 @@ struct SweepPlan {
     // kBucketMode only
     int logg = 0;               // one filter entry per 2^logg registers
     int fbits = 8;              // bits per filter entry: 8, or 4 (bounds saturate at 15, two entries per byte)
-    int nk_job = 1;             // ks per scatter job (1 or 2)
+    int nk_job = 1;             // ks per scatter job
+    int probe = 0;              // second-level filter: queued candidates are checked against the row itself
     int nb_log2 = 0;            // 2^nb_log2 index tiles of 64 KiB per row (replay)
     unsigned cap_chunks = 0;    // 1024-record chunks per row and epoch
     int nepochs = 0;
@@ -121,7 +122,7 @@ struct ScatterParams {
     unsigned cap_chunks;
 };
 void launch_scatter(const SweepGenome* genomes_dev, const SweepJob* jobs_dev, int njobs, int kclass,
-                    const SweepPlan& plan, const ScatterParams& sp, hipStream_t st);
+                    const SweepPlan& plan, const ScatterParams& sp, hipStream_t st, bool first_epoch);
 void launch_replay(const BucketRow* rows_dev, int nrows, const SweepPlan& plan, hipStream_t st);
 int sweep_max_lds_bytes();
 // small-k class: jobs carry ks <= kBitmapMaxK; records k-mer presence in genome.bitmap

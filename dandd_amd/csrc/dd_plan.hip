@@ -30,6 +30,7 @@ PlanKnobs PlanKnobs::from_env() {
     if (const char* e = getenv("DD_BUCKET_CAP")) k.bucket_cap_chunks = (size_t)std::max(1, atoi(e));
     if (const char* e = getenv("DD_BUCKET_LOGG")) k.bucket_logg = std::max(0, std::min(8, atoi(e))) + 1;  // stored + 1: 0 = not set
     if (const char* e = getenv("DD_BUCKET_FBITS")) k.bucket_fbits = atoi(e) == 4 ? 4 : 8;
+    if (const char* e = getenv("DD_BUCKET_PROBE")) k.bucket_probe = atoi(e) ? 1 : 0;
     if (const char* e = getenv("DD_BUCKET_GB")) k.bucket_budget = (size_t)std::max(1, atoi(e)) << 30;
     return k;
 }
@@ -78,16 +79,17 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
     }
 
     // Bucket mode (scatter + replay, dd_kernels.h): epochs are ranges of token tiles, the same for every row.
-    // The first holds one token per register (nothing can be filtered before the registers have been
-    // seen once), each later one is as long as everything before it -- the filter's bounds rise by about
+    // The first holds two tokens per register (nothing can be filtered before the registers have been
+    // seen), each later one is as long as everything before it -- the filter's bounds rise by about
     // one per doubling -- up to the length whose worst case (every update survives) fits the HBM budget.
     const bool bucket_mode = global_regs && knobs.buckets && knobs.filter;
     const int bucket_nk = 1;  // ks per scatter job (two were measured slower: dd_sweep.hip)
+    const int bucket_probe = knobs.bucket_probe >= 0 ? knobs.bucket_probe : 1;
     const int bucket_fbits = knobs.bucket_fbits ? knobs.bucket_fbits : 4;  // measured: 4-bit entries win at log2m 18, 19 and 20
     // a 64 KiB filter: 2^(p-16) registers per byte-wide entry, half as many per 4-bit entry
     int bucket_logg = knobs.bucket_logg ? knobs.bucket_logg - 1 : std::max(1, p - 16 - (bucket_fbits == 4 ? 1 : 0));
     // (a knob that asks for more filter than a workgroup can hold gets the finest one that fits; 16 bytes at least)
-    while ((m >> bucket_logg) * bucket_fbits / 8 + (kThreads / 64) * 512 > (size_t)sweep_max_lds_bytes()) ++bucket_logg;
+    while ((m >> bucket_logg) * bucket_fbits / 8 + (kThreads / 64) * 1024 > (size_t)sweep_max_lds_bytes()) ++bucket_logg;
     while (bucket_logg > 0 && (m >> bucket_logg) * bucket_fbits / 8 < 16) --bucket_logg;
     const int nb_log2 = std::max(0, p - 16);  // index tiles of 64 KiB
     std::vector<size_t> epoch_edge;           // epoch e covers tiles [epoch_edge[e], epoch_edge[e+1])
@@ -95,7 +97,9 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
     if (bucket_mode) {
         const int first_hashed = use_bitmaps ? std::max(kmin, kBitmapMaxK + 1) : kmin;
         const size_t nrows = (size_t)ngenomes * (size_t)std::max(0, kmax - first_hashed + 1);
-        const size_t e0 = knobs.bucket_e0_tiles ? knobs.bucket_e0_tiles : std::max<size_t>(1, m / kTileTokens);
+        // (the first epoch runs unfiltered and cheaply -- every register is zero, every update a record --, so it is
+        // made two tokens per register long, 16 tiles at least: measured best at log2m 18, 19 and 20)
+        const size_t e0 = knobs.bucket_e0_tiles ? knobs.bucket_e0_tiles : std::max<size_t>(16, 2 * m / kTileTokens);
         size_t emax = knobs.bucket_emax_tiles;
         bucket_row_tokens = knobs.bucket_budget / (std::max<size_t>(1, nrows) * 9 / 2);  // 4 B per record + slack
         if (!emax) emax = std::min<size_t>(256, bucket_row_tokens / kTileTokens);
@@ -179,6 +183,7 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
             sc.plan.logg = bucket_logg;
             sc.plan.fbits = bucket_fbits;
             sc.plan.nk_job = bucket_nk;
+            sc.plan.probe = bucket_probe;
             sc.plan.nb_log2 = nb_log2;
             sc.plan.nepochs = (int)nepochs;
         } else if (global_regs && kc != kBitmapClass && (filter_logg || knobs.xcd_affinity)) {
@@ -278,7 +283,7 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
             sc.plan.lds_bytes = (bitmap_offset(kb) + bitmap_words(kb) - bitmap_offset(ka)) * 4;
         } else if (bucket_mode) {
             sc.plan.mode = kBucketMode;  // the filter, then a 128-entry record queue per wave
-            sc.plan.lds_bytes = bucket_nk * ((int)((m >> bucket_logg) * bucket_fbits / 8) + (kThreads / 64) * 128 * 4);
+            sc.plan.lds_bytes = bucket_nk * ((int)((m >> bucket_logg) * bucket_fbits / 8) + (kThreads / 64) * 128 * 4 * (bucket_probe ? 2 : 1));
         } else if (filter_logg) {
             sc.plan.mode = filter_logg;  // the filter, then a 128-entry candidate queue per wave (dd_sweep.hip)
             sc.plan.lds_bytes = (int)(m >> filter_logg) + (kThreads / 64) * 128 * 4;

@@ -789,12 +789,40 @@ DD_D void scatter_block(const Scatter& s, uint32_t rec, uint32_t& cur) {
     cur += 64u;
     if ((cur & (kChunkRecords - 1u)) == 0u && lane == 0) gstore4(s.fill + (cur / kChunkRecords - 1u), kChunkRecords);
 }
-// One update.  Reached by whole waves (`valid`: the lane has a k-mer); `waiting` and `cur` are wave-uniform.
+// Second-level filter (PROBE): 64 queued candidates are checked against the ROW ITSELF -- one byte load per
+// lane from the registers as the last replay left them (the row of the jobs an XCD is running stays in that
+// XCD's L2: job order, dd_plan.hip) -- and only those that really exceed their register move on to a second
+// queue and, 64 at a time, to the stream.  The group-minimum filter lets ~25 % of the updates through at log2m
+// 20; about 10 % really raise a register.  Exact either way: a register only rises, so its last stored value is
+// a lower bound.
+DD_D void scatter_probe(const Scatter& s, uint32_t rec, uint32_t& waiting2, uint32_t& cur) {
+    bool live = (rec >> 24) != 0u;
+    if (live) live = (rec >> 24) > (uint32_t)*(const DD_GLOBAL uint8_t*)(s.regs + (rec & 0xFFFFFFu));
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
+    if (mask) {
+        if (live) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            lds32(s.queue + kQueueEntries * 4u + 4u * (waiting2 + rank)) = rec;
+        }
+        waiting2 += (uint32_t)__builtin_popcountll(mask);
+        if (waiting2 >= 64u) {
+            waiting2 -= 64u;
+            scatter_block(s, lds32(s.queue + kQueueEntries * 4u + 4u * (waiting2 + (threadIdx.x & 63u))), cur);
+        }
+    }
+}
+// One update.  Reached by whole waves (`valid`: the lane has a k-mer); `waiting`, `waiting2`, `cur` are wave-uniform.
 // NIB: the filter holds 4-bit bounds (saturating at 15), two register groups per byte -- twice the resolution
 // in the same 64 KiB of LDS for three more instructions per update.
-template <bool NIB>
-DD_D void scatter_update(const Scatter& s, uint32_t& waiting, uint32_t& cur, uint64_t h, int p, bool valid) {
+// FIRST: the call's first epoch -- every register is still zero, so every update is a record: no filter, no
+// queues, the wave's 64 records (null where a lane has no k-mer) leave as a block at once.
+template <bool NIB, bool PROBE, bool FIRST>
+DD_D void scatter_update(const Scatter& s, uint32_t& waiting, uint32_t& waiting2, uint32_t& cur, uint64_t h, int p, bool valid) {
     const Probe q = probe(h, p);
+    if (FIRST) {
+        scatter_block(s, valid ? (q.hi >> (32 - p)) | (rho_of(q, p) << 24) : 0u, cur);
+        return;
+    }
     uint32_t bound;
     if (NIB) {
         const uint32_t e = q.hi >> s.fshift;
@@ -812,7 +840,9 @@ DD_D void scatter_update(const Scatter& s, uint32_t& waiting, uint32_t& cur, uin
         waiting += (uint32_t)__builtin_popcountll(mask);
         if (waiting >= 64u) {
             waiting -= 64u;
-            scatter_block(s, lds32(s.queue + 4u * (waiting + (threadIdx.x & 63u))), cur);
+            const uint32_t rec = lds32(s.queue + 4u * (waiting + (threadIdx.x & 63u)));
+            if (PROBE) scatter_probe(s, rec, waiting2, cur);
+            else scatter_block(s, rec, cur);
         }
     }
 }
@@ -821,7 +851,7 @@ DD_D void scatter_update(const Scatter& s, uint32_t& waiting, uint32_t& cur, uin
 // push, 7 of the ~50 VALU instructions of an update; two 64 KiB filters = one workgroup per CU) measured
 // SLOWER on MI355X -- 35.1 / 40.7 / 49.4 ms against 28.2 / 33.2 / 43.3 at log2m 18 / 19 / 20
 // (profiles/r02_bucket_path.txt); the code path is kept for the record.
-template <int KC, bool CANON, bool NIB, int NK>
+template <int KC, bool CANON, bool NIB, bool PROBE, int NK, bool FIRST = false>
 __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __restrict__ genomes,
                                                       const SweepJob* __restrict__ jobs, int p, ScatterParams sp) {
     const SweepJob job = jobs[blockIdx.x];
@@ -859,23 +889,23 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
     // each row's filter as the previous epoch's replay left it (plain loads: written by an earlier kernel),
     // then the per-wave queues
     Scatter s[NK];
-    uint32_t waiting[NK], cur[NK];
+    uint32_t waiting[NK], waiting2[NK], cur[NK];
 #pragma unroll
     for (int j = 0; j < NK; ++j) {
         const BucketRow row = sp.rows[(size_t)job.genome * sp.K + job.krow + ((j == 0 || two) ? j : 0)];
-        if (j == 0 || two) {
+        if (!FIRST && (j == 0 || two)) {
             uint4* f4 = reinterpret_cast<uint4*>(g_lds + (uint32_t)j * nflt);
             for (uint32_t i = threadIdx.x; i < (nflt >> 4); i += blockDim.x) f4[i] = gload16(row.filter + (size_t)i * 16);
         }
         s[j].fbase = (uint32_t)j * nflt;
-        s[j].queue = (uint32_t)NK * nflt + ((threadIdx.x >> 6) * NK + j) * (kQueueEntries * 4u);
+        s[j].queue = (uint32_t)NK * nflt + ((threadIdx.x >> 6) * NK + j) * (kQueueEntries * 4u * (PROBE ? 2u : 1u));
         s[j].area = row.area;
         s[j].cursor = row.cursor;
         s[j].fill = row.fill;
         s[j].regs = row.regs;
         s[j].cap_chunks = sp.cap_chunks;
         s[j].fshift = 32 - p + sp.logg;
-        waiting[j] = cur[j] = 0;
+        waiting[j] = waiting2[j] = cur[j] = 0;
     }
     __syncthreads();
 
@@ -896,8 +926,8 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
 #pragma unroll 1
                 for (int i = 0; i < 16; ++i) {
                     win.push((cw[w] >> (2 * i)) & 3u);
-                    scatter_update<NIB>(s[0], waiting[0], cur[0], win.template hash<CANON>(k), p, true);
-                    if (NK == 2 && two) scatter_update<NIB>(s[NK - 1], waiting[NK - 1], cur[NK - 1], win.template hash<CANON>(k + 1), p, true);
+                    scatter_update<NIB, PROBE, FIRST>(s[0], waiting[0], waiting2[0], cur[0], win.template hash<CANON>(k), p, true);
+                    if (NK == 2 && two) scatter_update<NIB, PROBE, FIRST>(s[NK - 1], waiting[NK - 1], waiting2[NK - 1], cur[NK - 1], win.template hash<CANON>(k + 1), p, true);
                 }
             }
             continue;
@@ -911,8 +941,8 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
                 const uint32_t c = (cw[w] >> (2 * i)) & 3u;
                 run = ((bw >> i) & 1u) ? 0 : run + 1;
                 win.push(c);
-                scatter_update<NIB>(s[0], waiting[0], cur[0], win.template hash<CANON>(k), p, run >= k);
-                if (NK == 2 && two) scatter_update<NIB>(s[NK - 1], waiting[NK - 1], cur[NK - 1], win.template hash<CANON>(k + 1), p, run >= k + 1);
+                scatter_update<NIB, PROBE, FIRST>(s[0], waiting[0], waiting2[0], cur[0], win.template hash<CANON>(k), p, run >= k);
+                if (NK == 2 && two) scatter_update<NIB, PROBE, FIRST>(s[NK - 1], waiting[NK - 1], waiting2[NK - 1], cur[NK - 1], win.template hash<CANON>(k + 1), p, run >= k + 1);
             }
         }
     }
@@ -921,8 +951,11 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
 #pragma unroll
     for (int j = 0; j < NK; ++j) {
         if (j && !two) break;
-        if (waiting[j]) {
-            const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t lane = threadIdx.x & 63u;
+        if (PROBE) {
+            if (waiting[j]) scatter_probe(s[j], lane < waiting[j] ? lds32(s[j].queue + 4u * lane) : 0u, waiting2[j], cur[j]);
+            if (waiting2[j]) scatter_block(s[j], lane < waiting2[j] ? lds32(s[j].queue + kQueueEntries * 4u + 4u * lane) : 0u, cur[j]);
+        } else if (waiting[j]) {
             scatter_block(s[j], lane < waiting[j] ? lds32(s[j].queue + 4u * lane) : 0u, cur[j]);
         }
         if ((cur[j] & (kChunkRecords - 1u)) != 0u && (threadIdx.x & 63u) == 0)
@@ -1164,17 +1197,38 @@ void launch_bitmap_finish(const SweepGenome* genomes, int ngenomes, int kfirst, 
 
 
 void launch_scatter(const SweepGenome* genomes, const SweepJob* jobs, int njobs, int kclass, const SweepPlan& plan,
-                    const ScatterParams& sp, hipStream_t st) {
+                    const ScatterParams& sp, hipStream_t st, bool first_epoch) {
     if (njobs <= 0) return;
-#define DD_SCATTER_NN(KC, CN, NB, NKJ)                                                                  \
+    if (first_epoch) {
+        // every register of the call is still zero: the unfiltered form (no LDS at all)
+#define DD_FIRST(KC, CN) \
+    hipLaunchKernelGGL((scatter_kernel<KC, CN, false, false, 1, true>), dim3((unsigned)njobs), dim3((unsigned)plan.threads), 0, st, genomes, jobs, plan.log2m, sp)
+#define DD_FIRST_KC(CN)                   \
+    do {                                  \
+        if (kclass == 0) DD_FIRST(0, CN); \
+        else if (kclass == 1) DD_FIRST(1, CN); \
+        else if (kclass == 3) DD_FIRST(3, CN); \
+        else DD_FIRST(2, CN);             \
+    } while (0)
+        if (plan.canonical) DD_FIRST_KC(true);
+        else DD_FIRST_KC(false);
+#undef DD_FIRST_KC
+#undef DD_FIRST
+        return;
+    }
+#define DD_SCATTER_NN(KC, CN, NB, PR)                                                                   \
     do {                                                                                                \
-        auto kern = scatter_kernel<KC, CN, NB, NKJ>;                                                    \
+        auto kern = scatter_kernel<KC, CN, NB, PR, 1>;                                                  \
         static std::atomic<unsigned long long> attr_done{0};                                            \
         allow_full_lds(reinterpret_cast<const void*>(kern), attr_done);                                 \
         hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3((unsigned)plan.threads), (size_t)plan.lds_bytes, st, \
                            genomes, jobs, plan.log2m, sp);                                              \
     } while (0)
-#define DD_SCATTER_N(KC, CN, NB) DD_SCATTER_NN(KC, CN, NB, 1)
+#define DD_SCATTER_N(KC, CN, NB)                \
+    do {                                        \
+        if (plan.probe) DD_SCATTER_NN(KC, CN, NB, true); \
+        else DD_SCATTER_NN(KC, CN, NB, false);  \
+    } while (0)
 #define DD_SCATTER(KC, CN)                      \
     do {                                        \
         if (plan.fbits == 4) DD_SCATTER_N(KC, CN, true); \

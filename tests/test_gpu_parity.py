@@ -88,6 +88,7 @@ BUCKET_KNOBS = {
     "coarse_filter": {"DD_BUCKET_LOGG": "6", "DD_BUCKET_E0": "1"},    # 64 registers per filter entry
     "nibble_filter": {"DD_BUCKET_FBITS": "4", "DD_BUCKET_E0": "1"},   # 4-bit bounds (saturating), two entries per byte
     "byte_filter": {"DD_BUCKET_FBITS": "8", "DD_BUCKET_E0": "1"},
+    "no_row_probe": {"DD_BUCKET_PROBE": "0", "DD_BUCKET_E0": "1"},    # group filter only (no second-level check against the row)
     "no_xcd_order": {"DD_NO_XCD_AFFINITY": "1", "DD_BUCKET_E0": "1"},
     "cas_path": {"DD_NO_BUCKETS": "1"},                               # round 1's filtered compare-and-swap path, kept for A/B
 }

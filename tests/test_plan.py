@@ -47,11 +47,12 @@ def check(log2m, sizes, kmin, kmax):
         elif log2m >= 18:
             fbits = int(os.environ.get("DD_BUCKET_FBITS", 4))
             logg = int(os.environ.get("DD_BUCKET_LOGG", max(1, log2m - 16 - (1 if fbits == 4 else 0))))
-            while (m >> logg) * fbits // 8 + 16 * 512 > LDS_MAX:
+            queues = 2 if os.environ.get("DD_BUCKET_PROBE", "1") != "0" else 1
+            while (m >> logg) * fbits // 8 + 16 * 1024 > LDS_MAX:
                 logg += 1
             nkj = 1
             assert mode == 5 and nk == 1                           # scatter + replay, one k per job
-            assert j["lds_bytes"] == nkj * ((m >> logg) * fbits // 8 + 16 * 128 * 4)    # per k: filter + one record queue per wave
+            assert j["lds_bytes"] == nkj * ((m >> logg) * fbits // 8 + queues * 16 * 128 * 4)    # filter + the record queues of every wave
         else:
             assert mode == 0 and nk * m <= j["lds_bytes"]          # the group's registers fit the LDS asked for
         cover[g][k0 - kmin:k0 - kmin + nk, j["tile_begin"]:j["tile_end"]] += 1
@@ -95,7 +96,7 @@ def test_bucket_mode_epochs(monkeypatch):
             jobs = check(log2m, SIZES["ragged"], 8, 35)
             real = jobs[(jobs["tile_end"] > jobs["tile_begin"]) & (jobs["kclass"] >= 0)]
             if "DD_NO_BUCKETS" not in env and "DD_BUCKET_GB" not in env:
-                e0 = int(env.get("DD_BUCKET_E0", max(1, (1 << log2m) // TILE)))
+                e0 = int(env.get("DD_BUCKET_E0", max(16, 2 * (1 << log2m) // TILE)))
                 emax = max(e0, int(env.get("DD_BUCKET_EMAX", 256)))
                 edges = [0, e0]
                 while edges[-1] < 1000:
