@@ -318,6 +318,35 @@ struct Windows<1> {
     }
 };
 
+// The 64-bit class again, as 32-bit halves: a push is two funnel shifts and two shift-or instructions, and the
+// compiler has no 64-bit value to keep a copy of (with u64 members it spent three more instructions per push).
+// Used by the scatter kernels, where the push is paid per (token, k); sweep_kernel shares one push between the
+// ks of a group and keeps Windows<1> (measured equal there).
+template <>
+struct Windows<5> {
+    uint32_t fl = 0, fh = 0, rl = 0, rh = 0;
+    DD_D void prime(const uint4& hc) {
+        fh = pairrev32(hc.z);
+        fl = pairrev32(hc.w);
+        rh = ~hc.w;
+        rl = ~hc.z;
+    }
+    DD_D void push(uint32_t c) {
+        fh = __builtin_amdgcn_alignbit(fh, fl, 30);  // (fw << 2) high word
+        fl = (fl << 2) | c;
+        rl = __builtin_amdgcn_alignbit(rh, rl, 2);   // (rc >> 2) low word
+        rh = (rh >> 2) | ((3u - c) << 30);
+    }
+    template <bool CANON>
+    DD_D uint64_t hash(int k) const {
+        const uint32_t mhi = (k == 32) ? ~0u : ((1u << (2 * k - 32)) - 1u);
+        const uint64_t f = pack64(fh & mhi, fl);
+        if (!CANON) return wang64_fast<false>(f);
+        const uint64_t r = pack64(rh, rl) >> (64 - 2 * k);
+        return wang64_fast<false>(f < r ? f : r);
+    }
+};
+
 template <>
 struct Windows<2> {
     uint64_t fh = 0, fl = 0, rh = 0, rl = 0;
@@ -918,7 +947,7 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
         const uint4 hc = in.hc, sc = in.sc;
         const uint2 hb = in.hb, sb = in.sb;
         const uint32_t cw[4] = {sc.x, sc.y, sc.z, sc.w};
-        Windows<KC> win;
+        Windows<KC == 1 ? 5 : KC> win;
         win.prime(hc);
         if (__all((hb.x | hb.y | sb.x | sb.y) == 0u)) {
 #pragma unroll
