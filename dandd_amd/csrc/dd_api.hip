@@ -602,7 +602,8 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
         }
     }
     const size_t avg = std::max<size_t>(1, disk_bytes / (size_t)nfiles);
-    const size_t kBatchBytes = (size_t)(getenv("DD_BATCH_MB") ? std::max(1, atoi(getenv("DD_BATCH_MB"))) : 128) << 20;
+    // (log2m >= 18: the scatter/sort/replay path runs epoch by epoch over all rows of a launch and wants many rows)
+    const size_t kBatchBytes = (size_t)(getenv("DD_BATCH_MB") ? std::max(1, atoi(getenv("DD_BATCH_MB"))) : (c->p >= 18 ? 512 : 128)) << 20;
     const int batch_files = (int)std::max<size_t>(1, std::min<size_t>(64, kBatchBytes / avg));
     // loaders may run two batches ahead of the GPU
     const int window = std::max(nthreads + 2, 2 * batch_files + nthreads);

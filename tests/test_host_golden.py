@@ -298,3 +298,36 @@ def test_afproject_tuples_and_phylip_export(host, tmp_path):
     write_phylip(tuples, os.path.join(out, "j10.phy"), k=10)
     with pytest.raises(ValueError):
         write_phylip(tuples, os.path.join(out, "none.phy"), k=99)
+
+
+@pytest.mark.gpu
+def test_cli_at_the_reference_default_register_count_on_gpu(host, tmp_path, torch_cuda):
+    """DandD's default is `-r 20` (/root/reference/lib/dandd_cmd.py:187): the whole drop-in walk -- tree (hill-climb),
+    progressive --ksweep, kij --jaccard -- with 2^20 registers (K1 = scatter + sort + replay, 1 MiB per sketch file)
+    writes the rows the oracle backend writes behind the same host layer."""
+    import shutil
+    from dandd_amd.host import cli
+    import pickle
+
+    def walk(name, factory):
+        host.set_backend_factory(factory)
+        work = os.path.join(str(tmp_path), name)
+        data = os.path.join(work, "data")
+        shutil.copytree(os.path.join(hostcheck.GOLD, "fasta"), data)
+        out = os.path.join(work, "o")
+        cli.main(["tree", "-d", data, "-o", out, "-s", "gold", "-k", "10"])   # no -r: the default, 20
+        tree = os.path.join(out, "gold_5_dashing_dtree.pickle")
+        with open(os.path.join(out, "sketchdb", "gold_5_orderings.pickle"), "wb") as f:
+            pickle.dump({(0, 1, 2, 3, 4), (4, 2, 0, 3, 1)}, f)
+        cli.main(["progressive", "-d", tree, "-o", out, "--ksweep", "--mink", "9", "--maxk", "12"])
+        cli.main(["kij", "-d", tree, "-o", out, "--jaccard", "--mink", "9", "--maxk", "11"])
+        names = ["gold_5_dashing_deltas.csv", "gold_progu0_5_dashingsummary.csv", "gold_5_dashing.kij.csv", "gold_5_dashing.j.csv"]
+        rows = {n: hostcheck.read_rows(os.path.join(out, n)) for n in names}
+        assert os.path.getsize([os.path.join(dp, f) for dp, _, fs in os.walk(os.path.join(out, "sketchdb", "ngen1")) for f in fs][0]) == 12 + (1 << 20)
+        return rows
+
+    gpu = walk("gpu", None)
+    cpu = walk("cpu", lambda r, c: hostcheck.OracleBackend(r, c))
+    assert all(len(v) > 0 for v in gpu.values())
+    diffs = hostcheck.compare(gpu, cpu)
+    assert not diffs, "\n".join(diffs[:30])
