@@ -85,3 +85,20 @@ def test_bench_two_ranks_on_one_gpu_matches_single_process(torch_cuda):
     assert j2["delta_root"] == j1["delta_root"] and j2["argmax_k_root"] == j1["argmax_k_root"]
     assert j2["delta_genome0"] == j1["delta_genome0"]
     assert np.isfinite(j2["value"]) and j2["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config,extra", [("cfg3", ["--genomes", "8", "--mbp", "1"]), ("cfg4share", ["--mbp", "2"]),
+                                          ("cfg5share", ["--genomes", "2", "--mbp", "3", "--log2m", "18"])])
+def test_bench_config_presets_run(torch_cuda, config, extra):
+    """The --config presets (BASELINE cfg 3 / 4 / 5 shapes, shrunk) produce a well-formed line: right k range, the
+    extra schedule in the step, strong/weak scaling flag, finite throughput."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    want_k = {"cfg3": (2, 32), "cfg4share": (2, 32), "cfg5share": (4, 64)}[config]
+    assert (j["config"]["kmin"], j["config"]["kmax"]) == want_k
+    assert j["scaling"] == ("strong" if config == "cfg3" else "weak") and j["value"] > 0 and np.isfinite(j["delta_root"])
+    assert config in j["config"]["workload"] and j["roofline"]["kernel_ms_per_step"] > 0
+    assert "accuracy_vs_exact" not in j and "secondary" not in j      # only the headline config carries those
