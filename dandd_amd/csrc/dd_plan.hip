@@ -147,7 +147,7 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
                 if (!tile_rows) continue;
                 // ~8 jobs per resident workgroup slot; a job reloads its rows' filters, so not below 2 tiles
                 // once the epoch is long enough to allow it
-                const size_t slots = bucket_nk == 2 ? 2048 : 4096;  // two-k jobs: one workgroup per CU, twice the work each
+                const size_t slots = 4096;  // (1024 .. 16384 measured: 4096 is best at log2m 18 and 20)
                 const size_t tpj = std::max<size_t>(std::min<size_t>(2, t_hi - t_lo), (tile_rows / bucket_nk + slots - 1) / slots);
                 std::vector<std::vector<SweepJob>> per_xcd(8);
                 int row = 0;
