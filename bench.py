@@ -415,6 +415,8 @@ def main():
             extras["secondary"] = sec
         if not args.no_ingest:
             extras["ingest"] = ingest_probe(eng, ng, nb, cfg["nrec"], kmin, kmax, torch)
+            # the cfg 3 shape of the same path: many small files coalesced into a few launches
+            extras["ingest"]["small_files"] = ingest_probe(eng, 64, 5_000_000, cfg["nrec"], kmin, kmax, torch)
 
     # HBM-side traffic of K1 per step: PMC counters cannot be read from inside this process, so the
     # number comes from the committed rocprofv3 passes (profiles/traffic.json, made by
