@@ -312,7 +312,8 @@ int dd_set_stream(dd_ctx* c, void* hip_stream) {
         // Work queued on the old stream still uses the context's tables and workspaces (the cached K1 job
         // tables were uploaded there); nothing orders a new stream behind it, so it is drained first.
         DeviceGuard g(c->device);
-        DD_HIP(hipStreamSynchronize(c->stream));
+        // (best effort: a caller may hand over a new stream because it already destroyed the old one)
+        if (hipStreamSynchronize(c->stream) != hipSuccess) (void)hipGetLastError();
         c->stream = next;
     }
     return DD_OK;
