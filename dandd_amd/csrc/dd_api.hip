@@ -133,6 +133,9 @@ struct dd_ctx {
     DevBuf pipe_fasta[2], pipe_regs[2];
     HostBuf pipe_out[2];
     hipEvent_t pipe_h2d[2] = {nullptr, nullptr}, pipe_done[2] = {nullptr, nullptr}, pipe_d2h[2] = {nullptr, nullptr};
+    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};  // k classes of a small call run side by side
+    hipEvent_t side_done[4] = {nullptr, nullptr, nullptr, nullptr}, side_go = nullptr;
+    bool side_ready = false;
     int ingest_calls = 0;
     double ingest_ms[4] = {0, 0, 0, 0};  // last dd_sketch_files call: wall, waiting for loaders, batches, bytes (as a double)
     // stats of the last sketch call
@@ -299,6 +302,13 @@ void dd_destroy(dd_ctx* c) {
         c->pipe_out[i].release();
         for (hipEvent_t e : {c->pipe_h2d[i], c->pipe_done[i], c->pipe_d2h[i]})
             if (e) (void)hipEventDestroy(e);
+    }
+    if (c->side_ready) {
+        for (int i = 0; i < 4; ++i) {
+            (void)hipStreamDestroy(c->side[i]);
+            (void)hipEventDestroy(c->side_done[i]);
+        }
+        (void)hipEventDestroy(c->side_go);
     }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->out_stream) (void)hipStreamDestroy(c->out_stream);
@@ -492,21 +502,50 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     }
 
     // ---- K1 launches -------------------------------------------------------------------
+    // The k classes are independent.  On a big call they are launched back to back (running them side by side
+    // was measured neutral to slightly slower: they compete for the same VALUs).  On a SMALL call -- one batch of
+    // the ingestion pipeline, a single genome -- every class is only a few rounds of workgroups long and ends
+    // with a tail of idle CUs: there the classes go to side streams so that one's tail overlaps another's body.
     int blocks = 0;
+    size_t lds_jobs = 0;
+    int lds_classes = 0;
+    for (const dd::SweepClass& sc : classes)
+        if (sc.plan.mode != dd::kBucketMode) lds_jobs += sc.jobs.size(), ++lds_classes;
+    const bool side = !c->timing && lds_classes > 1 && lds_jobs < 12000 && !getenv("DD_NO_SIDE_STREAMS");
+    if (side && !c->side_ready) {
+        for (int i = 0; i < 4; ++i) {
+            DD_HIP(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+            DD_HIP(hipEventCreateWithFlags(&c->side_done[i], hipEventDisableTiming));
+        }
+        DD_HIP(hipEventCreateWithFlags(&c->side_go, hipEventDisableTiming));
+        c->side_ready = true;
+    }
+    if (side) DD_HIP(hipEventRecord(c->side_go, st));
+    int lane_no = 0;
     for (size_t i = 0; i < classes.size(); ++i) {
         const dd::SweepClass& sc = classes[i];
         if (sc.plan.mode == dd::kBucketMode) continue;
+        hipStream_t ks = st;
+        if (side) {
+            ks = c->side[lane_no & 3];
+            DD_HIP(hipStreamWaitEvent(ks, c->side_go, 0));
+        }
         Span sp(c, DD_KERNEL_SWEEP);
         if (sc.kclass == dd::kBitmapClass) {
             dd::launch_bitmap(reinterpret_cast<const dd::SweepGenome*>(tdev),
                               reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]),
-                              (int)sc.jobs.size(), sc.kfirst, sc.klast, c->canonical, st);
+                              (int)sc.jobs.size(), sc.kfirst, sc.klast, c->canonical, ks);
             dd::launch_bitmap_finish(reinterpret_cast<const dd::SweepGenome*>(tdev), ngenomes, sc.kfirst, sc.klast,
-                                     kmin, p, st);
+                                     kmin, p, ks);
         } else {
             dd::launch_sweep(reinterpret_cast<const dd::SweepGenome*>(tdev),
                              reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]),
-                             (int)sc.jobs.size(), sc.kclass, sc.plan, st);
+                             (int)sc.jobs.size(), sc.kclass, sc.plan, ks);
+        }
+        if (side) {
+            DD_HIP(hipEventRecord(c->side_done[lane_no & 3], ks));
+            DD_HIP(hipStreamWaitEvent(st, c->side_done[lane_no & 3], 0));
+            ++lane_no;
         }
         blocks += (int)sc.jobs.size();
     }
