@@ -521,10 +521,11 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         c->side_ready = true;
     }
     if (side) DD_HIP(hipEventRecord(c->side_go, st));
+    const bool side_b = bplan && !c->timing && !getenv("DD_NO_SIDE_STREAMS");  // log2m >= 18: see below
     int lane_no = 0;
     for (size_t i = 0; i < classes.size(); ++i) {
         const dd::SweepClass& sc = classes[i];
-        if (sc.plan.mode == dd::kBucketMode) continue;
+        if (sc.plan.mode == dd::kBucketMode || side_b) continue;
         hipStream_t ks = st;
         if (side) {
             ks = c->side[lane_no & 3];
@@ -550,25 +551,55 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         blocks += (int)sc.jobs.size();
     }
     if (bplan) {
-        // epoch by epoch: scatter launches of every k class, then one replay over all rows
+        // epoch by epoch: scatter launches of every k class (independent rows: side by side on side streams, so the
+        // tail of one overlaps the body of another), then one sort + replay over all rows
         const dd::ScatterParams sp{rows_dev, K, bplan->logg, bplan->cap_chunks};
-        for (int e = 0; e < bplan->nepochs; ++e) {
-            bool any = false;
-            for (size_t i = 0; i < classes.size(); ++i) {
-                const dd::SweepClass& sc = classes[i];
-                if (sc.plan.mode != dd::kBucketMode) continue;
+        if (side_b && !c->side_ready) {
+            for (int i = 0; i < 4; ++i) {
+                DD_HIP(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+                DD_HIP(hipEventCreateWithFlags(&c->side_done[i], hipEventDisableTiming));
+            }
+            DD_HIP(hipEventCreateWithFlags(&c->side_go, hipEventDisableTiming));
+            c->side_ready = true;
+        }
+        // Every k class is a pipeline of its own -- scatter(e), sort(e), replay(e), scatter(e+1) ... over its own rows
+        // -- so each gets a side stream: the tails of one class's launches are filled by the others' work.
+        if (side_b) DD_HIP(hipEventRecord(c->side_go, st));
+        int lane_b = 0;
+        for (size_t i = 0; i < classes.size(); ++i) {
+            const dd::SweepClass& sc = classes[i];
+            hipStream_t ks = st;
+            if (side_b) {
+                ks = c->side[lane_b & 3];
+                DD_HIP(hipStreamWaitEvent(ks, c->side_go, 0));
+            }
+            if (sc.plan.mode != dd::kBucketMode) {
+                if (!side_b) continue;  // (already launched above)
+                // the small-k class (its rows are not bucketed) runs beside the pipelines
+                if (sc.kclass == dd::kBitmapClass) {
+                    dd::launch_bitmap(reinterpret_cast<const dd::SweepGenome*>(tdev), reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]),
+                                      (int)sc.jobs.size(), sc.kfirst, sc.klast, c->canonical, ks);
+                    dd::launch_bitmap_finish(reinterpret_cast<const dd::SweepGenome*>(tdev), ngenomes, sc.kfirst, sc.klast, kmin, p, ks);
+                } else {
+                    dd::launch_sweep(reinterpret_cast<const dd::SweepGenome*>(tdev), reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]),
+                                     (int)sc.jobs.size(), sc.kclass, sc.plan, ks);
+                }
+                blocks += (int)sc.jobs.size();
+            }
+            for (int e = 0; sc.plan.mode == dd::kBucketMode && e < bplan->nepochs; ++e) {
                 const size_t j0 = sc.epoch_begin[e], j1 = sc.epoch_begin[e + 1];
                 if (j1 == j0) continue;
                 Span span(c, DD_KERNEL_SWEEP);
                 dd::launch_scatter(reinterpret_cast<const dd::SweepGenome*>(tdev),
                                    reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]) + j0, (int)(j1 - j0),
-                                   sc.kclass, sc.plan, sp, st, e == 0 && !getenv("DD_BUCKET_NO_FIRST"));
+                                   sc.kclass, sc.plan, sp, ks, e == 0 && !getenv("DD_BUCKET_NO_FIRST"));
+                dd::launch_replay(rows_dev, ngenomes, K, sc.kfirst - kmin, sc.klast - sc.kfirst + 1, *bplan, ks);
                 blocks += (int)(j1 - j0);
-                any = true;
             }
-            if (any) {
-                Span span(c, DD_KERNEL_SWEEP);
-                dd::launch_replay(rows_dev, nrows, *bplan, st);
+            if (side_b) {
+                DD_HIP(hipEventRecord(c->side_done[lane_b & 3], ks));
+                DD_HIP(hipStreamWaitEvent(st, c->side_done[lane_b & 3], 0));
+                ++lane_b;
             }
         }
     }

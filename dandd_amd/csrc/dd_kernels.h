@@ -123,7 +123,8 @@ struct ScatterParams {
 };
 void launch_scatter(const SweepGenome* genomes_dev, const SweepJob* jobs_dev, int njobs, int kclass,
                     const SweepPlan& plan, const ScatterParams& sp, hipStream_t st, bool first_epoch);
-void launch_replay(const BucketRow* rows_dev, int nrows, const SweepPlan& plan, hipStream_t st);
+// sort + replay + cursor reset of rows k0 .. k0+nks-1 (indices into a genome's K rows) of every genome
+void launch_replay(const BucketRow* rows_dev, int ngenomes, int K, int k0, int nks, const SweepPlan& plan, hipStream_t st);
 int sweep_max_lds_bytes();
 // small-k class: jobs carry ks <= kBitmapMaxK; records k-mer presence in genome.bitmap
 // (kfirst..klast: the ks of the class; the LDS image covers exactly their bitmaps)

@@ -421,6 +421,47 @@ struct Windows<3> {
     }
 };
 
+// The 96-bit class as three 32-bit words per window (see Windows<5>): used by the scatter kernels.
+template <>
+struct Windows<6> {
+    uint32_t f0 = 0, f1 = 0, f2 = 0;  // forward window, low .. high word
+    uint32_t r0 = 0, r1 = 0, r2 = 0;  // reverse complement, top-aligned in 96 bits: r2 holds bits 95..64
+    DD_D void prime(const uint4& hc) {
+        f0 = pairrev32(hc.w);
+        f1 = pairrev32(hc.z);
+        f2 = pairrev32(hc.y);
+        r2 = ~hc.w;
+        r1 = ~hc.z;
+        r0 = ~hc.y;
+    }
+    DD_D void push(uint32_t c) {
+        f2 = __builtin_amdgcn_alignbit(f2, f1, 30);
+        f1 = __builtin_amdgcn_alignbit(f1, f0, 30);
+        f0 = (f0 << 2) | c;
+        r0 = __builtin_amdgcn_alignbit(r1, r0, 2);
+        r1 = __builtin_amdgcn_alignbit(r2, r1, 2);
+        r2 = (r2 >> 2) | ((3u - c) << 30);
+    }
+    template <bool CANON>
+    DD_D uint64_t hash(int k) const {
+        const int hb = 2 * k - 64;  // 2..32 bits of the k-mer above bit 63
+        const uint32_t ah = (hb == 32) ? f2 : (f2 & ((1u << hb) - 1u));
+        const uint64_t fl = pack64(f1, f0);
+        uint32_t hi = ah;
+        uint64_t lo = fl;
+        if (CANON) {
+            const uint32_t s = 96u - 2u * (uint32_t)k;  // 0..30
+            const uint32_t bh = r2 >> s;
+            const uint64_t bl = pack64(__builtin_amdgcn_alignbit(r2, r1, s), __builtin_amdgcn_alignbit(r1, r0, s));
+            const bool f_lt = (ah < bh) | ((ah == bh) & (fl < bl));  // bitwise: no exec-mask short circuit
+            hi = f_lt ? ah : bh;
+            lo = f_lt ? fl : bl;
+        }
+        const uint64_t hg = (uint64_t)hi * 0x7F4A7C15u + ((uint64_t)(hi * 0x9E3779B9u) << 32);
+        return wang64_fast<false>(lo ^ hg);
+    }
+};
+
 // every k of the group for the token just pushed
 template <int KC, bool CANON, bool CHECK, typename MakeRegs>
 DD_D void sweep_token(const Windows<KC>& win, int run, int kfirst, int nk, int p, const MakeRegs& slot) {
@@ -780,6 +821,12 @@ __global__ __launch_bounds__(1024) void bitmap_finish_kernel(const SweepGenome* 
 // stream; the eight replay workgroups of a row (one per 128 KiB index tile) all read that stream -- they
 // run side by side on one XCD, so the stream comes from HBM once and from that XCD's L2 seven times --
 // and each applies only the records of its own tile.
+// The rows a sort / replay / reset launch covers: rows k0 .. k0+nks-1 of every genome (one k class), numbered
+// densely; table index = genome * K + k0 + local % nks.
+struct RowSet {
+    int K, k0, nks, nrows;  // nrows = genomes * nks
+    DD_D int index(uint32_t local) const { return (int)(local / (uint32_t)nks) * K + k0 + (int)(local % (uint32_t)nks); }
+};
 constexpr uint32_t kChunkRecords = 1024;         // 4 KiB; one global atomic hands out one chunk of the row's stream
 
 struct Scatter {
@@ -947,7 +994,7 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
         const uint4 hc = in.hc, sc = in.sc;
         const uint2 hb = in.hb, sb = in.sb;
         const uint32_t cw[4] = {sc.x, sc.y, sc.z, sc.w};
-        Windows<KC == 1 ? 5 : KC> win;
+        Windows<KC == 1 ? 5 : (KC == 3 ? 6 : KC)> win;
         win.prime(hc);
         if (__all((hb.x | hb.y | sb.x | sb.y) == 0u)) {
 #pragma unroll
@@ -997,11 +1044,11 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
 // and the start of each tile's segment is noted in seg[chunk][tile].  A replay workgroup then reads only
 // its own segments; without this every one of the 8 workgroups of a log2m 20 row (128 KiB tiles then)
 // inspected every record (measured: 42 of 72 ms).  HBM-bound: each record is read and written once more.
-__global__ __launch_bounds__(256) void sort_chunks_kernel(const BucketRow* __restrict__ rows, int p, int nb_log2,
+__global__ __launch_bounds__(256) void sort_chunks_kernel(const BucketRow* __restrict__ rows, RowSet rs, int p, int nb_log2,
                                                          uint32_t cap_chunks, int wgs_per_row) {
     __shared__ uint32_t sorted[4][kChunkRecords];
     __shared__ uint32_t hist[4][16];
-    const BucketRow row = rows[blockIdx.x / wgs_per_row];
+    const BucketRow row = rows[rs.index(blockIdx.x / (uint32_t)wgs_per_row)];
     if (!row.area) return;
     const uint32_t handed = gload4(row.cursor);
     const uint32_t nchunks = handed < cap_chunks ? handed : cap_chunks;
@@ -1059,13 +1106,13 @@ __global__ __launch_bounds__(256) void sort_chunks_kernel(const BucketRow* __res
 // CU.  A wave takes every 16th chunk of the row's stream, U at a time, and reads only the segment of its
 // own tile (all of a chunk when the row is a single tile and nothing was sorted); segment headers, records
 // and the LDS work of three consecutive steps overlap.
-__global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restrict__ rows, int nrows, int p, int logg,
+__global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restrict__ rows, RowSet rs, int p, int logg,
                                                      int nb_log2, uint32_t cap_chunks, int fbits) {
     const uint32_t nb = 1u << nb_log2;
     const uint32_t within = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
     const uint32_t r = (within >> nb_log2) * 8u + xcd, b = within & (nb - 1u);
-    if (r >= (uint32_t)nrows) return;
-    const BucketRow row = rows[r];
+    if (r >= (uint32_t)rs.nrows) return;
+    const BucketRow row = rows[rs.index(r)];
     if (!row.area) return;
     const uint32_t handed = gload4(row.cursor);
     if (handed == 0u) return;  // nothing was recorded for this row in this epoch: registers and filter stand
@@ -1165,9 +1212,9 @@ __global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restric
 
 // the stream cursors of all rows back to zero for the next epoch (replay's workgroups of a row cannot do
 // it themselves: its sibling tiles may still be reading the cursor)
-__global__ void reset_cursors_kernel(const BucketRow* __restrict__ rows, int nrows) {
+__global__ void reset_cursors_kernel(const BucketRow* __restrict__ rows, RowSet rs) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < nrows && rows[r].area) gstore4(rows[r].cursor, 0u);
+    if (r < rs.nrows && rows[rs.index((uint32_t)r)].area) gstore4(rows[rs.index((uint32_t)r)].cursor, 0u);
 }
 
 // Dynamic LDS above 64 KiB must be allowed per kernel AND per device (a process may hold contexts on
@@ -1278,20 +1325,21 @@ void launch_scatter(const SweepGenome* genomes, const SweepJob* jobs, int njobs,
 #undef DD_SCATTER_NN
 }
 
-void launch_replay(const BucketRow* rows, int nrows, const SweepPlan& plan, hipStream_t st) {
-    if (nrows <= 0) return;
+void launch_replay(const BucketRow* rows, int ngenomes, int K, int k0, int nks, const SweepPlan& plan, hipStream_t st) {
+    const RowSet rs{K, k0, nks, ngenomes * nks};
+    if (rs.nrows <= 0) return;
     const size_t tile = (size_t)1 << (plan.log2m - plan.nb_log2);
-    const unsigned blocks = (unsigned)((nrows + 7) / 8) * 8u << plan.nb_log2;
+    const unsigned blocks = (unsigned)((rs.nrows + 7) / 8) * 8u << plan.nb_log2;
     if (plan.nb_log2 >= 1) {  // several tiles per row: sort every chunk by tile first
         const int wgs_per_row = 32;
-        hipLaunchKernelGGL(sort_chunks_kernel, dim3((unsigned)nrows * wgs_per_row), dim3(256), 0, st, rows, plan.log2m,
+        hipLaunchKernelGGL(sort_chunks_kernel, dim3((unsigned)rs.nrows * wgs_per_row), dim3(256), 0, st, rows, rs, plan.log2m,
                            plan.nb_log2, plan.cap_chunks, wgs_per_row);
     }
     static std::atomic<unsigned long long> attr_done{0};
     allow_full_lds(reinterpret_cast<const void*>(replay_kernel), attr_done);
-    hipLaunchKernelGGL(replay_kernel, dim3(blocks), dim3(1024), tile, st, rows, nrows, plan.log2m, plan.logg, plan.nb_log2,
+    hipLaunchKernelGGL(replay_kernel, dim3(blocks), dim3(1024), tile, st, rows, rs, plan.log2m, plan.logg, plan.nb_log2,
                        plan.cap_chunks, plan.fbits);
-    hipLaunchKernelGGL(reset_cursors_kernel, dim3((unsigned)(nrows + 255) / 256), dim3(256), 0, st, rows, nrows);
+    hipLaunchKernelGGL(reset_cursors_kernel, dim3((unsigned)(rs.nrows + 255) / 256), dim3(256), 0, st, rows, rs);
 }
 
 void launch_sweep(const SweepGenome* genomes, const SweepJob* jobs, int njobs, int kclass,
