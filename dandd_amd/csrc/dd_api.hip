@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <chrono>
@@ -168,19 +169,20 @@ hipEvent_t get_event(dd_ctx* c) {
     return e;
 }
 
-struct Span {  // brackets a launch with events when timing is on
+struct Span {  // brackets a launch (or a whole phase) on the context's stream with events when timing is on
     dd_ctx* c;
     int which;
+    bool on;
     TimedSpan s{};
-    Span(dd_ctx* c_, int which_) : c(c_), which(which_) {
-        if (c->timing) {
+    Span(dd_ctx* c_, int which_, bool on_ = true) : c(c_), which(which_), on(on_ && c_->timing) {
+        if (on) {
             s.a = get_event(c);
             s.b = get_event(c);
             (void)hipEventRecord(s.a, c->stream);
         }
     }
     ~Span() {
-        if (c->timing) {
+        if (on) {
             (void)hipEventRecord(s.b, c->stream);
             c->spans[which].push_back(s);
         }
@@ -511,7 +513,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     int lds_classes = 0;
     for (const dd::SweepClass& sc : classes)
         if (sc.plan.mode != dd::kBucketMode) lds_jobs += sc.jobs.size(), ++lds_classes;
-    const bool side = !c->timing && lds_classes > 1 && lds_jobs < 12000 && !getenv("DD_NO_SIDE_STREAMS");
+    const bool side = lds_classes > 1 && lds_jobs < 12000 && !getenv("DD_NO_SIDE_STREAMS");
     if (side && !c->side_ready) {
         for (int i = 0; i < 4; ++i) {
             DD_HIP(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
@@ -520,8 +522,10 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         DD_HIP(hipEventCreateWithFlags(&c->side_go, hipEventDisableTiming));
         c->side_ready = true;
     }
+    const bool side_b = bplan && !getenv("DD_NO_SIDE_STREAMS");  // log2m >= 18: see below
+    // (launches that run side by side are timed as ONE span on the caller's stream: per-launch spans would overlap)
+    std::unique_ptr<Span> phase((side || side_b) ? new Span(c, DD_KERNEL_SWEEP) : nullptr);
     if (side) DD_HIP(hipEventRecord(c->side_go, st));
-    const bool side_b = bplan && !c->timing && !getenv("DD_NO_SIDE_STREAMS");  // log2m >= 18: see below
     int lane_no = 0;
     for (size_t i = 0; i < classes.size(); ++i) {
         const dd::SweepClass& sc = classes[i];
@@ -531,7 +535,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
             ks = c->side[lane_no & 3];
             DD_HIP(hipStreamWaitEvent(ks, c->side_go, 0));
         }
-        Span sp(c, DD_KERNEL_SWEEP);
+        Span sp(c, DD_KERNEL_SWEEP, !side);
         if (sc.kclass == dd::kBitmapClass) {
             dd::launch_bitmap(reinterpret_cast<const dd::SweepGenome*>(tdev),
                               reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]),
@@ -589,7 +593,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
             for (int e = 0; sc.plan.mode == dd::kBucketMode && e < bplan->nepochs; ++e) {
                 const size_t j0 = sc.epoch_begin[e], j1 = sc.epoch_begin[e + 1];
                 if (j1 == j0) continue;
-                Span span(c, DD_KERNEL_SWEEP);
+                Span span(c, DD_KERNEL_SWEEP, !side_b);
                 dd::launch_scatter(reinterpret_cast<const dd::SweepGenome*>(tdev),
                                    reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]) + j0, (int)(j1 - j0),
                                    sc.kclass, sc.plan, sp, ks, e == 0 && !getenv("DD_BUCKET_NO_FIRST"));
@@ -603,6 +607,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
             }
         }
     }
+    phase.reset();  // (closes the span: every side stream has been joined into the caller's stream above)
     DD_HIP(hipGetLastError());
     c->st_tokens = tokens_ub;
     c->st_updates = tokens_ub * (uint64_t)K;

@@ -451,7 +451,15 @@ def test_timing_spans_and_call_statistics(engine_factory, orc):
     pack_ms, pack_n = eng.timing_read(KERNEL_PACK)
     sweep_ms, sweep_n = eng.timing_read(KERNEL_SWEEP)
     assert pack_n == 1 and pack_ms > 0
-    assert sweep_n == 4 and sweep_ms > 0            # small-k class + the 32-, 64- and 96-bit classes
+    assert sweep_n == 1 and sweep_ms > 0            # a small call: the four k classes run side by side, timed as one span
+    import os
+    os.environ["DD_NO_SIDE_STREAMS"] = "1"
+    try:
+        eng.timing_reset()
+        assert np.array_equal(eng.sketch_buffer(fa, 4, 40), regs)
+        assert eng.timing_read(KERNEL_SWEEP)[1] == 4    # back to back: small-k class + the 32-, 64- and 96-bit classes
+    finally:
+        del os.environ["DD_NO_SIDE_STREAMS"]
     eng.card_batch(regs)
     assert eng.timing_read(KERNEL_UNION)[1] >= 1
     eng.timing_reset()
