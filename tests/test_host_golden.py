@@ -331,3 +331,37 @@ def test_cli_at_the_reference_default_register_count_on_gpu(host, tmp_path, torc
     assert all(len(v) > 0 for v in gpu.values())
     diffs = hostcheck.compare(gpu, cpu)
     assert not diffs, "\n".join(diffs[:30])
+
+
+@pytest.mark.gpu
+def test_cfg1_exact_ksweep_on_gpu_matches_exact_goldens(host, tmp_path, torch_cuda):
+    """BASELINE config 1 as stated: `dandd tree --exact --ksweep --mink 10 --maxk 20`.  Every node's cardinality at
+    every k from the GPU exact counter == what the reference's orchestration recorded over an exact counter
+    (ref_exact.json `tree_ksweep_10_20_cards`; the reference's own KMC branch recurses forever, SURVEY section 0, so
+    its Dashing-named files stand in: only the names differ)."""
+    import pickle
+    import re
+    import shutil
+    from dandd_amd.host import cli
+    gold = _golden("ref_exact.json")["scenarios"]["tree_ksweep_10_20_cards"]
+    host.set_backend_factory(None)
+    data = os.path.join(str(tmp_path), "data")
+    shutil.copytree(os.path.join(hostcheck.GOLD, "fasta"), data)
+    out = os.path.join(str(tmp_path), "o")
+    cli.main(["tree", "-d", data, "-o", out, "-s", "gold", "--exact", "--ksweep", "--mink", "10", "--maxk", "20"])
+    with open(os.path.join(out, "sketchdb", "gold_kmc_cardinalities.pickle"), "rb") as f:
+        got = {os.path.basename(k): v for k, v in pickle.load(f).items()}
+
+    def key(name):  # (leaf fasta or "root", k) from either naming scheme
+        m = re.match(r"(g\d\.fasta)(?:\.w\.(\d+)\.spacing\.\d+\.hll|_k(\d+))$", name)
+        if m:
+            return m.group(1), int(m.group(2) or m.group(3))
+        m = re.match(r"0x[0-9a-f]+_\d+n5k(\d+)(?:\.hll)?$", name)
+        assert m, name
+        return "root", int(m.group(1))
+
+    want = {key(n): v for n, v in gold.items()}
+    have = {key(n): v for n, v in got.items()}
+    assert len(want) == 6 * 11 and set(want) <= set(have)
+    for k2, v in want.items():
+        assert have[k2] == v, (k2, have[k2], v)
