@@ -513,7 +513,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     int lds_classes = 0;
     for (const dd::SweepClass& sc : classes)
         if (sc.plan.mode != dd::kBucketMode) lds_jobs += sc.jobs.size(), ++lds_classes;
-    const bool side = lds_classes > 1 && lds_jobs < 12000 && !getenv("DD_NO_SIDE_STREAMS");
+    const bool side = lds_classes > 1 && (lds_jobs < 12000 || getenv("DD_SIDE_ALWAYS")) && !getenv("DD_NO_SIDE_STREAMS");
     if (side && !c->side_ready) {
         for (int i = 0; i < 4; ++i) {
             DD_HIP(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
