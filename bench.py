@@ -345,19 +345,27 @@ def main():
     wl = Workload(torch, eng, ids, nb, cfg["nrec"], kmin, kmax)
     ng, nbytes = wl.ng, wl.nbytes
 
+    # progressive / pairwise schedules run over the JOB's leaves: with several ranks the leaf slabs are all-gathered
+    # first and the orderings split over the ranks (cfg 4 is a 4-GPU config)
+    n_sched = total_genomes if (cfg["strong"] and world > 1) else ng
     orderings = None
     if cfg["extra"] == "progressive":
         with open(os.path.join(ROOT, "tests", "golden", "cfg4_orderings.json")) as f:
             orderings = [o for o in json.load(f)["orderings"]]
-        if ng != 8:  # the fixture is for the 8-genome share; other shard sizes use rotations
-            orderings = [list(np.roll(np.arange(ng), s)) for s in range(min(10, max(1, ng)))]
+        if n_sched != 8:  # the fixture is for the 8-genome share; other sizes use seeded permutations
+            rng = np.random.default_rng(42)
+            orderings = [list(map(int, rng.permutation(n_sched))) for _ in range(10)]
+        orderings = orderings[rank::world] if n_sched != ng else orderings
 
     def step():
         out = wl.step(ddist)
-        if cfg["extra"] == "pairwise" and ng:
-            wl.pair = eng.pairwise_device(wl.regs.data_ptr(), ng, K)           # all local pairs x all k
-        elif cfg["extra"] == "progressive" and ng:
-            wl.prog = eng.progressive_device(wl.regs.data_ptr(), ng, K, orderings)
+        slab, n = wl.regs, ng
+        if cfg["extra"] and n_sched != ng:
+            slab, n = ddist.allgather_leaves(wl.regs[:ng], ids, total_genomes), total_genomes
+        if cfg["extra"] == "pairwise" and n:
+            wl.pair = eng.pairwise_device(slab.data_ptr(), n, K)                 # all pairs x all k
+        elif cfg["extra"] == "progressive" and n and orderings:
+            wl.prog = eng.progressive_device(slab.data_ptr(), n, K, orderings)   # this rank's orderings, every prefix, all k
         return out
 
     def fence():
@@ -383,6 +391,13 @@ def main():
     dt = ddist.max_over_ranks(dt, device="cuda")
 
     extras = {}
+    if cfg["extra"] == "progressive" and getattr(wl, "prog", None) is not None and n_sched == total_genomes:
+        # every ordering's last prefix is the union of all the job's genomes: its cardinalities must be the root's
+        ok = bool(np.array_equal(wl.prog[:, -1, :], np.broadcast_to(np.asarray(card[ng]), wl.prog[:, -1, :].shape)))
+        extras["schedule"] = {"kind": "progressive", "genomes": n_sched, "orderings_this_rank": len(orderings),
+                              "last_prefix_equals_root": ok}
+        if not ok:
+            raise SystemExit("bench.py: progressive schedule's full union differs from the root sketch")
     if rank == 0 and world == 1 and headline:
         if not args.no_accuracy:
             extras["accuracy_vs_exact"] = accuracy_block(

@@ -94,3 +94,36 @@ def gather_rows(rows, mine, n_total, device=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(full, op=dist.ReduceOp.SUM)
     return full.cpu().numpy()
+
+
+def allgather_leaves(leaves, mine, n_total):
+    """Every rank's leaf slabs (uint8 [len(mine)][K][m], genomes `mine` of the job) -> the job's whole
+    [n_total][K][m] slab on every rank, in genome order: what `progressive` and `kij` need before their
+    (ordering x k) / pair schedules can be split over the ranks (ncclAllGather over xGMI --
+    15 MiB for cfg 4 at log2m 14, nothing next to the sketching)."""
+    import torch
+    import torch.distributed as dist
+    live = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    K, m = leaves.shape[1], leaves.shape[2]
+    full = torch.zeros((n_total, K, m), dtype=torch.uint8, device=leaves.device)
+    if not live:
+        full[torch.tensor(list(mine), device=leaves.device, dtype=torch.long)] = leaves
+        return full
+    world = dist.get_world_size()
+    most = (n_total + world - 1) // world + 1  # shards differ by at most one genome in count when sizes are equal; pad generously
+    counts = [torch.zeros(1, dtype=torch.int64, device=leaves.device) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([len(mine)], dtype=torch.int64, device=leaves.device))
+    most = max(most, max(int(c.item()) for c in counts))
+    ids = torch.full((most,), -1, dtype=torch.int64, device=leaves.device)
+    ids[:len(mine)] = torch.tensor(list(mine), dtype=torch.int64, device=leaves.device)
+    padded = torch.zeros((most, K, m), dtype=torch.uint8, device=leaves.device)
+    padded[:len(mine)] = leaves
+    all_ids = [torch.empty_like(ids) for _ in range(world)]
+    all_slabs = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(all_ids, ids)
+    dist.all_gather(all_slabs, padded)
+    for r in range(world):
+        n = int(counts[r].item())
+        if n:
+            full[all_ids[r][:n]] = all_slabs[r][:n]
+    return full

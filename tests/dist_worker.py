@@ -43,11 +43,13 @@ def main():
     mine, regs, card = dd.sharded_ksweep(sizes, K, m, sketch_into, union_into, card_of)
     leaf_card = dd.gather_rows(card[:len(mine)], mine, len(fastas))
     root, root_card = regs[len(mine)], card[len(mine)]
+    gathered = dd.allgather_leaves(regs[:len(mine)], mine, len(fastas))   # the whole job's leaf slab on every rank
     slowest = dd.max_over_ranks(float(rank + 1))
     with open(f"{out_path}.{rank}", "w") as f:
         json.dump({"rank": rank, "world": world, "touched": touched, "leaf_card": leaf_card.tolist(),
                    "root_sha": int(np.frombuffer(root.numpy().tobytes(), dtype=np.uint8).astype(np.uint64).sum()),
-                   "root_card": root_card.tolist(), "slowest": slowest}, f)
+                   "root_card": root_card.tolist(), "slowest": slowest,
+                   "gathered_sums": [int(gathered[i].to(torch.int64).sum()) for i in range(len(fastas))]}, f)
     dist.barrier()
     dist.destroy_process_group()
 

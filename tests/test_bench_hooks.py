@@ -102,3 +102,19 @@ def test_bench_config_presets_run(torch_cuda, config, extra):
     assert j["scaling"] == ("strong" if config == "cfg3" else "weak") and j["value"] > 0 and np.isfinite(j["delta_root"])
     assert config in j["config"]["workload"] and j["roofline"]["kernel_ms_per_step"] > 0
     assert "accuracy_vs_exact" not in j and "secondary" not in j      # only the headline config carries those
+
+
+@pytest.mark.gpu
+def test_bench_cfg4_two_ranks_gathers_leaves_and_splits_orderings(torch_cuda):
+    """BASELINE cfg 4 (30 genomes, progressive) over two ranks: each rank sketches 15 genomes, the leaf slabs are
+    all-gathered, the 10 orderings are split 5 / 5 and every ordering's last prefix equals the all-reduced root
+    (bench.py exits non-zero otherwise)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", DD_BENCH_BACKEND="gloo", DD_BENCH_SHARE_DEVICE="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "cfg4",
+                        "--mbp", "1", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["genomes_per_gpu"] == 15
+    assert j["schedule"] == {"kind": "progressive", "genomes": 30, "orderings_this_rank": 5, "last_prefix_equals_root": True}

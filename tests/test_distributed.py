@@ -60,6 +60,7 @@ def test_two_rank_gloo_sweep_matches_single_process(orc, tmp_path):
         assert rr["leaf_card"] == want_leaf
         assert rr["root_card"] == want_root
         assert rr["root_sha"] == int(root.astype(np.uint64).sum())
+        assert rr["gathered_sums"] == [int(l.astype(np.int64).sum()) for l in leaves]   # all-gather: every leaf, in genome order
 
 
 def test_two_rank_cli_tree_matches_single_process(orc, tmp_path):
