@@ -475,7 +475,10 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
             }
         const size_t nhashed = (size_t)ngenomes * hashed_per_genome;
         const size_t tab_bytes = align_up(sizeof(dd::BucketRow) * nrows, 256);
-        const size_t cur_bytes = align_up((size_t)nrows * 4, 256);
+        // one cursor per row, each in a 256-byte slot of its own: every 64-record block of a row is reserved by one
+        // atomic add on it, and neighbouring rows are written from other XCDs
+        static const size_t cur_stride = [] { const char* e = getenv("DD_CURSOR_STRIDE"); return e ? (size_t)std::max(4, atoi(e)) : (size_t)256; }();
+        const size_t cur_bytes = align_up((size_t)nrows * cur_stride, 256);
         const size_t flt_tot = align_up(nhashed * flt_bytes, 256);
         if ((rc = c->buckets.reserve(tab_bytes + cur_bytes + flt_tot + nhashed * (fill_bytes + area_bytes)))) return rc;
         if ((rc = c->stage_rows.reserve(tab_bytes))) return rc;
@@ -488,7 +491,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
             for (int kk = 0; kk < K; ++kk) {
                 dd::BucketRow& r = rtab[(size_t)g * K + kk];
                 r.regs = regs_dev + ((size_t)g * K + kk) * m;
-                r.cursor = reinterpret_cast<uint32_t*>(bb + tab_bytes) + ((size_t)g * K + kk);
+                r.cursor = reinterpret_cast<uint32_t*>(bb + tab_bytes + ((size_t)g * K + kk) * cur_stride);
                 const bool hashed = kk >= first_hashed && kk < first_hashed + hashed_per_genome;
                 r.filter = hashed ? reinterpret_cast<uint8_t*>(bb + tab_bytes + cur_bytes + h * flt_bytes) : nullptr;
                 r.fill = hashed ? reinterpret_cast<uint32_t*>(fills + h * fill_bytes) : nullptr;
@@ -557,7 +560,8 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     if (bplan) {
         // epoch by epoch: scatter launches of every k class (independent rows: side by side on side streams, so the
         // tail of one overlaps the body of another), then one sort + replay over all rows
-        const dd::ScatterParams sp{rows_dev, K, bplan->logg, bplan->cap_chunks};
+        static const unsigned unit = [] { const char* e = getenv("DD_BUCKET_UNIT"); return e ? (unsigned)std::max(1, atoi(e)) * 64u : 256u; }();
+        const dd::ScatterParams sp{rows_dev, K, bplan->logg, bplan->cap_chunks, unit};
         if (side_b && !c->side_ready) {
             for (int i = 0; i < 4; ++i) {
                 DD_HIP(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));

@@ -110,8 +110,8 @@ void launch_sweep(const SweepGenome* genomes_dev, const SweepJob* jobs_dev, int 
 struct BucketRow {              // one per (genome, k) row of the call: table[genome * K + (k - kmin)]
     uint8_t* regs;              // the row's m registers in the caller's slab
     uint32_t* area;             // record stream: chunk c at area + c * 1024; null = row not bucketed
-    uint32_t* cursor;           // chunks handed out this epoch (may run past cap_chunks: overflow)
-    uint32_t* fill;             // [cap_chunks] valid records of each chunk
+    uint32_t* cursor;           // records reserved this epoch, in blocks of 64 (may run past the capacity: overflow)
+    uint32_t* fill;             // [cap_chunks] records of each chunk after the sort dropped the null ones
     uint16_t* seg;              // [cap_chunks][16] where each index tile's records start inside a sorted chunk
     uint8_t* filter;            // [m >> logg] lower bound per register group
 };
@@ -120,6 +120,7 @@ struct ScatterParams {
     int K;                      // rows per genome
     int logg;
     unsigned cap_chunks;
+    unsigned unit;              // records a wave reserves per atomic add on the row's cursor (multiple of 64)
 };
 void launch_scatter(const SweepGenome* genomes_dev, const SweepJob* jobs_dev, int njobs, int kclass,
                     const SweepPlan& plan, const ScatterParams& sp, hipStream_t st, bool first_epoch);

@@ -33,13 +33,14 @@ struct PlanKnobs {
     // registers in HBM, two-phase: scatter (idx, rho) records into per-(row, index tile) buckets, replay
     // each bucket into an LDS-resident tile (no global atomics); off = the filtered compare-and-swap path
     bool buckets = true;
-    size_t bucket_e0_tiles = 0;     // tiles in the first epoch; 0 = two tokens per register (2 m / 65536), at least 16
+    size_t bucket_e0_tiles = 0;     // tiles in the first epoch; 0 = four tokens per register (4 m / 65536), at least 16
     size_t bucket_emax_tiles = 0;   // longest epoch; 0 = what the budget below allows, at most 256 tiles
     size_t bucket_cap_chunks = 0;   // 64-record chunks per bucket; 0 = every token of the longest epoch fits
     int bucket_logg = 0;            // registers per filter entry (log2) PLUS ONE; 0 = default (a 64 KiB filter)
     int bucket_fbits = 0;           // bits per filter entry (8 or 4); 0 = 4
     int bucket_probe = -1;          // second-level filter against the row itself: 1 / 0; -1 = default
     size_t bucket_budget = (size_t)16 << 30;  // HBM for the record areas of one call
+    size_t bucket_slots = 8192;     // scatter jobs per (class, epoch) aimed at
     static PlanKnobs from_env();
     bool operator==(const PlanKnobs& o) const {
         return lds_budget == o.lds_budget && lds_budget_forced == o.lds_budget_forced && jobs_per_cu == o.jobs_per_cu &&
@@ -47,7 +48,7 @@ struct PlanKnobs {
                filter == o.filter && xcd_affinity == o.xcd_affinity && taper == o.taper && buckets == o.buckets &&
                bucket_e0_tiles == o.bucket_e0_tiles && bucket_emax_tiles == o.bucket_emax_tiles &&
                bucket_cap_chunks == o.bucket_cap_chunks && bucket_logg == o.bucket_logg && bucket_fbits == o.bucket_fbits && bucket_probe == o.bucket_probe &&
-               bucket_budget == o.bucket_budget;
+               bucket_budget == o.bucket_budget && bucket_slots == o.bucket_slots;
     }
 };
 

@@ -31,6 +31,7 @@ PlanKnobs PlanKnobs::from_env() {
     if (const char* e = getenv("DD_BUCKET_LOGG")) k.bucket_logg = std::max(0, std::min(8, atoi(e))) + 1;  // stored + 1: 0 = not set
     if (const char* e = getenv("DD_BUCKET_FBITS")) k.bucket_fbits = atoi(e) == 4 ? 4 : 8;
     if (const char* e = getenv("DD_BUCKET_PROBE")) k.bucket_probe = atoi(e) ? 1 : 0;
+    if (const char* e = getenv("DD_BUCKET_SLOTS")) k.bucket_slots = (size_t)std::max(64, atoi(e));
     if (const char* e = getenv("DD_BUCKET_GB")) k.bucket_budget = (size_t)std::max(1, atoi(e)) << 30;
     return k;
 }
@@ -98,8 +99,9 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
         const int first_hashed = use_bitmaps ? std::max(kmin, kBitmapMaxK + 1) : kmin;
         const size_t nrows = (size_t)ngenomes * (size_t)std::max(0, kmax - first_hashed + 1);
         // (the first epoch runs unfiltered and cheaply -- every register is zero, every update a record --, so it is
-        // made two tokens per register long, 16 tiles at least: measured best at log2m 18, 19 and 20)
-        const size_t e0 = knobs.bucket_e0_tiles ? knobs.bucket_e0_tiles : std::max<size_t>(16, 2 * m / kTileTokens);
+        // made four tokens per register long, 16 tiles at least: measured best at log2m 18, 19 and 20 with the
+        // dense record stream; two per register before that)
+        const size_t e0 = knobs.bucket_e0_tiles ? knobs.bucket_e0_tiles : std::max<size_t>(16, 4 * m / kTileTokens);
         size_t emax = knobs.bucket_emax_tiles;
         bucket_row_tokens = knobs.bucket_budget / (std::max<size_t>(1, nrows) * 9 / 2);  // 4 B per record + slack
         if (!emax) emax = std::min<size_t>(256, bucket_row_tokens / kTileTokens);
@@ -145,9 +147,9 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
                     if (nt > t_lo) tile_rows += (std::min(nt, t_hi) - t_lo) * (size_t)nks;
                 }
                 if (!tile_rows) continue;
-                // ~8 jobs per resident workgroup slot; a job reloads its rows' filters, so not below 2 tiles
+                // ~16 jobs per resident workgroup slot; a job reloads its rows' filters, so not below 2 tiles
                 // once the epoch is long enough to allow it
-                const size_t slots = 4096;  // (1024 .. 16384 measured: 4096 is best at log2m 18 and 20)
+                const size_t slots = knobs.bucket_slots;  // (2048 .. 16384 measured: 8192 is best at log2m 18 and 20)
                 const size_t tpj = std::max<size_t>(std::min<size_t>(2, t_hi - t_lo), (tile_rows / bucket_nk + slots - 1) / slots);
                 std::vector<std::vector<SweepJob>> per_xcd(8);
                 int row = 0;

@@ -832,10 +832,10 @@ constexpr uint32_t kChunkRecords = 1024;         // 4 KiB; one global atomic han
 struct Scatter {
     uint32_t queue;        // byte offset in g_lds of this wave's record queue (kQueueEntries x 4 B)
     uint32_t* area;        // the row's record stream, chunk c at area + c * kChunkRecords
-    uint32_t* cursor;      // chunks handed out so far
-    uint32_t* fill;        // valid records per chunk (written by the chunk's owner)
+    uint32_t* cursor;      // records reserved so far (may run past the capacity: readers clamp)
     uint8_t* regs;         // the row itself: where records go when the stream is full
     uint32_t cap_chunks;
+    uint32_t unit;         // records a wave reserves at a time (a multiple of 64)
     int fshift;            // hash high word >> fshift = index of the register group's filter entry (32 - p + logg)
     uint32_t fbase;        // byte offset in g_lds of this k's filter
 };
@@ -843,27 +843,34 @@ DD_D uint32_t& lds32(uint32_t off) { return *reinterpret_cast<uint32_t*>(g_lds +
 DD_D uint32_t gadd32(void* p, uint32_t v) {
     return __hip_atomic_fetch_add((DD_GLOBAL uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// 64 records (one per lane; null records have rho 0) leave for the row's stream.  `cur` = record offset
-// of the next block; a multiple of kChunkRecords means "no chunk in hand".  Whole waves, uniform state.
-DD_D void scatter_block(const Scatter& s, uint32_t rec, uint32_t& cur) {
+// 64 records (one per lane; null records have rho 0) leave for the row's stream.  The stream is DENSE: the row's
+// cursor counts records, every block is reserved by one atomic add of its own 64 (first epoch: 1024 at a time,
+// `cur` / `left` = the wave's reservation), so the 1024-record chunks the sort and the replay work on are all
+// full whatever the job sizes were.  (Round 2's first form gave every wave of every job a chunk of its own:
+// 4.4 M chunks per log2m 20 step for 1.7 G records, i.e. 38 % full, and the replay's per-tile segments 30 records
+// long.)  Whole waves, uniform state.
+template <bool FIRST>
+DD_D void scatter_block(const Scatter& s, uint32_t rec, uint32_t& cur, uint32_t& left) {
     const uint32_t lane = threadIdx.x & 63u;
-    if ((cur & (kChunkRecords - 1u)) == 0u) {
+    if (left == 0u) {
+        const uint32_t unit = FIRST ? kChunkRecords : s.unit;
         uint32_t c = 0;
-        if (lane == 0) c = gadd32(s.cursor, 1u);
-        c = __builtin_amdgcn_readfirstlane(c);
-        if (c >= s.cap_chunks) {
-            // the stream is full: the records go to their registers directly (exact, slow, rare)
-            if (rec >> 24) {
-                uint8_t* a = s.regs + (rec & 0xFFFFFFu);
-                (void)cas_raise<RegsGlobal>(a, RegsGlobal::load32(a), rec >> 24);
-            }
-            return;
-        }
-        cur = c * kChunkRecords;
+        if (lane == 0) c = gadd32(s.cursor, unit);
+        cur = __builtin_amdgcn_readfirstlane(c);
+        left = unit / 64u;
     }
-    gstore4(s.area + cur + lane, rec);
+    const uint32_t pos = cur;
     cur += 64u;
-    if ((cur & (kChunkRecords - 1u)) == 0u && lane == 0) gstore4(s.fill + (cur / kChunkRecords - 1u), kChunkRecords);
+    --left;
+    if (pos + 64u > s.cap_chunks * kChunkRecords) {
+        // the stream is full: the records go to their registers directly (exact, slow, rare)
+        if (rec >> 24) {
+            uint8_t* a = s.regs + (rec & 0xFFFFFFu);
+            (void)cas_raise<RegsGlobal>(a, RegsGlobal::load32(a), rec >> 24);
+        }
+        return;
+    }
+    gstore4(s.area + pos + lane, rec);
 }
 // Second-level filter (PROBE): 64 queued candidates are checked against the ROW ITSELF -- one byte load per
 // lane from the registers as the last replay left them (the row of the jobs an XCD is running stays in that
@@ -871,7 +878,7 @@ DD_D void scatter_block(const Scatter& s, uint32_t rec, uint32_t& cur) {
 // queue and, 64 at a time, to the stream.  The group-minimum filter lets ~25 % of the updates through at log2m
 // 20; about 10 % really raise a register.  Exact either way: a register only rises, so its last stored value is
 // a lower bound.
-DD_D void scatter_probe(const Scatter& s, uint32_t rec, uint32_t& waiting2, uint32_t& cur) {
+DD_D void scatter_probe(const Scatter& s, uint32_t rec, uint32_t& waiting2, uint32_t& cur, uint32_t& left) {
     bool live = (rec >> 24) != 0u;
     if (live) live = (rec >> 24) > (uint32_t)*(const DD_GLOBAL uint8_t*)(s.regs + (rec & 0xFFFFFFu));
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
@@ -883,7 +890,7 @@ DD_D void scatter_probe(const Scatter& s, uint32_t rec, uint32_t& waiting2, uint
         waiting2 += (uint32_t)__builtin_popcountll(mask);
         if (waiting2 >= 64u) {
             waiting2 -= 64u;
-            scatter_block(s, lds32(s.queue + kQueueEntries * 4u + 4u * (waiting2 + (threadIdx.x & 63u))), cur);
+            scatter_block<false>(s, lds32(s.queue + kQueueEntries * 4u + 4u * (waiting2 + (threadIdx.x & 63u))), cur, left);
         }
     }
 }
@@ -893,10 +900,10 @@ DD_D void scatter_probe(const Scatter& s, uint32_t rec, uint32_t& waiting2, uint
 // FIRST: the call's first epoch -- every register is still zero, so every update is a record: no filter, no
 // queues, the wave's 64 records (null where a lane has no k-mer) leave as a block at once.
 template <bool NIB, bool PROBE, bool FIRST>
-DD_D void scatter_update(const Scatter& s, uint32_t& waiting, uint32_t& waiting2, uint32_t& cur, uint64_t h, int p, bool valid) {
+DD_D void scatter_update(const Scatter& s, uint32_t& waiting, uint32_t& waiting2, uint32_t& cur, uint32_t& left, uint64_t h, int p, bool valid) {
     const Probe q = probe(h, p);
     if (FIRST) {
-        scatter_block(s, valid ? (q.hi >> (32 - p)) | (rho_of(q, p) << 24) : 0u, cur);
+        scatter_block<true>(s, valid ? (q.hi >> (32 - p)) | (rho_of(q, p) << 24) : 0u, cur, left);
         return;
     }
     uint32_t bound;
@@ -917,8 +924,8 @@ DD_D void scatter_update(const Scatter& s, uint32_t& waiting, uint32_t& waiting2
         if (waiting >= 64u) {
             waiting -= 64u;
             const uint32_t rec = lds32(s.queue + 4u * (waiting + (threadIdx.x & 63u)));
-            if (PROBE) scatter_probe(s, rec, waiting2, cur);
-            else scatter_block(s, rec, cur);
+            if (PROBE) scatter_probe(s, rec, waiting2, cur, left);
+            else scatter_block<false>(s, rec, cur, left);
         }
     }
 }
@@ -965,7 +972,7 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
     // each row's filter as the previous epoch's replay left it (plain loads: written by an earlier kernel),
     // then the per-wave queues
     Scatter s[NK];
-    uint32_t waiting[NK], waiting2[NK], cur[NK];
+    uint32_t waiting[NK], waiting2[NK], cur[NK], left[NK];
 #pragma unroll
     for (int j = 0; j < NK; ++j) {
         const BucketRow row = sp.rows[(size_t)job.genome * sp.K + job.krow + ((j == 0 || two) ? j : 0)];
@@ -977,11 +984,11 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
         s[j].queue = (uint32_t)NK * nflt + ((threadIdx.x >> 6) * NK + j) * (kQueueEntries * 4u * (PROBE ? 2u : 1u));
         s[j].area = row.area;
         s[j].cursor = row.cursor;
-        s[j].fill = row.fill;
         s[j].regs = row.regs;
         s[j].cap_chunks = sp.cap_chunks;
         s[j].fshift = 32 - p + sp.logg;
-        waiting[j] = waiting2[j] = cur[j] = 0;
+        waiting[j] = waiting2[j] = cur[j] = left[j] = 0;
+        s[j].unit = sp.unit;
     }
     __syncthreads();
 
@@ -1002,8 +1009,8 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
 #pragma unroll 1
                 for (int i = 0; i < 16; ++i) {
                     win.push((cw[w] >> (2 * i)) & 3u);
-                    scatter_update<NIB, PROBE, FIRST>(s[0], waiting[0], waiting2[0], cur[0], win.template hash<CANON>(k), p, true);
-                    if (NK == 2 && two) scatter_update<NIB, PROBE, FIRST>(s[NK - 1], waiting[NK - 1], waiting2[NK - 1], cur[NK - 1], win.template hash<CANON>(k + 1), p, true);
+                    scatter_update<NIB, PROBE, FIRST>(s[0], waiting[0], waiting2[0], cur[0], left[0], win.template hash<CANON>(k), p, true);
+                    if (NK == 2 && two) scatter_update<NIB, PROBE, FIRST>(s[NK - 1], waiting[NK - 1], waiting2[NK - 1], cur[NK - 1], left[NK - 1], win.template hash<CANON>(k + 1), p, true);
                 }
             }
             continue;
@@ -1017,25 +1024,25 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
                 const uint32_t c = (cw[w] >> (2 * i)) & 3u;
                 run = ((bw >> i) & 1u) ? 0 : run + 1;
                 win.push(c);
-                scatter_update<NIB, PROBE, FIRST>(s[0], waiting[0], waiting2[0], cur[0], win.template hash<CANON>(k), p, run >= k);
-                if (NK == 2 && two) scatter_update<NIB, PROBE, FIRST>(s[NK - 1], waiting[NK - 1], waiting2[NK - 1], cur[NK - 1], win.template hash<CANON>(k + 1), p, run >= k + 1);
+                scatter_update<NIB, PROBE, FIRST>(s[0], waiting[0], waiting2[0], cur[0], left[0], win.template hash<CANON>(k), p, run >= k);
+                if (NK == 2 && two) scatter_update<NIB, PROBE, FIRST>(s[NK - 1], waiting[NK - 1], waiting2[NK - 1], cur[NK - 1], left[NK - 1], win.template hash<CANON>(k + 1), p, run >= k + 1);
             }
         }
     }
-    // what still waits leaves as a block padded with null records; a chunk left partly filled is recorded
-    // as such (replay reads fill[c] records of chunk c)
+    // what still waits leaves as a block padded with null records; the first epoch's waves fill what is left of
+    // their last reservation with null blocks (the stream has no holes: sort and replay read all of it)
 #pragma unroll
     for (int j = 0; j < NK; ++j) {
         if (j && !two) break;
         const uint32_t lane = threadIdx.x & 63u;
-        if (PROBE) {
-            if (waiting[j]) scatter_probe(s[j], lane < waiting[j] ? lds32(s[j].queue + 4u * lane) : 0u, waiting2[j], cur[j]);
-            if (waiting2[j]) scatter_block(s[j], lane < waiting2[j] ? lds32(s[j].queue + kQueueEntries * 4u + 4u * lane) : 0u, cur[j]);
+        if (FIRST) {
+        } else if (PROBE) {
+            if (waiting[j]) scatter_probe(s[j], lane < waiting[j] ? lds32(s[j].queue + 4u * lane) : 0u, waiting2[j], cur[j], left[j]);
+            if (waiting2[j]) scatter_block<false>(s[j], lane < waiting2[j] ? lds32(s[j].queue + kQueueEntries * 4u + 4u * lane) : 0u, cur[j], left[j]);
         } else if (waiting[j]) {
-            scatter_block(s[j], lane < waiting[j] ? lds32(s[j].queue + 4u * lane) : 0u, cur[j]);
+            scatter_block<false>(s[j], lane < waiting[j] ? lds32(s[j].queue + 4u * lane) : 0u, cur[j], left[j]);
         }
-        if ((cur[j] & (kChunkRecords - 1u)) != 0u && (threadIdx.x & 63u) == 0)
-            gstore4(s[j].fill + cur[j] / kChunkRecords, cur[j] & (kChunkRecords - 1u));
+        while (left[j]) scatter_block<FIRST>(s[j], 0u, cur[j], left[j]);  // what is left of the last reservation
     }
 }
 
@@ -1051,11 +1058,12 @@ __global__ __launch_bounds__(256) void sort_chunks_kernel(const BucketRow* __res
     const BucketRow row = rows[rs.index(blockIdx.x / (uint32_t)wgs_per_row)];
     if (!row.area) return;
     const uint32_t handed = gload4(row.cursor);
-    const uint32_t nchunks = handed < cap_chunks ? handed : cap_chunks;
+    const uint32_t nrec = handed < cap_chunks * kChunkRecords ? handed : cap_chunks * kChunkRecords;  // reservations are multiples of 64, the capacity of 1024
+    const uint32_t nchunks = (nrec + kChunkRecords - 1u) / kChunkRecords;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, nb = 1u << nb_log2;
     const int tshift = p - nb_log2;
     for (uint32_t c = (blockIdx.x % wgs_per_row) * 4u + wave; c < nchunks; c += (uint32_t)wgs_per_row * 4u) {
-        const uint32_t f = gload4(row.fill + c);
+        const uint32_t f = nrec - c * kChunkRecords < kChunkRecords ? nrec - c * kChunkRecords : kChunkRecords;
         uint32_t e[16];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1116,7 +1124,8 @@ __global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restric
     if (!row.area) return;
     const uint32_t handed = gload4(row.cursor);
     if (handed == 0u) return;  // nothing was recorded for this row in this epoch: registers and filter stand
-    const uint32_t nchunks = handed < cap_chunks ? handed : cap_chunks;
+    const uint32_t nrec = handed < cap_chunks * kChunkRecords ? handed : cap_chunks * kChunkRecords;
+    const uint32_t nchunks = (nrec + kChunkRecords - 1u) / kChunkRecords;
     const uint32_t tile = 1u << (p - nb_log2);
     uint8_t* const tile_g = row.regs + (size_t)b * tile;
     uint4* l4 = reinterpret_cast<uint4*>(g_lds);
@@ -1145,8 +1154,8 @@ __global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restric
                 if (nb > 1u) {
                     h.st[u] = seg[(size_t)cc * 16u + b];
                     h.en[u] = b + 1u < nb ? (uint32_t)seg[(size_t)cc * 16u + b + 1u] : gload4(row.fill + cc);
-                } else {
-                    h.en[u] = gload4(row.fill + cc);
+                } else {  // unsorted single-tile rows: the raw stream, null records included
+                    h.en[u] = nrec - cc * kChunkRecords < kChunkRecords ? nrec - cc * kChunkRecords : kChunkRecords;
                 }
             }
         }
