@@ -776,36 +776,37 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void bit
         gstore4(complete + threadIdx.x, 1u);
 }
 
-// grid = (ks, genomes); registers of the row are built in LDS (or in place when they do not fit)
+// grid = (ks, genomes, index tiles): a workgroup builds one 64 KiB tile of the row in LDS (the whole row when it is
+// smaller) from ALL the k-mers of the set -- hashing a k-mer 16 times at log2m 20 costs nothing next to what one
+// workgroup per row doing global compare-and-swaps cost there (2.3 ms for the k = 9 rows alone).
 template <bool CANON_UNUSED>
 __global__ __launch_bounds__(1024) void bitmap_finish_kernel(const SweepGenome* __restrict__ genomes,
-                                                            int kfirst, int kmin, int p, int in_lds) {
+                                                            int kfirst, int kmin, int p, int tile_log2) {
     const SweepGenome g = genomes[blockIdx.y];
     const int k = kfirst + (int)blockIdx.x;
-    const uint32_t m = 1u << p;
-    uint8_t* const row = g.regs + ((size_t)(k - kmin) << p);
-    if (in_lds) {
-        uint4* z = reinterpret_cast<uint4*>(g_lds);
-        for (uint32_t i = threadIdx.x; i < (m >> 4); i += blockDim.x) z[i] = make_uint4(0, 0, 0, 0);
-    }
+    const uint32_t tile = 1u << tile_log2, b = blockIdx.z;
+    uint8_t* const out = g.regs + ((size_t)(k - kmin) << p) + (size_t)b * tile;
+    uint4* z = reinterpret_cast<uint4*>(g_lds);
+    for (uint32_t i = threadIdx.x; i < (tile >> 4); i += blockDim.x) z[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const uint32_t* bm = g.bitmap + c_bitmap_off[k];
     const int nw = c_bitmap_off[k + 1] - c_bitmap_off[k];
     for (int w = threadIdx.x; w < nw; w += blockDim.x) {
         uint32_t v = gload4(bm + w);
         while (v) {
-            const uint32_t b = (uint32_t)__builtin_ctz(v);
+            const uint32_t bit = (uint32_t)__builtin_ctz(v);
             v &= v - 1;
-            const uint64_t h = wang64_fast<true>(((uint32_t)w << 5) | b);
-            if (in_lds) hll_update(RegsLds{0u}, h, p);
-            else hll_update(RegsGlobal{row}, h, p);
+            const Probe q = probe(wang64_fast<true>(((uint32_t)w << 5) | bit), p);
+            const uint32_t idx = q.hi >> (32 - p);
+            if ((idx >> tile_log2) != b) continue;
+            const uint32_t a = idx & (tile - 1u), rho = rho_of(q, p);
+            const uint32_t wd = RegsLds::load32(a);
+            if (rho > ((wd >> RegsLds::shift(a)) & 0xFFu)) (void)cas_raise<RegsLds>(a, wd, rho);
         }
     }
     __syncthreads();
-    if (in_lds) {
-        const uint4* l4 = reinterpret_cast<const uint4*>(g_lds);
-        for (uint32_t i = threadIdx.x; i < (m >> 4); i += blockDim.x) gstore16(row + (size_t)i * 16, l4[i]);
-    }
+    const uint4* l4 = reinterpret_cast<const uint4*>(g_lds);
+    for (uint32_t i = threadIdx.x; i < (tile >> 4); i += blockDim.x) gstore16(out + (size_t)i * 16, l4[i]);
 }
 
 
@@ -1271,13 +1272,10 @@ void launch_bitmap(const SweepGenome* genomes, const SweepJob* jobs, int njobs, 
 void launch_bitmap_finish(const SweepGenome* genomes, int ngenomes, int kfirst, int klast, int kmin, int log2m,
                           hipStream_t st) {
     if (ngenomes <= 0 || klast < kfirst) return;
-    const size_t m = (size_t)1 << log2m;
-    const int in_lds = m <= (size_t)sweep_max_lds_bytes() ? 1 : 0;
+    const int tile_log2 = std::min(log2m, 16);
     auto kern = bitmap_finish_kernel<true>;
-    static std::atomic<unsigned long long> attr_done{0};
-    allow_full_lds(reinterpret_cast<const void*>(kern), attr_done);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(klast - kfirst + 1), (unsigned)ngenomes), dim3(1024),
-                       in_lds ? m : 0, st, genomes, kfirst, kmin, log2m, in_lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(klast - kfirst + 1), (unsigned)ngenomes, 1u << (log2m - tile_log2)), dim3(1024),
+                       (size_t)1 << tile_log2, st, genomes, kfirst, kmin, log2m, tile_log2);
 }
 
 
