@@ -114,7 +114,7 @@ struct dd_ctx {
     std::vector<TimedSpan> spans[DD_KERNEL_COUNT];
     std::vector<hipEvent_t> pool;
     // workspaces
-    DevBuf tokens, scratch, tables, jobtab, fasta, regs, ptrs, hist, est, ord, bitmaps, exact, buckets;
+    DevBuf tokens, scratch, tables, jobtab, fasta, regs, ptrs, hist, est, ord, bitmaps, bigmaps, exact, buckets;
     HostBuf stage, stage_jobs, stage_rows;  // genome/pack tables and K1 job tables are uploaded in two steps
     // the job tables of the last sketch call: a call over genomes of the same sizes and the same k range
     // (a pipeline sketching fixed-size batches, a benchmark loop) reuses them, on the host and in HBM
@@ -134,8 +134,8 @@ struct dd_ctx {
     DevBuf pipe_fasta[2], pipe_regs[2];
     HostBuf pipe_out[2];
     hipEvent_t pipe_h2d[2] = {nullptr, nullptr}, pipe_done[2] = {nullptr, nullptr}, pipe_d2h[2] = {nullptr, nullptr};
-    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};  // k classes of a small call run side by side
-    hipEvent_t side_done[4] = {nullptr, nullptr, nullptr, nullptr}, side_go = nullptr;
+    hipStream_t side[8] = {};  // k classes of a small call run side by side
+    hipEvent_t side_done[8] = {}, side_go = nullptr;
     bool side_ready = false;
     int ingest_calls = 0;
     double ingest_ms[4] = {0, 0, 0, 0};  // last dd_sketch_files call: wall, waiting for loaders, batches, bytes (as a double)
@@ -292,7 +292,7 @@ void dd_destroy(dd_ctx* c) {
     for (auto e : c->pool) (void)hipEventDestroy(e);
     if (c->stage_free) (void)hipEventDestroy(c->stage_free);
     for (DevBuf* b : {&c->tokens, &c->scratch, &c->tables, &c->jobtab, &c->fasta, &c->regs, &c->ptrs, &c->hist,
-                      &c->est, &c->ord, &c->bitmaps, &c->exact, &c->buckets})
+                      &c->est, &c->ord, &c->bitmaps, &c->bigmaps, &c->exact, &c->buckets})
         b->release();
     c->stage.release();
     c->stage_jobs.release();
@@ -306,7 +306,7 @@ void dd_destroy(dd_ctx* c) {
             if (e) (void)hipEventDestroy(e);
     }
     if (c->side_ready) {
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 8; ++i) {
             (void)hipStreamDestroy(c->side[i]);
             (void)hipEventDestroy(c->side_done[i]);
         }
@@ -392,6 +392,20 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         DD_HIP(hipMemsetAsync(bitmap_base, 0, bbytes, st));
     }
 
+    // ... and for k = 10 (, 11) at log2m >= 19 (dd_kernels.h)
+    uint32_t* bigmap_base = nullptr;
+    size_t bigmap_stride = 0;
+    {
+        int ka = 0, kb = 0;
+        if (dd::plan_bigmap_range(p, kmin, kmax, dd::PlanKnobs::from_env(), &ka, &kb)) {
+            bigmap_stride = dd::bigmap_offset_words(kb + 1, c->canonical != 0);
+            const size_t bbytes = (size_t)ngenomes * bigmap_stride * sizeof(uint32_t);
+            if ((rc = c->bigmaps.reserve(bbytes))) return rc;
+            bigmap_base = static_cast<uint32_t*>(c->bigmaps.p);
+            DD_HIP(hipMemsetAsync(bigmap_base, 0, bbytes, st));
+        }
+    }
+
     // ---- K0 / K1 genome tables -----------------------------------------------------------
     std::vector<dd::SweepGenome> gtab(ngenomes);
     std::vector<dd::PackGenome> ptab(ngenomes);
@@ -405,7 +419,8 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
                                  reinterpret_cast<long long*>(sb + off_scratch[g]), ts};
         max_chunks = std::max(max_chunks, ptab[g].nchunks);
         gtab[g] = dd::SweepGenome{ts.codes, ts.bad, ts.ntok, regs_dev + (size_t)g * K * m,
-                                  bitmap_base ? bitmap_base + (size_t)g * dd::kBitmapStride : nullptr};
+                                  bitmap_base ? bitmap_base + (size_t)g * dd::kBitmapStride : nullptr,
+                                  bigmap_base ? bigmap_base + (size_t)g * bigmap_stride : nullptr};
         tokens_ub += nbytes[g];
     }
     (void)max_n;
@@ -518,7 +533,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         if (sc.plan.mode != dd::kBucketMode) lds_jobs += sc.jobs.size(), ++lds_classes;
     const bool side = lds_classes > 1 && (lds_jobs < 12000 || getenv("DD_SIDE_ALWAYS")) && !getenv("DD_NO_SIDE_STREAMS");
     if (side && !c->side_ready) {
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 8; ++i) {
             DD_HIP(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
             DD_HIP(hipEventCreateWithFlags(&c->side_done[i], hipEventDisableTiming));
         }
@@ -535,7 +550,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         if (sc.plan.mode == dd::kBucketMode || side_b) continue;
         hipStream_t ks = st;
         if (side) {
-            ks = c->side[lane_no & 3];
+            ks = c->side[lane_no & 7];
             DD_HIP(hipStreamWaitEvent(ks, c->side_go, 0));
         }
         Span sp(c, DD_KERNEL_SWEEP, !side);
@@ -545,14 +560,18 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
                               (int)sc.jobs.size(), sc.kfirst, sc.klast, c->canonical, ks);
             dd::launch_bitmap_finish(reinterpret_cast<const dd::SweepGenome*>(tdev), ngenomes, sc.kfirst, sc.klast,
                                      kmin, p, ks);
+        } else if (sc.kclass == dd::kBigmapClass) {
+            dd::launch_bigmap(reinterpret_cast<const dd::SweepGenome*>(tdev), reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]),
+                              (int)sc.jobs.size(), c->canonical, ks);
+            dd::launch_bigmap_finish(reinterpret_cast<const dd::SweepGenome*>(tdev), ngenomes, sc.kfirst, sc.klast, kmin, p, c->canonical, ks);
         } else {
             dd::launch_sweep(reinterpret_cast<const dd::SweepGenome*>(tdev),
                              reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]),
                              (int)sc.jobs.size(), sc.kclass, sc.plan, ks);
         }
         if (side) {
-            DD_HIP(hipEventRecord(c->side_done[lane_no & 3], ks));
-            DD_HIP(hipStreamWaitEvent(st, c->side_done[lane_no & 3], 0));
+            DD_HIP(hipEventRecord(c->side_done[lane_no & 7], ks));
+            DD_HIP(hipStreamWaitEvent(st, c->side_done[lane_no & 7], 0));
             ++lane_no;
         }
         blocks += (int)sc.jobs.size();
@@ -563,7 +582,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         static const unsigned unit = [] { const char* e = getenv("DD_BUCKET_UNIT"); return e ? (unsigned)std::max(1, atoi(e)) * 64u : 256u; }();
         const dd::ScatterParams sp{rows_dev, K, bplan->logg, bplan->cap_chunks, unit};
         if (side_b && !c->side_ready) {
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 8; ++i) {
                 DD_HIP(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
                 DD_HIP(hipEventCreateWithFlags(&c->side_done[i], hipEventDisableTiming));
             }
@@ -578,7 +597,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
             const dd::SweepClass& sc = classes[i];
             hipStream_t ks = st;
             if (side_b) {
-                ks = c->side[lane_b & 3];
+                ks = c->side[lane_b & 7];
                 DD_HIP(hipStreamWaitEvent(ks, c->side_go, 0));
             }
             if (sc.plan.mode != dd::kBucketMode) {
@@ -588,6 +607,10 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
                     dd::launch_bitmap(reinterpret_cast<const dd::SweepGenome*>(tdev), reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]),
                                       (int)sc.jobs.size(), sc.kfirst, sc.klast, c->canonical, ks);
                     dd::launch_bitmap_finish(reinterpret_cast<const dd::SweepGenome*>(tdev), ngenomes, sc.kfirst, sc.klast, kmin, p, ks);
+                } else if (sc.kclass == dd::kBigmapClass) {
+                    dd::launch_bigmap(reinterpret_cast<const dd::SweepGenome*>(tdev), reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]),
+                                      (int)sc.jobs.size(), c->canonical, ks);
+                    dd::launch_bigmap_finish(reinterpret_cast<const dd::SweepGenome*>(tdev), ngenomes, sc.kfirst, sc.klast, kmin, p, c->canonical, ks);
                 } else {
                     dd::launch_sweep(reinterpret_cast<const dd::SweepGenome*>(tdev), reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]),
                                      (int)sc.jobs.size(), sc.kclass, sc.plan, ks);
@@ -605,8 +628,8 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
                 blocks += (int)(j1 - j0);
             }
             if (side_b) {
-                DD_HIP(hipEventRecord(c->side_done[lane_b & 3], ks));
-                DD_HIP(hipStreamWaitEvent(st, c->side_done[lane_b & 3], 0));
+                DD_HIP(hipEventRecord(c->side_done[lane_b & 7], ks));
+                DD_HIP(hipStreamWaitEvent(st, c->side_done[lane_b & 7], 0));
                 ++lane_b;
             }
         }
@@ -1386,7 +1409,7 @@ long dd_plan_sweep(int log2m, const size_t* nbytes, int ngenomes, int kmin, int 
         for (const dd::SweepJob& j : sc.jobs) {
             if (n < cap)
                 out[n] = dd_plan_job{sc.kclass, sc.plan.mode, sc.plan.lds_bytes, j.genome, j.kfirst, j.nk,
-                                     j.tile_begin, j.tile_end};
+                                     j.tile_begin, j.tile_end, j.slice};
             ++n;
         }
     }

@@ -51,6 +51,7 @@ struct SweepGenome {            // one per genome, device-resident table
     const unsigned long long* ntok;
     uint8_t* regs;              // [K][m] for this genome
     uint32_t* bitmap;           // presence bitmaps of the canonical k-mers, k = 1..kBitmapMaxK (or null)
+    uint32_t* bigmap;           // presence bitmaps of k = 10 (, 11) at log2m >= 19 (or null): bigmap_offset_words
 };
 
 // Small-k path: for k <= kBitmapMaxK there are at most 4^k <= 262144 distinct k-mers, so K1 only
@@ -65,12 +66,31 @@ inline constexpr int bitmap_offset(int k) {
     return off;
 }
 inline constexpr int bitmap_words(int k) { return (k < 3) ? 1 : (1 << (2 * k - 5)); }
+// Second small-k class, bucket mode at log2m >= 19 only: k = 10 (and k = 11 at log2m 20).  There a row has fewer
+// distinct k-mers than (about twice) its registers, a register group almost always holds an EMPTY register, the
+// group-minimum filter lets everything through and every update pays a probe of the row: 2.4 ms per k against
+// 1.0 for the other rows (10 x 50 Mbp).  The k-mer set itself is smaller than the row, so it is recorded
+// exactly, in 128 KiB slices of LDS (one workgroup per CU), and each distinct k-mer is hashed afterwards.
+// Index of a k-mer: the canonical value (2k bits); for odd k in canonical mode the strand whose MIDDLE base is
+// A or C with that base's high bit dropped (2k - 1 bits: one of a k-mer and its reverse complement always
+// qualifies), which halves the slices of k = 11.
+constexpr int kBigmapMinK = 10, kBigmapMaxK = 11;
+constexpr int kBigmapSliceWords = 1 << 15;  // 2^20 bits
+inline constexpr int bigmap_last_k(int log2m) { return log2m >= 20 ? 11 : (log2m >= 19 ? 10 : 0); }
+inline constexpr int bigmap_bits(int k, bool canon) { return (canon && (k & 1)) ? 2 * k - 1 : 2 * k; }
+inline constexpr int bigmap_slices(int k, bool canon) { return 1 << (bigmap_bits(k, canon) - 20); }
+inline constexpr size_t bigmap_offset_words(int k, bool canon) {  // k's first word in a genome's block
+    size_t off = 0;
+    for (int j = kBigmapMinK; j < k; ++j) off += (size_t)bigmap_slices(j, canon) * kBigmapSliceWords;
+    return off;
+}
 struct SweepJob {               // one per workgroup, device-resident table
     int genome;
     int kfirst;                 // first k of the group (consecutive ks)
     int nk;                     // number of ks in the group (<= slots that fit LDS)
     int krow;                   // row of kfirst in the genome's [K][m] slab
     unsigned tile_begin, tile_end;  // tiles of (threads x 64) tokens
+    int slice;                  // big-bitmap jobs: which 2^20-bit slice of k's index space the workgroup records
 };
 constexpr int kBucketMode = 5;
 struct SweepPlan {
@@ -132,6 +152,11 @@ int sweep_max_lds_bytes();
 void launch_bitmap(const SweepGenome* genomes_dev, const SweepJob* jobs_dev, int njobs, int kfirst, int klast,
                    int canonical, hipStream_t st);
 // one workgroup per (genome, k in [kfirst, klast]): hash every recorded k-mer once into slab row k-kmin
+// big-bitmap class (log2m >= 19): jobs carry one k and one slice each; finish hashes the recorded sets into rows
+// kfirst..klast, one workgroup per (k, genome, 64 KiB index tile)
+void launch_bigmap(const SweepGenome* genomes_dev, const SweepJob* jobs_dev, int njobs, int canonical, hipStream_t st);
+void launch_bigmap_finish(const SweepGenome* genomes_dev, int ngenomes, int kfirst, int klast, int kmin, int log2m,
+                          int canonical, hipStream_t st);
 void launch_bitmap_finish(const SweepGenome* genomes_dev, int ngenomes, int kfirst, int klast, int kmin,
                           int log2m, hipStream_t st);
 

@@ -11,6 +11,7 @@
 namespace dd {
 
 constexpr int kBitmapClass = -1;  // SweepClass::kclass of the small-k presence-bitmap class
+constexpr int kBigmapClass = -2;  // ... of the k = 10 (, 11) big-bitmap class of log2m >= 19 (dd_kernels.h)
 
 struct SweepClass {
     int kclass;      // kBitmapClass, or the window class of sweep_kernel: 0 (k <= 16), 1 (<= 32), 3 (33..48), 2 (49..64)
@@ -29,7 +30,7 @@ struct PlanKnobs {
     size_t jobs_per_cu = 32;
     size_t jobs_per_row = 0;        // filtered mode; 0 = heuristic
     int global_from_p = 18;         // registers stay in HBM from this log2m on
-    bool use_bitmaps = true, filter = true, xcd_affinity = true, taper = true;
+    bool use_bitmaps = true, use_bigmaps = true, filter = true, xcd_affinity = true, taper = true;
     // registers in HBM, two-phase: scatter (idx, rho) records into per-(row, index tile) buckets, replay
     // each bucket into an LDS-resident tile (no global atomics); off = the filtered compare-and-swap path
     bool buckets = true;
@@ -44,7 +45,7 @@ struct PlanKnobs {
     static PlanKnobs from_env();
     bool operator==(const PlanKnobs& o) const {
         return lds_budget == o.lds_budget && lds_budget_forced == o.lds_budget_forced && jobs_per_cu == o.jobs_per_cu &&
-               jobs_per_row == o.jobs_per_row && global_from_p == o.global_from_p && use_bitmaps == o.use_bitmaps &&
+               jobs_per_row == o.jobs_per_row && global_from_p == o.global_from_p && use_bitmaps == o.use_bitmaps && use_bigmaps == o.use_bigmaps &&
                filter == o.filter && xcd_affinity == o.xcd_affinity && taper == o.taper && buckets == o.buckets &&
                bucket_e0_tiles == o.bucket_e0_tiles && bucket_emax_tiles == o.bucket_emax_tiles &&
                bucket_cap_chunks == o.bucket_cap_chunks && bucket_logg == o.bucket_logg && bucket_fbits == o.bucket_fbits && bucket_probe == o.bucket_probe &&
@@ -52,6 +53,8 @@ struct PlanKnobs {
     }
 };
 
+// the ks of a call that go to the big-bitmap class (false: none)
+bool plan_bigmap_range(int log2m, int kmin, int kmax, const PlanKnobs& knobs, int* ka, int* kb);
 std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbytes, int ngenomes, int kmin,
                                    int kmax, const PlanKnobs& knobs);
 

@@ -21,6 +21,7 @@ PlanKnobs PlanKnobs::from_env() {
     if (const char* e = getenv("DD_JOBS_PER_ROW")) k.jobs_per_row = (size_t)std::max(1, atoi(e));
     if (const char* e = getenv("DD_GLOBAL_FROM_P")) k.global_from_p = std::max(16, std::min(18, atoi(e)));
     k.use_bitmaps = !getenv("DD_NO_BITMAP");
+    k.use_bigmaps = k.use_bitmaps && !getenv("DD_NO_BIGMAP");
     k.filter = !getenv("DD_NO_FILTER");
     k.xcd_affinity = !getenv("DD_NO_XCD_AFFINITY");
     k.taper = !getenv("DD_NO_TAPER");
@@ -51,10 +52,23 @@ SweepJob make_job(int genome, int kfirst, int nk, int kmin, size_t t0, size_t t1
     j.krow = kfirst - kmin;
     j.tile_begin = (unsigned)t0;
     j.tile_end = (unsigned)t1;
+    j.slice = 0;
     return j;
 }
 
 }  // namespace
+
+bool plan_bigmap_range(int log2m, int kmin, int kmax, const PlanKnobs& knobs, int* ka, int* kb) {
+    const size_t m = (size_t)1 << log2m;
+    const bool global_regs = m > (size_t)sweep_max_lds_bytes() || log2m >= knobs.global_from_p;
+    const bool bucket_mode = global_regs && knobs.buckets && knobs.filter;
+    const int last = (bucket_mode && knobs.use_bitmaps && knobs.use_bigmaps) ? bigmap_last_k(log2m) : 0;
+    const int a = std::max(kmin, kBigmapMinK), b = std::min(kmax, last);
+    if (a > b) return false;
+    if (ka) *ka = a;
+    if (kb) *kb = b;
+    return true;
+}
 
 std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbytes, int ngenomes, int kmin,
                                    int kmax, const PlanKnobs& knobs) {
@@ -72,6 +86,8 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
     const size_t lds_budget = std::max(knobs.lds_budget, m);
     const int slots = global_regs ? 64 : (int)std::min<size_t>(64, lds_budget / m);
     const bool use_bitmaps = knobs.use_bitmaps && kmin <= kBitmapMaxK;
+    int big_ka = 0, big_kb = 0;
+    const bool use_big = plan_bigmap_range(p, kmin, kmax, knobs, &big_ka, &big_kb);
 
     size_t total_tiles = 0, max_tiles = 0;
     for (int g = 0; g < ngenomes; ++g) {
@@ -96,7 +112,8 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
     std::vector<size_t> epoch_edge;           // epoch e covers tiles [epoch_edge[e], epoch_edge[e+1])
     size_t epoch_longest = 0, bucket_row_tokens = 0;
     if (bucket_mode) {
-        const int first_hashed = use_bitmaps ? std::max(kmin, kBitmapMaxK + 1) : kmin;
+        int first_hashed = use_bitmaps ? std::max(kmin, kBitmapMaxK + 1) : kmin;
+        if (use_big) first_hashed = std::max(first_hashed, big_kb + 1);
         const size_t nrows = (size_t)ngenomes * (size_t)std::max(0, kmax - first_hashed + 1);
         // (the first epoch runs unfiltered and cheaply -- every register is zero, every update a record --, so it is
         // made four tokens per register long, 16 tiles at least: measured best at log2m 18, 19 and 20 with the
@@ -115,9 +132,10 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
         }
     }
 
-    const int lo0 = use_bitmaps ? kBitmapMaxK + 1 : 1;
-    const struct { int kc, ka, kb; } class_tab[5] = {
-        {kBitmapClass, 1, use_bitmaps ? kBitmapMaxK : 0}, {0, lo0, 16}, {1, 17, 32}, {3, 33, 48}, {2, 49, 64}};
+    const int lo0 = use_big ? big_kb + 1 : (use_bitmaps ? kBitmapMaxK + 1 : 1);
+    const struct { int kc, ka, kb; } class_tab[6] = {
+        {kBitmapClass, 1, use_bitmaps ? kBitmapMaxK : 0}, {kBigmapClass, big_ka, use_big ? big_kb : 0},
+        {0, lo0, 16}, {1, 17, 32}, {3, 33, 48}, {2, 49, 64}};
     for (const auto& ct : class_tab) {
         const int kc = ct.kc;
         const int ka = std::max(kmin, ct.ka), kb = std::min(kmax, ct.kb);
@@ -132,7 +150,26 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
         sc.plan.threads = kThreads;
         int max_nk = 0;
 
-        if (bucket_mode && kc != kBitmapClass) {
+        if (kc == kBigmapClass) {
+            // one (genome, k, slice) pass over all the genome's tiles, cut into ~1024 jobs over the class (a job loads
+            // and merges its 128 KiB slice whatever its length: not below 8 tiles); tile-range major, so the passes
+            // that read the same tokens run at the same time
+            size_t passes = 0;
+            for (int k = ka; k <= kb; ++k) passes += (size_t)bigmap_slices(k, canonical != 0);
+            const size_t tpj = std::max<size_t>(8, (total_tiles * passes + 1023) / 1024);
+            for (size_t t0 = 0; t0 < max_tiles; t0 += tpj)
+                for (int g = 0; g < ngenomes; ++g) {
+                    const size_t ntiles = tiles_of(nbytes[g]);
+                    if (t0 >= ntiles) continue;
+                    for (int k = ka; k <= kb; ++k)
+                        for (int sl = 0; sl < bigmap_slices(k, canonical != 0); ++sl) {
+                            SweepJob j = make_job(g, k, 1, kmin, t0, std::min(ntiles, t0 + tpj));
+                            j.slice = sl;
+                            sc.jobs.push_back(j);
+                        }
+                }
+            max_nk = 1;
+        } else if (bucket_mode && kc != kBitmapClass) {
             // one k per job; row r of the class goes to XCD r % 8 in every epoch (its filter and the token
             // tiles its ks share stay in that XCD's L2); job 8*i + x is the i-th job of XCD x
             const size_t nepochs = epoch_edge.size() - 1;
@@ -283,6 +320,9 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
         if (kc == kBitmapClass) {
             sc.plan.mode = 0;
             sc.plan.lds_bytes = (bitmap_offset(kb) + bitmap_words(kb) - bitmap_offset(ka)) * 4;
+        } else if (kc == kBigmapClass) {
+            sc.plan.mode = 0;
+            sc.plan.lds_bytes = kBigmapSliceWords * 4;
         } else if (bucket_mode) {
             sc.plan.mode = kBucketMode;  // the filter, then a 128-entry record queue per wave
             sc.plan.lds_bytes = bucket_nk * ((int)((m >> bucket_logg) * bucket_fbits / 8) + (kThreads / 64) * 128 * 4 * (bucket_probe ? 2 : 1));

@@ -810,6 +810,117 @@ __global__ __launch_bounds__(1024) void bitmap_finish_kernel(const SweepGenome* 
 }
 
 
+// ---- big-bitmap class (dd_kernels.h): k = 10 (, 11) at log2m >= 19 ---------------------------------------
+// index of the k-mer whose forward / reverse-complement values are fw / rc (both 2k bits)
+template <bool CANON>
+DD_D uint32_t bigmap_index(uint32_t fw, uint32_t rc, int k) {
+    if (!CANON) return fw;
+    if (k & 1) {
+        const uint32_t y = ((fw >> k) & 1u) ? rc : fw;  // the strand whose middle base is A or C
+        return ((y >> (k + 1)) << k) | (y & ((1u << k) - 1u));
+    }
+    return fw < rc ? fw : rc;
+}
+// ... and back: the value that is hashed
+template <bool CANON>
+DD_D uint32_t bigmap_kmer(uint32_t idx, int k) {
+    if (!CANON || !(k & 1)) return idx;
+    const uint32_t y = ((idx >> k) << (k + 1)) | (idx & ((1u << k) - 1u));
+    uint32_t r = __brev(y);                                        // bases reversed, the two bits of each swapped
+    r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+    r = (~r) >> (32 - 2 * k);
+    return y < r ? y : r;
+}
+
+// One workgroup per CU (128 KiB of LDS): the slice as earlier jobs left it, this job's tiles, merge.
+template <bool CANON>
+__global__ __launch_bounds__(1024) void bigmap_kernel(const SweepGenome* __restrict__ genomes, const SweepJob* __restrict__ jobs) {
+    const SweepJob job = jobs[blockIdx.x];
+    const SweepGenome g = genomes[job.genome];
+    const int k = job.kfirst;
+    const uint32_t slice = (uint32_t)job.slice;
+    const unsigned long long ntok = gload8u(g.ntok);
+    uint32_t* const home = g.bigmap + bigmap_offset_words(k, CANON) + (size_t)slice * kBigmapSliceWords;
+    uint32_t* const bits = reinterpret_cast<uint32_t*>(g_lds);
+    for (int i = threadIdx.x; i < kBigmapSliceWords; i += blockDim.x) bits[i] = load4_fresh(home + i);
+    __syncthreads();
+    const uint32_t mask = (1u << (2 * k)) - 1u;
+    const int top = 2 * k - 2, prime = k - 1;
+    for (unsigned tile = job.tile_begin; tile < job.tile_end; ++tile) {
+        const unsigned long long seg = (unsigned long long)tile * blockDim.x + threadIdx.x;
+        if (seg * kSegTokens >= ntok) continue;
+        uint32_t fw = 0, rc = 0;
+        int run = 0;
+        if (seg > 0) {
+            const uint4 hc = gload16(g.codes + (seg - 1) * 4);
+            const uint2 hb = gload8(g.bad + (seg - 1) * 2);
+            const uint32_t cw = hc.w, bw = hb.y >> 16;  // last 16 tokens of the halo (prime <= 10)
+#pragma unroll 1
+            for (int i = 16 - prime; i < 16; ++i) {
+                const uint32_t c = (cw >> (2 * i)) & 3u;
+                run = ((bw >> i) & 1u) ? 0 : run + 1;
+                fw = ((fw << 2) | c) & mask;
+                rc = (rc >> 2) | ((3u - c) << top);
+            }
+        }
+        const uint4 sc = gload16(g.codes + seg * 4);
+        const uint2 sb = gload8(g.bad + seg * 2);
+        const uint32_t cws[4] = {sc.x, sc.y, sc.z, sc.w};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t bw = ((w & 2) ? sb.y : sb.x) >> ((w & 1) * 16);
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t c = (cws[w] >> (2 * i)) & 3u;
+                run = ((bw >> i) & 1u) ? 0 : run + 1;
+                fw = ((fw << 2) | c) & mask;
+                rc = (rc >> 2) | ((3u - c) << top);
+                const uint32_t idx = bigmap_index<CANON>(fw, rc, k);
+                if ((idx >> 20) == slice && run >= k) {
+                    const uint32_t at = (idx & 0xFFFFFu) >> 5, bit = 1u << (idx & 31u);
+                    if (!(bits[at] & bit)) atomicOr(&bits[at], bit);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kBigmapSliceWords; i += blockDim.x) {
+        const uint32_t mine = bits[i];
+        if (mine && (mine & ~load4_fresh(home + i))) gor32(home + i, mine);
+    }
+}
+
+// grid = (ks, genomes, index tiles), as bitmap_finish_kernel
+template <bool CANON>
+__global__ __launch_bounds__(1024) void bigmap_finish_kernel(const SweepGenome* __restrict__ genomes,
+                                                            int kfirst, int kmin, int p, int tile_log2) {
+    const SweepGenome g = genomes[blockIdx.y];
+    const int k = kfirst + (int)blockIdx.x;
+    const uint32_t tile = 1u << tile_log2, b = blockIdx.z;
+    uint8_t* const out = g.regs + ((size_t)(k - kmin) << p) + (size_t)b * tile;
+    uint4* z = reinterpret_cast<uint4*>(g_lds);
+    for (uint32_t i = threadIdx.x; i < (tile >> 4); i += blockDim.x) z[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const uint32_t* bm = g.bigmap + bigmap_offset_words(k, CANON);
+    const uint32_t nw = (uint32_t)bigmap_slices(k, CANON) * kBigmapSliceWords;
+    for (uint32_t w = threadIdx.x; w < nw; w += blockDim.x) {
+        uint32_t v = gload4(bm + w);
+        while (v) {
+            const uint32_t bit = (uint32_t)__builtin_ctz(v);
+            v &= v - 1;
+            const Probe q = probe(wang64_fast<true>(bigmap_kmer<CANON>((w << 5) | bit, k)), p);
+            const uint32_t idx = q.hi >> (32 - p);
+            if ((idx >> tile_log2) != b) continue;
+            const uint32_t a = idx & (tile - 1u), rho = rho_of(q, p);
+            const uint32_t wd = RegsLds::load32(a);
+            if (rho > ((wd >> RegsLds::shift(a)) & 0xFFu)) (void)cas_raise<RegsLds>(a, wd, rho);
+        }
+    }
+    __syncthreads();
+    const uint4* l4 = reinterpret_cast<const uint4*>(g_lds);
+    for (uint32_t i = threadIdx.x; i < (tile >> 4); i += blockDim.x) gstore16(out + (size_t)i * 16, l4[i]);
+}
+
 // ---- log2m >= 18, bucket mode: scatter + replay (dd_kernels.h) --------------------------------------
 // The compare-and-swap path above is bound by the device's scattered-atomic rate (27 G/s measured, any
 // atomic, any footprint: profiles/r01_ubench_atomics.txt).  Two earlier forms of this path were measured
@@ -1278,6 +1389,29 @@ void launch_bitmap_finish(const SweepGenome* genomes, int ngenomes, int kfirst, 
                        (size_t)1 << tile_log2, st, genomes, kfirst, kmin, log2m, tile_log2);
 }
 
+
+void launch_bigmap(const SweepGenome* genomes, const SweepJob* jobs, int njobs, int canonical, hipStream_t st) {
+    if (njobs <= 0) return;
+    static std::atomic<unsigned long long> attr_done[2] = {{0}, {0}};
+    if (canonical) {
+        allow_full_lds(reinterpret_cast<const void*>(bigmap_kernel<true>), attr_done[0]);
+        hipLaunchKernelGGL(bigmap_kernel<true>, dim3((unsigned)njobs), dim3(1024), (size_t)kBigmapSliceWords * 4, st, genomes, jobs);
+    } else {
+        allow_full_lds(reinterpret_cast<const void*>(bigmap_kernel<false>), attr_done[1]);
+        hipLaunchKernelGGL(bigmap_kernel<false>, dim3((unsigned)njobs), dim3(1024), (size_t)kBigmapSliceWords * 4, st, genomes, jobs);
+    }
+}
+
+void launch_bigmap_finish(const SweepGenome* genomes, int ngenomes, int kfirst, int klast, int kmin, int log2m,
+                          int canonical, hipStream_t st) {
+    if (ngenomes <= 0 || klast < kfirst) return;
+    const int tile_log2 = std::min(log2m, 16);
+    const dim3 grid((unsigned)(klast - kfirst + 1), (unsigned)ngenomes, 1u << (log2m - tile_log2));
+    if (canonical)
+        hipLaunchKernelGGL(bigmap_finish_kernel<true>, grid, dim3(1024), (size_t)1 << tile_log2, st, genomes, kfirst, kmin, log2m, tile_log2);
+    else
+        hipLaunchKernelGGL(bigmap_finish_kernel<false>, grid, dim3(1024), (size_t)1 << tile_log2, st, genomes, kfirst, kmin, log2m, tile_log2);
+}
 
 void launch_scatter(const SweepGenome* genomes, const SweepJob* jobs, int njobs, int kclass, const SweepPlan& plan,
                     const ScatterParams& sp, hipStream_t st, bool first_epoch) {

@@ -144,7 +144,8 @@ def synth_size(nbases, nrec=1):
 
 
 PLAN_JOB = np.dtype([("kclass", np.int32), ("mode", np.int32), ("lds_bytes", np.int32), ("genome", np.int32),
-                     ("kfirst", np.int32), ("nk", np.int32), ("tile_begin", np.uint32), ("tile_end", np.uint32)])
+                     ("kfirst", np.int32), ("nk", np.int32), ("tile_begin", np.uint32), ("tile_end", np.uint32),
+                     ("slice", np.int32)])
 
 
 def plan_sweep(log2m, nbytes, kmin, kmax):

@@ -158,6 +158,7 @@ typedef struct {
     int kclass, mode, lds_bytes;
     int genome, kfirst, nk;
     unsigned tile_begin, tile_end;
+    int slice; /* big-bitmap class (kclass -2, log2m >= 19): the slice of k's index space the job records */
 } dd_plan_job;
 long dd_plan_sweep(int log2m, const size_t *nbytes, int ngenomes, int kmin, int kmax, dd_plan_job *out,
                    long cap);

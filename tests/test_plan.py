@@ -12,7 +12,7 @@ from dandd_amd.engine import plan_sweep  # noqa: E402
 
 TILE = 1024 * 64  # tokens per tile; tokens <= FASTA bytes
 LDS_MAX = 160 * 1024
-KCLASS_RANGE = {-1: (1, 9), 0: (1, 16), 1: (16, 32), 3: (33, 48), 2: (49, 64)}
+KCLASS_RANGE = {-2: (10, 11), -1: (1, 9), 0: (1, 16), 1: (16, 32), 3: (33, 48), 2: (49, 64)}
 
 SIZES = {
     "cfg2": [50_600_000] * 10,
@@ -27,6 +27,7 @@ def check(log2m, sizes, kmin, kmax):
     m = 1 << log2m
     ntiles = [(n + TILE - 1) // TILE for n in sizes]
     cover = [np.zeros((kmax - kmin + 1, nt), dtype=np.int32) for nt in ntiles]
+    extra_slices = {}   # big-bitmap class: (genome, k, slice >= 1) -> coverage of the genome's tiles
     for j in jobs:
         lo, hi = KCLASS_RANGE[int(j["kclass"])]
         if j["tile_end"] <= j["tile_begin"]:
@@ -39,6 +40,14 @@ def check(log2m, sizes, kmin, kmax):
         mode = int(j["mode"])
         if j["kclass"] == -1:
             assert mode == 0
+        elif j["kclass"] == -2:
+            # log2m >= 19, bucket mode: k = 10 (and 11 at log2m 20) recorded exactly, one 2^20-bit slice of the
+            # index space per job; every slice of a k must see every tile once
+            assert log2m >= 19 and k0 <= (11 if log2m >= 20 else 10) and nk == 1 and mode == 0
+            assert j["lds_bytes"] == 128 * 1024 and 0 <= j["slice"] < (2 if k0 == 11 else 1)
+            if j["slice"] > 0:
+                extra_slices.setdefault((g, k0, int(j["slice"])), np.zeros(ntiles[g], dtype=np.int32))[j["tile_begin"]:j["tile_end"]] += 1
+                continue
         elif log2m >= 18 and os.environ.get("DD_NO_FILTER"):
             assert mode == 1 and j["lds_bytes"] == 0               # every update checked in HBM
         elif log2m >= 18 and os.environ.get("DD_NO_BUCKETS"):
@@ -58,6 +67,14 @@ def check(log2m, sizes, kmin, kmax):
         cover[g][k0 - kmin:k0 - kmin + nk, j["tile_begin"]:j["tile_end"]] += 1
     for g, c in enumerate(cover):
         assert c.size == 0 or (c.min() == 1 and c.max() == 1), f"genome {g}: tiles covered {c.min()}..{c.max()} times"
+    big = jobs[jobs["kclass"] == -2]
+    for g, k in {(int(j["genome"]), int(j["kfirst"])) for j in big if j["tile_end"] > j["tile_begin"]}:
+        for sl in range(1, 2 if k == 11 else 1):
+            c = extra_slices.get((g, k, sl))
+            assert c is not None and c.min() == 1 and c.max() == 1, f"genome {g} k {k} slice {sl}"
+    if log2m >= 19 and not any(os.environ.get(v) for v in ("DD_NO_BUCKETS", "DD_NO_FILTER", "DD_NO_BITMAP", "DD_NO_BIGMAP")):
+        want = {k for k in range(max(kmin, 10), min(kmax, 11 if log2m >= 20 else 10) + 1)} if any(ntiles) else set()
+        assert {int(k) for k in big["kfirst"]} == want
     return jobs
 
 
@@ -69,9 +86,9 @@ def test_every_tile_of_every_k_is_covered_once(name, log2m):
     check(log2m, SIZES[name], 4, 40)
 
 
-@pytest.mark.parametrize("krange", [(1, 64), (1, 1), (9, 10), (16, 17), (32, 33), (48, 49), (64, 64), (10, 20)])
+@pytest.mark.parametrize("krange", [(1, 64), (1, 1), (9, 10), (16, 17), (32, 33), (48, 49), (64, 64), (10, 20), (10, 11), (11, 12)])
 def test_k_ranges_and_class_boundaries(krange):
-    for log2m in (12, 14, 19):
+    for log2m in (12, 14, 19, 20):
         check(log2m, SIZES["ragged"], *krange)
 
 
