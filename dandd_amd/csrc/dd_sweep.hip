@@ -866,6 +866,26 @@ __global__ __launch_bounds__(1024) void bigmap_kernel(const SweepGenome* __restr
         const uint4 sc = gload16(g.codes + seg * 4);
         const uint2 sb = gload8(g.bad + seg * 2);
         const uint32_t cws[4] = {sc.x, sc.y, sc.z, sc.w};
+        auto record = [&](uint32_t idx, bool ok) {
+            if ((idx >> 20) == slice && ok) {
+                const uint32_t at = (idx & 0xFFFFFu) >> 5, bit = 1u << (idx & 31u);
+                if (!(bits[at] & bit)) atomicOr(&bits[at], bit);
+            }
+        };
+        if (__all((sb.x | sb.y) == 0u && run >= prime)) {
+            // the usual case: no BREAK anywhere in the wave's 64 x 64 tokens, every window valid
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+#pragma unroll 4
+                for (int i = 0; i < 16; ++i) {
+                    const uint32_t c = (cws[w] >> (2 * i)) & 3u;
+                    fw = ((fw << 2) | c) & mask;
+                    rc = (rc >> 2) | ((3u - c) << top);
+                    record(bigmap_index<CANON>(fw, rc, k), true);
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const uint32_t bw = ((w & 2) ? sb.y : sb.x) >> ((w & 1) * 16);
@@ -875,11 +895,7 @@ __global__ __launch_bounds__(1024) void bigmap_kernel(const SweepGenome* __restr
                 run = ((bw >> i) & 1u) ? 0 : run + 1;
                 fw = ((fw << 2) | c) & mask;
                 rc = (rc >> 2) | ((3u - c) << top);
-                const uint32_t idx = bigmap_index<CANON>(fw, rc, k);
-                if ((idx >> 20) == slice && run >= k) {
-                    const uint32_t at = (idx & 0xFFFFFu) >> 5, bit = 1u << (idx & 31u);
-                    if (!(bits[at] & bit)) atomicOr(&bits[at], bit);
-                }
+                record(bigmap_index<CANON>(fw, rc, k), run >= k);
             }
         }
     }
@@ -1405,8 +1421,12 @@ void launch_bigmap(const SweepGenome* genomes, const SweepJob* jobs, int njobs, 
 void launch_bigmap_finish(const SweepGenome* genomes, int ngenomes, int kfirst, int klast, int kmin, int log2m,
                           int canonical, hipStream_t st) {
     if (ngenomes <= 0 || klast < kfirst) return;
-    const int tile_log2 = std::min(log2m, 16);
+    // 128 KiB tiles, one workgroup per CU: every workgroup hashes the row's whole set (up to 2 M k-mers), so fewer,
+    // larger tiles are less work (1.49 -> ms with 64 KiB tiles at log2m 20)
+    const int tile_log2 = std::min(log2m, 17);
     const dim3 grid((unsigned)(klast - kfirst + 1), (unsigned)ngenomes, 1u << (log2m - tile_log2));
+    static std::atomic<unsigned long long> attr_done[2] = {{0}, {0}};
+    allow_full_lds(reinterpret_cast<const void*>(canonical ? bigmap_finish_kernel<true> : bigmap_finish_kernel<false>), attr_done[canonical ? 0 : 1]);
     if (canonical)
         hipLaunchKernelGGL(bigmap_finish_kernel<true>, grid, dim3(1024), (size_t)1 << tile_log2, st, genomes, kfirst, kmin, log2m, tile_log2);
     else

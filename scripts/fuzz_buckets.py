@@ -37,6 +37,9 @@ for it in range(n_cfg):
     k1, k2 = sorted(int(x) for x in rng.integers(1, 65, size=2))
     if k2 - k1 > 6:
         k2 = k1 + 6
+    if rng.integers(0, 4) == 0:  # the class boundaries around the big-bitmap ks (10, 11 at log2m >= 19)
+        k1 = int(rng.integers(8, 12))
+        k2 = k1 + int(rng.integers(0, 4))
     fas = []
     for g in range(int(rng.integers(1, 5))):
         parts = []

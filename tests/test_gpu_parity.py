@@ -128,6 +128,30 @@ def test_bucket_mode_batched_unequal_genomes(engine_factory, torch_cuda, orc, mo
         assert np.array_equal(got[g], orc.sketch_sweep(f, 15, 18, 19)), g
 
 
+@pytest.mark.parametrize("canon", [True, False])
+@pytest.mark.parametrize("p", [19, 20])
+def test_big_bitmap_class(engine_factory, torch_cuda, orc, canon, p):
+    """log2m >= 19: k = 10 (and 11 at log2m 20) are recorded as exact k-mer sets (128 KiB LDS slices; the odd-k
+    middle-base index in canonical mode, four slices for k = 11 otherwise) and hashed once afterwards.  Batched
+    unequal genomes -- one empty, one shorter than k, one with N runs and lower case, one spanning several jobs --
+    over k 9..12, i.e. with the small-k class below and the hashed class above in the same call."""
+    torch = torch_cuda
+    eng = engine_factory(p, canon)
+    fas = [orc.synth_fasta(SEED, 0, 1_300_000, 3), np.zeros(0, np.uint8), np.frombuffer(b">s\nACGTACGTA\n", dtype=np.uint8),
+           np.concatenate([np.frombuffer(RAGGED["lower_and_n"] + RAGGED["short_records"], dtype=np.uint8), orc.synth_fasta(SEED, 5, 70_000, 2)]),
+           orc.synth_fasta(SEED, 9, 66_000, 1)]
+    bufs = [torch.from_numpy(f.copy()).cuda() if f.size else torch.empty(16, dtype=torch.uint8, device="cuda") for f in fas]
+    regs = torch.empty((len(fas), 4, eng.m), dtype=torch.uint8, device="cuda")
+    eng.sketch_device([b.data_ptr() for b in bufs], [f.size for f in fas], 9, 12, regs.data_ptr())
+    eng.synchronize()
+    got = regs.cpu().numpy()
+    for g, f in enumerate(fas):
+        assert np.array_equal(got[g], orc.sketch_sweep(f, 9, 12, p, canon)), (g, canon, p)
+    # the class alone (no other class in the call), and a k range that starts inside it
+    _sweep_check(eng, orc, fas[0], 10, 11, canon)
+    _sweep_check(eng, orc, fas[3], 11, 13, canon)
+
+
 def test_sweep_parity_long_lines_and_headers(engine_factory, orc):
     """A 20 kB header and a 50 kB single sequence line cross several 4 KiB pack chunks."""
     rng = np.random.default_rng(5)
