@@ -477,7 +477,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "K1: sweep_kernel launches of one step" + (" (scatter + sort + replay at log2m >= 18)" if p >= 18 else ""),
+                "kernel": "K1: sweep_kernel launches of one step" + (" (scatter + sort + replay at log2m >= 17)" if p >= 17 else ""),
                 "achieved": achieved_gbs,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

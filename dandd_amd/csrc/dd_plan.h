@@ -29,7 +29,7 @@ struct PlanKnobs {
     bool lds_budget_forced = false;
     size_t jobs_per_cu = 32;
     size_t jobs_per_row = 0;        // filtered mode; 0 = heuristic
-    int global_from_p = 18;         // registers stay in HBM from this log2m on
+    int global_from_p = 17;         // registers stay in HBM from this log2m on (17: 22.8 Gbp/s through scatter + replay, 18.7 with one 128 KiB row per workgroup in LDS)
     bool use_bitmaps = true, use_bigmaps = true, filter = true, xcd_affinity = true, taper = true;
     // registers in HBM, two-phase: scatter (idx, rho) records into per-(row, index tile) buckets, replay
     // each bucket into an LDS-resident tile (no global atomics); off = the filtered compare-and-swap path

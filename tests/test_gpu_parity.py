@@ -128,6 +128,17 @@ def test_bucket_mode_batched_unequal_genomes(engine_factory, torch_cuda, orc, mo
         assert np.array_equal(got[g], orc.sketch_sweep(f, 15, 18, 19)), g
 
 
+def test_log2m17_both_register_modes(engine_factory, orc, monkeypatch):
+    """log2m 17 goes through scatter + replay by default (two index tiles per row); DD_GLOBAL_FROM_P=18 keeps the
+    one-128-KiB-row-per-workgroup LDS form alive.  Same registers either way."""
+    fa = np.concatenate([orc.synth_fasta(SEED, 2, 400_000, 3), np.frombuffer(RAGGED["lower_and_n"], dtype=np.uint8)])
+    eng = engine_factory(17, True)
+    a = _sweep_check(eng, orc, fa, 8, 19, True)
+    monkeypatch.setenv("DD_GLOBAL_FROM_P", "18")
+    b = _sweep_check(eng, orc, fa, 8, 19, True)
+    assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("canon", [True, False])
 @pytest.mark.parametrize("p", [19, 20])
 def test_big_bitmap_class(engine_factory, torch_cuda, orc, canon, p):

@@ -48,12 +48,12 @@ def check(log2m, sizes, kmin, kmax):
             if j["slice"] > 0:
                 extra_slices.setdefault((g, k0, int(j["slice"])), np.zeros(ntiles[g], dtype=np.int32))[j["tile_begin"]:j["tile_end"]] += 1
                 continue
-        elif log2m >= 18 and os.environ.get("DD_NO_FILTER"):
+        elif log2m >= 17 and os.environ.get("DD_NO_FILTER"):
             assert mode == 1 and j["lds_bytes"] == 0               # every update checked in HBM
-        elif log2m >= 18 and os.environ.get("DD_NO_BUCKETS"):
+        elif log2m >= 17 and os.environ.get("DD_NO_BUCKETS"):
             assert mode == max(2, log2m - 16) and nk == 1          # one k per job behind the filter
             assert j["lds_bytes"] == (m >> mode) + 16 * 128 * 4    # filter + one queue per wave
-        elif log2m >= 18:
+        elif log2m >= 17:
             fbits = int(os.environ.get("DD_BUCKET_FBITS", 4))
             logg = int(os.environ.get("DD_BUCKET_LOGG", max(1, log2m - 16 - (1 if fbits == 4 else 0))))
             queues = 2 if os.environ.get("DD_BUCKET_PROBE", "1") != "0" else 1
@@ -109,7 +109,7 @@ def test_bucket_mode_epochs(monkeypatch):
                 {"DD_NO_BUCKETS": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        for log2m in (18, 19, 20):
+        for log2m in (17, 18, 19, 20):
             jobs = check(log2m, SIZES["ragged"], 8, 35)
             real = jobs[(jobs["tile_end"] > jobs["tile_begin"]) & (jobs["kclass"] >= 0)]
             if "DD_NO_BUCKETS" not in env and "DD_BUCKET_GB" not in env:
