@@ -114,18 +114,22 @@ struct dd_ctx {
     std::vector<TimedSpan> spans[DD_KERNEL_COUNT];
     std::vector<hipEvent_t> pool;
     // workspaces
-    DevBuf tokens, scratch, tables, jobtab, fasta, regs, ptrs, hist, est, ord, bitmaps, bigmaps, exact, buckets;
+    DevBuf tokens, scratch, tables, fasta, regs, ptrs, hist, est, ord, bitmaps, bigmaps, exact, buckets;
     HostBuf stage, stage_jobs, stage_rows;  // genome/pack tables and K1 job tables are uploaded in two steps
-    // the job tables of the last sketch call: a call over genomes of the same sizes and the same k range
-    // (a pipeline sketching fixed-size batches, a benchmark loop) reuses them, on the host and in HBM
-    struct {
+    // the job tables of the last few sketch calls: a call over genomes of the same sizes and the same k range (a
+    // pipeline sketching batches of a few recurring shapes, a benchmark loop) reuses them, on the host and in HBM
+    struct PlanEntry {
         bool valid = false;
         int kmin = 0, kmax = 0;
         std::vector<size_t> sizes;
         dd::PlanKnobs knobs;
         std::vector<dd::SweepClass> classes;
         std::vector<size_t> job_off;
-    } plan;
+        DevBuf jobtab;
+        unsigned long long last_use = 0;
+    };
+    PlanEntry plans[8];
+    unsigned long long plan_clock = 0;
     hipEvent_t stage_free = nullptr;  // signalled when the last upload from `stage` completed
     // ingestion pipeline (dd_sketch_files): pinned host buffers for the loader threads, a copy stream, two
     // device buffer sets (FASTA bytes in, register slabs out) and two pinned bounce buffers for the results
@@ -291,7 +295,8 @@ void dd_destroy(dd_ctx* c) {
         }
     for (auto e : c->pool) (void)hipEventDestroy(e);
     if (c->stage_free) (void)hipEventDestroy(c->stage_free);
-    for (DevBuf* b : {&c->tokens, &c->scratch, &c->tables, &c->jobtab, &c->fasta, &c->regs, &c->ptrs, &c->hist,
+    for (auto& pe : c->plans) pe.jobtab.release();
+    for (DevBuf* b : {&c->tokens, &c->scratch, &c->tables, &c->fasta, &c->regs, &c->ptrs, &c->hist,
                       &c->est, &c->ord, &c->bitmaps, &c->bigmaps, &c->exact, &c->buckets})
         b->release();
     c->stage.release();
@@ -444,10 +449,19 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
 
     // ---- K1 job tables (dd_plan.hip), built while K0 runs -----------------------------------
     const dd::PlanKnobs knobs = dd::PlanKnobs::from_env();
-    auto& pc = c->plan;
-    const bool same_plan = pc.valid && pc.kmin == kmin && pc.kmax == kmax && pc.knobs == knobs &&
-                           pc.sizes.size() == (size_t)ngenomes && std::equal(pc.sizes.begin(), pc.sizes.end(), nbytes);
-    if (!same_plan) {
+    dd_ctx::PlanEntry* hit = nullptr;
+    dd_ctx::PlanEntry* oldest = &c->plans[0];
+    for (auto& pe : c->plans) {
+        if (pe.valid && pe.kmin == kmin && pe.kmax == kmax && pe.knobs == knobs && pe.sizes.size() == (size_t)ngenomes &&
+            std::equal(pe.sizes.begin(), pe.sizes.end(), nbytes))
+            hit = &pe;
+        if (pe.last_use < oldest->last_use) oldest = &pe;
+    }
+    auto& pc = hit ? *hit : *oldest;
+    pc.last_use = ++c->plan_clock;
+    if (!hit) {
+        // (the entry being replaced may still be read by kernels of an earlier call: its device table is only ever
+        // written by copies on this same stream, and a table that must grow is freed by hipFree, which waits)
         pc.valid = false;
         pc.classes = dd::plan_sweep(p, c->canonical, nbytes, ngenomes, kmin, kmax, knobs);
         size_t job_bytes = 0;
@@ -456,10 +470,10 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
             pc.job_off[i] = job_bytes;
             job_bytes += align_up(sizeof(dd::SweepJob) * pc.classes[i].jobs.size(), 256);
         }
-        if ((rc = c->jobtab.reserve(job_bytes))) return rc;
+        if ((rc = pc.jobtab.reserve(job_bytes))) return rc;
         if ((rc = c->stage_jobs.reserve(job_bytes))) return rc;
         for (size_t i = 0; i < pc.classes.size(); ++i)
-            if ((rc = upload(c, c->stage_jobs, static_cast<char*>(c->jobtab.p) + pc.job_off[i], pc.classes[i].jobs.data(),
+            if ((rc = upload(c, c->stage_jobs, static_cast<char*>(pc.jobtab.p) + pc.job_off[i], pc.classes[i].jobs.data(),
                              sizeof(dd::SweepJob) * pc.classes[i].jobs.size(), pc.job_off[i])))
                 return rc;
         pc.kmin = kmin;
@@ -470,7 +484,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     }
     const std::vector<dd::SweepClass>& classes = pc.classes;
     const std::vector<size_t>& job_off = pc.job_off;
-    char* jdev = static_cast<char*>(c->jobtab.p);
+    char* jdev = static_cast<char*>(pc.jobtab.p);
     DD_HIP(hipEventRecord(c->stage_free, st));
 
     // ---- bucket mode (log2m >= 18): row table, cursors, filters and record areas ----------------
@@ -680,6 +694,25 @@ int dd_sketch_fasta(dd_ctx* c, const char* path, int kmin, int kmax, uint8_t* re
 //                    launching 77 workgroups per file.
 // The reference's loop is one genome at a time, each re-read and re-inflated once per k
 // (lib/huffman_dandd.py:402-407).
+// bounce buffer -> the caller's (pageable) array: one thread moves ~10 GB/s, and a log2m 20 batch is 37 MB per file
+static void parallel_copy(uint8_t* dst, const uint8_t* src, size_t n, int nthreads) {
+    const size_t kPer = (size_t)8 << 20;
+    const int parts = (int)std::min<size_t>((size_t)std::max(1, std::min(nthreads, 8)), (n + kPer - 1) / kPer);
+    if (parts <= 1) {
+        memcpy(dst, src, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const size_t step = ((n / parts) + 4095) & ~(size_t)4095;
+    for (int t = 1; t < parts; ++t) {
+        const size_t off = step * t;
+        if (off >= n) break;
+        th.emplace_back([=] { memcpy(dst + off, src + off, std::min(step, n - off)); });
+    }
+    memcpy(dst, src, std::min(step, n));
+    for (auto& t : th) t.join();
+}
+
 int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, int kmax, uint8_t* regs,
                     int nthreads) {
     if (check_ctx(c)) return DD_EINVAL;
@@ -705,8 +738,10 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
         }
     }
     const size_t avg = std::max<size_t>(1, disk_bytes / (size_t)nfiles);
-    // (log2m >= 18: the scatter/sort/replay path runs epoch by epoch over all rows of a launch and wants many rows)
-    const size_t kBatchBytes = (size_t)(getenv("DD_BATCH_MB") ? std::max(1, atoi(getenv("DD_BATCH_MB"))) : (c->p >= 18 ? 512 : 128)) << 20;
+    // (log2m >= 17: the scatter/sort/replay path runs epoch by epoch over all rows of a launch and wants many rows)
+    // (Batches that grow -- 64, 128, 256 MB -- were measured against fixed 128 MB ones once the job tables of several
+    // batch shapes could be kept: 20.6-22.9 ms against 19.1 for 10 x 50 Mbp.  Fixed it is.)
+    const size_t kBatchBytes = (size_t)(getenv("DD_BATCH_MB") ? std::max(1, atoi(getenv("DD_BATCH_MB"))) : (c->p >= 17 ? 512 : 128)) << 20;
     const int batch_files = (int)std::max<size_t>(1, std::min<size_t>(64, kBatchBytes / avg));
     // loaders may run two batches ahead of the GPU
     const int window = std::max(nthreads + 2, 2 * batch_files + nthreads);
@@ -848,7 +883,7 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
         if (!f.active) return DD_OK;
         f.active = false;
         if (hipEventSynchronize(c->pipe_d2h[set]) != hipSuccess) return fail(DD_EHIP, "ingestion pipeline: D2H failed");
-        memcpy(regs + (size_t)f.first * slab, c->pipe_out[set].p, (size_t)f.count * slab);
+        parallel_copy(regs + (size_t)f.first * slab, static_cast<const uint8_t*>(c->pipe_out[set].p), (size_t)f.count * slab, nthreads);
         {
             std::lock_guard<std::mutex> lk(mu);
             for (int i = f.first; i < f.first + f.count; ++i) free_bufs.push_back(slots[i].buf);

@@ -34,7 +34,7 @@ struct PlanKnobs {
     // registers in HBM, two-phase: scatter (idx, rho) records into per-(row, index tile) buckets, replay
     // each bucket into an LDS-resident tile (no global atomics); off = the filtered compare-and-swap path
     bool buckets = true;
-    size_t bucket_e0_tiles = 0;     // tiles in the first epoch; 0 = four tokens per register (4 m / 65536), at least 16
+    size_t bucket_e0_tiles = 0;     // tiles in the first epoch; 0 = four tokens per register (4 m / 65536), at least 8
     size_t bucket_emax_tiles = 0;   // longest epoch; 0 = what the budget below allows, at most 256 tiles
     size_t bucket_cap_chunks = 0;   // 64-record chunks per bucket; 0 = every token of the longest epoch fits
     int bucket_logg = 0;            // registers per filter entry (log2) PLUS ONE; 0 = default (a 64 KiB filter)

@@ -116,9 +116,9 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
         if (use_big) first_hashed = std::max(first_hashed, big_kb + 1);
         const size_t nrows = (size_t)ngenomes * (size_t)std::max(0, kmax - first_hashed + 1);
         // (the first epoch runs unfiltered and cheaply -- every register is zero, every update a record --, so it is
-        // made four tokens per register long, 16 tiles at least: measured best at log2m 18, 19 and 20 with the
+        // made four tokens per register long, 8 tiles at least: measured best at log2m 18, 19 and 20 with the
         // dense record stream; two per register before that)
-        const size_t e0 = knobs.bucket_e0_tiles ? knobs.bucket_e0_tiles : std::max<size_t>(16, 4 * m / kTileTokens);
+        const size_t e0 = knobs.bucket_e0_tiles ? knobs.bucket_e0_tiles : std::max<size_t>(8, 4 * m / kTileTokens);
         size_t emax = knobs.bucket_emax_tiles;
         bucket_row_tokens = knobs.bucket_budget / (std::max<size_t>(1, nrows) * 9 / 2);  // 4 B per record + slack
         if (!emax) emax = std::min<size_t>(256, bucket_row_tokens / kTileTokens);

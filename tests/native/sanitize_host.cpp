@@ -50,6 +50,7 @@ static void check_plan(int log2m, const std::vector<size_t>& sizes, int kmin, in
         }
         for (const dd::SweepJob& j : sc.jobs) {
             if (j.tile_end <= j.tile_begin) continue;
+            if (sc.kclass == dd::kBigmapClass && j.slice > 0) continue;  // further slices of a k's index space re-read the same tiles
             CHECK(j.genome >= 0 && j.genome < (int)sizes.size(), "genome %d", j.genome);
             const size_t nt = (sizes[j.genome] + tile - 1) / tile;
             CHECK(j.tile_end <= nt && j.kfirst >= kmin && j.kfirst + j.nk - 1 <= kmax && j.krow == j.kfirst - kmin, "job range");

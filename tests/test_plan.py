@@ -113,7 +113,7 @@ def test_bucket_mode_epochs(monkeypatch):
             jobs = check(log2m, SIZES["ragged"], 8, 35)
             real = jobs[(jobs["tile_end"] > jobs["tile_begin"]) & (jobs["kclass"] >= 0)]
             if "DD_NO_BUCKETS" not in env and "DD_BUCKET_GB" not in env:
-                e0 = int(env.get("DD_BUCKET_E0", max(16, 4 * (1 << log2m) // TILE)))
+                e0 = int(env.get("DD_BUCKET_E0", max(8, 4 * (1 << log2m) // TILE)))
                 emax = max(e0, int(env.get("DD_BUCKET_EMAX", 256)))
                 edges = [0, e0]
                 while edges[-1] < 1000:
