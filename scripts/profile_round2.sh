@@ -9,9 +9,12 @@ for P in 14 18 20; do
   cp $(find $OUT/stats$P -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_p$P.csv
   rm -rf $OUT/stats$P
 done
+for P in 16 17 19; do
+  timeout 600 python bench.py --steps 10 --warmup 2 --log2m $P --no-cpu-baseline --no-accuracy --no-secondary --no-ingest > $OUT/bench_p$P.json 2> $OUT/bench_p$P.err
+done
 python3 - <<PY
 import json
-for p in (14, 18, 20):
+for p in (14, 16, 17, 18, 19, 20):
     d = json.load(open("$OUT/bench_p%d.json" % p))
     print(p, round(d["value"], 2), "Gbp/s", round(d["ms_per_step"], 2), "ms/step")
 PY
