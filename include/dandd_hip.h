@@ -149,8 +149,9 @@ int dd_synth_fasta_device(dd_ctx *, uint64_t seed, int genome_index, uint64_t nb
  * What stands in for `parallel -j 95%`'s process-per-k scheduling (lib/huffman_dandd.py:214-218):
  * how dd_sketch_device would cut (genome x k x 65536-token tile) into workgroup jobs for genomes of
  * these sizes.  Writes at most `cap` jobs in launch order and returns how many there are (or a
- * negative DD_E* code).  kclass: -1 small-k bitmap class, else the window class of the launch
- * (0: k <= 16, 1: <= 32, 3: 33..48, 2: 49..64); mode: 0 registers in LDS; 5 (log2m >= 18) registers in HBM
+ * negative DD_E* code).  kclass: -1 small-k bitmap class (k <= 9), -2 the exact k-mer sets of k = 10 (, 11)
+ * at log2m >= 19 (one job per slice of the k-mer index space: `slice`), else the window class of the launch
+ * (0: k <= 16, 1: <= 32, 3: 33..48, 2: 49..64); mode: 0 registers in LDS; 5 (log2m >= 17) registers in HBM
  * through scatter + chunk sort + replay, jobs listed epoch by epoch; 1 in HBM with every update checked there
  * and 2..4 in HBM behind an LDS filter byte per 2^mode registers with compare-and-swap (round 1's paths,
  * DD_NO_FILTER / DD_NO_BUCKETS). */

@@ -25,7 +25,7 @@ def probe(eng, ng, nb, gz, kmin=4, kmax=40, log=print):
         best = None
         for it in range(6):
             t0 = time.perf_counter()
-            regs = eng.sketch_files(paths, kmin, kmax, 0)
+            regs = eng.sketch_files(paths, kmin, kmax, int(os.environ.get("NT", "0")))
             dt = time.perf_counter() - t0
             wall, wait, batches, nbytes = eng.last_ingest_stats()
             log(f"  call {it}: {dt*1e3:.1f} ms ({ng*nb/dt/1e9:.2f} Gbp/s); loader wait {wait:.1f} ms, {batches} launches, {nbytes/1e6:.0f} MB")
