@@ -46,7 +46,7 @@ def build(force=False, extra=(), verbose=False):
     if not force and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc()] + FLAGS + list(extra) + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lz", "-lpthread"]
+    cmd = [hipcc()] + FLAGS + list(extra) + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lz", "-ldl", "-lpthread"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd, cwd=CSRC)

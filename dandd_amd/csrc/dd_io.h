@@ -2,11 +2,14 @@
 // directories hold them, /root/reference/lib/species_specifics.py:93) into reusable host buffers.  Host code only
 // (no kernels): tests/native/sanitize_host.cpp builds it with AddressSanitizer / ThreadSanitizer on the CPU.
 #pragma once
+#include <dlfcn.h>
+#include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -62,8 +65,102 @@ struct FileBuf {
     size_t size() const { return len; }
 };
 
+// libdeflate, when the machine has it (this image ships libdeflate.so.0 as somebody's dependency, without
+// headers): whole-buffer gzip decoding 2-3x faster than zlib's streaming inflate, which is what bounds a
+// directory of .fa.gz genomes (zlib: ~190 MB/s of FASTA per loader thread).  Looked up once with dlopen, the four
+// entry points declared here as its stable C ABI has them; absent or failing, zlib does the work as before.
+struct Deflate {
+    void* (*alloc)() = nullptr;
+    void (*release)(void*) = nullptr;
+    int (*gunzip_ex)(void*, const void*, size_t, void*, size_t, size_t*, size_t*) = nullptr;  // 0 ok, 1 bad data, 3 no room
+    static const Deflate& get() {
+        static const Deflate d = [] {
+            Deflate r;
+            if (getenv("DD_NO_LIBDEFLATE")) return r;
+            void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+            if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
+            if (!h) return r;
+            r.alloc = reinterpret_cast<void* (*)()>(dlsym(h, "libdeflate_alloc_decompressor"));
+            r.release = reinterpret_cast<void (*)(void*)>(dlsym(h, "libdeflate_free_decompressor"));
+            r.gunzip_ex = reinterpret_cast<int (*)(void*, const void*, size_t, void*, size_t, size_t*, size_t*)>(
+                dlsym(h, "libdeflate_gzip_decompress_ex"));
+            if (!r.alloc || !r.release || !r.gunzip_ex) r = Deflate();
+            return r;
+        }();
+        return d;
+    }
+};
+
+// A gzip file (any number of members) through libdeflate.  Returns 1 done, 0 not applicable (not gzip, no library,
+// anything unexpected: the caller's zlib path then decides and words the error), -1 out of memory.
+inline int read_gzip_whole(const char* path, FileBuf& out) {
+    const Deflate& lib = Deflate::get();
+    if (!lib.gunzip_ex) return 0;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return 0;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 18) {
+        close(fd);
+        return 0;
+    }
+    const size_t n = (size_t)sb.st_size;
+    uint8_t magic[2] = {0, 0};
+    if (pread(fd, magic, 2, 0) != 2 || magic[0] != 0x1f || magic[1] != 0x8b) {  // a plain file: nothing to do here
+        close(fd);
+        return 0;
+    }
+    uint8_t* in = static_cast<uint8_t*>(malloc(n));
+    if (!in) {
+        close(fd);
+        return 0;
+    }
+    size_t have = 0;
+    while (have < n) {
+        const ssize_t got = pread(fd, in + have, n - have, (off_t)have);
+        if (got <= 0) break;
+        have += (size_t)got;
+    }
+    close(fd);
+    int rc = 0;
+    void* d = nullptr;
+    if (have == n && in[0] == 0x1f && in[1] == 0x8b && (d = lib.alloc())) {
+        // ISIZE of the last member: the whole size of a one-member file, a lower bound otherwise
+        const size_t isize = (size_t)in[n - 4] | ((size_t)in[n - 3] << 8) | ((size_t)in[n - 2] << 16) | ((size_t)in[n - 1] << 24);
+        out.len = 0;
+        rc = out.reserve(std::max(out.cap, std::max(isize + 64, 3 * n))) ? 1 : -1;
+        size_t pos = 0;
+        while (rc == 1 && pos < n) {
+            if (n - pos < 18 || in[pos] != 0x1f || in[pos + 1] != 0x8b) {
+                // zeros / garbage after the last member are ignored, as gzread ignores them; anything else is zlib's call
+                if (!out.len) rc = 0;
+                break;
+            }
+            size_t used = 0, made = 0;
+            const int r = lib.gunzip_ex(d, in + pos, n - pos, out.p + out.len, out.cap - out.len, &used, &made);
+            if (r == 0) {
+                out.len += made;
+                pos += used;
+            } else if (r == 3) {
+                if (!out.reserve(out.cap * 2)) rc = -1;
+            } else {
+                rc = 0;  // bad data: let zlib find and word it
+            }
+        }
+        lib.release(d);
+    }
+    free(in);
+    if (rc != 1) out.len = 0;
+    return rc;
+}
+
 // Whole FASTA file into memory; gzip (any number of members) or plain, decided by zlib itself.
 inline bool read_fasta_file(const char* path, FileBuf& out, std::string& err) {
+    const int fast = read_gzip_whole(path, out);
+    if (fast == 1) return true;
+    if (fast < 0) {
+        err = std::string("out of host memory reading ") + path;
+        return false;
+    }
     gzFile f = gzopen(path, "rb");
     if (!f) {
         err = std::string("cannot open ") + path;

@@ -168,6 +168,47 @@ static void check_loaders(const std::string& dir) {
     CHECK(!dd::read_fasta_file((dir + "/missing.fa").c_str(), fb, err) && !err.empty(), "a missing file must fail");
 }
 
+static void check_gzip_edges(const std::string& dir) {
+    // what zlib's gzread tolerates or refuses, the libdeflate path must tolerate or refuse the same way
+    std::string body = ">e\n";
+    for (int j = 0; j < 300000; ++j) body += "ACGT"[(j * 7 + j / 13) & 3];
+    const std::string one = write_file(dir, 900, body, 1);
+    auto slurp = [](const std::string& p) {
+        std::string s;
+        FILE* f = fopen(p.c_str(), "rb");
+        char buf[65536];
+        size_t n;
+        while ((n = fread(buf, 1, sizeof buf, f)) > 0) s.append(buf, n);
+        fclose(f);
+        return s;
+    };
+    auto spit = [](const std::string& p, const std::string& s) {
+        FILE* f = fopen(p.c_str(), "wb");
+        fwrite(s.data(), 1, s.size(), f);
+        fclose(f);
+    };
+    const std::string gz = slurp(one);
+    dd::FileBuf fb;
+    std::string err;
+    spit(dir + "/pad.fa.gz", gz + std::string(512, '\0'));                    // zero padding after the member
+    CHECK(dd::read_fasta_file((dir + "/pad.fa.gz").c_str(), fb, err) && fb.size() == body.size() && memcmp(fb.data(), body.data(), body.size()) == 0,
+          "padded gzip: %s", err.c_str());
+    spit(dir + "/cut.fa.gz", gz.substr(0, gz.size() / 2));                    // truncated: an error, not silence
+    err.clear();
+    const bool cut_ok = dd::read_fasta_file((dir + "/cut.fa.gz").c_str(), fb, err);
+    CHECK(!cut_ok || fb.size() < body.size(), "truncated gzip read back whole");
+    const std::string empty = write_file(dir, 901, std::string(), 1);         // an empty member
+    CHECK(dd::read_fasta_file(empty.c_str(), fb, err) && fb.size() == 0, "empty gzip member");
+    spit(dir + "/tiny.fa", ">t\nAC\n");                                       // shorter than any gzip file
+    CHECK(dd::read_fasta_file((dir + "/tiny.fa").c_str(), fb, err) && fb.size() == 6, "tiny plain file");
+    std::string flip = gz;                                                    // a damaged stream
+    flip[flip.size() / 2] ^= 0x55;
+    spit(dir + "/bad.fa.gz", flip);
+    err.clear();
+    const bool bad_ok = dd::read_fasta_file((dir + "/bad.fa.gz").c_str(), fb, err);
+    CHECK(!bad_ok || fb.size() != body.size() || memcmp(fb.data(), body.data(), body.size()) != 0, "damaged gzip read back as if intact");
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
     dd::PlanKnobs base;
@@ -189,6 +230,7 @@ int main(int argc, char** argv) {
     k2.use_bitmaps = false;
     check_plan(18, ragged, 2, 20, k2);
     check_loaders(argv[1]);
+    check_gzip_edges(argv[1]);
     if (failures) fprintf(stderr, "%d failure(s)\n", failures);
     else printf("sanitize_host: ok\n");
     return failures ? 1 : 0;
