@@ -245,8 +245,9 @@ def accuracy_block(wl, card, what):
     }
 
 
-def ingest_probe(eng, ng, nb, nrec, kmin, kmax, torch):
+def ingest_probe(eng, ng, nb, nrec, kmin, kmax, torch, gz=False):
     """dd_sketch_files over FASTA files (tmpfs when there is one: a warm page cache), third call."""
+    import zlib
     from dandd_amd.engine import synth_size
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     d = tempfile.mkdtemp(prefix="dd_ingest_", dir=base)
@@ -257,8 +258,13 @@ def ingest_probe(eng, ng, nb, nrec, kmin, kmax, torch):
         for g in range(ng):
             eng.synth_fasta_device(SEED, g, nb, nrec, buf.data_ptr())
             eng.synchronize()
-            p = os.path.join(d, f"g{g:03d}.fasta")
-            buf[:n].cpu().numpy().tofile(p)
+            p = os.path.join(d, f"g{g:03d}.fasta" + (".gz" if gz else ""))
+            if gz:  # one gzip member, level 1 (what `gzip -1` writes)
+                co = zlib.compressobj(1, zlib.DEFLATED, 31)
+                with open(p, "wb") as f:
+                    f.write(co.compress(buf[:n].cpu().numpy().tobytes()) + co.flush())
+            else:
+                buf[:n].cpu().numpy().tofile(p)
             paths.append(p)
         best = None
         for _ in range(6):  # the context's host buffers are pinned as they are reused: steady from the 4th call on
@@ -268,7 +274,7 @@ def ingest_probe(eng, ng, nb, nrec, kmin, kmax, torch):
             best = dt if best is None else min(best, dt)
         _, wait, batches, nbytes = eng.last_ingest_stats()
         return {"value": ng * nb / best / 1e9, "unit": "Gbp/s", "ms": best * 1e3, "launches": batches, "fasta_MB": nbytes / 1e6,
-                "what": f"dd_sketch_files: {ng} x {nb/1e6:g} Mbp plain FASTA files in {base or 'the temp dir'} (warm page cache) -> "
+                "what": f"dd_sketch_files: {ng} x {nb/1e6:g} Mbp {'gzip -1' if gz else 'plain'} FASTA files in {base or 'the temp dir'} (warm page cache) -> "
                         f"pinned host buffers -> H2D on a copy stream overlapped with K0/K1 -> registers back to the host; "
                         f"k {kmin}-{kmax}; best of 6 calls on one context (PCIe-inclusive: reported beside `value`, never as it)"}
     finally:
@@ -432,6 +438,8 @@ def main():
             extras["ingest"] = ingest_probe(eng, ng, nb, cfg["nrec"], kmin, kmax, torch)
             # the cfg 3 shape of the same path: many small files coalesced into a few launches
             extras["ingest"]["small_files"] = ingest_probe(eng, 64, 5_000_000, cfg["nrec"], kmin, kmax, torch)
+            # ... and as most genome directories really are: .gz (host inflate: libdeflate or zlib, one thread per file)
+            extras["ingest"]["gzip_files"] = ingest_probe(eng, ng, nb, cfg["nrec"], kmin, kmax, torch, gz=True)
 
     # HBM-side traffic of K1 per step: PMC counters cannot be read from inside this process, so the
     # number comes from the committed rocprofv3 passes (profiles/traffic.json, made by

@@ -614,7 +614,17 @@ class DeltaTree:
         and return the paths as [leaf][k]."""
         rows = []
         for leaf in leaves:
+            before = set(leaf.experiment["baseset"])
             leaf.ksweep_update_node(lo, hi)
+            # ksweep_update_node notes every k of the range in the experiment's base set, as the reference's does
+            # (lib/huffman_dandd.py:174) -- there every such k is then visited (node_ksweep) and registered.  This
+            # window is a prefetch of OURS: a k the search never visits must not reach `save`, whose sketch/DB table
+            # (lib/huffman_dandd.py:503) looks every base up and would die on it (hill-climb `progressive` did).
+            # In a hill-climb run the reference never calls it at all: nothing of the window stays on the record.
+            fresh = leaf.experiment["baseset"] - before
+            if leaf.experiment.get("ksweep") is not None:
+                fresh = {b for b in fresh if b not in self.speciesinfo.sketchinfo}
+            leaf.experiment["baseset"].difference_update(fresh)
             tmpl = leaf.ksketches[0].sfp
             rows.append([tmpl.with_k(k) for k in range(lo, hi + 1)])
         return rows

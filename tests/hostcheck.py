@@ -39,6 +39,42 @@ class OracleBackend:
         return self.orc.card(regs, log2m)
 
 
+class ScheduleBackend(OracleBackend):
+    """The oracle backend with the GPU backend's batch entry points (leaf_many, pairwise_cards,
+    progressive_cards): the host layer then takes the same prefetch paths it takes on the GPU."""
+    name = "oracle+schedules"
+
+    def leaf_many(self, fastas, kmin, kmax, path_of):
+        ks = list(range(kmin, kmax + 1))
+        for i, f in enumerate(fastas):
+            OracleBackend.leaf(self, f, ks, [path_of(i, k) for k in ks])
+
+    def _slab(self, leaf_paths):
+        return [[self.B.read_sketch_file(p)[0] for p in row] for row in leaf_paths]
+
+    def pairwise_cards(self, leaf_paths):
+        slab = self._slab(leaf_paths)
+        n, K = len(slab), len(slab[0])
+        out = np.zeros((n, n, K))
+        for i in range(n):
+            for j in range(n):
+                for kk in range(K):
+                    out[i, j, kk] = self.orc.card(self.orc.union(slab[i][kk], slab[j][kk]), self.log2m)
+        return out
+
+    def progressive_cards(self, leaf_paths, orderings):
+        slab = self._slab(leaf_paths)
+        n, K = len(slab), len(slab[0])
+        out = np.zeros((len(orderings), n, K))
+        for o, order in enumerate(orderings):
+            for kk in range(K):
+                acc = None
+                for j, g in enumerate(order):
+                    acc = slab[g][kk] if acc is None else self.orc.union(acc, slab[g][kk])
+                    out[o, j, kk] = self.orc.card(acc, self.log2m)
+        return out
+
+
 class ExactBackend:
     """KMC stand-in: a 'sketch' is the list of FASTAs, its cardinality the exact distinct count."""
     name = "exact"

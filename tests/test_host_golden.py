@@ -365,3 +365,53 @@ def test_cfg1_exact_ksweep_on_gpu_matches_exact_goldens(host, tmp_path, torch_cu
     assert len(want) == 6 * 11 and set(want) <= set(have)
     for k2, v in want.items():
         assert have[k2] == v, (k2, have[k2], v)
+
+
+@pytest.mark.gpu
+def test_progressive_hill_climb_on_gpu(host, tmp_path, torch_cuda):
+    """The same walk with the product backend (HipBackend: leaf_many + whole-schedule launches) in hill-climb mode."""
+    _schedule_walk(host, tmp_path, [], lambda r, c: hostcheck.OracleBackend(r, c), None)
+
+
+@pytest.mark.parametrize("sweep", [[], ["--ksweep", "--mink", "4", "--maxk", "14"]])
+def test_progressive_and_kij_with_schedule_hooks(host, tmp_path, sweep):
+    _schedule_walk(host, tmp_path, sweep, lambda r, c: hostcheck.OracleBackend(r, c), lambda r, c: hostcheck.ScheduleBackend(r, c))
+
+
+def _schedule_walk(host, tmp_path, sweep, plain_factory, hooked_factory):
+    """A backend WITH the schedule entry points (the GPU one; here the oracle dressed up the same way) sends
+    `progressive` and `kij` through the prefetch paths: leaf windows sketched ahead, union cardinalities taken from
+    whole-schedule tables.  Same rows as the plain three-method backend, and `save` finds every base it recorded --
+    the hill-climb `progressive` used to die in save on a k its prefetch window had noted and the search never
+    visited (found on the GPU box by scripts/e2e_cli.py --hillclimb)."""
+    import shutil
+    from dandd_amd.host import cli
+
+    orderings = os.path.join(str(tmp_path), "orderings.pickle")   # drawn by the first run, replayed by the second
+
+    def run(factory, name):
+        host.set_backend_factory(factory)
+        data = os.path.join(str(tmp_path), name, "data")
+        shutil.copytree(os.path.join(hostcheck.GOLD, "fasta"), data)
+        out = os.path.join(str(tmp_path), name, "o")
+        cli.main(["tree", "-d", data, "-o", out, "-s", "gold", "-r", "12"] + sweep)
+        pk = os.path.join(out, "gold_5_dashing_dtree.pickle")
+        cli.main(["progressive", "-d", pk, "-o", out, "-n", "3", "--orderings", orderings] + sweep)
+        cli.main(["kij", "-d", pk, "-o", out] + (["--jaccard"] + sweep if sweep else []))
+        rows = {}
+        for f in sorted(os.listdir(out)):
+            if f.endswith(".csv") and "ordering" not in f:
+                rows[f] = hostcheck.read_rows(os.path.join(out, f))
+        db = hostcheck.read_rows(os.path.join(out, "gold_progu3_5_dashing_sketchdb.txt"))
+        return rows, db
+
+    try:
+        plain, db_plain = run(plain_factory, "plain")
+        hooked, db_hooked = run(hooked_factory, "hooked")
+    finally:
+        host.set_backend_factory(None)
+    assert sorted(plain) == sorted(hooked) and any("progu3" in f for f in plain)
+    for f in plain:
+        strip = lambda rows: sorted(tuple(sorted((k, v) for k, v in r.items() if k not in ("sketchloc",))) for r in rows)
+        assert strip(plain[f]) == strip(hooked[f]), f
+    assert sorted(r["sketchbase"] for r in db_plain) == sorted(r["sketchbase"] for r in db_hooked)
