@@ -25,10 +25,12 @@ def host():
     deltatree.set_backend_factory(None)
 
 
-@pytest.mark.parametrize("which", ["hll", "exact"])
+@pytest.mark.parametrize("which", ["hll", "exact", "hll+schedules"])
 def test_cli_rows_match_reference_with_checker_backend(host, tmp_path, which):
-    gold = _golden(f"ref_{which}.json")
-    factory = hostcheck.OracleBackend if which == "hll" else hostcheck.ExactBackend
+    """"hll+schedules": the oracle behind the GPU backend's batch entry points, i.e. every prefetch path of the host
+    layer (leaf windows, whole-schedule union cardinalities) on the CPU, against the same reference rows."""
+    gold = _golden("ref_exact.json" if which == "exact" else "ref_hll.json")
+    factory = {"hll": hostcheck.OracleBackend, "exact": hostcheck.ExactBackend, "hll+schedules": hostcheck.ScheduleBackend}[which]
     host.set_backend_factory(lambda registers, canon: factory(registers, canon))
     got = hostcheck.run_scenarios(str(tmp_path), gold["registers"])
     diffs = hostcheck.compare(got, gold["scenarios"])
