@@ -444,7 +444,9 @@ class DeltaTree:
         (files are read/inflated ahead while the GPU sketches); sharded over the ranks when several."""
         be = backend_for(self.experiment)
         lo = max(int(lo), 1)
-        if self.experiment["tool"] == "dashing" and not self.experiment.get("allow_k64"):
+        # (a hill-climb never asks Dashing for k > 32, lib/huffman_dandd.py:109; an explicit --ksweep range is taken
+        # as given, there as here -- the per-leaf path sketches those ks too, one genome at a time)
+        if self.experiment["tool"] == "dashing" and not self.experiment.get("allow_k64") and self.experiment["ksweep"] is None:
             hi = min(int(hi), 32)
         if hi < lo or not hasattr(be, "leaf_many"):
             return 0

@@ -389,7 +389,10 @@ def _schedule_walk(host, tmp_path, sweep, plain_factory, hooked_factory):
     import shutil
     from dandd_amd.host import cli
 
-    orderings = os.path.join(str(tmp_path), "orderings.pickle")   # drawn by the first run, replayed by the second
+    import pickle
+    orderings = os.path.join(str(tmp_path), "orderings.pickle")   # fixed: both runs load the same set the same way
+    with open(orderings, "wb") as f:
+        pickle.dump({(0, 1, 2, 3, 4), (4, 2, 0, 3, 1), (1, 3, 4, 0, 2)}, f)
 
     def run(factory, name):
         host.set_backend_factory(factory)
