@@ -780,6 +780,7 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
     };
     std::vector<Item> items;
     const size_t kPiece = (size_t)8 << 20;
+    const size_t kFirstPiece = (size_t)(getenv("DD_FIRST_PIECE_MB") ? std::max(1, atoi(getenv("DD_FIRST_PIECE_MB"))) : 2) << 20;
     for (int i = 0; i < nfiles; ++i) {
         struct stat sb;
         unsigned char magic[2] = {0, 0};
@@ -792,8 +793,11 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
         }
         if (plain) {
             slots[i].plain_size = (size_t)sb.st_size;
-            for (size_t off = 0; off < slots[i].plain_size; off += kPiece) {
-                items.push_back(Item{i, off, std::min(kPiece, slots[i].plain_size - off)});
+            // (the first files in finer pieces still: every loader works on file 0 until it is complete, and the GPU
+            // sits idle until then)
+            const size_t piece = i < 2 ? kFirstPiece : kPiece;
+            for (size_t off = 0; off < slots[i].plain_size; off += piece) {
+                items.push_back(Item{i, off, std::min(piece, slots[i].plain_size - off)});
                 ++slots[i].pieces_left;
             }
         } else {
