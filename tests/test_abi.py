@@ -92,3 +92,22 @@ def test_product_never_imports_oracle():
                     if s.startswith(("#include", "import", "from")):
                         assert "oracle" not in s, f"{f}: {s}"
                 assert "liboracle" not in text and "dd_oracle.py" not in text, f
+
+
+def test_header_is_plain_c_and_links_from_c(lib, tmp_path):
+    """include/dandd_hip.h compiled as C99 with -pedantic -Werror by gcc, a C program linked against the library:
+    the boundary a cgo / JNI / FFI binding would see -- no C++ or torch types leak into it."""
+    import shutil
+    from dandd_amd import engine
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc needed")
+    exe = str(tmp_path / "abi_consumer")
+    libdir = os.path.dirname(engine.LIB_PATH)
+    cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "native", "abi_consumer.c"), "-o", exe, "-L" + libdir, "-ldandd_hip",
+           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"]
+    b = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert b.returncode == 0, b.stderr[-3000:]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "abi_consumer: ok" in r.stdout, (r.returncode, r.stdout, r.stderr[-2000:])
