@@ -128,6 +128,20 @@ def test_bucket_mode_batched_unequal_genomes(engine_factory, torch_cuda, orc, mo
         assert np.array_equal(got[g], orc.sketch_sweep(f, 15, 18, 19)), g
 
 
+@pytest.mark.parametrize("p", [14, 17, 19, 20])
+def test_inputs_without_a_single_kmer(engine_factory, p):
+    """Empty file, header only, sequence shorter than k, all N: every register zero in every register mode (at
+    log2m >= 19 the k range 9..12 spans the small-k class, the exact-set class and a hashed class) -- also right
+    after a call that left the context's buffers full of something else."""
+    for canon in (True, False):
+        eng = engine_factory(p, canon)
+        big = np.frombuffer(b">x\n" + b"ACGTTGCAAGGCTTAACCGGTT" * 3000, dtype=np.uint8)
+        assert eng.sketch_buffer(big, 9, 12).any()
+        for fa in (b"", b">only header\n", b">h\nACGT\n", b"NNNNNNNNNNNNNNNNNNNNNNNN"):
+            regs = eng.sketch_buffer(np.frombuffer(fa, dtype=np.uint8), 9, 12)
+            assert regs.shape == (4, 1 << p) and not regs.any(), (p, canon, fa)
+
+
 def test_log2m17_both_register_modes(engine_factory, orc, monkeypatch):
     """log2m 17 goes through scatter + replay by default (two index tiles per row); DD_GLOBAL_FROM_P=18 keeps the
     one-128-KiB-row-per-workgroup LDS form alive.  Same registers either way."""
