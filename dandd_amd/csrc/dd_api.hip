@@ -405,7 +405,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     size_t bigmap_stride = 0;
     {
         int ka = 0, kb = 0;
-        if (dd::plan_bigmap_range(p, kmin, kmax, dd::PlanKnobs::from_env(), &ka, &kb)) {
+        if (dd::plan_bigmap_range(p, kmin, kmax, dd::PlanKnobs::from_env(), nbytes, ngenomes, &ka, &kb)) {
             bigmap_stride = dd::bigmap_offset_words(kb + 1, c->canonical != 0);
             const size_t bbytes = (size_t)ngenomes * bigmap_stride * sizeof(uint32_t);
             if ((rc = c->bigmaps.reserve(bbytes))) return rc;
@@ -599,7 +599,8 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         // epoch by epoch: scatter launches of every k class (independent rows: side by side on side streams, so the
         // tail of one overlaps the body of another), then one sort + replay over all rows
         static const unsigned unit = [] { const char* e = getenv("DD_BUCKET_UNIT"); return e ? (unsigned)std::max(1, atoi(e)) * 64u : 256u; }();
-        const dd::ScatterParams sp{rows_dev, K, bplan->logg, bplan->cap_chunks, unit};
+        const int presorted = bplan->nb_log2 >= 1 && !getenv("DD_NO_PRESORT") ? 1 : 0;
+        const dd::ScatterParams sp{rows_dev, K, bplan->logg, bplan->cap_chunks, unit, bplan->nb_log2, presorted};
         if (side_b && !c->side_ready) {
             for (int i = 0; i < 8; ++i) {
                 DD_HIP(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
@@ -640,10 +641,11 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
                 const size_t j0 = sc.epoch_begin[e], j1 = sc.epoch_begin[e + 1];
                 if (j1 == j0) continue;
                 Span span(c, DD_KERNEL_SWEEP, !side_b);
+                const bool first = e == 0 && !getenv("DD_BUCKET_NO_FIRST");
                 dd::launch_scatter(reinterpret_cast<const dd::SweepGenome*>(tdev),
                                    reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]) + j0, (int)(j1 - j0),
-                                   sc.kclass, sc.plan, sp, ks, e == 0 && !getenv("DD_BUCKET_NO_FIRST"));
-                dd::launch_replay(rows_dev, ngenomes, K, sc.kfirst - kmin, sc.klast - sc.kfirst + 1, *bplan, ks);
+                                   sc.kclass, sc.plan, sp, ks, first);
+                dd::launch_replay(rows_dev, ngenomes, K, sc.kfirst - kmin, sc.klast - sc.kfirst + 1, *bplan, ks, first && presorted);
                 blocks += (int)(j1 - j0);
             }
             if (side_b) {

@@ -31,6 +31,7 @@ struct PlanKnobs {
     size_t jobs_per_row = 0;        // filtered mode; 0 = heuristic
     int global_from_p = 17;         // registers stay in HBM from this log2m on (17: 22.8 Gbp/s through scatter + replay, 18.7 with one 128 KiB row per workgroup in LDS)
     bool use_bitmaps = true, use_bigmaps = true, filter = true, xcd_affinity = true, taper = true;
+    bool bigmap_any_size = false;   // tests: the exact-set class whatever the genomes' sizes
     // registers in HBM, two-phase: scatter (idx, rho) records into per-(row, index tile) buckets, replay
     // each bucket into an LDS-resident tile (no global atomics); off = the filtered compare-and-swap path
     bool buckets = true;
@@ -45,7 +46,7 @@ struct PlanKnobs {
     static PlanKnobs from_env();
     bool operator==(const PlanKnobs& o) const {
         return lds_budget == o.lds_budget && lds_budget_forced == o.lds_budget_forced && jobs_per_cu == o.jobs_per_cu &&
-               jobs_per_row == o.jobs_per_row && global_from_p == o.global_from_p && use_bitmaps == o.use_bitmaps && use_bigmaps == o.use_bigmaps &&
+               jobs_per_row == o.jobs_per_row && global_from_p == o.global_from_p && use_bitmaps == o.use_bitmaps && use_bigmaps == o.use_bigmaps && bigmap_any_size == o.bigmap_any_size &&
                filter == o.filter && xcd_affinity == o.xcd_affinity && taper == o.taper && buckets == o.buckets &&
                bucket_e0_tiles == o.bucket_e0_tiles && bucket_emax_tiles == o.bucket_emax_tiles &&
                bucket_cap_chunks == o.bucket_cap_chunks && bucket_logg == o.bucket_logg && bucket_fbits == o.bucket_fbits && bucket_probe == o.bucket_probe &&
@@ -54,7 +55,9 @@ struct PlanKnobs {
 };
 
 // the ks of a call that go to the big-bitmap class (false: none)
-bool plan_bigmap_range(int log2m, int kmin, int kmax, const PlanKnobs& knobs, int* ka, int* kb);
+// (`nbytes`: the call's genomes -- an exact set only pays when a genome has several times more tokens than the
+// set can have members, because every index tile's workgroup hashes the whole set afterwards)
+bool plan_bigmap_range(int log2m, int kmin, int kmax, const PlanKnobs& knobs, const size_t* nbytes, int ngenomes, int* ka, int* kb);
 std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbytes, int ngenomes, int kmin,
                                    int kmax, const PlanKnobs& knobs);
 

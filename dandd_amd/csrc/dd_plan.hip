@@ -22,6 +22,7 @@ PlanKnobs PlanKnobs::from_env() {
     if (const char* e = getenv("DD_GLOBAL_FROM_P")) k.global_from_p = std::max(16, std::min(18, atoi(e)));
     k.use_bitmaps = !getenv("DD_NO_BITMAP");
     k.use_bigmaps = k.use_bitmaps && !getenv("DD_NO_BIGMAP");
+    k.bigmap_any_size = getenv("DD_BIGMAP_ANY_SIZE") != nullptr;
     k.filter = !getenv("DD_NO_FILTER");
     k.xcd_affinity = !getenv("DD_NO_XCD_AFFINITY");
     k.taper = !getenv("DD_NO_TAPER");
@@ -58,11 +59,20 @@ SweepJob make_job(int genome, int kfirst, int nk, int kmin, size_t t0, size_t t1
 
 }  // namespace
 
-bool plan_bigmap_range(int log2m, int kmin, int kmax, const PlanKnobs& knobs, int* ka, int* kb) {
+bool plan_bigmap_range(int log2m, int kmin, int kmax, const PlanKnobs& knobs, const size_t* nbytes, int ngenomes, int* ka, int* kb) {
     const size_t m = (size_t)1 << log2m;
     const bool global_regs = m > (size_t)sweep_max_lds_bytes() || log2m >= knobs.global_from_p;
     const bool bucket_mode = global_regs && knobs.buckets && knobs.filter;
-    const int last = (bucket_mode && knobs.use_bitmaps && knobs.use_bigmaps) ? bigmap_last_k(log2m) : 0;
+    int last = (bucket_mode && knobs.use_bitmaps && knobs.use_bigmaps) ? bigmap_last_k(log2m) : 0;
+    // The finish kernel hashes a k's whole set (up to 4^k / 2 k-mers) once per 128 KiB index tile of the row; going
+    // through the record stream hashes every token once.  Small genomes (64 x 5 Mbp at log2m 20: 7 ms of finish
+    // kernel for 640 M tokens' worth of rows) keep the hashed path, whose unfiltered first epoch covers most of
+    // them anyway.
+    size_t total = 0;
+    for (int g = 0; g < ngenomes; ++g) total += nbytes[g];
+    const size_t avg = ngenomes > 0 ? total / (size_t)ngenomes : 0;
+    const size_t tiles = (size_t)1 << std::max(0, log2m - 17);
+    while (!knobs.bigmap_any_size && last >= kBigmapMinK && avg < tiles * ((size_t)1 << (2 * last))) --last;
     const int a = std::max(kmin, kBigmapMinK), b = std::min(kmax, last);
     if (a > b) return false;
     if (ka) *ka = a;
@@ -87,7 +97,7 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
     const int slots = global_regs ? 64 : (int)std::min<size_t>(64, lds_budget / m);
     const bool use_bitmaps = knobs.use_bitmaps && kmin <= kBitmapMaxK;
     int big_ka = 0, big_kb = 0;
-    const bool use_big = plan_bigmap_range(p, kmin, kmax, knobs, &big_ka, &big_kb);
+    const bool use_big = plan_bigmap_range(p, kmin, kmax, knobs, nbytes, ngenomes, &big_ka, &big_kb);
 
     size_t total_tiles = 0, max_tiles = 0;
     for (int g = 0; g < ngenomes; ++g) {

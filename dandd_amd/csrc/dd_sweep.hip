@@ -961,6 +961,9 @@ struct Scatter {
     uint32_t queue;        // byte offset in g_lds of this wave's record queue (kQueueEntries x 4 B)
     uint32_t* area;        // the row's record stream, chunk c at area + c * kChunkRecords
     uint32_t* cursor;      // records reserved so far (may run past the capacity: readers clamp)
+    uint32_t* fill;        // first epoch, chunks sorted on the way out: non-null records per chunk ...
+    uint16_t* seg;         // ... and where each index tile's segment starts (as sort_chunks_kernel leaves them)
+    int tshift, nb;        // index tile of a record = idx >> tshift; tiles per row
     uint8_t* regs;         // the row itself: where records go when the stream is full
     uint32_t cap_chunks;
     uint32_t unit;         // records a wave reserves at a time (a multiple of 64)
@@ -1000,6 +1003,66 @@ DD_D void scatter_block(const Scatter& s, uint32_t rec, uint32_t& cur, uint32_t&
     }
     gstore4(s.area + pos + lane, rec);
 }
+// First epoch, rows of several index tiles: the wave collects its records in LDS (4 KiB at `s.queue`, 64 bytes of
+// counters behind it) and sends every 1024 of them out as one chunk ALREADY sorted by index tile, segment table
+// and record count included -- what sort_chunks_kernel would otherwise do in a pass of its own that reads and
+// writes every record once more (the first epoch holds 60 % of a 10 x 50 Mbp call's records at log2m 20 and
+// nearly all of a 64 x 5 Mbp call's, and those calls are bound by the records' HBM traffic).
+DD_D void scatter_flush_sorted(const Scatter& s, uint32_t& n) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t have = n;
+    n = 0;
+    uint32_t pos = 0;
+    if (lane == 0) pos = gadd32(s.cursor, kChunkRecords);
+    pos = __builtin_amdgcn_readfirstlane(pos);
+    auto record = [&](int i) { return ((uint32_t)i * 64u + lane < have) ? lds32(s.queue + 4u * ((uint32_t)i * 64u + lane)) : 0u; };
+    if (pos + kChunkRecords > s.cap_chunks * kChunkRecords) {
+        // the stream is full: the records go to their registers directly (exact, slow, rare)
+#pragma unroll 1
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t e = record(i);
+            if (e >> 24) {
+                uint8_t* a = s.regs + (e & 0xFFFFFFu);
+                (void)cas_raise<RegsGlobal>(a, RegsGlobal::load32(a), e >> 24);
+            }
+        }
+        return;
+    }
+    // (two passes over the collection area, a record in flight at a time: holding all 16 of a lane in registers,
+    // as sort_chunks_kernel does, costs this kernel its second workgroup per CU)
+    const uint32_t hist = s.queue + kChunkRecords * 4u;  // 16 counters
+    if (lane < 16) lds32(hist + 4u * lane) = 0;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t e = record(i);
+        if (e >> 24) atomicAdd(&lds32(hist + 4u * ((e & 0xFFFFFFu) >> s.tshift)), 1u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t mine = lane < (uint32_t)s.nb ? lds32(hist + 4u * lane) : 0u;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d);
+        if (lane >= (uint32_t)d) incl += up;
+    }
+    const uint32_t total = __shfl(incl, s.nb - 1);
+    const uint32_t chunk = pos / kChunkRecords;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < (uint32_t)s.nb) {
+        lds32(hist + 4u * lane) = incl - mine;
+        ((DD_GLOBAL uint16_t*)s.seg)[(size_t)chunk * 16u + lane] = (uint16_t)(incl - mine);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // the chunk's 4 KiB are written by this wave within a few hundred cycles: the 4-byte stores meet in the L2
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t e = record(i);
+        if (e >> 24) gstore4(s.area + pos + atomicAdd(&lds32(hist + 4u * ((e & 0xFFFFFFu) >> s.tshift)), 1u), e);
+    }
+    if (lane == 0) gstore4(s.fill + chunk, total);
+    __builtin_amdgcn_wave_barrier();
+}
 // Second-level filter (PROBE): 64 queued candidates are checked against the ROW ITSELF -- one byte load per
 // lane from the registers as the last replay left them (the row of the jobs an XCD is running stays in that
 // XCD's L2: job order, dd_plan.hip) -- and only those that really exceed their register move on to a second
@@ -1031,7 +1094,14 @@ template <bool NIB, bool PROBE, bool FIRST>
 DD_D void scatter_update(const Scatter& s, uint32_t& waiting, uint32_t& waiting2, uint32_t& cur, uint32_t& left, uint64_t h, int p, bool valid) {
     const Probe q = probe(h, p);
     if (FIRST) {
-        scatter_block<true>(s, valid ? (q.hi >> (32 - p)) | (rho_of(q, p) << 24) : 0u, cur, left);
+        const uint32_t rec = valid ? (q.hi >> (32 - p)) | (rho_of(q, p) << 24) : 0u;
+        if (NIB) {  // (first-epoch kernels have no filter: the flag selects chunks sorted on the way out, `cur` = records collected)
+            lds32(s.queue + 4u * (cur + (threadIdx.x & 63u))) = rec;
+            cur += 64u;
+            if (cur == kChunkRecords) scatter_flush_sorted(s, cur);
+        } else {
+            scatter_block<true>(s, rec, cur, left);
+        }
         return;
     }
     uint32_t bound;
@@ -1110,6 +1180,11 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
         }
         s[j].fbase = (uint32_t)j * nflt;
         s[j].queue = (uint32_t)NK * nflt + ((threadIdx.x >> 6) * NK + j) * (kQueueEntries * 4u * (PROBE ? 2u : 1u));
+        if (FIRST) s[j].queue = (threadIdx.x >> 6) * (kChunkRecords * 4u + 64u);  // (sorted chunks: the wave's collection area + 16 counters)
+        s[j].fill = row.fill;
+        s[j].seg = row.seg;
+        s[j].tshift = p - sp.nb_log2;
+        s[j].nb = 1 << sp.nb_log2;
         s[j].area = row.area;
         s[j].cursor = row.cursor;
         s[j].regs = row.regs;
@@ -1164,6 +1239,7 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
         if (j && !two) break;
         const uint32_t lane = threadIdx.x & 63u;
         if (FIRST) {
+            if (NIB && cur[j]) scatter_flush_sorted(s[j], cur[j]);
         } else if (PROBE) {
             if (waiting[j]) scatter_probe(s[j], lane < waiting[j] ? lds32(s[j].queue + 4u * lane) : 0u, waiting2[j], cur[j], left[j]);
             if (waiting2[j]) scatter_block<false>(s[j], lane < waiting2[j] ? lds32(s[j].queue + kQueueEntries * 4u + 4u * lane) : 0u, cur[j], left[j]);
@@ -1309,10 +1385,37 @@ __global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restric
         h1 = h2;
         heads(c + 2u * step, h2);      // headers two steps ahead
         records(c + step, h1, v1);     // records one step ahead
+        // The 2U records of the step in three sweeps -- all register words read, all first compare-and-swaps
+        // issued, then the (rare) retries -- instead of read / compare / CAS record by record: the LDS round trips
+        // of one lane's records overlap (an LDS atomic orders every later LDS access of the wave behind it, so
+        // the record-by-record form ran them back to back; while the registers are still filling, half the
+        // records raise one).  A word changed in between -- by a neighbour, or by this lane's previous record --
+        // fails its CAS and is retried from the value that came back.
+        // (U at a time: all 2U together need 75+ VGPRs, and above 64 only one 1024-thread workgroup fits a CU)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint32_t wd[U];
+            uint32_t retry = 0;  // bit i: record i's first CAS found another value than the one read
+#pragma unroll
+            for (int i = 0; i < U; ++i) wd[i] = RegsLds::load32((half ? v0.r1[i] : v0.r0[i]) & (tile - 1u));
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                const uint32_t e = half ? v0.r1[i] : v0.r0[i];
+                const uint32_t a = e & (tile - 1u), rho = e >> 24, sh = RegsLds::shift(a), cur = (wd[i] >> sh) & 0xFFu;
+                if (rho > cur) {
+                    const uint32_t prev = RegsLds::cas32(a, wd[i], wd[i] + ((rho - cur) << sh));
+                    if (prev != wd[i]) retry |= 1u << i;
+                    wd[i] = prev;
+                }
+            }
+            if (__any(retry != 0u)) {
+#pragma unroll
+                for (int i = 0; i < U; ++i)
+                    if ((retry >> i) & 1u) (void)cas_raise<RegsLds>((half ? v0.r1[i] : v0.r0[i]) & (tile - 1u), wd[i], (half ? v0.r1[i] : v0.r0[i]) >> 24);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            apply(v0.r0[u]);
-            apply(v0.r1[u]);
             const uint32_t* base = row.area + (size_t)(c + 16u * u) * kChunkRecords;
             for (uint32_t i = h0.st[u] + 128u + lane; i < h0.en[u]; i += 64u) apply(gload4(base + i));  // longer than twice the expected size
         }
@@ -1437,9 +1540,21 @@ void launch_scatter(const SweepGenome* genomes, const SweepJob* jobs, int njobs,
                     const ScatterParams& sp, hipStream_t st, bool first_epoch) {
     if (njobs <= 0) return;
     if (first_epoch) {
-        // every register of the call is still zero: the unfiltered form (no LDS at all)
-#define DD_FIRST(KC, CN) \
-    hipLaunchKernelGGL((scatter_kernel<KC, CN, false, false, 1, true>), dim3((unsigned)njobs), dim3((unsigned)plan.threads), 0, st, genomes, jobs, plan.log2m, sp)
+        // every register of the call is still zero: the unfiltered form (no filter, no queues; rows of several index
+        // tiles get their chunks sorted on the way out: 4 KiB + 64 B of LDS per wave)
+#define DD_FIRST(KC, CN)                                                                                                           \
+    do {                                                                                                                           \
+        if (sp.presorted) {                                                                                                        \
+            auto kern = scatter_kernel<KC, CN, true, false, 1, true>;                                                              \
+            static std::atomic<unsigned long long> attr_done{0};                                                                   \
+            allow_full_lds(reinterpret_cast<const void*>(kern), attr_done);                                                        \
+            hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3((unsigned)plan.threads),                                          \
+                               (size_t)(plan.threads / 64) * (kChunkRecords * 4 + 64), st, genomes, jobs, plan.log2m, sp);         \
+        } else {                                                                                                                   \
+            hipLaunchKernelGGL((scatter_kernel<KC, CN, false, false, 1, true>), dim3((unsigned)njobs), dim3((unsigned)plan.threads), 0, \
+                               st, genomes, jobs, plan.log2m, sp);                                                                 \
+        }                                                                                                                          \
+    } while (0)
 #define DD_FIRST_KC(CN)                   \
     do {                                  \
         if (kclass == 0) DD_FIRST(0, CN); \
@@ -1486,12 +1601,12 @@ void launch_scatter(const SweepGenome* genomes, const SweepJob* jobs, int njobs,
 #undef DD_SCATTER_NN
 }
 
-void launch_replay(const BucketRow* rows, int ngenomes, int K, int k0, int nks, const SweepPlan& plan, hipStream_t st) {
+void launch_replay(const BucketRow* rows, int ngenomes, int K, int k0, int nks, const SweepPlan& plan, hipStream_t st, bool presorted) {
     const RowSet rs{K, k0, nks, ngenomes * nks};
     if (rs.nrows <= 0) return;
     const size_t tile = (size_t)1 << (plan.log2m - plan.nb_log2);
     const unsigned blocks = (unsigned)((rs.nrows + 7) / 8) * 8u << plan.nb_log2;
-    if (plan.nb_log2 >= 1) {  // several tiles per row: sort every chunk by tile first
+    if (plan.nb_log2 >= 1 && !presorted) {  // several tiles per row: sort every chunk by tile first (the first epoch's scatter did it itself)
         const int wgs_per_row = 32;
         hipLaunchKernelGGL(sort_chunks_kernel, dim3((unsigned)rs.nrows * wgs_per_row), dim3(256), 0, st, rows, rs, plan.log2m,
                            plan.nb_log2, plan.cap_chunks, wgs_per_row);

@@ -91,6 +91,7 @@ BUCKET_KNOBS = {
     "no_row_probe": {"DD_BUCKET_PROBE": "0", "DD_BUCKET_E0": "1"},    # group filter only (no second-level check against the row)
     "no_xcd_order": {"DD_NO_XCD_AFFINITY": "1", "DD_BUCKET_E0": "1"},
     "cas_path": {"DD_NO_BUCKETS": "1"},                               # round 1's filtered compare-and-swap path, kept for A/B
+    "exact_sets": {"DD_BIGMAP_ANY_SIZE": "1"},                        # k = 10, 11 as exact k-mer sets whatever the genome size
 }
 
 
@@ -155,12 +156,13 @@ def test_log2m17_both_register_modes(engine_factory, orc, monkeypatch):
 
 @pytest.mark.parametrize("canon", [True, False])
 @pytest.mark.parametrize("p", [19, 20])
-def test_big_bitmap_class(engine_factory, torch_cuda, orc, canon, p):
+def test_big_bitmap_class(engine_factory, torch_cuda, orc, canon, p, monkeypatch):
     """log2m >= 19: k = 10 (and 11 at log2m 20) are recorded as exact k-mer sets (128 KiB LDS slices; the odd-k
     middle-base index in canonical mode, four slices for k = 11 otherwise) and hashed once afterwards.  Batched
     unequal genomes -- one empty, one shorter than k, one with N runs and lower case, one spanning several jobs --
     over k 9..12, i.e. with the small-k class below and the hashed class above in the same call."""
     torch = torch_cuda
+    monkeypatch.setenv("DD_BIGMAP_ANY_SIZE", "1")   # (the class is only planned for genomes of tens of Mbp otherwise)
     eng = engine_factory(p, canon)
     fas = [orc.synth_fasta(SEED, 0, 1_300_000, 3), np.zeros(0, np.uint8), np.frombuffer(b">s\nACGTACGTA\n", dtype=np.uint8),
            np.concatenate([np.frombuffer(RAGGED["lower_and_n"] + RAGGED["short_records"], dtype=np.uint8), orc.synth_fasta(SEED, 5, 70_000, 2)]),

@@ -44,6 +44,7 @@ def check(log2m, sizes, kmin, kmax):
             # log2m >= 19, bucket mode: k = 10 (and 11 at log2m 20) recorded exactly, one 2^20-bit slice of the
             # index space per job; every slice of a k must see every tile once
             assert log2m >= 19 and k0 <= (11 if log2m >= 20 else 10) and nk == 1 and mode == 0
+            assert sum(sizes) // len(sizes) >= (1 << max(0, log2m - 17)) * 4 ** k0 or os.environ.get("DD_BIGMAP_ANY_SIZE")
             assert j["lds_bytes"] == 128 * 1024 and 0 <= j["slice"] < (2 if k0 == 11 else 1)
             if j["slice"] > 0:
                 extra_slices.setdefault((g, k0, int(j["slice"])), np.zeros(ntiles[g], dtype=np.int32))[j["tile_begin"]:j["tile_end"]] += 1
@@ -73,7 +74,12 @@ def check(log2m, sizes, kmin, kmax):
             c = extra_slices.get((g, k, sl))
             assert c is not None and c.min() == 1 and c.max() == 1, f"genome {g} k {k} slice {sl}"
     if log2m >= 19 and not any(os.environ.get(v) for v in ("DD_NO_BUCKETS", "DD_NO_FILTER", "DD_NO_BITMAP", "DD_NO_BIGMAP")):
-        want = {k for k in range(max(kmin, 10), min(kmax, 11 if log2m >= 20 else 10) + 1)} if any(ntiles) else set()
+        # ... for genomes with several times more tokens than the set can have members (the finish kernel hashes the
+        # whole set once per 128 KiB index tile): on average >= tiles x 4^k bytes
+        last, avg, tiles = (11 if log2m >= 20 else 10), sum(sizes) // max(1, len(sizes)), 1 << max(0, log2m - 17)
+        while last >= 10 and avg < tiles * 4 ** last and not os.environ.get("DD_BIGMAP_ANY_SIZE"):
+            last -= 1
+        want = {k for k in range(max(kmin, 10), min(kmax, last) + 1)} if any(ntiles) else set()
         assert {int(k) for k in big["kfirst"]} == want
     return jobs
 
@@ -143,3 +149,17 @@ def test_knobs_change_the_plan_not_the_coverage(monkeypatch):
             assert all(c.size == 0 or (c.min() == 1 and c.max() == 1) for c in cover), env
         for k in env:
             monkeypatch.delenv(k)
+
+
+def test_exact_set_class_is_planned_by_genome_size(monkeypatch):
+    """log2m 20: k = 10, 11 go to the exact-set class for 50 Mbp genomes, only k = 10 for 10 Mbp ones, neither for
+    5 Mbp ones (the set's finish kernel would hash more k-mers than the genome has tokens); DD_BIGMAP_ANY_SIZE forces it."""
+    def big_ks(sizes, log2m=20):
+        jobs = check(log2m, sizes, 4, 40)
+        return sorted({int(k) for k in jobs[jobs["kclass"] == -2]["kfirst"]})
+    assert big_ks([50_600_000] * 10) == [10, 11]
+    assert big_ks([10_000_000] * 10) == [10]
+    assert big_ks([5_000_000] * 64) == []
+    assert big_ks([50_600_000] * 10, 19) == [10] and big_ks([3_000_000] * 4, 19) == []
+    monkeypatch.setenv("DD_BIGMAP_ANY_SIZE", "1")
+    assert big_ks([5_000_000] * 64) == [10, 11] and big_ks([70_000, 0, 5], 19) == [10]
