@@ -785,12 +785,28 @@ __global__ __launch_bounds__(1024) void bitmap_finish_kernel(const SweepGenome* 
     const SweepGenome g = genomes[blockIdx.y];
     const int k = kfirst + (int)blockIdx.x;
     const uint32_t tile = 1u << tile_log2, b = blockIdx.z;
+    const uint32_t* bm = g.bitmap + c_bitmap_off[k];
+    const int nw = c_bitmap_off[k + 1] - c_bitmap_off[k];
+    if (gridDim.z > 1 && nw <= 512) {
+        // k <= 7 in a row of several tiles: at most 8256 k-mers for a row of 2^17 .. 2^20 registers that the call
+        // zeroed when it started -- ONE workgroup raises the few registers in place instead of 16 writing tiles of
+        // zeros (64 genomes at log2m 20: 4096 of the launch's 6144 workgroups)
+        if (b != 0) return;
+        uint8_t* const row = g.regs + ((size_t)(k - kmin) << p);
+        for (int w = threadIdx.x; w < nw; w += blockDim.x) {
+            uint32_t v = gload4(bm + w);
+            while (v) {
+                const uint32_t bit = (uint32_t)__builtin_ctz(v);
+                v &= v - 1;
+                hll_update(RegsGlobal{row}, wang64_fast<true>(((uint32_t)w << 5) | bit), p);
+            }
+        }
+        return;
+    }
     uint8_t* const out = g.regs + ((size_t)(k - kmin) << p) + (size_t)b * tile;
     uint4* z = reinterpret_cast<uint4*>(g_lds);
     for (uint32_t i = threadIdx.x; i < (tile >> 4); i += blockDim.x) z[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    const uint32_t* bm = g.bitmap + c_bitmap_off[k];
-    const int nw = c_bitmap_off[k + 1] - c_bitmap_off[k];
     for (int w = threadIdx.x; w < nw; w += blockDim.x) {
         uint32_t v = gload4(bm + w);
         while (v) {

@@ -120,6 +120,9 @@ def test_bucket_mode_epochs(monkeypatch):
             real = jobs[(jobs["tile_end"] > jobs["tile_begin"]) & (jobs["kclass"] >= 0)]
             if "DD_NO_BUCKETS" not in env and "DD_BUCKET_GB" not in env:
                 e0 = int(env.get("DD_BUCKET_E0", max(8, 4 * (1 << log2m) // TILE)))
+                ntiles = [(n + TILE - 1) // TILE for n in SIZES["ragged"]]
+                if "DD_BUCKET_E0" not in env and max(ntiles) <= e0 + e0 // 4:
+                    e0 = max(e0, max(ntiles))   # genomes barely longer than the first epoch: one epoch
                 emax = max(e0, int(env.get("DD_BUCKET_EMAX", 256)))
                 edges = [0, e0]
                 while edges[-1] < 1000:
