@@ -979,7 +979,7 @@ struct Scatter {
     uint32_t* cursor;      // records reserved so far (may run past the capacity: readers clamp)
     uint32_t* fill;        // first epoch, chunks sorted on the way out: non-null records per chunk ...
     uint16_t* seg;         // ... and where each index tile's segment starts (as sort_chunks_kernel leaves them)
-    int tshift, nb;        // index tile of a record = idx >> tshift; tiles per row
+    int tshift, nb, nb_log2;  // index tile of a record = idx >> tshift; tiles per row
     uint8_t* regs;         // the row itself: where records go when the stream is full
     uint32_t cap_chunks;
     uint32_t unit;         // records a wave reserves at a time (a multiple of 64)
@@ -1019,7 +1019,7 @@ DD_D void scatter_block(const Scatter& s, uint32_t rec, uint32_t& cur, uint32_t&
     }
     gstore4(s.area + pos + lane, rec);
 }
-// First epoch, rows of several index tiles: the wave collects its records in LDS (4 KiB at `s.queue`, 64 bytes of
+// First epoch, rows of several index tiles: the wave collects its records in LDS (4 KiB at `s.queue`, 256 bytes of
 // counters behind it) and sends every 1024 of them out as one chunk ALREADY sorted by index tile, segment table
 // and record count included -- what sort_chunks_kernel would otherwise do in a pass of its own that reads and
 // writes every record once more (the first epoch holds 60 % of a 10 x 50 Mbp call's records at log2m 20 and
@@ -1046,35 +1046,40 @@ DD_D void scatter_flush_sorted(const Scatter& s, uint32_t& n) {
     }
     // (two passes over the collection area, a record in flight at a time: holding all 16 of a lane in registers,
     // as sort_chunks_kernel does, costs this kernel its second workgroup per CU)
-    const uint32_t hist = s.queue + kChunkRecords * 4u;  // 16 counters
+    // 16 counters = (tile, copy): with fewer than 16 tiles per row a lane counts in copy `lane % (16 / tiles)`, so the
+    // 64 lanes of an LDS atomic always spread over 16 addresses (same-address lanes are served one after the other:
+    // 4 tiles = 4 addresses cost 64 x 5 Mbp at log2m 18 6 %; 64 addresses, tried at log2m 20, were SLOWER than 16)
+    const uint32_t hist = s.queue + kChunkRecords * 4u;
+    const int cshift = 4 - s.nb_log2;  // log2 copies
+    const uint32_t copy = lane & ((1u << cshift) - 1u);
     if (lane < 16) lds32(hist + 4u * lane) = 0;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
         const uint32_t e = record(i);
-        if (e >> 24) atomicAdd(&lds32(hist + 4u * ((e & 0xFFFFFFu) >> s.tshift)), 1u);
+        if (e >> 24) atomicAdd(&lds32(hist + 4u * ((((e & 0xFFFFFFu) >> s.tshift) << cshift) | copy)), 1u);
     }
     __builtin_amdgcn_wave_barrier();
-    const uint32_t mine = lane < (uint32_t)s.nb ? lds32(hist + 4u * lane) : 0u;
+    const uint32_t mine = lane < 16 ? lds32(hist + 4u * lane) : 0u;  // entry `lane` = (tile lane >> cshift, copy)
     uint32_t incl = mine;
 #pragma unroll
     for (int d = 1; d < 16; d <<= 1) {
         const uint32_t up = __shfl_up(incl, d);
         if (lane >= (uint32_t)d) incl += up;
     }
-    const uint32_t total = __shfl(incl, s.nb - 1);
+    const uint32_t total = __shfl(incl, 15);
     const uint32_t chunk = pos / kChunkRecords;
     __builtin_amdgcn_wave_barrier();
-    if (lane < (uint32_t)s.nb) {
+    if (lane < 16) {
         lds32(hist + 4u * lane) = incl - mine;
-        ((DD_GLOBAL uint16_t*)s.seg)[(size_t)chunk * 16u + lane] = (uint16_t)(incl - mine);
+        if (copy == 0u) ((DD_GLOBAL uint16_t*)s.seg)[(size_t)chunk * 16u + (lane >> cshift)] = (uint16_t)(incl - mine);
     }
     __builtin_amdgcn_wave_barrier();
     // the chunk's 4 KiB are written by this wave within a few hundred cycles: the 4-byte stores meet in the L2
 #pragma unroll 4
     for (int i = 0; i < 16; ++i) {
         const uint32_t e = record(i);
-        if (e >> 24) gstore4(s.area + pos + atomicAdd(&lds32(hist + 4u * ((e & 0xFFFFFFu) >> s.tshift)), 1u), e);
+        if (e >> 24) gstore4(s.area + pos + atomicAdd(&lds32(hist + 4u * ((((e & 0xFFFFFFu) >> s.tshift) << cshift) | copy)), 1u), e);
     }
     if (lane == 0) gstore4(s.fill + chunk, total);
     __builtin_amdgcn_wave_barrier();
@@ -1196,11 +1201,12 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
         }
         s[j].fbase = (uint32_t)j * nflt;
         s[j].queue = (uint32_t)NK * nflt + ((threadIdx.x >> 6) * NK + j) * (kQueueEntries * 4u * (PROBE ? 2u : 1u));
-        if (FIRST) s[j].queue = (threadIdx.x >> 6) * (kChunkRecords * 4u + 64u);  // (sorted chunks: the wave's collection area + 16 counters)
+        if (FIRST) s[j].queue = (threadIdx.x >> 6) * (kChunkRecords * 4u + 256u);  // (sorted chunks: the wave's collection area + 64 counters)
         s[j].fill = row.fill;
         s[j].seg = row.seg;
         s[j].tshift = p - sp.nb_log2;
         s[j].nb = 1 << sp.nb_log2;
+        s[j].nb_log2 = sp.nb_log2;
         s[j].area = row.area;
         s[j].cursor = row.cursor;
         s[j].regs = row.regs;
@@ -1557,7 +1563,7 @@ void launch_scatter(const SweepGenome* genomes, const SweepJob* jobs, int njobs,
     if (njobs <= 0) return;
     if (first_epoch) {
         // every register of the call is still zero: the unfiltered form (no filter, no queues; rows of several index
-        // tiles get their chunks sorted on the way out: 4 KiB + 64 B of LDS per wave)
+        // tiles get their chunks sorted on the way out: 4 KiB + 256 B of LDS per wave)
 #define DD_FIRST(KC, CN)                                                                                                           \
     do {                                                                                                                           \
         if (sp.presorted) {                                                                                                        \
@@ -1565,7 +1571,7 @@ void launch_scatter(const SweepGenome* genomes, const SweepJob* jobs, int njobs,
             static std::atomic<unsigned long long> attr_done{0};                                                                   \
             allow_full_lds(reinterpret_cast<const void*>(kern), attr_done);                                                        \
             hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3((unsigned)plan.threads),                                          \
-                               (size_t)(plan.threads / 64) * (kChunkRecords * 4 + 64), st, genomes, jobs, plan.log2m, sp);         \
+                               (size_t)(plan.threads / 64) * (kChunkRecords * 4 + 256), st, genomes, jobs, plan.log2m, sp);         \
         } else {                                                                                                                   \
             hipLaunchKernelGGL((scatter_kernel<KC, CN, false, false, 1, true>), dim3((unsigned)njobs), dim3((unsigned)plan.threads), 0, \
                                st, genomes, jobs, plan.log2m, sp);                                                                 \
