@@ -598,7 +598,8 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     if (bplan) {
         // epoch by epoch: scatter launches of every k class (independent rows: side by side on side streams, so the
         // tail of one overlaps the body of another), then one sort + replay over all rows
-        static const unsigned unit = [] { const char* e = getenv("DD_BUCKET_UNIT"); return e ? (unsigned)std::max(1, atoi(e)) * 64u : 256u; }();
+        const char* unit_env = getenv("DD_BUCKET_UNIT");
+        const unsigned unit = unit_env ? (unsigned)std::max(1, std::min(16, atoi(unit_env))) * 64u : 256u;
         const int presorted = bplan->nb_log2 >= 1 && !getenv("DD_NO_PRESORT") ? 1 : 0;
         const dd::ScatterParams sp{rows_dev, K, bplan->logg, bplan->cap_chunks, unit, bplan->nb_log2, presorted};
         if (side_b && !c->side_ready) {
