@@ -1127,8 +1127,12 @@ DD_D void scatter_update(const Scatter& s, uint32_t& waiting, uint32_t& waiting2
     }
     uint32_t bound;
     if (NIB) {
-        const uint32_t e = q.hi >> s.fshift;
-        bound = (g_lds[s.fbase + (e >> 1)] >> ((e & 1u) * 4u)) & 15u;
+        // entry e = hi >> fshift sits in nibble e & 1 of byte e >> 1: address and nibble shift straight from hi (three
+        // instructions instead of five; fshift >= 32 - 20 + 1).  The byte is read at its absolute LDS address: this
+        // kernel has no static LDS, so the dynamic array starts at 0 (checked when the job starts), and going through
+        // the g_lds symbol costs a v_add of its link-time address, 0, on every update.
+        const uint32_t at = s.fbase + (q.hi >> (s.fshift + 1));
+        bound = __builtin_amdgcn_ubfe((uint32_t)*(const __attribute__((address_space(3))) uint8_t*)(uintptr_t)at, (q.hi >> (s.fshift - 2)) & 4u, 4u);
     } else {
         bound = g_lds[s.fbase + (q.hi >> s.fshift)];
     }
@@ -1158,6 +1162,7 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
                                                       const SweepJob* __restrict__ jobs, int p, ScatterParams sp) {
     const SweepJob job = jobs[blockIdx.x];
     if (job.tile_begin >= job.tile_end) return;  // filler of the XCD-affine order
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)g_lds != 0u) __builtin_trap();  // scatter_update reads the filter at absolute LDS addresses
     const SweepGenome g = genomes[job.genome];
     const int k = job.kfirst;
     const bool two = NK == 2 && job.nk == 2;
@@ -1199,7 +1204,7 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
             uint4* f4 = reinterpret_cast<uint4*>(g_lds + (uint32_t)j * nflt);
             for (uint32_t i = threadIdx.x; i < (nflt >> 4); i += blockDim.x) f4[i] = gload16(row.filter + (size_t)i * 16);
         }
-        s[j].fbase = (uint32_t)j * nflt;
+        s[j].fbase = NK == 1 ? 0u : (uint32_t)j * nflt;
         s[j].queue = (uint32_t)NK * nflt + ((threadIdx.x >> 6) * NK + j) * (kQueueEntries * 4u * (PROBE ? 2u : 1u));
         if (FIRST) s[j].queue = (threadIdx.x >> 6) * (kChunkRecords * 4u + 256u);  // (sorted chunks: the wave's collection area + 64 counters)
         s[j].fill = row.fill;
