@@ -71,6 +71,11 @@ DD_D uint64_t wang64_fast(uint64_t x) {
 }
 
 // ---- register stores -------------------------------------------------------------------------
+// kernels that address LDS absolutely (RegsLds, scatter_update's filter read) call this first
+DD_D void lds_starts_at_zero() {
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)g_lds != 0u) __builtin_trap();
+}
+
 // LDS: byte registers, 32-bit compare-and-swap on the containing word when a register must rise.
 struct RegsLds {
     uint32_t slot;  // the slot's registers start at byte slot << p of g_lds
@@ -78,8 +83,12 @@ struct RegsLds {
     // address of register  hi >> (32-p)  (the top p bits of the hash): one v_alignbit of slot:hi
     DD_D Addr at(uint32_t hi, int p) const { return __builtin_amdgcn_alignbit(slot, hi, 32 - p); }
     DD_D static uint32_t shift(Addr a) { return (a & 3u) * 8u; }
-    DD_D uint32_t bound(Addr a) const { return g_lds[a]; }  // the register itself
-    DD_D static uint32_t load32(Addr a) { return *reinterpret_cast<const uint32_t*>(g_lds + (a & ~3u)); }
+    // Registers are read at their ABSOLUTE LDS address: every kernel that uses this struct has no static LDS, so the
+    // dynamic array g_lds starts at 0 (lds_starts_at_zero() at the top of each checks it), and indexing through the
+    // g_lds symbol would cost a `v_add_u32 v, 0, v` of its link-time address on every read -- 1.5 of the 31.5 VALU
+    // instructions of a k 17..32 update at log2m <= 16.
+    DD_D uint32_t bound(Addr a) const { return *(const __attribute__((address_space(3))) uint8_t*)(uintptr_t)a; }  // the register itself
+    DD_D static uint32_t load32(Addr a) { return *(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(a & ~3u); }
     DD_D static uint32_t cas32(Addr a, uint32_t expect, uint32_t desired) {
         return atomicCAS(reinterpret_cast<uint32_t*>(g_lds + (a & ~3u)), expect, desired);
     }
@@ -486,6 +495,7 @@ DD_D void sweep_token(const Windows<KC>& win, int run, int kfirst, int nk, int p
 template <int KC, bool CANON, int MODE>
 __global__ __launch_bounds__(1024) void sweep_kernel(const SweepGenome* __restrict__ genomes,
                                                     const SweepJob* __restrict__ jobs, int p) {
+    lds_starts_at_zero();
     const SweepJob job = jobs[blockIdx.x];
     const SweepGenome g = genomes[job.genome];
     const int nk = job.nk, kfirst = job.kfirst;
@@ -782,6 +792,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_sgpr(72))) void bit
 template <bool CANON_UNUSED>
 __global__ __launch_bounds__(1024) void bitmap_finish_kernel(const SweepGenome* __restrict__ genomes,
                                                             int kfirst, int kmin, int p, int tile_log2) {
+    lds_starts_at_zero();
     const SweepGenome g = genomes[blockIdx.y];
     const int k = kfirst + (int)blockIdx.x;
     const uint32_t tile = 1u << tile_log2, b = blockIdx.z;
@@ -926,6 +937,7 @@ __global__ __launch_bounds__(1024) void bigmap_kernel(const SweepGenome* __restr
 template <bool CANON>
 __global__ __launch_bounds__(1024) void bigmap_finish_kernel(const SweepGenome* __restrict__ genomes,
                                                             int kfirst, int kmin, int p, int tile_log2) {
+    lds_starts_at_zero();
     const SweepGenome g = genomes[blockIdx.y];
     const int k = kfirst + (int)blockIdx.x;
     const uint32_t tile = 1u << tile_log2, b = blockIdx.z;
@@ -1162,7 +1174,7 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
                                                       const SweepJob* __restrict__ jobs, int p, ScatterParams sp) {
     const SweepJob job = jobs[blockIdx.x];
     if (job.tile_begin >= job.tile_end) return;  // filler of the XCD-affine order
-    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)g_lds != 0u) __builtin_trap();  // scatter_update reads the filter at absolute LDS addresses
+    lds_starts_at_zero();  // scatter_update reads the filter at absolute LDS addresses
     const SweepGenome g = genomes[job.genome];
     const int k = job.kfirst;
     const bool two = NK == 2 && job.nk == 2;
@@ -1347,6 +1359,7 @@ __global__ __launch_bounds__(256) void sort_chunks_kernel(const BucketRow* __res
 // and the LDS work of three consecutive steps overlap.
 __global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restrict__ rows, RowSet rs, int p, int logg,
                                                      int nb_log2, uint32_t cap_chunks, int fbits) {
+    lds_starts_at_zero();
     const uint32_t nb = 1u << nb_log2;
     const uint32_t within = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
     const uint32_t r = (within >> nb_log2) * 8u + xcd, b = within & (nb - 1u);
