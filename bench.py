@@ -44,7 +44,7 @@ sys.path.insert(0, ROOT)
 SEED = 0xD4ADD
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 VALU_PEAK_LANEOPS = 78.6e12    # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
-VALU_PROFILE = "profiles/r01_v6_pmc.txt (K1 v6; the k <= 48 hashed classes are unchanged since)"
+VALU_PROFILE = "profiles/r02_v9_pmc_p14.txt (bash scripts/pmc_p14.sh: SQ_INSTS_VALU per (wave, token, k) of each K1 class, end of round 2)"
 
 CONFIGS = {
     # name: genomes (total or per GPU), Mbp, nrec, kmin, kmax, sharded over ranks?, extra schedule
@@ -160,7 +160,7 @@ def valu_bound(kmin, kmax, updates_per_s):
     (VALU_PROFILE) per k class (k 49..64: estimated from the 33..48 class plus its 9 extra instructions); a wave64
     instruction occupies a SIMD-32 for 2 cycles at best, so the chip retires at most 256 CU x 4 SIMD x 2.4 GHz / 2
     wave instructions per second (= 78.6 T lane-ops/s)."""
-    per_class = [(1, 9, 11.2), (10, 16, 30.0), (17, 32, 33.9), (33, 48, 43.4), (49, 64, 52.0)]
+    per_class = [(1, 9, 2.5), (10, 16, 29.2), (17, 32, 32.9), (33, 48, 42.9), (49, 64, 51.5)]
     tot = n = 0
     for lo, hi, instr in per_class:
         ks = max(0, min(hi, kmax) - max(lo, kmin) + 1)
