@@ -996,6 +996,8 @@ struct Scatter {
     uint32_t cap_chunks;
     uint32_t unit;         // records a wave reserves at a time (a multiple of 64)
     int fshift;            // hash high word >> fshift = index of the register group's filter entry (32 - p + logg)
+    int ishift;            // hash high word >> ishift = register index (32 - p)
+    uint32_t himask;       // the index bits of the hash high word
     uint32_t fbase;        // byte offset in g_lds of this k's filter
 };
 DD_D uint32_t& lds32(uint32_t off) { return *reinterpret_cast<uint32_t*>(g_lds + off); }
@@ -1102,14 +1104,18 @@ DD_D void scatter_flush_sorted(const Scatter& s, uint32_t& n) {
 // queue and, 64 at a time, to the stream.  The group-minimum filter lets ~25 % of the updates through at log2m
 // 20; about 10 % really raise a register.  Exact either way: a register only rises, so its last stored value is
 // a lower bound.
-DD_D void scatter_probe(const Scatter& s, uint32_t rec, uint32_t& waiting2, uint32_t& cur, uint32_t& left) {
-    bool live = (rec >> 24) != 0u;
-    if (live) live = (rec >> 24) > (uint32_t)*(const DD_GLOBAL uint8_t*)(s.regs + (rec & 0xFFFFFFu));
+// Candidates wait in the first queue as the hash word's index bits with rho - 1 in the low byte (one v_and_or when
+// they are queued -- that code runs on nearly every update of the wave; 0xFF = no candidate); what survives the
+// probe is put into record form, idx | rho << 24, here, once per 64 candidates.
+DD_D void scatter_probe(const Scatter& s, uint32_t cand, uint32_t& waiting2, uint32_t& cur, uint32_t& left) {
+    const uint32_t rm1 = cand & 0xFFu, idx = cand >> s.ishift;
+    bool live = rm1 != 0xFFu;
+    if (live) live = rm1 >= (uint32_t)*(const DD_GLOBAL uint8_t*)(s.regs + idx);  // rho > register
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
     if (mask) {
         if (live) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            lds32(s.queue + kQueueEntries * 4u + 4u * (waiting2 + rank)) = rec;
+            lds32(s.queue + kQueueEntries * 4u + 4u * (waiting2 + rank)) = idx | ((rm1 + 1u) << 24);
         }
         waiting2 += (uint32_t)__builtin_popcountll(mask);
         if (waiting2 >= 64u) {
@@ -1153,7 +1159,8 @@ DD_D void scatter_update(const Scatter& s, uint32_t& waiting, uint32_t& waiting2
     if (mask) {
         if (cand) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            lds32(s.queue + 4u * (waiting + rank)) = (q.hi >> (32 - p)) | (rho_of(q, p) << 24);
+            lds32(s.queue + 4u * (waiting + rank)) = PROBE ? (q.hi & s.himask) | (rho_of(q, p) - 1u)  // (scatter_probe's form)
+                                                           : (q.hi >> (32 - p)) | (rho_of(q, p) << 24);
         }
         waiting += (uint32_t)__builtin_popcountll(mask);
         if (waiting >= 64u) {
@@ -1229,6 +1236,8 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
         s[j].regs = row.regs;
         s[j].cap_chunks = sp.cap_chunks;
         s[j].fshift = 32 - p + sp.logg;
+        s[j].ishift = 32 - p;
+        s[j].himask = ~((1u << (32 - p)) - 1u);
         waiting[j] = waiting2[j] = cur[j] = left[j] = 0;
         s[j].unit = sp.unit;
     }
@@ -1280,7 +1289,7 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
         if (FIRST) {
             if (NIB && cur[j]) scatter_flush_sorted(s[j], cur[j]);
         } else if (PROBE) {
-            if (waiting[j]) scatter_probe(s[j], lane < waiting[j] ? lds32(s[j].queue + 4u * lane) : 0u, waiting2[j], cur[j], left[j]);
+            if (waiting[j]) scatter_probe(s[j], lane < waiting[j] ? lds32(s[j].queue + 4u * lane) : 0xFFu, waiting2[j], cur[j], left[j]);
             if (waiting2[j]) scatter_block<false>(s[j], lane < waiting2[j] ? lds32(s[j].queue + kQueueEntries * 4u + 4u * lane) : 0u, cur[j], left[j]);
         } else if (waiting[j]) {
             scatter_block<false>(s[j], lane < waiting[j] ? lds32(s[j].queue + 4u * lane) : 0u, cur[j], left[j]);
