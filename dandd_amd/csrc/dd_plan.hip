@@ -134,6 +134,9 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
         if (!knobs.bucket_e0_tiles && max_tiles <= e0 + e0 / 4) e0 = std::max<size_t>(e0, max_tiles);
         size_t emax = knobs.bucket_emax_tiles;
         bucket_row_tokens = knobs.bucket_budget / (std::max<size_t>(1, nrows) * 9 / 2);  // 4 B per record + slack
+        // (so many rows that the budget cannot hold four tokens per register of each: a shorter first epoch rather
+        // than one whose records overflow into the compare-and-swap path)
+        if (!knobs.bucket_e0_tiles) e0 = std::max<size_t>(1, std::min(e0, bucket_row_tokens / kTileTokens));
         if (!emax) emax = std::min<size_t>(256, bucket_row_tokens / kTileTokens);
         emax = std::max(emax, e0);
         epoch_edge.push_back(0);
@@ -229,7 +232,13 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
             // the capacity are not lost: they go straight to the row by compare-and-swap (dd_sweep.hip).
             // (a call with so many rows that even the first epoch's worst case exceeds the budget gets what
             // the budget allows; the overflow path keeps it exact)
-            const size_t per_row = std::min(epoch_longest * kTileTokens, bucket_row_tokens);
+            // Capacity of a row's stream.  Only the first epoch turns every token into a record; a later epoch that
+            // starts after s tokens and is L long leaves about m L / s of them (m or fewer with the doubling schedule),
+            // so four records per register cover it several times over -- and what should still not fit goes to the
+            // registers by compare-and-swap, exactly.  (Sized for the longest epoch's every token the areas of a
+            // 10 x 50 Mbp call at log2m 20 were 20 GB; 5.4 GB measure the same 26.8 ms.)
+            const size_t first_tokens = (epoch_edge[1] - epoch_edge[0]) * kTileTokens;
+            const size_t per_row = std::min(std::max(first_tokens, 4 * m), bucket_row_tokens);
             sc.plan.cap_chunks = (unsigned)(knobs.bucket_cap_chunks ? knobs.bucket_cap_chunks
                                                 : per_row / 1024 + max_jobs_row_epoch * (kThreads / 64) + 16);
             sc.plan.logg = bucket_logg;
