@@ -114,18 +114,21 @@ void launch_sweep(const SweepGenome* genomes_dev, const SweepJob* jobs_dev, int 
                   const SweepPlan& plan, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------
-// K1 for log2m >= 18 (one register array no longer fits LDS; DandD's default is -r 20,
-// /root/reference/lib/dandd_cmd.py:187): two phases per EPOCH (a range of token tiles).
+// K1 for log2m >= 17 (one register array does not fit LDS twice per CU, or at all; DandD's default is -r 20,
+// /root/reference/lib/dandd_cmd.py:187): three kernels per EPOCH (a range of token tiles).
 //   scatter: hash every k-mer of the epoch; an update whose rho cannot exceed the filter's lower bound
-//            for its register group is dropped, the others are appended as 4-byte records
-//            (idx | rho << 24) to the ROW's record stream: queued per wave in LDS, stored 64 at a time as
-//            one 256-byte block into a wave-private 1024-record chunk (one global atomic per chunk).
-//   sort   : every 1024-record chunk is sorted by index tile in place (HBM-bound streaming pass).
+//            for its register group is dropped, the others are queued per wave in LDS, checked 64 at a time
+//            against the row itself, and what survives leaves as 4-byte records (idx | rho << 24), one 256-byte
+//            block at a time, for the ROW's record stream -- a dense stream: waves reserve 256 records per atomic
+//            add on the row's cursor.  The first epoch (registers all zero) has no filter and no queues: its waves
+//            collect 1024 records and store them as a chunk already sorted by index tile.
+//   sort   : every 1024-record chunk is sorted by index tile in place (HBM-bound streaming pass; not needed
+//            after the first epoch).
 //   replay : one workgroup per (row, 64 KiB index tile): tile into LDS, apply the tile's segment of every
 //            chunk with LDS operations, store the tile back with plain 16-byte stores and refresh the
 //            tile's filter.
 // The filter of epoch e is exact knowledge of the registers after epoch e-1, so what scatter drops can
-// never matter; epochs double in length (one token per register first), because bounds rise fast early.
+// never matter; the first epoch is four tokens per register long, each later one as long as all before it.
 // ---------------------------------------------------------------------------------------
 struct BucketRow {              // one per (genome, k) row of the call: table[genome * K + (k - kmin)]
     uint8_t* regs;              // the row's m registers in the caller's slab

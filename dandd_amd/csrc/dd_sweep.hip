@@ -965,7 +965,7 @@ __global__ __launch_bounds__(1024) void bigmap_finish_kernel(const SweepGenome* 
     for (uint32_t i = threadIdx.x; i < (tile >> 4); i += blockDim.x) gstore16(out + (size_t)i * 16, l4[i]);
 }
 
-// ---- log2m >= 18, bucket mode: scatter + replay (dd_kernels.h) --------------------------------------
+// ---- log2m >= 17, bucket mode: scatter + sort + replay (dd_kernels.h) -------------------------------
 // The compare-and-swap path above is bound by the device's scattered-atomic rate (27 G/s measured, any
 // atomic, any footprint: profiles/r01_ubench_atomics.txt).  Two earlier forms of this path were measured
 // (profiles/r02_bucket_path.txt): records stored one by one to per-index-tile chunks ran into the same
@@ -974,9 +974,8 @@ __global__ __launch_bounds__(1024) void bigmap_finish_kernel(const SweepGenome* 
 // cost 30 VALU + 30 SALU per wave-update for the staging -- the kernel is issue-bound, so that doubled it.
 // Hence: scatter does NO partitioning.  A wave appends its surviving records to one LDS queue (ballot +
 // mbcnt + one ds_write) and, whenever 64 wait, stores them as one 256-byte block to the ROW's record
-// stream; the eight replay workgroups of a row (one per 128 KiB index tile) all read that stream -- they
-// run side by side on one XCD, so the stream comes from HBM once and from that XCD's L2 seven times --
-// and each applies only the records of its own tile.
+// stream; the chunks of the stream are sorted by index tile afterwards (sort_chunks_kernel, or the first epoch's
+// scatter itself), and the replay workgroups of a row (one per 64 KiB index tile) read only their own segments.
 // The rows a sort / replay / reset launch covers: rows k0 .. k0+nks-1 of every genome (one k class), numbered
 // densely; table index = genome * K + k0 + local % nks.
 struct RowSet {
