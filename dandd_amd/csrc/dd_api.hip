@@ -923,6 +923,11 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
             // as many as a batch wants and are already loaded (at least one): the GPU is never kept waiting for a
             // full batch; equal batches also let dd_sketch_device reuse its job tables and the buffers below
             while (count < batch_files && i + count < nfiles && slots[i + count].done) ++count;
+            // (a directory of small files: batch sizes come from a short list -- powers of two, the full batch, the
+            // tail -- so that the job tables of every shape are in the plan cache from the second call on; planning
+            // a shape never seen costs ~2 ms of host time with the GPU waiting)
+            if (count < batch_files && i + count < nfiles)
+                while (count & (count - 1)) count &= count - 1;
         }
         t_wait += now() - ta;
         if (rc == DD_OK) {
