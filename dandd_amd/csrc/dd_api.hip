@@ -511,7 +511,8 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         const size_t tab_bytes = align_up(sizeof(dd::BucketRow) * nrows, 256);
         // one cursor per row, each in a 256-byte slot of its own: every 64-record block of a row is reserved by one
         // atomic add on it, and neighbouring rows are written from other XCDs
-        static const size_t cur_stride = [] { const char* e = getenv("DD_CURSOR_STRIDE"); return e ? (size_t)std::max(4, atoi(e)) : (size_t)256; }();
+        const char* stride_env = getenv("DD_CURSOR_STRIDE");
+        const size_t cur_stride = stride_env ? (size_t)std::max(4, atoi(stride_env)) / 4 * 4 : (size_t)256;
         const size_t cur_bytes = align_up((size_t)nrows * cur_stride, 256);
         const size_t flt_tot = align_up(nhashed * flt_bytes, 256);
         if ((rc = c->buckets.reserve(tab_bytes + cur_bytes + flt_tot + nhashed * (fill_bytes + area_bytes)))) return rc;

@@ -92,6 +92,9 @@ BUCKET_KNOBS = {
     "no_xcd_order": {"DD_NO_XCD_AFFINITY": "1", "DD_BUCKET_E0": "1"},
     "cas_path": {"DD_NO_BUCKETS": "1"},                               # round 1's filtered compare-and-swap path, kept for A/B
     "exact_sets": {"DD_BIGMAP_ANY_SIZE": "1"},                        # k = 10, 11 as exact k-mer sets whatever the genome size
+    "sort_kernel_only": {"DD_NO_PRESORT": "1", "DD_BUCKET_E0": "2"},  # first-epoch chunks sorted by sort_chunks_kernel, not by the scatter
+    "single_blocks": {"DD_BUCKET_UNIT": "1", "DD_BUCKET_E0": "1"},    # one 64-record block per reservation
+    "packed_cursors": {"DD_CURSOR_STRIDE": "4"},                      # row cursors 4 bytes apart
 }
 
 
