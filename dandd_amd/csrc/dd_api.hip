@@ -751,7 +751,10 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
     // (Batches that grow -- 64, 128, 256 MB -- were measured against fixed 128 MB ones once the job tables of several
     // batch shapes could be kept: 20.6-22.9 ms against 19.1 for 10 x 50 Mbp.  Fixed it is.)
     const size_t kBatchBytes = (size_t)(getenv("DD_BATCH_MB") ? std::max(1, atoi(getenv("DD_BATCH_MB"))) : (c->p >= 17 ? 512 : 128)) << 20;
-    const int batch_files = (int)std::max<size_t>(1, std::min<size_t>(64, kBatchBytes / avg));
+    // (at most 256 files per launch: the loaders' window is two batches of host buffers of 2 MiB at least; with 64,
+    // a thousand 100 kbp plasmids took 23 launches of ~3 ms each)
+    const size_t kMaxBatchFiles = getenv("DD_BATCH_FILES") ? (size_t)std::max(1, atoi(getenv("DD_BATCH_FILES"))) : 256;
+    const int batch_files = (int)std::max<size_t>(1, std::min<size_t>(kMaxBatchFiles, kBatchBytes / avg));
     // loaders may run two batches ahead of the GPU
     const int window = std::max(nthreads + 2, 2 * batch_files + nthreads);
     // Pinning host memory costs ~0.4 ms per MB: a buffer starts pageable (a one-shot `dandd tree` process never
