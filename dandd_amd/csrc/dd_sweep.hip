@@ -1055,6 +1055,8 @@ DD_D void scatter_flush_sorted(const Scatter& s, uint32_t& n) {
                 (void)cas_raise<RegsGlobal>(a, RegsGlobal::load32(a), e >> 24);
             }
         }
+        if (lane < 16) lds32(s.queue + kChunkRecords * 4u + 4u * lane) = 0;
+        __builtin_amdgcn_wave_barrier();
         return;
     }
     // (two passes over the collection area, a record in flight at a time: holding all 16 of a lane in registers,
@@ -1065,14 +1067,7 @@ DD_D void scatter_flush_sorted(const Scatter& s, uint32_t& n) {
     const uint32_t hist = s.queue + kChunkRecords * 4u;
     const int cshift = 4 - s.nb_log2;  // log2 copies
     const uint32_t copy = lane & ((1u << cshift) - 1u);
-    if (lane < 16) lds32(hist + 4u * lane) = 0;
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-    for (int i = 0; i < 16; ++i) {
-        const uint32_t e = record(i);
-        if (e >> 24) atomicAdd(&lds32(hist + 4u * ((((e & 0xFFFFFFu) >> s.tshift) << cshift) | copy)), 1u);
-    }
-    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_wave_barrier();  // (the counters were kept by scatter_update as the records came in)
     const uint32_t mine = lane < 16 ? lds32(hist + 4u * lane) : 0u;  // entry `lane` = (tile lane >> cshift, copy)
     uint32_t incl = mine;
 #pragma unroll
@@ -1095,6 +1090,8 @@ DD_D void scatter_flush_sorted(const Scatter& s, uint32_t& n) {
         if (e >> 24) gstore4(s.area + pos + atomicAdd(&lds32(hist + 4u * ((((e & 0xFFFFFFu) >> s.tshift) << cshift) | copy)), 1u), e);
     }
     if (lane == 0) gstore4(s.fill + chunk, total);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 16) lds32(hist + 4u * lane) = 0;  // for the next chunk's records
     __builtin_amdgcn_wave_barrier();
 }
 // Second-level filter (PROBE): 64 queued candidates are checked against the ROW ITSELF -- one byte load per
@@ -1135,6 +1132,9 @@ DD_D void scatter_update(const Scatter& s, uint32_t& waiting, uint32_t& waiting2
         const uint32_t rec = valid ? (q.hi >> (32 - p)) | (rho_of(q, p) << 24) : 0u;
         if (NIB) {  // (first-epoch kernels have no filter: the flag selects chunks sorted on the way out, `cur` = records collected)
             lds32(s.queue + 4u * (cur + (threadIdx.x & 63u))) = rec;
+            // counted here, between the hashes, rather than in a pass of the flush: the same LDS atomics, but not in one
+            // burst with every other wave of the CU doing the same, and without re-reading the records
+            if (valid) atomicAdd(&lds32(s.queue + kChunkRecords * 4u + 4u * (((q.hi >> (32 - p + s.tshift)) << (4 - s.nb_log2)) | ((threadIdx.x & 63u) & ((1u << (4 - s.nb_log2)) - 1u)))), 1u);
             cur += 64u;
             if (cur == kChunkRecords) scatter_flush_sorted(s, cur);
         } else {
@@ -1224,7 +1224,10 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
         }
         s[j].fbase = NK == 1 ? 0u : (uint32_t)j * nflt;
         s[j].queue = (uint32_t)NK * nflt + ((threadIdx.x >> 6) * NK + j) * (kQueueEntries * 4u * (PROBE ? 2u : 1u));
-        if (FIRST) s[j].queue = (threadIdx.x >> 6) * (kChunkRecords * 4u + 256u);  // (sorted chunks: the wave's collection area + 64 counters)
+        if (FIRST) {
+            s[j].queue = (threadIdx.x >> 6) * (kChunkRecords * 4u + 256u);  // (sorted chunks: the wave's collection area + counters)
+            if (NIB && (threadIdx.x & 63u) < 16u) lds32(s[j].queue + kChunkRecords * 4u + 4u * (threadIdx.x & 63u)) = 0;
+        }
         s[j].fill = row.fill;
         s[j].seg = row.seg;
         s[j].tshift = p - sp.nb_log2;
