@@ -14,7 +14,8 @@
 namespace dd {
 namespace {
 
-constexpr int HCOPIES = 16;  // privatised LDS histograms per workgroup
+constexpr int HCOPIES = 32;  // privatised LDS histograms per workgroup
+constexpr int HSTRIDE = 65;  // words per copy: 64 bins + 1, so that the same bin of different copies sits in different LDS banks
 
 DD_D uint4 bmax16(uint4 a, uint4 b) {
     return make_uint4(bmax4(a.x, b.x), bmax4(a.y, b.y), bmax4(a.z, b.z), bmax4(a.w, b.w));
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(256) void union_kernel(const uint8_t* const* __rest
 }
 
 // add the 16 register bytes of v to the workgroup's privatised histograms
-DD_D void hist_add16(uint32_t (*h)[64], uint4 v) {
+DD_D void hist_add16(uint32_t (*h)[HSTRIDE], uint4 v) {
     uint32_t* mine = h[threadIdx.x & (HCOPIES - 1)];
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -41,12 +42,12 @@ DD_D void hist_add16(uint32_t (*h)[64], uint4 v) {
     }
 }
 
-DD_D void hist_zero(uint32_t (*h)[64]) {
-    for (int i = threadIdx.x; i < HCOPIES * 64; i += blockDim.x) (&h[0][0])[i] = 0;
+DD_D void hist_zero(uint32_t (*h)[HSTRIDE]) {
+    for (int i = threadIdx.x; i < HCOPIES * HSTRIDE; i += blockDim.x) (&h[0][0])[i] = 0;
 }
 
 // fold the privatised copies and add them to a global 64-bin histogram
-DD_D void hist_flush(uint32_t (*h)[64], uint32_t* __restrict__ gh, bool exclusive) {
+DD_D void hist_flush(uint32_t (*h)[HSTRIDE], uint32_t* __restrict__ gh, bool exclusive) {
     if (threadIdx.x < 64) {
         uint32_t s = 0;
 #pragma unroll
@@ -58,42 +59,53 @@ DD_D void hist_flush(uint32_t (*h)[64], uint32_t* __restrict__ gh, bool exclusiv
     }
 }
 
-// one workgroup per (sketch, 16 KiB tile of its registers)
+// PC = 16-byte pieces per thread: a workgroup's tile is PC x 16 KiB of a row.  Rows of 64 KiB and more use PC = 4:
+// four times fewer barriers, histogram folds and (rows of several tiles add their partial histograms with global
+// atomics) global atomics per byte -- 264 M of those for the pairs of 64 sketches of 1 MiB before.
+// one workgroup per (sketch, tile of its registers)
+template <int PC>
 __global__ __launch_bounds__(1024) void hist_kernel(const uint8_t* __restrict__ regs, int p,
                                                     int tiles, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t h[HCOPIES][64];
+    __shared__ uint32_t h[HCOPIES][HSTRIDE];
     const int job = blockIdx.x / tiles, tile = blockIdx.x % tiles;
     const size_t m16 = ((size_t)1 << p) >> 4;
-    const size_t piece = (size_t)tile * blockDim.x + threadIdx.x;
+    const size_t piece = (size_t)tile * blockDim.x * PC + threadIdx.x;
     hist_zero(h);
     __syncthreads();
-    if (piece < m16) hist_add16(h, reinterpret_cast<const uint4*>(regs + ((size_t)job << p))[piece]);
+#pragma unroll
+    for (int q = 0; q < PC; ++q)
+        if (piece + (size_t)q * blockDim.x < m16)
+            hist_add16(h, reinterpret_cast<const uint4*>(regs + ((size_t)job << p))[piece + (size_t)q * blockDim.x]);
     __syncthreads();
     hist_flush(h, hist + (size_t)job * 64, tiles == 1);
 }
 
 // one workgroup per (ordering, k, tile): running max over the ordering, one histogram per prefix
+template <int PC>
 __global__ __launch_bounds__(1024) void progressive_kernel(const uint8_t* __restrict__ leaf, int n,
                                                            int K, int p, int tiles,
                                                            const int32_t* __restrict__ ord,
                                                            uint32_t* __restrict__ hist) {
-    __shared__ uint32_t h[HCOPIES][64];
+    __shared__ uint32_t h[HCOPIES][HSTRIDE];
     const int tile = blockIdx.x % tiles;
     const int kk = (blockIdx.x / tiles) % K;
     const int o = blockIdx.x / tiles / K;
     const size_t m16 = ((size_t)1 << p) >> 4;
-    const size_t piece = (size_t)tile * blockDim.x + threadIdx.x;
-    const bool live = piece < m16;
-    uint4 run = make_uint4(0, 0, 0, 0);
+    const size_t piece = (size_t)tile * blockDim.x * PC + threadIdx.x;
+    uint4 run[PC];
+#pragma unroll
+    for (int q = 0; q < PC; ++q) run[q] = make_uint4(0, 0, 0, 0);
     for (int j = 0; j < n; ++j) {
         const int gi = ord[(size_t)o * n + j];
         hist_zero(h);
         __syncthreads();
-        if (live) {
-            const uint8_t* src = leaf + (((size_t)gi * K + kk) << p);
-            run = bmax16(run, reinterpret_cast<const uint4*>(src)[piece]);
-            hist_add16(h, run);
-        }
+        const uint8_t* src = leaf + (((size_t)gi * K + kk) << p);
+#pragma unroll
+        for (int q = 0; q < PC; ++q)
+            if (piece + (size_t)q * blockDim.x < m16) {
+                run[q] = bmax16(run[q], reinterpret_cast<const uint4*>(src)[piece + (size_t)q * blockDim.x]);
+                hist_add16(h, run[q]);
+            }
         __syncthreads();
         hist_flush(h, hist + (((size_t)o * n + j) * K + kk) * 64, tiles == 1);
         __syncthreads();
@@ -101,25 +113,31 @@ __global__ __launch_bounds__(1024) void progressive_kernel(const uint8_t* __rest
 }
 
 // one workgroup per (i, k, tile): row i of the pair matrix, j = i..n-1
+template <int PC>
 __global__ __launch_bounds__(1024) void pairwise_kernel(const uint8_t* __restrict__ leaf, int n,
                                                         int K, int p, int tiles,
                                                         uint32_t* __restrict__ hist) {
-    __shared__ uint32_t h[HCOPIES][64];
+    __shared__ uint32_t h[HCOPIES][HSTRIDE];
     const int tile = blockIdx.x % tiles;
     const int kk = (blockIdx.x / tiles) % K;
     const int i = blockIdx.x / tiles / K;
     const size_t m16 = ((size_t)1 << p) >> 4;
-    const size_t piece = (size_t)tile * blockDim.x + threadIdx.x;
-    const bool live = piece < m16;
-    uint4 a = make_uint4(0, 0, 0, 0);
-    if (live) a = reinterpret_cast<const uint4*>(leaf + (((size_t)i * K + kk) << p))[piece];
+    const size_t piece = (size_t)tile * blockDim.x * PC + threadIdx.x;
+    uint4 a[PC];
+#pragma unroll
+    for (int q = 0; q < PC; ++q) {
+        a[q] = make_uint4(0, 0, 0, 0);
+        if (piece + (size_t)q * blockDim.x < m16)
+            a[q] = reinterpret_cast<const uint4*>(leaf + (((size_t)i * K + kk) << p))[piece + (size_t)q * blockDim.x];
+    }
     for (int j = i; j < n; ++j) {
         hist_zero(h);
         __syncthreads();
-        if (live) {
-            const uint8_t* src = leaf + (((size_t)j * K + kk) << p);
-            hist_add16(h, bmax16(a, reinterpret_cast<const uint4*>(src)[piece]));
-        }
+        const uint8_t* src = leaf + (((size_t)j * K + kk) << p);
+#pragma unroll
+        for (int q = 0; q < PC; ++q)
+            if (piece + (size_t)q * blockDim.x < m16)
+                hist_add16(h, bmax16(a[q], reinterpret_cast<const uint4*>(src)[piece + (size_t)q * blockDim.x]));
         __syncthreads();
         hist_flush(h, hist + (((size_t)i * n + j) * K + kk) * 64, tiles == 1);
         __syncthreads();
@@ -190,9 +208,10 @@ __global__ __launch_bounds__(256) void synth_kernel(uint64_t seed, uint64_t seed
     }
 }
 
+inline int pieces_for(int p) { return p >= 16 ? 4 : 1; }  // 16-byte pieces per thread (the kernels' PC)
 inline int tiles_for(int p) {
-    const size_t m16 = ((size_t)1 << p) >> 4;
-    return (int)((m16 + 1023) / 1024);
+    const size_t m16 = ((size_t)1 << p) >> 4, per_tile = (size_t)1024 * pieces_for(p);
+    return (int)((m16 + per_tile - 1) / per_tile);
 }
 inline int threads_for(int p) {
     const size_t m16 = ((size_t)1 << p) >> 4;
@@ -215,8 +234,10 @@ void launch_hist(const uint8_t* regs_dev, int njobs, int p, uint32_t* hist_dev, 
     if (njobs <= 0) return;
     const int tiles = tiles_for(p);
     if (tiles > 1) (void)hipMemsetAsync(hist_dev, 0, (size_t)njobs * 64 * sizeof(uint32_t), st);
-    hipLaunchKernelGGL(hist_kernel, dim3((unsigned)(njobs * tiles)), dim3(threads_for(p)), 0, st,
-                       regs_dev, p, tiles, hist_dev);
+    if (pieces_for(p) == 4)
+        hipLaunchKernelGGL(hist_kernel<4>, dim3((unsigned)(njobs * tiles)), dim3(threads_for(p)), 0, st, regs_dev, p, tiles, hist_dev);
+    else
+        hipLaunchKernelGGL(hist_kernel<1>, dim3((unsigned)(njobs * tiles)), dim3(threads_for(p)), 0, st, regs_dev, p, tiles, hist_dev);
 }
 
 void launch_progressive(const uint8_t* leaf_dev, int n, int K, int p, const int32_t* ord_dev,
@@ -224,16 +245,20 @@ void launch_progressive(const uint8_t* leaf_dev, int n, int K, int p, const int3
     if (n <= 0 || K <= 0 || norder <= 0) return;
     const int tiles = tiles_for(p);
     if (tiles > 1) (void)hipMemsetAsync(hist_dev, 0, (size_t)norder * n * K * 64 * sizeof(uint32_t), st);
-    hipLaunchKernelGGL(progressive_kernel, dim3((unsigned)(norder * K * tiles)), dim3(threads_for(p)),
-                       0, st, leaf_dev, n, K, p, tiles, ord_dev, hist_dev);
+    if (pieces_for(p) == 4)
+        hipLaunchKernelGGL(progressive_kernel<4>, dim3((unsigned)(norder * K * tiles)), dim3(threads_for(p)), 0, st, leaf_dev, n, K, p, tiles, ord_dev, hist_dev);
+    else
+        hipLaunchKernelGGL(progressive_kernel<1>, dim3((unsigned)(norder * K * tiles)), dim3(threads_for(p)), 0, st, leaf_dev, n, K, p, tiles, ord_dev, hist_dev);
 }
 
 void launch_pairwise(const uint8_t* leaf_dev, int n, int K, int p, uint32_t* hist_dev, hipStream_t st) {
     if (n <= 0 || K <= 0) return;
     const int tiles = tiles_for(p);
     (void)hipMemsetAsync(hist_dev, 0, (size_t)n * n * K * 64 * sizeof(uint32_t), st);
-    hipLaunchKernelGGL(pairwise_kernel, dim3((unsigned)(n * K * tiles)), dim3(threads_for(p)), 0, st,
-                       leaf_dev, n, K, p, tiles, hist_dev);
+    if (pieces_for(p) == 4)
+        hipLaunchKernelGGL(pairwise_kernel<4>, dim3((unsigned)(n * K * tiles)), dim3(threads_for(p)), 0, st, leaf_dev, n, K, p, tiles, hist_dev);
+    else
+        hipLaunchKernelGGL(pairwise_kernel<1>, dim3((unsigned)(n * K * tiles)), dim3(threads_for(p)), 0, st, leaf_dev, n, K, p, tiles, hist_dev);
 }
 
 void launch_mle(const uint32_t* hist_dev, size_t njobs, int p, double* est_dev, hipStream_t st) {
