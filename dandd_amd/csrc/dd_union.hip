@@ -7,7 +7,8 @@
 //   * running max along an ordering     (DeltaTree.sketch_ordering, lib/huffman_dandd.py:644-663;
 //                                        equals the flat prefix unions because max is associative)
 //   * all pairs                         (DeltaTree.pairwise_spiders, lib/huffman_dandd.py:666-695)
-// HBM/L2-bound: 16-byte loads, SWAR byte max, LDS histograms privatised 16 ways.
+// HBM/L2-bound: 16-byte loads, SWAR byte max, LDS histograms privatised 32 ways (copies 65 words apart: with 64
+// the same bin of every copy shared an LDS bank, which halved every kernel here).
 #include "dd_common.h"
 #include "dd_kernels.h"
 
