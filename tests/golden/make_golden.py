@@ -216,6 +216,29 @@ def scenario(backend, fdir, registers):
                  "--maxk", "20"], env, work)
         out["tree_ksweep_10_20"] = read_csv(os.path.join(o6, "gold_5_dashing_deltas.csv"))
         out["tree_ksweep_10_20_cards"] = card_table(os.path.join(o6, "sketchdb"), "gold")
+        # 7. tree with three children per node
+        o7 = outdir("t5")
+        run_ref(["tree", "-d", data, "-o", o7, "-s", "gold", "-k", "11", "-r", str(registers), "-n", "3"], env, work)
+        out["tree_n3_k11"] = read_csv(os.path.join(o7, "gold_5_dashing_deltas.csv"))
+        # 8. progressive in steps of two genomes, ksweep 9..12 (same tree, same orderings as 2.)
+        o8 = outdir("p3")
+        run_ref(["progressive", "-d", tree_pickle, "-o", o8, "--ksweep", "--mink", "9", "--maxk", "12", "--step", "2"], env, work)
+        out["progressive_step2_9_12"] = read_csv(os.path.join(o8, "gold_progu0_5_dashing.csv"))
+        # 9. progressive over a sub-list of four FASTAs given in a file, in the file's order (-n 1: the one "sorted" ordering)
+        flist = os.path.join(work, "four.txt")
+        with open(flist, "w") as f:
+            f.write("\n".join(os.path.join(data, n) for n in ("g3.fasta", "g0.fasta", "g4.fasta", "g1.fasta")) + "\n")
+        o9 = outdir("p4")
+        run_ref(["progressive", "-d", tree_pickle, "-o", o9, "-f", flist, "-n", "1", "--ksweep", "--mink", "9", "--maxk", "11"], env, work)
+        out["progressive_flist_n1_9_11"] = read_csv(os.path.join(o9, "gold_progu1_5_dashing.csv"))
+        # 10. kij with the AFproject tuples (over all five: `kij -f list` dies in the reference itself -- the names are
+        #     handed to SubSpider as strings, lib/dandd_cmd.py:113-122 -> lib/huffman_dandd.py:753)
+        o10 = outdir("k2")
+        run_ref(["kij", "-d", tree_pickle, "-o", o10, "--jaccard", "--afproject", "--mink", "9", "--maxk", "11"], env, work)
+        out["kij_af"] = read_csv(os.path.join(o10, "gold_5_dashing.kij.csv"))
+        out["kij_af_jaccard_9_11"] = read_csv(os.path.join(o10, "gold_5_dashing.j.csv"))
+        with open(os.path.join(o10, "gold_5_dashing_AFtuples.pickle"), "rb") as f:
+            out["kij_af_tuples"] = sorted([["" if x is None else str(x) for x in t] for t in pickle.load(f)])
         with open(os.path.join(work, "trace.log")) as f:
             out["_n_external_commands"] = sum(1 for _ in f)
         return out

@@ -157,6 +157,24 @@ def run_scenarios(work, registers):
     cli.main(["tree", "-d", data, "-o", o6, "-s", "gold", "-r", str(registers), "--ksweep", "--mink", "10", "--maxk", "20"])
     out["tree_ksweep_10_20"] = read_rows(os.path.join(o6, "gold_5_dashing_deltas.csv"))
     out["tree_ksweep_10_20_cards"] = card_table(os.path.join(o6, "sketchdb"), "gold")
+    o7 = od("t5")
+    cli.main(["tree", "-d", data, "-o", o7, "-s", "gold", "-k", "11", "-r", str(registers), "-n", "3"])
+    out["tree_n3_k11"] = read_rows(os.path.join(o7, "gold_5_dashing_deltas.csv"))
+    o8 = od("p3")
+    cli.main(["progressive", "-d", tree_pickle, "-o", o8, "--ksweep", "--mink", "9", "--maxk", "12", "--step", "2"])
+    out["progressive_step2_9_12"] = read_rows(os.path.join(o8, "gold_progu0_5_dashing.csv"))
+    flist = os.path.join(work, "four.txt")
+    with open(flist, "w") as f:
+        f.write("\n".join(os.path.join(data, n) for n in ("g3.fasta", "g0.fasta", "g4.fasta", "g1.fasta")) + "\n")
+    o9 = od("p4")
+    cli.main(["progressive", "-d", tree_pickle, "-o", o9, "-f", flist, "-n", "1", "--ksweep", "--mink", "9", "--maxk", "11"])
+    out["progressive_flist_n1_9_11"] = read_rows(os.path.join(o9, "gold_progu1_5_dashing.csv"))
+    o10 = od("k2")
+    cli.main(["kij", "-d", tree_pickle, "-o", o10, "--jaccard", "--afproject", "--mink", "9", "--maxk", "11"])
+    out["kij_af"] = read_rows(os.path.join(o10, "gold_5_dashing.kij.csv"))
+    out["kij_af_jaccard_9_11"] = read_rows(os.path.join(o10, "gold_5_dashing.j.csv"))
+    with open(os.path.join(o10, "gold_5_dashing_AFtuples.pickle"), "rb") as f:
+        out["kij_af_tuples"] = sorted([["" if x is None else str(x) for x in t] for t in pickle.load(f)])
     return out
 
 
@@ -188,6 +206,11 @@ def compare(got, want):
             continue
         if g is None or len(g) != len(rows):
             diffs.append(f"{name}: {None if g is None else len(g)} rows, expected {len(rows)}")
+            continue
+        if rows and isinstance(rows[0], list):  # tuples (the AFproject pickle), already sorted
+            for i, (r, w) in enumerate(zip(g, rows)):
+                if len(r) != len(w) or not all(same_cell(a, b) for a, b in zip(r, w)):
+                    diffs.append(f"{name}[{i}]: got {r!r}, expected {w!r}")
             continue
         for i, (r, w) in enumerate(zip(g, rows)):
             for key in w:
