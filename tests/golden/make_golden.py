@@ -239,6 +239,12 @@ def scenario(backend, fdir, registers):
         out["kij_af_jaccard_9_11"] = read_csv(os.path.join(o10, "gold_5_dashing.j.csv"))
         with open(os.path.join(o10, "gold_5_dashing_AFtuples.pickle"), "rb") as f:
             out["kij_af_tuples"] = sorted([["" if x is None else str(x) for x in t] for t in pickle.load(f)])
+        # 11. tree over a FASTA list, with a label, its own sketch directory and --fast (no pickle, no sketch/DB table)
+        o11 = outdir("t6")
+        run_ref(["tree", "-d", data, "-f", flist, "-o", o11, "-s", "gold", "-l", "lab", "-c", os.path.join(work, "sk6"), "-k", "9",
+                 "-r", str(registers), "--fast"], env, work)
+        out["tree_flist_label_fast"] = read_csv(os.path.join(o11, "gold_lab_4_dashing_deltas.csv"))
+        out["tree_flist_label_fast_files"] = sorted(os.listdir(o11))
         with open(os.path.join(work, "trace.log")) as f:
             out["_n_external_commands"] = sum(1 for _ in f)
         return out

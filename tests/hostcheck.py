@@ -175,6 +175,11 @@ def run_scenarios(work, registers):
     out["kij_af_jaccard_9_11"] = read_rows(os.path.join(o10, "gold_5_dashing.j.csv"))
     with open(os.path.join(o10, "gold_5_dashing_AFtuples.pickle"), "rb") as f:
         out["kij_af_tuples"] = sorted([["" if x is None else str(x) for x in t] for t in pickle.load(f)])
+    o11 = od("t6")
+    cli.main(["tree", "-d", data, "-f", flist, "-o", o11, "-s", "gold", "-l", "lab", "-c", os.path.join(work, "sk6"), "-k", "9",
+              "-r", str(registers), "--fast"])
+    out["tree_flist_label_fast"] = read_rows(os.path.join(o11, "gold_lab_4_dashing_deltas.csv"))
+    out["tree_flist_label_fast_files"] = sorted(os.listdir(o11))
     return out
 
 
@@ -206,6 +211,10 @@ def compare(got, want):
             continue
         if g is None or len(g) != len(rows):
             diffs.append(f"{name}: {None if g is None else len(g)} rows, expected {len(rows)}")
+            continue
+        if rows and isinstance(rows[0], str):  # a directory listing
+            if list(g) != list(rows):
+                diffs.append(f"{name}: got {g!r}, expected {rows!r}")
             continue
         if rows and isinstance(rows[0], list):  # tuples (the AFproject pickle), already sorted
             for i, (r, w) in enumerate(zip(g, rows)):
