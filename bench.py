@@ -267,7 +267,7 @@ def ingest_probe(eng, ng, nb, nrec, kmin, kmax, torch, gz=False):
                 buf[:n].cpu().numpy().tofile(p)
             paths.append(p)
         best = None
-        for _ in range(6):  # the context's host buffers are pinned as they are reused: steady from the 4th call on
+        for _ in range(10):  # the context's host buffers are pinned as they are reused: steady from the 4th call on
             t0 = time.perf_counter()
             eng.sketch_files(paths, kmin, kmax, 0)
             dt = time.perf_counter() - t0
@@ -276,7 +276,7 @@ def ingest_probe(eng, ng, nb, nrec, kmin, kmax, torch, gz=False):
         return {"value": ng * nb / best / 1e9, "unit": "Gbp/s", "ms": best * 1e3, "launches": batches, "fasta_MB": nbytes / 1e6,
                 "what": f"dd_sketch_files: {ng} x {nb/1e6:g} Mbp {'gzip -1' if gz else 'plain'} FASTA files in {base or 'the temp dir'} (warm page cache) -> "
                         f"pinned host buffers -> H2D on a copy stream overlapped with K0/K1 -> registers back to the host; "
-                        f"k {kmin}-{kmax}; best of 6 calls on one context (PCIe-inclusive: reported beside `value`, never as it)"}
+                        f"k {kmin}-{kmax}; best of 10 calls on one context (PCIe-inclusive: reported beside `value`, never as it)"}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
