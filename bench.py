@@ -281,6 +281,39 @@ def ingest_probe(eng, ng, nb, nrec, kmin, kmax, torch, gz=False):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def spawn_ranks(n, argv, backend_env=None):
+    """`python3 bench.py --gpus N` without a launcher: start the N ranks ourselves, as FRESH child processes of a
+    parent that has not imported torch or touched HIP (a process that has initialised the GPU must never exec or be
+    replaced on this pool), through the same `python -m torch.distributed.run` line the driver would use.  Rank 0's
+    JSON line is relayed on stdout, everything else the ranks print goes to stderr; exit code = the launcher's."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this pool
+    env["DD_BENCH_SPAWNED"] = "1"
+    env.update(backend_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for l in r.stdout.splitlines():
+        if l.startswith("{") and '"metric"' in l:
+            line = l
+        else:
+            print(l, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    elif r.returncode == 0:
+        print("bench.py: the ranks exited 0 without a result line", file=sys.stderr)
+        return 1
+    return r.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -298,6 +331,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-ingest", action="store_true")
     ap.add_argument("--cpu-sample-mbp", type=float, default=32.0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run through the launcher and a process group even at --gpus 1 (world size 1): the RCCL "
+                         "all-reduce / all-gather of the N>1 path execute in librccl on a one-GPU box")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     for key in ("genomes", "mbp", "kmin", "kmax", "nrec"):
@@ -308,10 +344,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ   # under torch.distributed.run (ours or the driver's)
+    if launched and args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch through torch.distributed.run (one rank per GPU)")
+    if not launched and (args.gpus > 1 or args.force_dist):
+        # no launcher around us: be the launcher (nothing in this process has touched torch or HIP yet)
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    use_group = world > 1 or args.force_dist
 
     # CPU baseline first (rank 0, N=1 only), before this process touches the GPU
     cpu = None
@@ -328,8 +367,11 @@ def main():
     backend = os.environ.get("DD_BENCH_BACKEND", "nccl")
     if os.environ.get("DD_BENCH_SHARE_DEVICE"):
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank} but this node shows {torch.cuda.device_count()} GPU(s) "
+                         f"(--gpus {args.gpus})")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if use_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world,
@@ -354,6 +396,7 @@ def main():
     # progressive / pairwise schedules run over the JOB's leaves: with several ranks the leaf slabs are all-gathered
     # first and the orderings split over the ranks (cfg 4 is a 4-GPU config)
     n_sched = total_genomes if (cfg["strong"] and world > 1) else ng
+    gather = bool(cfg["extra"]) and (n_sched != ng or args.force_dist)   # leaf slabs go through the all-gather
     orderings = None
     if cfg["extra"] == "progressive":
         with open(os.path.join(ROOT, "tests", "golden", "cfg4_orderings.json")) as f:
@@ -366,8 +409,8 @@ def main():
     def step():
         out = wl.step(ddist)
         slab, n = wl.regs, ng
-        if cfg["extra"] and n_sched != ng:
-            slab, n = ddist.allgather_leaves(wl.regs[:ng], ids, total_genomes), total_genomes
+        if gather:
+            slab, n = ddist.allgather_leaves(wl.regs[:ng], ids if cfg["strong"] else list(range(ng)), n_sched), n_sched
         if cfg["extra"] == "pairwise" and n:
             wl.pair = eng.pairwise_device(slab.data_ptr(), n, K)                 # all pairs x all k
         elif cfg["extra"] == "progressive" and n and orderings:
@@ -376,7 +419,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_group:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -395,6 +438,9 @@ def main():
     union_ms, union_n = eng.timing_read(KERNEL_UNION)
     eng.timing_enable(False)
     dt = ddist.max_over_ranks(dt, device="cuda")
+    # which GPU every rank really ran on (rank 0 prints them: one entry per rank, all different on a real node)
+    gpus_active = ddist.gather_strings(f"cuda:{local_rank} {torch.cuda.get_device_name(local_rank)} "
+                                       f"uuid={getattr(torch.cuda.get_device_properties(local_rank), 'uuid', '?')}")
 
     extras = {}
     if cfg["extra"] == "progressive" and getattr(wl, "prog", None) is not None and n_sched == total_genomes:
@@ -489,6 +535,10 @@ def main():
             "value": total_bases / dt / 1e9,
             "unit": "Gbp/s",
             "n_gpus": world,
+            "gpus_active": gpus_active,
+            "collectives": dict(ddist.STATS, backend=(dist.get_backend() if use_group else None),
+                                launcher=("bench.py self-spawn" if os.environ.get("DD_BENCH_SPAWNED") else
+                                          "torch.distributed.run" if launched else None)),
             "steps": steps,
             "warmup": args.warmup,
             "ms_per_step": dt / steps * 1e3,
@@ -502,7 +552,7 @@ def main():
                             f"HLL log2m={p}, k-sweep {kmin}-{kmax} (K={K}), leaf sketches + root union + all cardinalities + delta"
                             + (f" + {cfg['extra']} schedule" if cfg["extra"] else ""),
                 "genomes_per_gpu": ng, "bases_per_genome": nb, "kmin": kmin, "kmax": kmax, "log2m": p,
-                "parallelism": f"genomes sharded over {world} GPU(s)" + ("; RCCL max all-reduce of the root" if world > 1 else ""),
+                "parallelism": f"genomes sharded over {world} GPU(s)" + ("; RCCL max all-reduce of the root" if use_group else ""),
             },
             "roofline": {
                 "bound": "hbm",
@@ -540,7 +590,7 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
-    if world > 1:
+    if use_group:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()

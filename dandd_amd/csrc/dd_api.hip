@@ -332,8 +332,10 @@ int dd_set_stream(dd_ctx* c, void* hip_stream) {
         // Work queued on the old stream still uses the context's tables and workspaces (the cached K1 job
         // tables were uploaded there); nothing orders a new stream behind it, so it is drained first.
         DeviceGuard g(c->device);
-        // (best effort: a caller may hand over a new stream because it already destroyed the old one)
-        if (hipStreamSynchronize(c->stream) != hipSuccess) (void)hipGetLastError();
+        // The old handle is not touched: a caller may hand over a new stream because it already destroyed the old
+        // one, and synchronising a destroyed hipStream_t is undefined.  Draining the device covers the old stream
+        // whether it still exists or not (destroying a stream lets its queued work finish); switching streams is rare.
+        DD_HIP(hipDeviceSynchronize());
         c->stream = next;
     }
     return DD_OK;
@@ -898,15 +900,19 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
         InFlight& f = fly[set];
         if (!f.active) return DD_OK;
         f.active = false;
-        if (hipEventSynchronize(c->pipe_d2h[set]) != hipSuccess) return fail(DD_EHIP, "ingestion pipeline: D2H failed");
-        parallel_copy(regs + (size_t)f.first * slab, static_cast<const uint8_t*>(c->pipe_out[set].p), (size_t)f.count * slab, nthreads);
+        const bool arrived = hipEventSynchronize(c->pipe_d2h[set]) == hipSuccess;
+        if (arrived)
+            parallel_copy(regs + (size_t)f.first * slab, static_cast<const uint8_t*>(c->pipe_out[set].p), (size_t)f.count * slab, nthreads);
+        else
+            (void)hipStreamSynchronize(c->copy_stream);  // nothing may still read the host buffers that go back below
         {
             std::lock_guard<std::mutex> lk(mu);
             for (int i = f.first; i < f.first + f.count; ++i) free_bufs.push_back(slots[i].buf);
             consumed = f.first + f.count;
         }
         cv.notify_all();
-        return DD_OK;
+        // (a failed batch has still given its buffers back: the loaders must never wait for ever)
+        return arrived ? DD_OK : fail(DD_EHIP, "ingestion pipeline: D2H failed");
     };
     auto release_unsent = [&](int first, int count) {  // error path: the loaders must never wait for ever
         std::lock_guard<std::mutex> lk(mu);

@@ -237,7 +237,8 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
             // so four records per register cover it several times over -- and what should still not fit goes to the
             // registers by compare-and-swap, exactly.  (Sized for the longest epoch's every token the areas of a
             // 10 x 50 Mbp call at log2m 20 were 20 GB; 5.4 GB measure the same 26.8 ms.)
-            const size_t first_tokens = (epoch_edge[1] - epoch_edge[0]) * kTileTokens;
+            // (no epoch at all when every genome of the call is empty: epoch_edge is {0} then)
+            const size_t first_tokens = nepochs ? (epoch_edge[1] - epoch_edge[0]) * kTileTokens : 0;
             const size_t per_row = std::min(std::max(first_tokens, 4 * m), bucket_row_tokens);
             sc.plan.cap_chunks = (unsigned)(knobs.bucket_cap_chunks ? knobs.bucket_cap_chunks
                                                 : per_row / 1024 + max_jobs_row_epoch * (kThreads / 64) + 16);

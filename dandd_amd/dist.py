@@ -12,6 +12,18 @@ import os
 import numpy as np
 
 
+# collectives issued by this process since import, by kind (bench.py prints them: a line that claims the N>1 path
+# shows how often each exchange really ran)
+STATS = {"all_reduce_max_u8": 0, "all_gather": 0, "all_reduce_scalar": 0}
+
+
+def group_live():
+    """A process group exists.  World size 1 counts: the collectives then still go through the backend (RCCL on a
+    GPU box), which is how a one-GPU machine exercises the N>1 path's calls."""
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 def env_ranks():
     """(rank, local_rank, world_size) from the torch.distributed.run environment."""
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
@@ -37,19 +49,31 @@ def shard_by_weight(weights, world):
 def allreduce_max_u8(t):
     """In-place MAX all-reduce of a uint8 tensor (the HLL union across ranks)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if group_live():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        STATS["all_reduce_max_u8"] += 1
     return t
 
 
 def max_over_ranks(value, device=None):
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not group_live():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    STATS["all_reduce_scalar"] += 1
     return float(t.item())
+
+
+def gather_strings(text):
+    """One short string per rank -> the list of all ranks' strings on every rank."""
+    import torch.distributed as dist
+    if not group_live():
+        return [text]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, text)
+    return out
 
 
 def sharded_ksweep(weights, K, m, sketch_into, union_into, card_of, regs=None, mine=None, device=None):
@@ -91,7 +115,7 @@ def gather_rows(rows, mine, n_total, device=None):
     full = torch.zeros((n_total, rows.shape[1] if rows.ndim == 2 else 0), dtype=torch.float64, device=device)
     if len(mine):
         full[torch.tensor(list(mine), device=device)] = torch.as_tensor(rows, dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if group_live():
         dist.all_reduce(full, op=dist.ReduceOp.SUM)
     return full.cpu().numpy()
 
@@ -103,7 +127,7 @@ def allgather_leaves(leaves, mine, n_total):
     15 MiB for cfg 4 at log2m 14, nothing next to the sketching)."""
     import torch
     import torch.distributed as dist
-    live = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    live = group_live()
     K, m = leaves.shape[1], leaves.shape[2]
     full = torch.zeros((n_total, K, m), dtype=torch.uint8, device=leaves.device)
     if not live:
@@ -122,6 +146,7 @@ def allgather_leaves(leaves, mine, n_total):
     all_slabs = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(all_ids, ids)
     dist.all_gather(all_slabs, padded)
+    STATS["all_gather"] += 3
     for r in range(world):
         n = int(counts[r].item())
         if n:

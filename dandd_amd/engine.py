@@ -18,6 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdandd_hip.so")
 
 KERNEL_PACK, KERNEL_SWEEP, KERNEL_UNION = 0, 1, 2
+ABI_VERSION = 2   # include/dandd_hip.h: DD_ABI_VERSION
 
 EXPORTS = [
     "dd_abi_version", "dd_last_error", "dd_create", "dd_destroy", "dd_set_stream", "dd_synchronize",
@@ -66,6 +67,9 @@ def load_library(path=None):
     vp, sz, i32, u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint64
     lib.dd_abi_version.restype = i32
     lib.dd_abi_version.argtypes = []
+    if lib.dd_abi_version() != ABI_VERSION:
+        raise EngineError(f"{p} has ABI version {lib.dd_abi_version()}, this binding is written against {ABI_VERSION} "
+                          "(include/dandd_hip.h: DD_ABI_VERSION); rebuild with `python -m dandd_amd.build --force`")
     lib.dd_last_error.restype = C.c_char_p
     lib.dd_last_error.argtypes = []
     lib.dd_create.restype = vp

@@ -97,14 +97,33 @@ def read_sketch_file(path):
     return regs, int(np_), _name_k(path), not os.path.basename(path).endswith("nc.hll")
 
 
+def convert_main(argv):
+    """`python -m dandd_amd.host.backend export <sketch.hll> <out.hll>`  (native -> Dashing's container, gzip)
+    `python -m dandd_amd.host.backend import <in.hll> <sketch.hll> K [--no-canon]`  (Dashing's -> native; k and the
+    canonical flag are not part of Dashing's container, they live in its file NAME)."""
+    if len(argv) >= 3 and argv[0] == "export":
+        regs, log2m, k, canon = read_sketch_file(argv[1])
+        write_sketch_file(argv[2], regs, log2m, k, canon, fmt="dashing")
+        return 0
+    if len(argv) >= 4 and argv[0] == "import":
+        regs, log2m, _k, _canon = read_sketch_file(argv[1])
+        write_sketch_file(argv[2], regs, log2m, int(argv[3]), "--no-canon" not in argv, fmt="native")
+        return 0
+    print(convert_main.__doc__)
+    return 2
+
+
 class HipExactBackend:
     """`--exact`: the KMC branch of the reference (lib/sketch_classes.py:377-465), which counts
-    distinct canonical k-mers exactly.  A "database" here is a small JSON file naming the FASTAs it
-    covers (base names plus the directories they were seen in) and, once it has been asked for, their
-    exact distinct k-mer count -- computed on the GPU (sort + distinct, dd_exact_count).  Like a KMC
+    distinct canonical k-mers exactly.  A "database" here is a small JSON file listing the FASTAs it
+    covers -- base name, the directory it was seen in and its size in bytes -- and, once it has been asked
+    for, their exact distinct k-mer count, computed on the GPU (sort + distinct, dd_exact_count).  Like a KMC
     database it answers `info` on its own afterwards, and it survives a moved genome directory as long as
-    DANDD_GENOMEDIR (or the recorded directory) still holds files of those names.  The reference's own KMC
-    branch recurses forever at this commit; this one works."""
+    DANDD_GENOMEDIR (or the recorded directory) still holds files of those names AND sizes.  A genome is
+    identified the way DandD's catalog identifies it, by base name (lib/species_specifics.py keys `fastahex` by
+    basename) -- plus its size, so that two different files of one name in different directories are refused
+    instead of silently counted as one, and a cached count is dropped when the file it was made from has been
+    replaced.  The reference's own KMC branch recurses forever at this commit; this one works."""
 
     name = "hip-exact"
 
@@ -131,43 +150,70 @@ class HipExactBackend:
         import json
         with open(path) as f:
             db = json.load(f)
-        if "names" not in db:  # round-1 files: absolute paths only
-            db["names"] = [os.path.basename(p) for p in db["fastas"]]
-            db["dirs"] = sorted({os.path.dirname(p) for p in db["fastas"]})
+        if "members" not in db:  # files of rounds 1 and 2: absolute paths, or names + directories, no sizes
+            if "names" in db:
+                dirs = list(db.get("dirs", []))
+                db["members"] = [{"name": n, "dir": next((d for d in dirs if os.path.exists(os.path.join(d, n))), dirs[0] if dirs else ""),
+                                  "size": None} for n in db["names"]]
+            else:
+                db["members"] = [{"name": os.path.basename(p), "dir": os.path.dirname(p), "size": None} for p in db["fastas"]]
+            for key in ("names", "dirs", "fastas"):
+                db.pop(key, None)
         return db
 
     @staticmethod
-    def _locate(db):
-        dirs = [d for d in [os.environ.get("DANDD_GENOMEDIR")] + list(db.get("dirs", [])) if d]
-        found = []
-        for name in db["names"]:
-            for d in dirs:
-                cand = os.path.join(d, name)
-                if os.path.exists(cand):
-                    found.append(cand)
-                    break
+    def _find(member):
+        """The file a member stands for: DANDD_GENOMEDIR first (a moved collection), then where it was seen.
+        A candidate of another size is not that genome."""
+        tried = []
+        for d in [os.environ.get("DANDD_GENOMEDIR"), member.get("dir")]:
+            if not d:
+                continue
+            cand = os.path.join(d, member["name"])
+            if os.path.exists(cand):
+                if member.get("size") is None or os.path.getsize(cand) == member["size"]:
+                    return cand
+                tried.append(f"{cand} ({os.path.getsize(cand)} bytes, recorded {member['size']})")
             else:
-                raise FileNotFoundError(f"{name}: not in {dirs} (set DANDD_GENOMEDIR to where the genomes are now)")
-        return found
+                tried.append(cand)
+        raise FileNotFoundError(f"{member['name']}: not found as recorded -- tried {tried} (set DANDD_GENOMEDIR to where the genomes are now)")
 
     def leaf(self, fasta, ks, out_paths):
         full = os.path.abspath(fasta)
+        member = {"name": os.path.basename(full), "dir": os.path.dirname(full), "size": os.path.getsize(full)}
         for k, out in zip(ks, out_paths):
-            self._write(out, {"k": int(k), "canonical": self.canonical, "names": [os.path.basename(full)],
-                              "dirs": [os.path.dirname(full)]})
+            self._write(out, {"k": int(k), "canonical": self.canonical, "members": [member]})
 
     def union(self, in_paths, out_path):
         parts = [self._read(p) for p in in_paths]
-        self._write(out_path, {"k": parts[0]["k"], "canonical": self.canonical,
-                               "names": sorted({n for p in parts for n in p["names"]}),
-                               "dirs": sorted({d for p in parts for d in p.get("dirs", [])})})
+        by_name = {}
+        for part in parts:
+            for mem in part["members"]:
+                seen = by_name.setdefault(mem["name"], mem)
+                if seen is not mem and None not in (seen.get("size"), mem.get("size")) and seen["size"] != mem["size"]:
+                    raise ValueError(f"two different genomes named {mem['name']}: {os.path.join(seen['dir'], seen['name'])} ({seen['size']} bytes) "
+                                     f"and {os.path.join(mem['dir'], mem['name'])} ({mem['size']} bytes); DandD identifies genomes by base name")
+        self._write(out_path, {"k": parts[0]["k"], "canonical": self.canonical, "members": [by_name[n] for n in sorted(by_name)]})
 
     def card(self, path):
         db = self._read(path)
-        if db.get("distinct") is None:
-            db["distinct"] = int(self.engine.exact_count(self._locate(db), db["k"]))
-            db.pop("fastas", None)
-            self._write(path, db)
+        files = None
+        if db.get("distinct") is not None:
+            # a database answers on its own -- unless its genomes are where they were and are no longer the files
+            # the count was made from
+            try:
+                files = [self._find(m) for m in db["members"]]
+            except FileNotFoundError as e:
+                if "recorded" in str(e):     # found, but replaced by another file: the cached count is stale
+                    raise
+                return float(db["distinct"])  # moved away altogether: nothing to compare with
+            return float(db["distinct"])
+        files = [self._find(m) for m in db["members"]]
+        for m, f in zip(db["members"], files):
+            if m.get("size") is None:
+                m["size"] = os.path.getsize(f)
+        db["distinct"] = int(self.engine.exact_count(files, db["k"]))
+        self._write(path, db)
         return float(db["distinct"])
 
     def close(self):
@@ -240,3 +286,8 @@ class HipBackend:
 
     def close(self):
         self.engine.close()
+
+
+if __name__ == "__main__":
+    import sys
+    sys.exit(convert_main(sys.argv[1:]))

@@ -83,8 +83,9 @@ def kij_command(args):
         tree.experiment["ksweep"] = (int(args.mink), int(args.maxk))
     if deltatree.dist_ranks()[1] > 1:
         # every rank sketches its share of the leaves for the whole range; rank 0 finishes alone
-        tree.presketch_range(int(args.mink), int(args.maxk))
-        if deltatree.dist_ranks()[0] != 0:
+        rank = deltatree.dist_ranks()[0]
+        tree.presketch_range(int(args.mink), int(args.maxk))   # (ends at the barrier, which switches sharding off)
+        if rank != 0:
             return
     tree.ksweep(mink=int(args.mink), maxk=int(args.maxk))
     kij_rows, j_rows = tree.pairwise_spiders(sublist=sub, mink=args.mink, maxk=args.maxk, jaccard=args.jaccard)
@@ -172,6 +173,16 @@ def main(argv=None):
         args.func(args)
         if dist is not None:
             dist.barrier()
+    except BaseException as e:
+        if dist is not None and not (isinstance(e, SystemExit) and not e.code):
+            # a rank that fails must not leave its peers waiting in a barrier it will never reach: leave at once with
+            # a non-zero status and let the launcher (torch.distributed.run) end the others
+            import traceback
+            traceback.print_exc()
+            sys.stderr.flush()
+            sys.stdout.flush()
+            os._exit(1)
+        raise
     finally:
         deltatree.set_dist_active(False)
         if dist is not None:

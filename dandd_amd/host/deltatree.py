@@ -79,6 +79,10 @@ def dist_ranks():
 
 
 def dist_barrier():
+    """The ONE meeting point of a multi-rank command: every rank's share of the leaf sketches is on disk.  Behind
+    it rank 0 finishes alone, so the sharding is switched off here: from now on `_batch_leaf_sketch` batches ALL
+    leaves again and the hill-climb's batch hook is back (a rank 0 that kept seeing world > 1 would batch only its
+    own shard and sketch the other leaves one genome at a time)."""
     if not _dist_active:
         return
     try:
@@ -87,6 +91,7 @@ def dist_barrier():
         return
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
+    set_dist_active(False)
 
 
 def write_listdict_to_csv(outfile, listdict, suffix="", last_col=None):
@@ -515,8 +520,9 @@ class DeltaTree:
         nodes.sort()
         self._presketch_leaves(nodes)
         if not leafnodes and dist_ranks()[1] > 1:  # a tree built from FASTA names in a multi-rank run
+            rank = dist_ranks()[0]
             dist_barrier()
-            if dist_ranks()[0] != 0:
+            if rank != 0:
                 raise WorkerDone()
         global _leaf_batch
         _leaf_batch = self._leaf_batch_hook(nodes) if self.experiment["ksweep"] is None else None

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 1
+#define DD_ABI_VERSION 2
 
 #define DD_OK 0
 #define DD_EINVAL (-1)   /* bad argument */

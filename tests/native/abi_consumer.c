@@ -12,7 +12,7 @@ int main(void) {
     long n, got;
     dd_plan_job *jobs;
     dd_ctx *ctx;
-    if (dd_abi_version() != 1) return 10;
+    if (dd_abi_version() != DD_ABI_VERSION) return 10;
     n = dd_plan_sweep(14, sizes, 2, 4, 40, NULL, 0);
     if (n <= 0) return 11;
     jobs = (dd_plan_job *)malloc((size_t)n * sizeof *jobs);

@@ -216,6 +216,13 @@ int main(int argc, char** argv) {
     for (int log2m : {10, 14, 17, 18, 20})
         for (auto kr : {std::pair<int, int>{4, 40}, {1, 64}, {9, 10}, {32, 33}}) check_plan(log2m, ragged, kr.first, kr.second, base);
     check_plan(14, {3100000000ull}, 4, 64, base);
+    // calls whose every genome is empty (a 0-byte FASTA at DandD's default -r 20): no epoch exists in bucket mode
+    for (int log2m : {14, 17, 18, 19, 20})
+        for (const std::vector<size_t>& sizes : {std::vector<size_t>{0}, std::vector<size_t>{0, 0, 0}}) {
+            check_plan(log2m, sizes, 4, 40, base);
+            for (const dd::SweepClass& sc : dd::plan_sweep(log2m, 1, sizes.data(), (int)sizes.size(), 4, 40, base))
+                CHECK(sc.jobs.empty() || sc.plan.cap_chunks < (1u << 20), "log2m %d: empty input asks for %u chunks per row", log2m, sc.plan.cap_chunks);
+        }
     check_plan(20, std::vector<size_t>(13, 3040000000ull), 4, 64, base);
     dd::PlanKnobs k2 = base;
     k2.buckets = false;

@@ -118,3 +118,67 @@ def test_bench_cfg4_two_ranks_gathers_leaves_and_splits_orderings(torch_cuda):
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["genomes_per_gpu"] == 15
     assert j["schedule"] == {"kind": "progressive", "genomes": 30, "orderings_this_rank": 5, "last_prefix_equals_root": True}
+
+
+def _line(r):
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.gpu
+def test_bench_world1_rccl_through_own_launcher(torch_cuda):
+    """`python3 bench.py --gpus 1 --force-dist`: bench.py starts its own rank through torch.distributed.run, the rank
+    opens an `nccl` (= RCCL) group of world size 1 and the N>1 path's exchanges -- all_reduce(MAX) of the uint8 root
+    slab, the scalar max over ranks, the barrier -- all execute inside librccl.  The numbers must be the plain run's."""
+    common = ["--steps", "2", "--warmup", "1", "--mbp", "5", "--no-cpu-baseline", "--no-accuracy", "--no-secondary", "--no-ingest"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DD_BENCH_BACKEND", "DD_BENCH_SHARE_DEVICE")}
+    plain = _line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common,
+                                 env=env, capture_output=True, text=True, timeout=600, cwd=ROOT))
+    forced = _line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist"] + common,
+                                  env=env, capture_output=True, text=True, timeout=600, cwd=ROOT))
+    assert plain["collectives"]["backend"] is None and plain["collectives"]["all_reduce_max_u8"] == 0
+    c = forced["collectives"]
+    assert c["backend"] == "nccl" and c["launcher"] == "bench.py self-spawn"
+    assert c["all_reduce_max_u8"] == 3 and c["all_reduce_scalar"] >= 1     # one root reduce per step (2 + 1 warmup)
+    assert forced["n_gpus"] == 1 and forced["scaling"] == "weak" and len(forced["gpus_active"]) == 1
+    assert forced["gpus_active"][0].startswith("cuda:0 ")
+    for key in ("delta_root", "argmax_k_root", "delta_genome0", "argmax_k_genome0"):
+        assert forced[key] == plain[key], key
+    assert "RCCL" in forced["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+def test_bench_world1_rccl_allgather_of_leaves(torch_cuda):
+    """The second exchange of the N>1 path (progressive / kij need every leaf: dist.allgather_leaves) through RCCL at
+    world size 1: the gathered slab must reproduce the local schedule (last prefix == root, checked inside bench.py)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DD_BENCH_BACKEND", "DD_BENCH_SHARE_DEVICE")}
+    j = _line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--config", "cfg4share",
+                              "--mbp", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                             env=env, capture_output=True, text=True, timeout=600, cwd=ROOT))
+    assert j["collectives"]["backend"] == "nccl" and j["collectives"]["all_gather"] == 6     # 3 per step, 1 + 1 steps
+    assert j["schedule"]["last_prefix_equals_root"] is True and j["schedule"]["genomes"] == 8
+
+
+@pytest.mark.gpu
+def test_bench_plain_gpus2_starts_its_own_ranks(torch_cuda):
+    """`python3 bench.py --gpus 2` with no launcher and no WORLD_SIZE (the shape of the driver's command): bench.py
+    spawns the two ranks itself.  On a one-GPU box the ranks share cuda:0 and reduce through gloo (functional only)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(DD_BENCH_BACKEND="gloo", DD_BENCH_SHARE_DEVICE="1")
+    j = _line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--mbp", "2",
+                              "--no-cpu-baseline", "--no-accuracy", "--no-secondary", "--no-ingest"],
+                             env=env, capture_output=True, text=True, timeout=600, cwd=ROOT))
+    assert j["n_gpus"] == 2 and len(j["gpus_active"]) == 2 and j["collectives"]["launcher"] == "bench.py self-spawn"
+    assert j["collectives"]["all_reduce_max_u8"] == 2 and j["value"] > 0
+
+
+def test_bench_without_enough_gpus_fails_loudly():
+    """No GPU here: the self-spawned ranks must exit non-zero with a message, not hang and not print a line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this node really has two GPUs")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "wants cuda:1" in r.stderr

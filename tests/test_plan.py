@@ -98,6 +98,15 @@ def test_k_ranges_and_class_boundaries(krange):
         check(log2m, SIZES["ragged"], *krange)
 
 
+@pytest.mark.parametrize("sizes", [[0], [0, 0, 0], [0, 1, 0]])
+def test_calls_with_only_empty_genomes(sizes):
+    """A 0-byte FASTA at any register count (bucket mode has no epoch then): no job with tiles, nothing out of range."""
+    for log2m in (14, 17, 18, 19, 20):
+        jobs = check(log2m, sizes, 4, 40)
+        real = jobs[jobs["tile_end"] > jobs["tile_begin"]]
+        assert len(real) == (0 if not any(sizes) else len(real)) and all(int(j["genome"]) == 1 for j in real)
+
+
 def test_launch_shape_of_the_headline_config():
     jobs = check(14, SIZES["cfg2"], 4, 40)
     by_class = {int(c): jobs[jobs["kclass"] == c] for c in np.unique(jobs["kclass"])}

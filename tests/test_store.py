@@ -74,16 +74,64 @@ def test_dashing_container_round_trip(tmp_path):
     32 bytes the module documents, and the native <-> Dashing conversion keeps the registers."""
     import gzip
     import numpy as np
-    from dandd_amd.host import backend, dashing_hll
+    from dandd_amd.host import backend
     rng = np.random.default_rng(3)
     regs = rng.integers(0, 40, size=1 << 12, dtype=np.uint8)
     native, exported, back = (str(tmp_path / n) for n in ("a.hll", "a.dashing.hll", "b.hll"))
     backend.write_sketch_file(native, regs, 12, 21, True)
-    assert dashing_hll.main(["export", native, exported]) == 0
+    assert backend.convert_main(["export", native, exported]) == 0
     raw = gzip.open(exported, "rb").read()
     assert len(raw) == 32 + (1 << 12) and raw[20:24] == (12).to_bytes(4, "little")
-    got, np_, est = dashing_hll.read_dashing_hll(exported)
-    assert np_ == 12 and est is None and np.array_equal(got, regs)
-    assert dashing_hll.main(["import", exported, back, "21"]) == 0
+    got, np_, k_name, _ = backend.read_sketch_file(exported)
+    assert np_ == 12 and k_name == 0 and np.array_equal(got, regs)    # k is not in Dashing's container (nor in this name)
+    assert backend.convert_main(["import", exported, back, "21"]) == 0
     r2, log2m, k, canon = backend.read_sketch_file(back)
     assert (log2m, k, canon) == (12, 21, True) and np.array_equal(r2, regs)
+
+
+def test_exact_databases_identify_genomes_by_name_and_size(tmp_path, monkeypatch):
+    """`--exact` databases (the KMC stand-in): a genome is its base name + size.  The same file seen twice is one
+    member, two different files of one name are refused, a replaced file invalidates the cached count, a moved
+    collection is found through DANDD_GENOMEDIR, and files of rounds 1-2 (names + dirs, no sizes) still load."""
+    import json
+    from dandd_amd.host.backend import HipExactBackend
+    be = object.__new__(HipExactBackend)      # no GPU here: everything below is host logic
+    be.canonical = True
+    counted = []
+
+    class FakeEngine:
+        def exact_count(self, files, k):
+            counted.append(list(files))
+            return sum(os.path.getsize(f) for f in files)
+    be.engine = FakeEngine()
+    d1, d2 = tmp_path / "a", tmp_path / "b"
+    d1.mkdir(), d2.mkdir()
+    (d1 / "g.fa").write_text(">x\nACGT\n")
+    (d1 / "h.fa").write_text(">y\nACGTACGT\n")
+    (d2 / "g.fa").write_text(">x\nACGTTTTTTT\n")     # another genome under the same name
+    monkeypatch.delenv("DANDD_GENOMEDIR", raising=False)
+    db = lambda n: str(tmp_path / n)
+    be.leaf(str(d1 / "g.fa"), [7], [db("g1")])
+    be.leaf(str(d1 / "h.fa"), [7], [db("h1")])
+    be.leaf(str(d2 / "g.fa"), [7], [db("g2")])
+    be.union([db("g1"), db("h1"), db("g1")], db("u"))
+    assert [m["name"] for m in json.load(open(db("u")))["members"]] == ["g.fa", "h.fa"]
+    with pytest.raises(ValueError, match="two different genomes named g.fa"):
+        be.union([db("g1"), db("g2")], db("bad"))
+    assert be.card(db("u")) == float(os.path.getsize(d1 / "g.fa") + os.path.getsize(d1 / "h.fa"))
+    assert be.card(db("u")) == be.card(db("u")) and len(counted) == 1          # answered from the database afterwards
+    (d1 / "g.fa").write_text(">x\nACGTACGTACGTAAAA\n")                         # replaced: the cached count is stale
+    with pytest.raises(FileNotFoundError, match="recorded"):
+        be.card(db("u"))
+    # a moved collection
+    moved = tmp_path / "moved"
+    moved.mkdir()
+    (moved / "h.fa").write_text(">y\nACGTACGT\n")
+    os.remove(d1 / "h.fa")
+    with pytest.raises(FileNotFoundError):
+        be.card(db("h1"))
+    monkeypatch.setenv("DANDD_GENOMEDIR", str(moved))
+    assert be.card(db("h1")) == float(os.path.getsize(moved / "h.fa"))
+    # a round-2 file
+    json.dump({"k": 7, "canonical": True, "names": ["h.fa"], "dirs": [str(moved)]}, open(db("old"), "w"))
+    assert be.card(db("old")) == float(os.path.getsize(moved / "h.fa"))
