@@ -399,9 +399,12 @@ def main():
     gather = bool(cfg["extra"]) and (n_sched != ng or args.force_dist)   # leaf slabs go through the all-gather
     orderings = None
     if cfg["extra"] == "progressive":
-        with open(os.path.join(ROOT, "tests", "golden", "cfg4_orderings.json")) as f:
-            orderings = [o for o in json.load(f)["orderings"]]
-        if n_sched != 8:  # the fixture is for the 8-genome share; other sizes use seeded permutations
+        # committed fixtures for the 8-genome share and for cfg 4 itself (30 genomes); other sizes: seeded permutations
+        fixture = {8: "cfg4_orderings.json", 30: "cfg4_orderings_n30.json"}.get(n_sched)
+        if fixture:
+            with open(os.path.join(ROOT, "tests", "golden", fixture)) as f:
+                orderings = [o for o in json.load(f)["orderings"]]
+        else:
             rng = np.random.default_rng(42)
             orderings = [list(map(int, rng.permutation(n_sched))) for _ in range(10)]
         orderings = orderings[rank::world] if n_sched != ng else orderings

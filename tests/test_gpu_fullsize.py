@@ -272,3 +272,145 @@ def test_exact_count_of_a_union_larger_than_the_key_budget(engine_factory, torch
     eng.union_device([regs[g].data_ptr() for g in range(4)], eng.m, regs[4].data_ptr())
     est = eng.card_batch_device(regs[4].data_ptr(), 1)[0]
     assert abs(est - total) / total < 4 * 1.04 / np.sqrt(eng.m), (est, total)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# DandD's DEFAULT register count (-r 20, /root/reference/lib/dandd_cmd.py:187) at the sizes of configs 4 and 5:
+# the scatter + sort + replay path with u32 record cursors, capacity clamps and the compare-and-swap overflow
+# (dd_sweep.hip) at the sizes where those can actually break.
+# ------------------------------------------------------------------------------------------------------------
+def _halves(torch, buf, size, nrec):
+    starts = _record_starts(torch, buf, size)
+    assert starts.size == nrec
+    cut = int(starts[nrec // 2])
+    return cut, buf[cut:size].clone()      # the second half gets its own (aligned) buffer
+
+
+def test_default_registers_whole_genome_3gbp(engine_factory, torch_cuda, orc):
+    """3 Gbp x log2m 20 x k 21..64 (64-, 96- and 128-bit window classes in one call): whole == max(two halves split at
+    a record boundary), deterministic, HLL within 4 sigma of the GPU exact counter at k 21 and 55; and the oracle
+    itself on a 1 Gbp genome at log2m 20 for k 31 (64-bit class) and k 61 (128-bit class)."""
+    torch = torch_cuda
+    eng = engine_factory(20, True)
+    kmin, kmax = 21, 64
+    K = kmax - kmin + 1
+    (buf,), (size,) = _device_genomes(torch, eng, [(200, 3_000_000_000, 24)])
+    cut, second = _halves(torch, buf, size, 24)
+    regs = torch.empty((3, K, eng.m), dtype=torch.uint8, device="cuda")
+    eng.sketch_device([buf.data_ptr()], [size], kmin, kmax, regs[0].data_ptr())
+    eng.sketch_device([buf.data_ptr(), second.data_ptr()], [cut, size - cut], kmin, kmax, regs[1].data_ptr())
+    eng.synchronize()
+    whole, parts = regs[0], torch.maximum(regs[1], regs[2])
+    for k in (21, 40, 55, 64):     # named so that a failure says which class broke
+        assert torch.equal(whole[k - kmin], parts[k - kmin]), f"k={k}: whole != max(halves)"
+    assert torch.equal(whole, parts)
+    again = torch.empty((K, eng.m), dtype=torch.uint8, device="cuda")
+    eng.sketch_device([buf.data_ptr()], [size], kmin, kmax, again.data_ptr())
+    eng.synchronize()
+    assert torch.equal(again, whole)
+    card = eng.card_batch_device(whole.data_ptr(), K)
+    del second, again
+    torch.cuda.empty_cache()
+    for k in (21, 55):
+        exact = eng.exact_count_device([buf.data_ptr()], [size], k)
+        assert abs(card[k - kmin] - exact) / exact < 4 * 1.04 / np.sqrt(eng.m), (k, card[k - kmin], exact)
+    del buf, regs
+    torch.cuda.empty_cache()
+    (g1,), (s1,) = _device_genomes(torch, eng, [(201, 1_000_000_000, 24)])
+    fa = _host(g1, s1)
+    for k in (31, 61):
+        one = torch.empty((1, eng.m), dtype=torch.uint8, device="cuda")
+        eng.sketch_device([g1.data_ptr()], [s1], k, k, one.data_ptr())
+        eng.synchronize()
+        got, want = one[0].cpu().numpy(), orc.sketch(fa, k, 20, True)
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, f"1 Gbp, log2m 20, k={k}: {bad.size} registers differ, first idx {bad[0]}: got {got[bad[0]]} want {want[bad[0]]}"
+
+
+@pytest.mark.parametrize("p", [14, 20])
+def test_cfg5_share_as_benchmarked(engine_factory, torch_cuda, p):
+    """BASELINE cfg 5, one GPU's share exactly as `bench.py --config cfg5share` runs it: 13 x 3 Gbp (39.5 GB of
+    FASTA) in ONE dd_sketch_device call, k 4..64 (K = 61).  Rows of the first and the last genome == their own
+    single-genome calls (which test_default_registers_whole_genome_3gbp / test_cfg5_share_whole_genome pin through
+    halves, the exact counter and the oracle); the call is deterministic; no row is empty."""
+    torch = torch_cuda
+    eng = engine_factory(p, True)
+    ng, nb, kmin, kmax = 13, 3_000_000_000, 4, 64
+    K = kmax - kmin + 1
+    bufs, sizes = _device_genomes(torch, eng, [(g, nb, 24) for g in range(ng)])
+    regs = torch.empty((ng, K, eng.m), dtype=torch.uint8, device="cuda")
+    eng.sketch_device([b.data_ptr() for b in bufs], sizes, kmin, kmax, regs.data_ptr())
+    eng.synchronize()
+    one = torch.empty((K, eng.m), dtype=torch.uint8, device="cuda")
+    for g in (0, 12):
+        eng.sketch_device([bufs[g].data_ptr()], [sizes[g]], kmin, kmax, one.data_ptr())
+        eng.synchronize()
+        for k in range(kmin, kmax + 1):
+            assert torch.equal(one[k - kmin], regs[g, k - kmin]), f"log2m {p}: genome {g}, k={k}: batched row != single-genome call"
+    assert bool((regs.view(ng * K, eng.m).max(dim=1).values > 0).all())
+    again = torch.empty_like(regs)
+    eng.sketch_device([b.data_ptr() for b in bufs], sizes, kmin, kmax, again.data_ptr())
+    eng.synchronize()
+    assert torch.equal(again, regs)
+    # genomes differ (1 % substitutions): a row copied from a neighbour would pass the checks above for g = 0, 12 only
+    card = eng.card_batch_device(regs.data_ptr(), ng * K).reshape(ng, K)
+    assert len({float(c) for c in card[:, 31 - kmin]}) == ng
+
+
+@pytest.mark.parametrize("p", [14, 20])
+def test_cfg4_progressive_at_its_true_size(engine_factory, torch_cuda, orc, p):
+    """BASELINE cfg 4 whole: n = 30 genomes of 250 Mbp (7.6 GB: one MI355X holds the 4-GPU job), 10 committed
+    orderings, k 2..32.  dd_progressive_device == running torch.maximum along every ordering + dd_card_batch_device
+    (the flat prefix unions of /root/reference/lib/huffman_dandd.py:644-663), at log2m 14 and at DandD's default 20."""
+    torch = torch_cuda
+    eng = engine_factory(p, True)
+    with open(os.path.join(HERE, "golden", "cfg4_orderings_n30.json")) as f:
+        ords = json.load(f)["orderings"]
+    n, nb, kmin, kmax = 30, 250_000_000, 2, 32
+    assert len(ords) == 10 and all(sorted(o) == list(range(n)) for o in ords)
+    K = kmax - kmin + 1
+    bufs, sizes = _device_genomes(torch, eng, [(100 + g, nb, 1) for g in range(n)])
+    regs = torch.empty((n, K, eng.m), dtype=torch.uint8, device="cuda")
+    eng.sketch_device([b.data_ptr() for b in bufs], sizes, kmin, kmax, regs.data_ptr())
+    eng.synchronize()
+    g, k = 17, 25
+    assert np.array_equal(regs[g, k - kmin].cpu().numpy(), orc.sketch(_host(bufs[g], sizes[g]), k, p, True)), (g, k)
+    del bufs
+    torch.cuda.empty_cache()
+    prog = eng.progressive_device(regs.data_ptr(), n, K, ords)
+    assert prog.shape == (10, n, K)
+    for o, order in enumerate(ords):       # one ordering at a time: 30 x 31 MiB of running unions at log2m 20
+        run = torch.empty((n, K, eng.m), dtype=torch.uint8, device="cuda")
+        acc = torch.zeros((K, eng.m), dtype=torch.uint8, device="cuda")
+        for j, gi in enumerate(order):
+            acc = torch.maximum(acc, regs[gi])
+            run[j] = acc
+        torch.cuda.synchronize()
+        want = eng.card_batch_device(run.data_ptr(), n * K).reshape(n, K)
+        assert np.array_equal(prog[o], want), f"log2m {p}: ordering {o} differs from the running maximum"
+        del run
+    assert all(np.array_equal(prog[o, n - 1], prog[0, n - 1]) for o in range(10))
+
+
+@pytest.mark.parametrize("p", [18, 20])
+def test_record_stream_overflow_at_full_size(engine_factory, torch_cuda, orc, monkeypatch, p):
+    """DD_BUCKET_CAP=1: one 1024-record chunk per row, so nearly every record of the 50 Mbp genome takes the
+    compare-and-swap fallback of the scatter kernels (dd_sweep.hip) -- thousands of waves contending for the same
+    registers, which the 330 kbp knob test cannot produce.  Registers must still be the oracle's."""
+    torch = torch_cuda
+    monkeypatch.setenv("DD_BUCKET_CAP", "1")
+    eng = engine_factory(p, True)
+    bufs, sizes = _device_genomes(torch, eng, [(0, 50_000_000, 5)])
+    kmin, kmax = 12, 34
+    K = kmax - kmin + 1
+    regs = torch.empty((1, K, eng.m), dtype=torch.uint8, device="cuda")
+    eng.sketch_device([bufs[0].data_ptr()], sizes, kmin, kmax, regs.data_ptr())
+    eng.synchronize()
+    monkeypatch.delenv("DD_BUCKET_CAP")
+    ref = torch.empty_like(regs)
+    eng.sketch_device([bufs[0].data_ptr()], sizes, kmin, kmax, ref.data_ptr())     # the roomy record streams
+    eng.synchronize()
+    assert torch.equal(regs, ref)
+    fa = _host(bufs[0], sizes[0])
+    for k in (13, 33):
+        assert np.array_equal(regs[0, k - kmin].cpu().numpy(), orc.sketch(fa, k, p, True)), (p, k)
