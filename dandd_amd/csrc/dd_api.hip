@@ -114,7 +114,7 @@ struct dd_ctx {
     std::vector<TimedSpan> spans[DD_KERNEL_COUNT];
     std::vector<hipEvent_t> pool;
     // workspaces
-    DevBuf tokens, scratch, tables, fasta, regs, ptrs, hist, est, ord, bitmaps, bigmaps, exact, buckets;
+    DevBuf tokens, scratch, tables, fasta, regs, ptrs, hist, est, ord, bitmaps, bigmaps, exact, buckets, gram;
     HostBuf stage, stage_jobs, stage_rows;  // genome/pack tables and K1 job tables are uploaded in two steps
     // the job tables of the last few sketch calls: a call over genomes of the same sizes and the same k range (a
     // pipeline sketching batches of a few recurring shapes, a benchmark loop) reuses them, on the host and in HBM
@@ -300,7 +300,7 @@ void dd_destroy(dd_ctx* c) {
     if (c->stage_free) (void)hipEventDestroy(c->stage_free);
     for (auto& pe : c->plans) pe.jobtab.release();
     for (DevBuf* b : {&c->tokens, &c->scratch, &c->tables, &c->fasta, &c->regs, &c->ptrs, &c->hist,
-                      &c->est, &c->ord, &c->bitmaps, &c->bigmaps, &c->exact, &c->buckets})
+                      &c->est, &c->ord, &c->bitmaps, &c->bigmaps, &c->exact, &c->buckets, &c->gram})
         b->release();
     c->stage.release();
     c->stage_jobs.release();
@@ -1379,9 +1379,18 @@ int dd_pairwise_device(dd_ctx* c, const uint8_t* leaf_dev, int n, int K, double*
     const size_t njobs = (size_t)n * n * K;
     int rc;
     if ((rc = c->hist.reserve(njobs * 64 * sizeof(uint32_t)))) return rc;
+    // all pairs as int8 Gram matrices on the matrix cores (dd_gram.hip); DD_PAIRWISE_STREAM=1 keeps the streaming
+    // kernel of dd_union.hip (one LDS atomic per register per pair) for A/B runs and for the equality test
+    const bool gram = dd::gram_usable(n, c->p) && !getenv("DD_PAIRWISE_STREAM");
+    if (gram && (rc = c->gram.reserve(dd::gram_scratch_bytes(n, K, c->p, nullptr)))) return rc;
     {
         Span sp(c, DD_KERNEL_UNION);
-        dd::launch_pairwise(leaf_dev, n, K, c->p, static_cast<uint32_t*>(c->hist.p), c->stream);
+        if (gram) {
+            DD_HIP(hipMemsetAsync(c->hist.p, 0, njobs * 64 * sizeof(uint32_t), c->stream));
+            dd::launch_pairwise_gram(leaf_dev, n, K, c->p, static_cast<uint32_t*>(c->hist.p), c->gram.p, c->stream);
+        } else {
+            dd::launch_pairwise(leaf_dev, n, K, c->p, static_cast<uint32_t*>(c->hist.p), c->stream);
+        }
     }
     DD_HIP(hipGetLastError());
     // lower triangle histograms are all-zero: give them the mirrored estimate afterwards

@@ -177,6 +177,11 @@ void launch_progressive(const uint8_t* leaf_dev, int n, int K, int log2m, const 
 // hist[((i*n)+j)*K + kk][64] for i <= j
 void launch_pairwise(const uint8_t* leaf_dev, int n, int K, int log2m, uint32_t* hist_dev,
                      hipStream_t st);
+// the same histograms through int8 Gram matrices on the matrix cores (dd_gram.hip); hist_dev zeroed by the caller
+bool gram_usable(int n, int log2m);
+size_t gram_scratch_bytes(int n, int K, int log2m, int* sp_per_launch);
+void launch_pairwise_gram(const uint8_t* leaf_dev, int n, int K, int log2m, uint32_t* hist_dev, void* scratch,
+                          hipStream_t st);
 void launch_mle(const uint32_t* hist_dev, size_t njobs, int log2m, double* est_dev, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------

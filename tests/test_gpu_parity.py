@@ -521,3 +521,43 @@ def test_timing_spans_and_call_statistics(engine_factory, orc):
     eng.timing_enable(False)
     tokens, updates, blocks = eng.last_sketch_stats()
     assert tokens == fa.size and updates == fa.size * 37 and blocks > 0
+
+
+def _random_slab(rng, n, K, p, kind):
+    """Register slabs shaped like real sketches (geometric values) and the corner cases of the threshold range:
+    a column whose registers are all equal (no threshold carries information), one that uses the whole 0..64-p+1
+    range, one that is empty."""
+    m = 1 << p
+    q = 64 - p
+    slab = np.minimum(rng.geometric(0.5, size=(n, K, m)) + rng.integers(0, 3, size=(n, K, 1)), q + 1).astype(np.uint8)
+    slab[rng.random((n, K, m)) < 0.05] = 0
+    if kind == "corners" and K >= 3:
+        slab[:, 0, :] = 7                       # vmin == vmax
+        slab[:, 1, :] = 0                       # empty sketches
+        slab[:, 2, :] = rng.integers(0, q + 2, size=(n, m), dtype=np.uint8)   # every value up to q + 1
+        slab[0, 2, :5] = [0, q + 1, q + 1, 0, q]
+    return slab
+
+
+@pytest.mark.parametrize("p,n,K", [(12, 2, 3), (12, 33, 4), (14, 64, 5), (14, 70, 3), (16, 31, 3), (18, 130, 2), (20, 5, 3), (20, 64, 2)])
+def test_pairwise_gram_equals_streaming_kernel(engine_factory, torch_cuda, orc, monkeypatch, p, n, K):
+    """dd_pairwise_device through the int8 Gram matrices on the matrix cores (dd_gram.hip) == the streaming byte-max
+    kernel (DD_PAIRWISE_STREAM=1, dd_union.hip) for every (i, j, k), as doubles -- n not a multiple of 32 or 64, more
+    than one 64-row super-block (n = 70, 130: the off-diagonal kernel), several register ranges per row (log2m 18,
+    20), degenerate threshold ranges -- and == the oracle's estimator on the byte-max for sampled pairs."""
+    torch = torch_cuda
+    eng = engine_factory(p, True)
+    rng = np.random.default_rng(1000 * p + n)
+    slab = _random_slab(rng, n, K, p, "corners" if n != 64 else "plain")
+    dev = torch.from_numpy(slab).cuda()
+    gram = eng.pairwise_device(dev.data_ptr(), n, K)
+    monkeypatch.setenv("DD_PAIRWISE_STREAM", "1")
+    stream = eng.pairwise_device(dev.data_ptr(), n, K)
+    monkeypatch.delenv("DD_PAIRWISE_STREAM")
+    bad = np.argwhere(gram != stream)
+    assert bad.size == 0, f"{len(bad)} of {gram.size} entries differ, first (i, j, k) = {bad[0]}: gram {gram[tuple(bad[0])]} stream {stream[tuple(bad[0])]}"
+    assert np.array_equal(gram, gram.transpose(1, 0, 2))
+    for _ in range(6):
+        i, j, k = int(rng.integers(n)), int(rng.integers(n)), int(rng.integers(K))
+        want = orc.card(np.maximum(slab[i, k], slab[j, k]), p)
+        assert gram[i, j, k] == want or (np.isinf(want) and np.isinf(gram[i, j, k])), (i, j, k)
