@@ -19,11 +19,20 @@
 // Only thresholds between the smallest and the largest register of a k column are computed (gram_range_kernel):
 // F is 0 below and m above.
 //
-// Work unit = one WAVE: (super-block pair of 64 rows, k, register range of <= 65 536, group of TS thresholds).
-// The four waves of a workgroup hold four threshold groups of the same rows and registers, so the row bytes they
-// stream (64-byte pieces of 64 rows) are fetched once into the CU's L1.  Partial counts of the register ranges are
-// stored (plain, coalesced, in the accumulator layout) and summed by gram_finish_kernel, which also turns F into
-// the histogram layout dd_union.hip's kernels write: hist[((i * n) + j) * K + kk][64], i <= j.
+// Register bytes must be HLL registers (<= 63), as everywhere in this library.
+//
+// Work unit = one WAVE: (super-block pair of 64 rows, k, register range, <= TS thresholds).  A k column's thresholds
+// are shared out evenly over ceil(T / 4 TS) workgroups and over the four waves of each, which stream the same rows:
+// 64-byte pieces of every row, brought into an LDS ring by LDS-DMA (global_load_lds_dwordx4), seven stages in flight
+// -- the 192 accumulator registers leave no room for a register prefetch that deep, and the rows come from HBM or the
+// Infinity Cache.  Two waves per SIMD.  Partial counts of the register ranges are stored (plain, coalesced, in the
+// accumulator layout) and summed by gram_finish_kernel, which also turns F into the histogram layout dd_union.hip's
+// kernels write: hist[((i * n) + j) * K + kk][64], i <= j.
+//
+// Measured (MI355X, 64 sketches of 2^20 registers x 31 k, ~30 thresholds per column; profiles/r03_k2_gram.txt):
+// 2.2 ms for the Gram kernel (matrix pipes 64 % busy at the 2.06 GHz the chip holds under this load: the rest is VALU
+// issue -- six thresholding instructions per MFMA share the SIMD's issue port with it), 0.38 ms for the range pass
+// (the slab read once at 5.6 TB/s), 0.11 ms for the finish; 14.0 ms for the streaming kernel.
 #include "dd_common.h"
 #include "dd_kernels.h"
 
@@ -73,10 +82,20 @@ __global__ __launch_bounds__(256) void gram_range_kernel(const uint8_t* __restri
         hi8 = x > hi8 ? x : hi8;
         lo8 = y < lo8 ? y : lo8;
     }
-    if ((threadIdx.x & 63) == 0) {
+    __shared__ uint32_t s_hi[4], s_lo[4];
+    if ((threadIdx.x & 63) == 0) s_hi[threadIdx.x >> 6] = hi8, s_lo[threadIdx.x >> 6] = lo8;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            hi8 = s_hi[w] > hi8 ? s_hi[w] : hi8;
+            lo8 = s_lo[w] < lo8 ? s_lo[w] : lo8;
+        }
+        // 62 addresses for ~30 000 workgroups: only a workgroup that would move a bound touches it (a stale read
+        // costs a needless atomic, never a wrong bound)
         const int k = (int)(row % (size_t)K);
-        atomicMin(&rng[2 * k], lo8);
-        atomicMax(&rng[2 * k + 1], hi8);
+        if (lo8 < gload4_fresh(&rng[2 * k])) atomicMin(&rng[2 * k], lo8);
+        if (hi8 > gload4_fresh(&rng[2 * k + 1])) atomicMax(&rng[2 * k + 1], hi8);
     }
 }
 
@@ -105,28 +124,131 @@ DD_D v4i threshold16(const uint4& x, uint32_t thr) {
     t.w = (int)((thr - x.w) & 0x80808080u);
     return t;
 }
-DD_D uint4 mask63(uint4 x) {
-    x.x &= 0x3f3f3f3fu, x.y &= 0x3f3f3f3fu, x.z &= 0x3f3f3f3fu, x.w &= 0x3f3f3f3fu;
-    return x;
-}
-
 // DIAG: both operands are the 64 rows of super-block P: blocks (0,0), (0,1), (1,1) of its 2 x 2 halves.
 // !DIAG: rows of P against rows of Q > P: blocks (0,0), (0,1), (1,0), (1,1).
 template <bool DIAG>
 struct GramShape {
-    static constexpr int TS = DIAG ? 4 : 3;   // thresholds per wave: TS x NB x 16 accumulator registers
+    static constexpr int TS = DIAG ? 4 : 3;   // thresholds per wave at most: TS x NB x 16 = 192 accumulator registers, two waves per SIMD
     static constexpr int NB = DIAG ? 3 : 4;   // 32 x 32 blocks per wave
 };
 
+// LDS ring: a stage is 64 bytes of every row of the unit (NH x 32 rows), filled by LDS-DMA (global_load_lds_dwordx4:
+// no staging registers, so kRingDepth stages stay in flight per workgroup -- the rows are streamed from HBM / the
+// Infinity Cache with ~1 us of latency to cover and the accumulators leave no registers for a deep prefetch).  A DMA
+// writes 1 KiB = lane x 16 B contiguously, its SOURCE address is per lane: lane l of the DMA for 16-row group g
+// fetches bytes [16 (l / 16), +16) of row 16 g + l % 16, so the image of a stage is [group][16-byte chunk][row % 16]
+// and the 16 lanes that ds_read_b128 services together (rows distinct mod 16, one chunk) hit 64 distinct banks.
+constexpr int kRingSlots = 8, kRingDepth = kRingSlots - 1;
+
+DD_D void glds16(const uint8_t* src, uint8_t* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const DD_GLOBAL void*)src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+template <int N>
+DD_D void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 // part[(((unit_sp * K + k) * RR + rr) * slots + slot) * NB * 1024 + block * 1024 + reg * 64 + lane], slot = threshold - vmin_k
-template <bool DIAG>
-__global__ __launch_bounds__(256, DIAG ? 2 : 1) void gram_kernel(const uint8_t* __restrict__ leaf, int n, int K, int p,
+// The streaming loop of one wave with NT thresholds (NT = 0: a wave that only feeds the ring), fully unrolled over
+// its thresholds: NT x NB x 16 accumulator registers.
+template <bool DIAG, int NT>
+DD_D void gram_body(const uint8_t* const* src, uint8_t* ring, uint32_t ring_lds, int wave, int lane, int nst, uint32_t thr0,
+                    uint32_t* __restrict__ out) {
+    constexpr int NB = GramShape<DIAG>::NB;
+    constexpr int NH = DIAG ? 2 : 4;         // 32-row operand sets of a stage
+    constexpr int G = NH / 2;                // DMAs per wave and stage: NH * 2 groups of 16 rows over 4 waves
+    constexpr int STAGE = NH * 32 * 64;      // bytes
+    constexpr int NA = NT ? NT : 1;
+    auto issue = [&](int s) {
+        uint8_t* dst = ring + (s % kRingSlots) * STAGE;
+#pragma unroll
+        for (int g = 0; g < G; ++g) glds16(src[g] + (size_t)s * 64, dst + (wave + 4 * g) * 1024);
+    };
+    v16i acc[NA][NB];
+#pragma unroll
+    for (int t = 0; t < NA; ++t)
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][q][e] = 0;
+    // operand reads: lane (r = lane % 32, half = lane / 32) takes chunk 2 u + half of rows r (+ 32 h) for k-step u
+    const int r = lane & 31, half = lane >> 5;
+    const int rd0 = 16 * ((r >> 4) * 64 + half * 16 + (r & 15));   // operand set 0, step 0; set h: + h * 2048; step 1: + 512
+
+    for (int s = 0; s < kRingDepth && s < nst; ++s) issue(s);
+    for (int i = 0; i < nst; ++i) {
+        if (nst - i >= kRingDepth)
+            wait_vm<(kRingDepth - 1) * G>();   // this wave's DMAs of stage i have landed ...
+        else
+            wait_vm<0>();
+        __builtin_amdgcn_s_barrier();          // ... and so have the other waves'; everyone is done with stage i - 1
+        if (i + kRingDepth < nst) issue(i + kRingDepth);
+        if (NT == 0) continue;
+        // (read by hand: the compiler cannot tell which DMA a ds_read of the ring depends on and would drain them all
+        // -- s_waitcnt vmcnt(0) -- in front of every read; the counted wait and the barrier above are the ordering)
+        const uint32_t st = ring_lds + (uint32_t)((i % kRingSlots) * STAGE + rd0);
+        dd_u32x4 raw[2][NH];
+        if (DIAG)
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:512\n\tds_read_b128 %2, %4 offset:2048\n\t"
+                         "ds_read_b128 %3, %4 offset:2560\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(raw[0][0]), "=&v"(raw[1][0]), "=&v"(raw[0][1]), "=&v"(raw[1][1])
+                         : "v"(st)
+                         : "memory");
+        else
+            asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:512\n\tds_read_b128 %2, %8 offset:2048\n\t"
+                         "ds_read_b128 %3, %8 offset:2560\n\tds_read_b128 %4, %8 offset:4096\n\tds_read_b128 %5, %8 offset:4608\n\t"
+                         "ds_read_b128 %6, %8 offset:6144\n\tds_read_b128 %7, %8 offset:6656\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(raw[0][0]), "=&v"(raw[1][0]), "=&v"(raw[0][1]), "=&v"(raw[1][1]), "=&v"(raw[0][2 % NH]),
+                           "=&v"(raw[1][2 % NH]), "=&v"(raw[0][3 % NH]), "=&v"(raw[1][3 % NH])
+                         : "v"(st)
+                         : "memory");
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            uint4 x[NH];
+#pragma unroll
+            for (int h = 0; h < NH; ++h) x[h] = make_uint4(raw[u][h].x, raw[u][h].y, raw[u][h].z, raw[u][h].w);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const uint32_t thr = thr0 + (uint32_t)t * 0x01010101u;
+                if (DIAG) {
+                    const v4i a0 = threshold16(x[0], thr), a1 = threshold16(x[1], thr);
+                    acc[t][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, a0, acc[t][0], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, a1, acc[t][1], 0, 0, 0);
+                    acc[t][2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, a1, acc[t][2], 0, 0, 0);
+                } else {
+                    const v4i a0 = threshold16(x[0], thr), a1 = threshold16(x[1], thr);
+                    const v4i b0 = threshold16(x[2], thr), b1 = threshold16(x[3], thr);
+                    acc[t][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc[t][0], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc[t][1], 0, 0, 0);
+                    acc[t][2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc[t][2], 0, 0, 0);
+                    acc[t][3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[t][3], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // counts out: accumulator = 2^14 x hits
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) gstore4(out + ((size_t)t * NB + q) * 1024 + e * 64, (uint32_t)acc[t][q][e] >> 14);
+}
+
+// part[(((unit_sp * K + k) * RR + rr) * slots + slot) * NB * 1024 + block * 1024 + reg * 64 + lane], slot = threshold - vmin_k
+template <bool DIAG, int TS>
+__global__ __launch_bounds__(256, 2) void gram_kernel(const uint8_t* __restrict__ leaf, int n, int K, int p,
                                                       const uint32_t* __restrict__ rng, int sp_base, int ns,
-                                                      int RR, int slots, uint32_t* __restrict__ part) {
-    constexpr int TS = GramShape<DIAG>::TS, NB = GramShape<DIAG>::NB;
+                                                      int RR, int len, int slots, uint32_t* __restrict__ part) {
+    constexpr int NB = GramShape<DIAG>::NB;
+    constexpr int NH = DIAG ? 2 : 4;
+    constexpr int G = NH / 2;
+    constexpr int STAGE = NH * 32 * 64;
+    __shared__ __attribute__((aligned(1024))) uint8_t ring[kRingSlots * STAGE];
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)ring;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int groups = slots / TS, quads = (groups + 3) >> 2;
-    // blockIdx -> (threshold-group quad, register range, k, super-block pair): quad fastest, so the workgroups that
+    const int quads = (slots + 4 * TS - 1) / (4 * TS);
+    // blockIdx -> (threshold quad, register range, k, super-block pair): quad fastest, so the workgroups that
     // stream the same bytes are launched next to each other
     int b = blockIdx.x;
     const int quad = b % quads;
@@ -135,143 +257,103 @@ __global__ __launch_bounds__(256, DIAG ? 2 : 1) void gram_kernel(const uint8_t* 
     b /= RR;
     const int k = b % K;
     const int sp = b / K;
-    const int tg = quad * 4 + wave;
+    // thresholds vmin .. vmax-1 carry information (F = 0 below vmin, m from vmax on): T of them, 4 TS per workgroup,
+    // shared out evenly over its four waves (one wave per SIMD: the matrix pipes of a CU finish together)
     const int vmin = (int)rng[2 * k], vmax = (int)rng[2 * k + 1];
-    const int slot0 = tg * TS;
-    // thresholds vmin .. vmax-1 carry information (F = 0 below vmin, m from vmax on)
-    if (tg >= groups || vmin + slot0 > vmax - 1) return;
+    const int T = vmax - vmin;
+    const int nq = (T + 4 * TS - 1) / (4 * TS);       // workgroups that share the column's thresholds, evenly
+    if (quad >= nq) return;
+    const int q0 = quad * (T / nq) + (quad < T % nq ? quad : T % nq);
+    const int mine_all = T / nq + (quad < T % nq ? 1 : 0);
+    const int per = (mine_all + 3) >> 2;
+    const int slot0 = q0 + wave * per;                                   // first threshold of this wave, relative to vmin
+    const int left = mine_all - wave * per;
+    const int nthr = __builtin_amdgcn_readfirstlane(left < per ? (left > 0 ? left : 0) : per);
     const int2 PQ = gram_pair<DIAG>(sp_base + sp, ns);
-    const int r = lane & 31, half = lane >> 5;
-    const size_t m = (size_t)1 << p;
-    const size_t len = m < (size_t)kGramRange ? m : (size_t)kGramRange;
-    const size_t off0 = (size_t)rr * len + (size_t)half * 32;
-    const uint8_t* rows[DIAG ? 2 : 4];
+    // this lane's DMA sources: rows 16 (wave + 4 g) + lane % 16 of the stage, chunk lane / 16
+    const uint8_t* src[G];
 #pragma unroll
-    for (int h = 0; h < (DIAG ? 2 : 4); ++h) {
-        int row = ((h < 2 ? PQ.x : PQ.y) << 6) + ((h & 1) << 5) + r;
+    for (int g = 0; g < G; ++g) {
+        const int srow = 16 * (wave + 4 * g) + (lane & 15);          // row of the stage: operand set srow / 32
+        int row = ((srow < 64 ? PQ.x : PQ.y) << 6) + (srow & 63);
         row = row < n ? row : n - 1;  // rows beyond n: any valid row, their counts are never read
-        rows[h] = leaf + (((size_t)row * K + k) << p) + off0;
+        src[g] = leaf + (((size_t)row * K + k) << p) + (size_t)rr * (size_t)len + (size_t)(lane >> 4) * 16;
     }
-    uint32_t thr[TS];
-#pragma unroll
-    for (int t = 0; t < TS; ++t) thr[t] = (uint32_t)(0x80 + vmin + slot0 + t) * 0x01010101u;
-    v16i acc[TS][NB];
-#pragma unroll
-    for (int t = 0; t < TS; ++t)
-#pragma unroll
-        for (int q = 0; q < NB; ++q)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[t][q][e] = 0;
-
-    // 64 registers per iteration: this lane's 32 bytes (two 16-byte k-slices) of each of its rows
-    uint4 cur[DIAG ? 2 : 4][2], nxt[DIAG ? 2 : 4][2];
-#pragma unroll
-    for (int h = 0; h < (DIAG ? 2 : 4); ++h) {
-        cur[h][0] = gload16(rows[h]);
-        cur[h][1] = gload16(rows[h] + 16);
-    }
-    for (size_t o = 0; o < len; o += 64) {
-        const size_t on = o + 64 < len ? o + 64 : o;  // (the last iteration re-reads its own bytes)
-#pragma unroll
-        for (int h = 0; h < (DIAG ? 2 : 4); ++h) {
-            nxt[h][0] = gload16(rows[h] + on);
-            nxt[h][1] = gload16(rows[h] + on + 16);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            uint4 x[DIAG ? 2 : 4];
-#pragma unroll
-            for (int h = 0; h < (DIAG ? 2 : 4); ++h) x[h] = mask63(cur[h][u]);
-#pragma unroll
-            for (int t = 0; t < TS; ++t) {
-                if (DIAG) {
-                    const v4i a0 = threshold16(x[0], thr[t]), a1 = threshold16(x[1], thr[t]);
-                    acc[t][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, a0, acc[t][0], 0, 0, 0);
-                    acc[t][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, a1, acc[t][1], 0, 0, 0);
-                    acc[t][2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, a1, acc[t][2], 0, 0, 0);
-                } else {
-                    const v4i a0 = threshold16(x[0], thr[t]), a1 = threshold16(x[1], thr[t]);
-                    const v4i b0 = threshold16(x[2], thr[t]), b1 = threshold16(x[3], thr[t]);
-                    acc[t][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc[t][0], 0, 0, 0);
-                    acc[t][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc[t][1], 0, 0, 0);
-                    acc[t][2] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc[t][2], 0, 0, 0);
-                    acc[t][3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[t][3], 0, 0, 0);
-                }
-            }
-        }
-#pragma unroll
-        for (int h = 0; h < (DIAG ? 2 : 4); ++h) {
-            cur[h][0] = nxt[h][0];
-            cur[h][1] = nxt[h][1];
-        }
-    }
-    // counts out: accumulator = 2^14 x hits
+    const uint32_t thr0 = (uint32_t)(0x80 + vmin + slot0) * 0x01010101u;
     uint32_t* out = part + ((((size_t)sp * K + k) * RR + rr) * slots + slot0) * (size_t)(NB * 1024) + lane;
-#pragma unroll
-    for (int t = 0; t < TS; ++t) {
-        if (vmin + slot0 + t > vmax - 1) break;
-#pragma unroll
-        for (int q = 0; q < NB; ++q)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) gstore4(out + ((size_t)t * NB + q) * 1024 + e * 64, (uint32_t)acc[t][q][e] >> 14);
+    const int nst = len >> 6;
+    switch (nthr) {
+#define DD_GRAM_CASE(NT) \
+    case NT: gram_body<DIAG, (NT <= TS ? NT : 0)>(src, ring, ring_lds, wave, lane, nst, thr0, out); break;   // (NT > TS never occurs)
+        DD_GRAM_CASE(1) DD_GRAM_CASE(2) DD_GRAM_CASE(3) DD_GRAM_CASE(4)
+#undef DD_GRAM_CASE
+        default: gram_body<DIAG, 0>(src, ring, ring_lds, wave, lane, nst, thr0, out); break;
     }
 }
 
-// One wave per (pair i <= j of the super-block pairs [sp_begin, sp_begin + sp_count), k): lane v sums the partial
-// counts of threshold v over the register ranges, the wave differences F into hist[((i * n) + j) * K + k][64].
+// One workgroup per (super-block pair, k, 32 x 32 block, accumulator register): the 64 entries one accumulator register
+// holds across the wave's lanes.  Wave w sums the partial counts of thresholds w, w + 4, ... over the register ranges
+// (256-byte reads in the layout the Gram kernel stored), the sums are transposed through LDS, and every entry's
+// cumulative counts are differenced into its histogram row hist[((i * n) + j) * K + k][64] (256-byte writes).
 __global__ __launch_bounds__(256) void gram_finish_kernel(const uint32_t* __restrict__ part, int n, int K, int p,
                                                           const uint32_t* __restrict__ rng, int diag, int sp_base, int ns,
-                                                          int sp_count, int RR, int slots, uint32_t* __restrict__ hist) {
-    const int lane = threadIdx.x & 63;
-    const size_t job = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (sp, il, jl, k), k fastest
-    const int k = (int)(job % (size_t)K);
-    size_t rest = job / (size_t)K;
-    const int jl = (int)(rest & 63);
-    rest >>= 6;
-    const int il = (int)(rest & 63);
-    const int sp = (int)(rest >> 6);
-    if (sp >= sp_count) return;
-    const int2 PQ = diag ? gram_pair<true>(sp_base + sp, ns) : gram_pair<false>(sp_base + sp, ns);
-    const int i = (PQ.x << 6) + il, j = (PQ.y << 6) + jl;
-    if (i >= n || j >= n || i > j) return;
-    const int bi = il >> 5, bj = jl >> 5, rr_ = il & 31, cc = jl & 31;
+                                                          int RR, int slots, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t F[64][65];   // [entry][threshold]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int NB = diag ? 3 : 4;
-    const int block = diag ? bi + bj : bi * 2 + bj;
-    const int reg = (rr_ & 3) + 4 * (rr_ >> 3), ln = cc + 32 * ((rr_ >> 2) & 1);
+    int b = blockIdx.x;
+    const int reg = b & 15;
+    b >>= 4;
+    const int block = b % NB;
+    b /= NB;
+    const int k = b % K;
+    const int sp = b / K;
     const int vmin = (int)rng[2 * k], vmax = (int)rng[2 * k + 1];
     const uint32_t m = 1u << p;
-    uint32_t F;
-    if (lane < vmin)
-        F = 0;
-    else if (lane >= vmax)
-        F = m;
-    else {
-        F = 0;
-        const uint32_t* src = part + (((size_t)sp * K + k) * RR * slots + (size_t)(lane - vmin)) * (size_t)(NB * 1024) +
-                              (size_t)block * 1024 + reg * 64 + ln;
-        for (int rr = 0; rr < RR; ++rr) F += gload4(src + (size_t)rr * slots * (size_t)(NB * 1024));
+    const uint32_t* src = part + ((size_t)sp * K + k) * RR * slots * (size_t)(NB * 1024) + (size_t)block * 1024 + reg * 64 + lane;
+    for (int v = wave; v < 64; v += 4) {
+        uint32_t f = v < vmin ? 0u : m;
+        if (v >= vmin && v < vmax) {
+            f = 0;
+            for (int rr = 0; rr < RR; ++rr) f += gload4(src + ((size_t)rr * slots + (size_t)(v - vmin)) * (size_t)(NB * 1024));
+        }
+        F[lane][v] = f;
     }
-    const uint32_t prev = __shfl_up(F, 1);
-    gstore4(hist + (((size_t)i * n + j) * K + k) * 64 + lane, lane ? F - prev : F);
+    __syncthreads();
+    const int2 PQ = diag ? gram_pair<true>(sp_base + sp, ns) : gram_pair<false>(sp_base + sp, ns);
+    const int bi = diag ? (block == 2) : (block >> 1), bj = diag ? (block >= 1) : (block & 1);
+    for (int e = wave; e < 64; e += 4) {
+        // entry e of accumulator register `reg`: row (reg & 3) + 8 (reg >> 2) + 4 (e >> 5), column e & 31 of the block
+        const int i = (PQ.x << 6) + bi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (e >> 5);
+        const int j = (PQ.y << 6) + bj * 32 + (e & 31);
+        if (i >= n || j >= n || i > j) continue;
+        const uint32_t f = F[e][lane], prev = lane ? F[e][lane - 1] : 0u;
+        gstore4(hist + (((size_t)i * n + j) * K + k) * 64 + lane, f - prev);
+    }
 }
 
 }  // namespace
 
 bool gram_usable(int n, int p) { return p >= 12 && n >= 2; }
 
-// thresholds a k column can need: registers live in 0 .. 64 - p + 1
-static int gram_slots(int p, int ts) {
-    const int t = 64 - p + 1;  // thresholds 0 .. 64 - p
-    return (t + ts - 1) / ts * ts;
+// thresholds a k column can need: registers live in 0 .. 64 - p + 1, thresholds vmin .. vmax - 1
+static int gram_slots(int p) { return 64 - p + 1; }
+
+// registers per wave: the whole row up to 2^16 (the accumulator's headroom), less when that leaves too few
+// workgroups to fill the chip -- two per CU at least, not below 1024 registers
+static int gram_len(int nsp, int K, int p) {
+    size_t len = std::min<size_t>((size_t)1 << p, (size_t)kGramRange);
+    while (len > 1024 && (size_t)nsp * K * (((size_t)1 << p) / len) < 512) len >>= 1;
+    return (int)len;
 }
 
 size_t gram_scratch_bytes(int n, int K, int p, int* sp_per_launch) {
     const int ns = (n + 63) / 64;
-    const size_t m = (size_t)1 << p;
-    const size_t RR = (m + kGramRange - 1) / kGramRange;
-    // a launch covers as many super-block pairs as fit ~1 GiB of partial counts (at least one)
-    const size_t per_sp = (size_t)K * RR * (size_t)gram_slots(p, 3) * 4096 * sizeof(uint32_t);
     const size_t total_sp = (size_t)ns * (ns + 1) / 2;
+    const size_t m = (size_t)1 << p;
+    const size_t RR = m / (size_t)gram_len(ns, K, p);   // (the diagonal launch has the fewest units: its split is the finest)
+    // a launch covers as many super-block pairs as fit ~1 GiB of partial counts (at least one)
+    const size_t per_sp = (size_t)K * RR * (size_t)gram_slots(p) * 4096 * sizeof(uint32_t);
     size_t fit = ((size_t)1 << 30) / per_sp;
     fit = fit < 1 ? 1 : fit > total_sp ? total_sp : fit;
     if (sp_per_launch) *sp_per_launch = (int)fit;
@@ -283,7 +365,6 @@ void launch_pairwise_gram(const uint8_t* leaf_dev, int n, int K, int p, uint32_t
                           hipStream_t st) {
     const int ns = (n + 63) / 64;
     const size_t m = (size_t)1 << p;
-    const int RR = (int)((m + kGramRange - 1) / kGramRange);
     int sp_fit = 1;
     (void)gram_scratch_bytes(n, K, p, &sp_fit);
     uint8_t* base = static_cast<uint8_t*>(scratch);
@@ -294,21 +375,22 @@ void launch_pairwise_gram(const uint8_t* leaf_dev, int n, int K, int p, uint32_t
     const int pieces = (int)((m + 65535) / 65536);
     hipLaunchKernelGGL(gram_range_kernel, dim3((unsigned)((size_t)n * K * pieces)), dim3(256), 0, st, leaf_dev, K, p, pieces, rng);
     // the diagonal super-block pairs (P, P), then the pairs P < Q; sp_fit of them per launch
+    const int slots = gram_slots(p);
+    const int len = gram_len(ns, K, p);
+    const int RR = (int)(m / (size_t)len);
     for (int diag = 1; diag >= 0; --diag) {
         const int total = diag ? ns : ns * (ns - 1) / 2;
         const int ts = diag ? GramShape<true>::TS : GramShape<false>::TS;
-        const int slots = gram_slots(p, ts);
-        const int quads = (slots / ts + 3) / 4;
+        const int quads = (slots + 4 * ts - 1) / (4 * ts);
         for (int a = 0; a < total; a += sp_fit) {
             const int cnt = std::min(sp_fit, total - a);
             const unsigned grid = (unsigned)((size_t)cnt * K * RR * quads);
             if (diag)
-                hipLaunchKernelGGL(gram_kernel<true>, dim3(grid), dim3(256), 0, st, leaf_dev, n, K, p, rng, a, ns, RR, slots, part);
+                hipLaunchKernelGGL((gram_kernel<true, GramShape<true>::TS>), dim3(grid), dim3(256), 0, st, leaf_dev, n, K, p, rng, a, ns, RR, len, slots, part);
             else
-                hipLaunchKernelGGL(gram_kernel<false>, dim3(grid), dim3(256), 0, st, leaf_dev, n, K, p, rng, a, ns, RR, slots, part);
-            const size_t jobs = (size_t)cnt * 64 * 64 * K;
-            hipLaunchKernelGGL(gram_finish_kernel, dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0, st, part, n, K, p, rng, diag, a, ns, cnt,
-                               RR, slots, hist_dev);
+                hipLaunchKernelGGL((gram_kernel<false, GramShape<false>::TS>), dim3(grid), dim3(256), 0, st, leaf_dev, n, K, p, rng, a, ns, RR, len, slots, part);
+            hipLaunchKernelGGL(gram_finish_kernel, dim3((unsigned)((size_t)cnt * K * (diag ? 3 : 4) * 16)), dim3(256), 0, st, part, n, K, p, rng,
+                               diag, a, ns, RR, slots, hist_dev);
         }
     }
 }

@@ -7,8 +7,7 @@
 //   * running max along an ordering     (DeltaTree.sketch_ordering, lib/huffman_dandd.py:644-663;
 //                                        equals the flat prefix unions because max is associative)
 //   * all pairs                         (DeltaTree.pairwise_spiders, lib/huffman_dandd.py:666-695)
-// HBM/L2-bound: 16-byte loads, SWAR byte max, LDS histograms privatised 32 ways (copies 65 words apart: with 64
-// the same bin of every copy shared an LDS bank, which halved every kernel here).
+// HBM/L2-bound: 16-byte loads, SWAR byte max, LDS histograms privatised 32 ways, bin-major (one bank per copy).
 #include "dd_common.h"
 #include "dd_kernels.h"
 
@@ -16,7 +15,18 @@ namespace dd {
 namespace {
 
 constexpr int HCOPIES = 32;  // privatised LDS histograms per workgroup
-constexpr int HSTRIDE = 65;  // words per copy: 64 bins + 1, so that the same bin of different copies sits in different LDS banks
+
+// Histogram image: h[bin][copy], copy = lane % 32.  ds_add_u32 is serviced in two groups of 32 lanes, each over 32
+// banks of 4 bytes: with the copy as the fastest index every lane of a group adds into ITS OWN bank whatever bins the
+// bytes name -- no bank conflict is possible (lanes l and l + 32 share a copy but not a group).  The copy-major
+// image this replaces (h[copy][65]) put (copy + bin) % 32 on the bank: ~3.5 lanes of a group collided on average.
+#ifdef DD_HIST_COPY_MAJOR   // (A/B builds only)
+typedef uint32_t HistImage[HCOPIES][65];
+#define DD_HIST_AT(h, bin, copy) (h)[copy][bin]
+#else
+typedef uint32_t HistImage[64][HCOPIES];
+#define DD_HIST_AT(h, bin, copy) (h)[bin][copy]
+#endif
 
 DD_D uint4 bmax16(uint4 a, uint4 b) {
     return make_uint4(bmax4(a.x, b.x), bmax4(a.y, b.y), bmax4(a.z, b.z), bmax4(a.w, b.w));
@@ -33,26 +43,26 @@ __global__ __launch_bounds__(256) void union_kernel(const uint8_t* const* __rest
 }
 
 // add the 16 register bytes of v to the workgroup's privatised histograms
-DD_D void hist_add16(uint32_t (*h)[HSTRIDE], uint4 v) {
-    uint32_t* mine = h[threadIdx.x & (HCOPIES - 1)];
+DD_D void hist_add16(HistImage h, uint4 v) {
+    const int copy = threadIdx.x & (HCOPIES - 1);
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) atomicAdd(&mine[(w[q] >> (8 * b)) & 63u], 1u);
+        for (int b = 0; b < 4; ++b) atomicAdd(&DD_HIST_AT(h, (w[q] >> (8 * b)) & 63u, copy), 1u);
     }
 }
 
-DD_D void hist_zero(uint32_t (*h)[HSTRIDE]) {
-    for (int i = threadIdx.x; i < HCOPIES * HSTRIDE; i += blockDim.x) (&h[0][0])[i] = 0;
+DD_D void hist_zero(HistImage h) {
+    for (int i = threadIdx.x; i < (int)(sizeof(HistImage) / 4); i += blockDim.x) (&h[0][0])[i] = 0;
 }
 
 // fold the privatised copies and add them to a global 64-bin histogram
-DD_D void hist_flush(uint32_t (*h)[HSTRIDE], uint32_t* __restrict__ gh, bool exclusive) {
+DD_D void hist_flush(HistImage h, uint32_t* __restrict__ gh, bool exclusive) {
     if (threadIdx.x < 64) {
         uint32_t s = 0;
 #pragma unroll
-        for (int c = 0; c < HCOPIES; ++c) s += h[c][threadIdx.x];
+        for (int c = 0; c < HCOPIES; ++c) s += DD_HIST_AT(h, threadIdx.x, (c + threadIdx.x) & (HCOPIES - 1));  // (rotated: thread t starts at bank t)
         if (exclusive)
             gh[threadIdx.x] = s;
         else if (s)
@@ -67,7 +77,7 @@ DD_D void hist_flush(uint32_t (*h)[HSTRIDE], uint32_t* __restrict__ gh, bool exc
 template <int PC>
 __global__ __launch_bounds__(1024) void hist_kernel(const uint8_t* __restrict__ regs, int p,
                                                     int tiles, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t h[HCOPIES][HSTRIDE];
+    __shared__ HistImage h;
     const int job = blockIdx.x / tiles, tile = blockIdx.x % tiles;
     const size_t m16 = ((size_t)1 << p) >> 4;
     const size_t piece = (size_t)tile * blockDim.x * PC + threadIdx.x;
@@ -87,7 +97,7 @@ __global__ __launch_bounds__(1024) void progressive_kernel(const uint8_t* __rest
                                                            int K, int p, int tiles,
                                                            const int32_t* __restrict__ ord,
                                                            uint32_t* __restrict__ hist) {
-    __shared__ uint32_t h[HCOPIES][HSTRIDE];
+    __shared__ HistImage h;
     const int tile = blockIdx.x % tiles;
     const int kk = (blockIdx.x / tiles) % K;
     const int o = blockIdx.x / tiles / K;
@@ -118,7 +128,7 @@ template <int PC>
 __global__ __launch_bounds__(1024) void pairwise_kernel(const uint8_t* __restrict__ leaf, int n,
                                                         int K, int p, int tiles,
                                                         uint32_t* __restrict__ hist) {
-    __shared__ uint32_t h[HCOPIES][HSTRIDE];
+    __shared__ HistImage h;
     const int tile = blockIdx.x % tiles;
     const int kk = (blockIdx.x / tiles) % K;
     const int i = blockIdx.x / tiles / K;

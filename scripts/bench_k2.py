@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dandd_amd.engine import Engine, KERNEL_UNION
 
 p = int(sys.argv[1]) if len(sys.argv) > 1 else 14
+only = sys.argv[2] if len(sys.argv) > 2 else ""
 m = 1 << p
 eng = Engine(0, p, True)
 rng = np.random.default_rng(0)
@@ -48,6 +49,8 @@ print(f"pairwise  n={n} K={K} p={p}: wall {wall:.2f} ms, union/hist kernels {dev
       f"{pairs * K} union jobs, {bytes_read / dev / 1e6:.1f} GB/s algorithmic (2 inputs/job), "
       f"{pairs * K * m / dev / 1e6:.1f} GB/s counting the streamed operand only")
 
+if only == "pairwise":
+    sys.exit(0)
 # cfg 4: progressive, 30 genomes, 10 orderings, k 4..40
 n, K, no = 30, 37, 10
 leaf = slab(n, K)
