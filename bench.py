@@ -402,7 +402,7 @@ def main():
     ap.add_argument("--no-accuracy", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-ingest", action="store_true")
-    ap.add_argument("--cpu-sample-mbp", type=float, default=32.0)
+    ap.add_argument("--cpu-sample-mbp", type=float, default=256.0)
     ap.add_argument("--force-dist", action="store_true",
                     help="run through the launcher and a process group even at --gpus 1 (world size 1): the RCCL "
                          "all-reduce / all-gather of the N>1 path execute in librccl on a one-GPU box")
