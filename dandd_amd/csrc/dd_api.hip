@@ -114,7 +114,7 @@ struct dd_ctx {
     std::vector<TimedSpan> spans[DD_KERNEL_COUNT];
     std::vector<hipEvent_t> pool;
     // workspaces
-    DevBuf tokens, scratch, tables, fasta, regs, ptrs, hist, est, ord, bitmaps, bigmaps, exact, buckets, gram;
+    DevBuf tokens, scratch, tables, fasta, regs, ptrs, hist, est, ord, bitmaps, bigmaps, exact, buckets, gram, synth;
     HostBuf stage, stage_jobs, stage_rows;  // genome/pack tables and K1 job tables are uploaded in two steps
     // the job tables of the last few sketch calls: a call over genomes of the same sizes and the same k range (a
     // pipeline sketching batches of a few recurring shapes, a benchmark loop) reuses them, on the host and in HBM
@@ -300,7 +300,7 @@ void dd_destroy(dd_ctx* c) {
     if (c->stage_free) (void)hipEventDestroy(c->stage_free);
     for (auto& pe : c->plans) pe.jobtab.release();
     for (DevBuf* b : {&c->tokens, &c->scratch, &c->tables, &c->fasta, &c->regs, &c->ptrs, &c->hist,
-                      &c->est, &c->ord, &c->bitmaps, &c->bigmaps, &c->exact, &c->buckets, &c->gram})
+                      &c->est, &c->ord, &c->bitmaps, &c->bigmaps, &c->exact, &c->buckets, &c->gram, &c->synth})
         b->release();
     c->stage.release();
     c->stage_jobs.release();
@@ -1499,6 +1499,28 @@ int dd_synth_fasta_device(dd_ctx* c, uint64_t seed, int genome_index, uint64_t n
         return fail(DD_EINVAL, "bad argument");
     DeviceGuard guard(c->device);
     dd::launch_synth(seed, genome_index, nbases, nrec, out_dev, c->stream);
+    DD_HIP(hipGetLastError());
+    return DD_OK;
+}
+
+size_t dd_synth_realistic_size(uint64_t seed, uint64_t nbases) {
+    if (!nbases) return 0;
+    const std::vector<uint64_t> tab = dd::synth_realistic_table(seed, nbases);
+    return (size_t)tab[tab.size() - 2];
+}
+
+int dd_synth_realistic_device(dd_ctx* c, uint64_t seed, int genome_index, uint64_t nbases, uint8_t* out_dev) {
+    if (check_ctx(c)) return DD_EINVAL;
+    if (genome_index < 0 || genome_index > 65535 || !out_dev) return fail(DD_EINVAL, "bad argument");
+    if (!nbases) return DD_OK;
+    DeviceGuard guard(c->device);
+    const std::vector<uint64_t> tab = dd::synth_realistic_table(seed, nbases);
+    int rc;
+    if ((rc = c->synth.reserve(tab.size() * sizeof(uint64_t)))) return rc;
+    DD_HIP(hipMemcpyAsync(c->synth.p, tab.data(), tab.size() * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+    DD_HIP(hipStreamSynchronize(c->stream));   // (`tab` is pageable host memory about to go out of scope)
+    dd::launch_synth_realistic(seed, genome_index, static_cast<const uint64_t*>(c->synth.p), (uint32_t)(tab.size() / 2 - 1),
+                               tab[tab.size() - 2], out_dev, c->stream);
     DD_HIP(hipGetLastError());
     return DD_OK;
 }

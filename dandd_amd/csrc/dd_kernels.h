@@ -1,5 +1,6 @@
 // dd_kernels.h -- host-callable launchers of the gfx950 kernels behind the C ABI.
 #pragma once
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -210,5 +211,9 @@ hipError_t launch_exact_sort_count(uint64_t* lo, uint64_t* hi, uint64_t* lo_alt,
 // synthetic FASTA
 void launch_synth(uint64_t seed, int gi, uint64_t nbases, int nrec, uint8_t* out_dev, hipStream_t st);
 size_t synth_size(uint64_t nbases, int nrec);
+// "realistic" mode (dd_synth.hip): contig table on the host, bytes on the device
+std::vector<uint64_t> synth_realistic_table(uint64_t seed, uint64_t nbases);
+void launch_synth_realistic(uint64_t seed, int gi, const uint64_t* tab_dev, uint32_t ncontigs, uint64_t total, uint8_t* out_dev,
+                            hipStream_t st);
 
 }  // namespace dd

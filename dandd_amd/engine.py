@@ -27,7 +27,7 @@ EXPORTS = [
     "dd_progressive", "dd_progressive_device", "dd_pairwise", "dd_pairwise_device",
     "dd_exact_count", "dd_exact_count_device",
     "dd_timing_enable", "dd_timing_read", "dd_timing_reset", "dd_last_sketch_stats",
-    "dd_synth_size", "dd_synth_fasta_device", "dd_plan_sweep",
+    "dd_synth_size", "dd_synth_fasta_device", "dd_synth_realistic_size", "dd_synth_realistic_device", "dd_plan_sweep",
 ]
 
 
@@ -128,6 +128,10 @@ def load_library(path=None):
     lib.dd_synth_size.argtypes = [u64, i32]
     lib.dd_synth_fasta_device.restype = i32
     lib.dd_synth_fasta_device.argtypes = [vp, u64, i32, u64, i32, vp]
+    lib.dd_synth_realistic_size.restype = sz
+    lib.dd_synth_realistic_size.argtypes = [u64, u64]
+    lib.dd_synth_realistic_device.restype = i32
+    lib.dd_synth_realistic_device.argtypes = [vp, u64, i32, u64, vp]
     lib.dd_plan_sweep.restype = C.c_long
     lib.dd_plan_sweep.argtypes = [i32, C.POINTER(sz), i32, i32, i32, vp, C.c_long]
     if path is None:
@@ -141,6 +145,10 @@ def ertl_mle(hist, log2m):
     if h.size != 64:
         raise ValueError("histogram must have 64 bins")
     return float(load_library().dd_ertl_mle(h.ctypes.data, int(log2m)))
+
+
+def synth_realistic_size(seed, nbases):
+    return int(load_library().dd_synth_realistic_size(int(seed), int(nbases)))
 
 
 def synth_size(nbases, nrec=1):
@@ -346,6 +354,9 @@ class Engine:
         t, u, b = C.c_uint64(), C.c_uint64(), C.c_int()
         self._check(self._lib.dd_last_sketch_stats(self._ctx, C.byref(t), C.byref(u), C.byref(b)))
         return t.value, u.value, b.value
+
+    def synth_realistic_device(self, seed, genome_index, nbases, out_ptr):
+        self._check(self._lib.dd_synth_realistic_device(self._ctx, int(seed), int(genome_index), int(nbases), C.c_void_p(int(out_ptr))))
 
     def synth_fasta_device(self, seed, genome_index, nbases, nrec, out_ptr):
         self._check(self._lib.dd_synth_fasta_device(self._ctx, int(seed), int(genome_index), int(nbases),

@@ -144,6 +144,10 @@ int dd_last_sketch_stats(dd_ctx *, uint64_t *tokens, uint64_t *updates, int *swe
 size_t dd_synth_size(uint64_t nbases, int nrec);
 int dd_synth_fasta_device(dd_ctx *, uint64_t seed, int genome_index, uint64_t nbases, int nrec,
                           uint8_t *out_dev);
+/* "realistic" mode: GC 35 %, 30 % soft-masked repeats (interspersed + tandem), 2 % N, contigs of 2..200 kbp; byte-identical
+ * to oracle/dd_oracle.c:orc_synth_realistic_fasta.  The contig structure (and so the size) depends on the seed. */
+size_t dd_synth_realistic_size(uint64_t seed, uint64_t nbases);
+int dd_synth_realistic_device(dd_ctx *, uint64_t seed, int genome_index, uint64_t nbases, uint8_t *out_dev);
 
 /* ---- the K1 job table of a sketch call, without running it (tests; needs no GPU) --------
  * What stands in for `parallel -j 95%`'s process-per-k scheduling (lib/huffman_dandd.py:214-218):

@@ -367,3 +367,81 @@ size_t orc_synth_fasta(uint64_t seed, int gi, uint64_t nbases, int nrec, uint8_t
     }
     return o;
 }
+
+/* ---- "realistic" synthetic genomes: the i.i.d. uniform generator above is the BEST case of
+ * the k <= 9 "set complete" early exit and of every hash-spread assumption.  This one has what assemblies have:
+ * GC 35 %, 20 % interspersed repeats (copies of 64 elements of 300..6000 bases), 10 % tandem repeats (units of 2..60
+ * bases, 512-base blocks), soft-masked (lowercase) repeats, 2 % N in 100-base runs, contigs of 2..200 kbp, and 1 % per-base
+ * divergence between the genomes of one seed.  Counter-based like the other: base g of genome gi depends on (seed, gi, g)
+ * only.  dandd_amd/csrc/dd_synth.hip generates the same bytes on the device (tests/test_gpu_parity.py pins the two). */
+static uint64_t real_contig_len(uint64_t seed, uint64_t idx) {
+    const uint64_t h = orc_splitmix64(seed ^ 0xC047160000000000ull ^ idx);
+    const uint64_t base = 2000ull << ((h >> 40) % 7);
+    const uint64_t len = base + h % base;
+    return len < 200000 ? len : 200000;
+}
+
+static uint8_t real_base(uint64_t seed, uint64_t seed_g, uint64_t g) {
+    static const char up[4] = {'A', 'C', 'G', 'T'};
+    const uint64_t blk = g >> 9;
+    const uint64_t hb = orc_splitmix64(seed ^ 0x5EED5EED00000000ull ^ blk);
+    const unsigned kind = (unsigned)(hb % 100);
+    uint64_t r;
+    if (kind < 20) {
+        const uint64_t e = (hb >> 8) & 63;
+        const uint64_t elen = 300 + orc_splitmix64(seed ^ 0xE1E100000000ull ^ e) % 5700;
+        const uint64_t off = ((hb >> 16) % elen + (g & 511)) % elen;
+        r = orc_splitmix64(seed ^ ((0xABCD0000ull + e) << 32) ^ off);
+    } else if (kind < 30) {
+        const uint64_t u = 2 + (hb >> 8) % 59;
+        r = orc_splitmix64(seed ^ 0x7A7A000000000000ull ^ (blk << 8) ^ ((g & 511) % u));
+    } else {
+        r = orc_splitmix64(seed ^ g);
+    }
+    const unsigned hi = (unsigned)((r >> 32) & 1);
+    unsigned b = (r % 100) < 35 ? 1 + hi : 3 * hi;
+    const uint64_t rg = orc_splitmix64(seed_g ^ g);
+    if (rg % 100 == 0) b = (b + 1 + (unsigned)((rg >> 32) % 3)) & 3;
+    uint8_t ch = (uint8_t)up[b];
+    if (orc_splitmix64(seed_g ^ 0x4E4E4E4E00000000ull ^ (g / 100)) % 50 == 0) ch = 'N';
+    if (kind < 30) ch |= 0x20;
+    return ch;
+}
+
+size_t orc_synth_realistic_size(uint64_t seed, uint64_t nbases) {
+    size_t tot = 0;
+    uint64_t done = 0;
+    for (uint64_t c = 0; done < nbases; ++c) {
+        uint64_t L = real_contig_len(seed, c);
+        if (L > nbases - done) L = nbases - done;
+        tot += SYN_HDR + L + (L + SYN_LINE - 1) / SYN_LINE;
+        done += L;
+    }
+    return tot;
+}
+
+size_t orc_synth_realistic_fasta(uint64_t seed, int gi, uint64_t nbases, uint8_t *out) {
+    static const char hexd[] = "0123456789abcdef";
+    const uint64_t seed_g = orc_splitmix64(seed + (uint64_t)gi + 1);
+    size_t o = 0;
+    uint64_t pos = 0;
+    for (uint64_t c = 0; pos < nbases; ++c) {
+        uint64_t L = real_contig_len(seed, c);
+        if (L > nbases - pos) L = nbases - pos;
+        uint8_t *h = out + o;
+        h[0] = '>';
+        h[1] = 'g';
+        for (int d = 0; d < 4; ++d) h[2 + d] = (uint8_t)hexd[(gi >> (12 - 4 * d)) & 15];
+        h[6] = '.';
+        h[7] = 'r';
+        for (int d = 0; d < 4; ++d) h[8 + d] = (uint8_t)hexd[(c >> (12 - 4 * d)) & 15];
+        h[12] = h[13] = h[14] = ' ';
+        h[15] = '\n';
+        o += SYN_HDR;
+        for (uint64_t j = 0; j < L; ++j) {
+            out[o++] = real_base(seed, seed_g, pos++);
+            if (j % SYN_LINE == SYN_LINE - 1 || j == L - 1) out[o++] = '\n';
+        }
+    }
+    return o;
+}

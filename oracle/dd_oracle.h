@@ -84,6 +84,9 @@ int orc_exact_count(const uint8_t *const *fas, const size_t *ns, int nbuf, int k
 size_t orc_synth_size(uint64_t nbases, int nrec);
 size_t orc_synth_fasta(uint64_t seed, int gi, uint64_t nbases, int nrec, uint8_t *out);
 uint64_t orc_splitmix64(uint64_t x);
+/* "realistic" mode: GC 35 %, 30 % repeats (soft-masked), 2 % N, contigs of 2..200 kbp (dd_oracle.c) */
+size_t orc_synth_realistic_size(uint64_t seed, uint64_t nbases);
+size_t orc_synth_realistic_fasta(uint64_t seed, int gi, uint64_t nbases, uint8_t *out);
 
 #ifdef __cplusplus
 }

@@ -55,6 +55,10 @@ def _bind(lib):
     lib.orc_synth_size.argtypes = [C.c_uint64, C.c_int]
     lib.orc_synth_fasta.restype = C.c_size_t
     lib.orc_synth_fasta.argtypes = [C.c_uint64, C.c_int, C.c_uint64, C.c_int, C.c_void_p]
+    lib.orc_synth_realistic_size.restype = C.c_size_t
+    lib.orc_synth_realistic_size.argtypes = [C.c_uint64, C.c_uint64]
+    lib.orc_synth_realistic_fasta.restype = C.c_size_t
+    lib.orc_synth_realistic_fasta.argtypes = [C.c_uint64, C.c_int, C.c_uint64, C.c_void_p]
     lib.orc_splitmix64.restype = C.c_uint64
     lib.orc_splitmix64.argtypes = [C.c_uint64]
     return lib
@@ -172,6 +176,15 @@ def synth_fasta(seed, gi, nbases, nrec=1):
     n = lib().orc_synth_size(nbases, nrec)
     out = np.empty(n, dtype=np.uint8)
     w = lib().orc_synth_fasta(C.c_uint64(seed), gi, C.c_uint64(nbases), nrec, out.ctypes.data)
+    assert w == n, (w, n)
+    return out
+
+
+def synth_realistic(seed, gi, nbases):
+    """GC 35 %, 30 % soft-masked repeats, 2 % N, contigs of 2..200 kbp (dd_oracle.c)."""
+    n = lib().orc_synth_realistic_size(C.c_uint64(seed), C.c_uint64(nbases))
+    out = np.empty(n, dtype=np.uint8)
+    w = lib().orc_synth_realistic_fasta(C.c_uint64(seed), gi, C.c_uint64(nbases), out.ctypes.data)
     assert w == n, (w, n)
     return out
 

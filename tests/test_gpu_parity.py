@@ -561,3 +561,30 @@ def test_pairwise_gram_equals_streaming_kernel(engine_factory, torch_cuda, orc, 
         i, j, k = int(rng.integers(n)), int(rng.integers(n)), int(rng.integers(K))
         want = orc.card(np.maximum(slab[i, k], slab[j, k]), p)
         assert gram[i, j, k] == want or (np.isinf(want) and np.isinf(gram[i, j, k])), (i, j, k)
+
+
+def test_realistic_synth_bytes_match_oracle(engine_factory, torch_cuda, orc):
+    """The hard-case generator (GC 35 %, 30 % soft-masked repeats, 2 % N, contigs of 2..200 kbp): device bytes ==
+    oracle bytes, sizes from the C ABI == the oracle's, for several genomes, sizes and seeds."""
+    torch = torch_cuda
+    from dandd_amd.engine import synth_realistic_size
+    eng = engine_factory()
+    for seed, gi, nb in [(SEED, 0, 1), (SEED, 0, 1999), (SEED, 3, 70_001), (SEED + 5, 9, 1_300_000)]:
+        want = orc.synth_realistic(seed, gi, nb)
+        n = synth_realistic_size(seed, nb)
+        assert n == want.size
+        buf = torch.empty(n + 16, dtype=torch.uint8, device="cuda")
+        eng.synth_realistic_device(seed, gi, nb, buf.data_ptr())
+        eng.synchronize()
+        assert np.array_equal(buf[:n].cpu().numpy(), want), (seed, gi, nb)
+    assert synth_realistic_size(SEED, 0) == 0
+
+
+@pytest.mark.parametrize("p,krange", [(14, (4, 40)), (14, (41, 64)), (18, (8, 24)), (20, (9, 13)), (20, (30, 34))])
+def test_sweep_parity_on_realistic_genome(engine_factory, orc, p, krange):
+    """Registers bit-exact vs the oracle on repeat-rich, GC-poor, N-riddled, short-contig input: the k <= 9 sets that
+    never complete (GC 35 % starves the GC-rich k-mers), repeat-heavy register contention at log2m 18 / 20, thousands of
+    record boundaries."""
+    eng = engine_factory(p, True)
+    fa = orc.synth_realistic(SEED, 1, 3_000_000)
+    _sweep_check(eng, orc, fa, krange[0], krange[1], True)
