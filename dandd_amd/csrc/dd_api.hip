@@ -690,7 +690,8 @@ int dd_sketch_fasta(dd_ctx* c, const char* path, int kmin, int kmax, uint8_t* re
     if (!path) return fail(DD_EINVAL, "null path");
     FileBuf buf;
     std::string err;
-    if (!read_fasta_file(path, buf, err)) return fail(DD_EIO, "%s", err.c_str());
+    // (one file: a .gz is inflated by every CPU this process may use -- BGZF blocks, or pieces of a plain member)
+    if (!read_fasta_file(path, buf, err, usable_cpus())) return fail(DD_EIO, "%s", err.c_str());
     return dd_sketch_buffer(c, buf.data(), buf.size(), kmin, kmax, regs);
 }
 
@@ -819,6 +820,12 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
             slots[i].pieces_left = 1;
         }
     }
+    // A gzip file is one item, but not one thread's worth of work: with fewer .gz files than loaders every one of them
+    // is inflated by its share of the CPUs (BGZF blocks / pieces of a plain member, dd_inflate.h); a directory of many
+    // .gz files keeps one (libdeflate) thread per file, which is the faster decoder per core.
+    int ngz = 0;
+    for (int i = 0; i < nfiles; ++i) ngz += slots[i].plain_size == 0;
+    const int gz_par = ngz ? std::max(1, nthreads / ngz) : 1;
     std::mutex mu;
     std::condition_variable cv;
     std::atomic<size_t> next{0};
@@ -867,7 +874,7 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
                 cv.notify_all();
             }
             if (it.len == 0) {
-                ok = read_fasta_file(paths[it.file], fb, err);
+                ok = read_fasta_file(paths[it.file], fb, err, gz_par);
             } else if (ok && fb.cap >= sl.plain_size) {
                 FILE* f = fopen(paths[it.file], "rb");
                 ok = f && fseeko(f, (off_t)it.off, SEEK_SET) == 0 && fread(fb.p + it.off, 1, it.len, f) == it.len;
@@ -1224,7 +1231,7 @@ int dd_exact_count(dd_ctx* c, const char* const* paths, int n, int k, uint64_t* 
     size_t tot = 0;
     for (int i = 0; i < n; ++i) {
         std::string err;
-        if (!paths[i] || !read_fasta_file(paths[i], bufs[i], err)) return fail(DD_EIO, "%s", err.c_str());
+        if (!paths[i] || !read_fasta_file(paths[i], bufs[i], err, usable_cpus())) return fail(DD_EIO, "%s", err.c_str());
         sizes[i] = bufs[i].size();
         offs[i] = tot;
         tot += align_up(sizes[i] + 16, 256);

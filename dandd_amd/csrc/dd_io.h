@@ -15,6 +15,8 @@
 #include <algorithm>
 #include <string>
 
+#include "dd_inflate.h"
+
 namespace dd {
 
 // Host bytes of one file.  Pageable flavour: malloc storage in 2 MiB-aligned blocks the kernel may back
@@ -91,11 +93,37 @@ struct Deflate {
     }
 };
 
-// A gzip file (any number of members) through libdeflate.  Returns 1 done, 0 not applicable (not gzip, no library,
-// anything unexpected: the caller's zlib path then decides and words the error), -1 out of memory.
-inline int read_gzip_whole(const char* path, FileBuf& out) {
+// one whole gzip member with zlib (the machine has no libdeflate): false on any error
+inline bool zlib_gunzip_member(const uint8_t* in, size_t n, uint8_t* dst, size_t cap, size_t* used, size_t* made) {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, 15 + 16) != Z_OK) return false;
+    zs.next_in = const_cast<Bytef*>(in);
+    zs.next_out = dst;
+    size_t in_left = n, out_left = cap;
+    int rc = Z_OK;
+    while (rc == Z_OK) {
+        zs.avail_in = (uInt)std::min<size_t>(in_left, (size_t)1 << 30);
+        zs.avail_out = (uInt)std::min<size_t>(out_left, (size_t)1 << 30);
+        const uInt ai = zs.avail_in, ao = zs.avail_out;
+        rc = inflate(&zs, Z_NO_FLUSH);
+        in_left -= ai - zs.avail_in;
+        out_left -= ao - zs.avail_out;
+        if (rc == Z_OK && ai == zs.avail_in && ao == zs.avail_out) break;   // no progress: out of input or room
+    }
+    inflateEnd(&zs);
+    if (rc != Z_STREAM_END) return false;
+    *used = n - in_left;
+    *made = cap - out_left;
+    return true;
+}
+
+// A gzip file (any number of members) decoded in memory: BGZF blocks and large single members in parallel over `par`
+// threads (dd_inflate.h), everything else member by member through libdeflate (zlib when the machine has none).
+// Returns 1 done, 0 not applicable (not gzip, anything unexpected: the caller's zlib streaming path then decides and
+// words the error), -1 out of memory.
+inline int read_gzip_whole(const char* path, FileBuf& out, int par = 1) {
     const Deflate& lib = Deflate::get();
-    if (!lib.gunzip_ex) return 0;
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return 0;
     struct stat sb;
@@ -123,7 +151,30 @@ inline int read_gzip_whole(const char* path, FileBuf& out) {
     close(fd);
     int rc = 0;
     void* d = nullptr;
-    if (have == n && in[0] == 0x1f && in[1] == 0x8b && (d = lib.alloc())) {
+    if (have == n && in[0] == 0x1f && in[1] == 0x8b) {
+        out.len = 0;
+        if (par > 1 && !getenv("DD_NO_PARALLEL_GZIP")) {
+            // bgzip: independent blocks; a big plain member: pieces decoded without their history, then resolved
+            rc = gunzip_bgzf_parallel(in, n, out, par, [&lib](const uint8_t* src, size_t len, uint8_t* dst, size_t cap, size_t* used, size_t* made) {
+                if (lib.gunzip_ex) {
+                    void* dd = lib.alloc();
+                    if (!dd) return false;
+                    const int r = lib.gunzip_ex(dd, src, len, dst, cap, used, made);
+                    lib.release(dd);
+                    return r == 0;
+                }
+                return zlib_gunzip_member(src, len, dst, cap, used, made);
+            });
+            if (rc == 0 && par >= 3) rc = gunzip_member_parallel(in, n, out, par);
+            if (rc != 0) {
+                free(in);
+                if (rc != 1) out.len = 0;
+                return rc;
+            }
+        }
+        if (lib.gunzip_ex) d = lib.alloc();
+    }
+    if (have == n && in[0] == 0x1f && in[1] == 0x8b && (d || !lib.gunzip_ex)) {
         // ISIZE of the last member: the whole size of a one-member file, a lower bound otherwise
         const size_t isize = (size_t)in[n - 4] | ((size_t)in[n - 3] << 8) | ((size_t)in[n - 2] << 16) | ((size_t)in[n - 1] << 24);
         out.len = 0;
@@ -136,17 +187,21 @@ inline int read_gzip_whole(const char* path, FileBuf& out) {
                 break;
             }
             size_t used = 0, made = 0;
-            const int r = lib.gunzip_ex(d, in + pos, n - pos, out.p + out.len, out.cap - out.len, &used, &made);
-            if (r == 0) {
-                out.len += made;
-                pos += used;
-            } else if (r == 3) {
-                if (!out.reserve(out.cap * 2)) rc = -1;
+            if (d) {
+                const int r = lib.gunzip_ex(d, in + pos, n - pos, out.p + out.len, out.cap - out.len, &used, &made);
+                if (r == 0) {
+                    out.len += made;
+                    pos += used;
+                } else if (r == 3) {
+                    if (!out.reserve(out.cap * 2)) rc = -1;
+                } else {
+                    rc = 0;  // bad data: let zlib find and word it
+                }
             } else {
-                rc = 0;  // bad data: let zlib find and word it
+                rc = 0;      // no libdeflate: the streaming zlib path below reads the file as before
             }
         }
-        lib.release(d);
+        if (d) lib.release(d);
     }
     free(in);
     if (rc != 1) out.len = 0;
@@ -154,8 +209,8 @@ inline int read_gzip_whole(const char* path, FileBuf& out) {
 }
 
 // Whole FASTA file into memory; gzip (any number of members) or plain, decided by zlib itself.
-inline bool read_fasta_file(const char* path, FileBuf& out, std::string& err) {
-    const int fast = read_gzip_whole(path, out);
+inline bool read_fasta_file(const char* path, FileBuf& out, std::string& err, int par = 1) {
+    const int fast = read_gzip_whole(path, out, par);
     if (fast == 1) return true;
     if (fast < 0) {
         err = std::string("out of host memory reading ") + path;

@@ -209,6 +209,152 @@ static void check_gzip_edges(const std::string& dir) {
     CHECK(!bad_ok || fb.size() != body.size() || memcmp(fb.data(), body.data(), body.size()) != 0, "damaged gzip read back as if intact");
 }
 
+// ---- dd_inflate.h: a gzip member decoded in pieces without their history, BGZF blocks in parallel -------------------
+struct TestBuf {   // the part of FileBuf the decoders use
+    uint8_t* p = nullptr;
+    size_t len = 0, cap = 0;
+    ~TestBuf() { free(p); }
+    bool reserve(size_t n) {
+        if (n <= cap) return true;
+        uint8_t* q = static_cast<uint8_t*>(realloc(p, n));
+        if (!q) return false;
+        p = q;
+        cap = n;
+        return true;
+    }
+};
+
+static std::string gz_member(const std::string& body, int level, int strategy = Z_DEFAULT_STRATEGY, const std::string& extra = std::string()) {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, strategy);
+    gz_header hd;
+    memset(&hd, 0, sizeof hd);
+    std::string name = "x.fa";
+    if (!extra.empty()) {
+        hd.extra = reinterpret_cast<Bytef*>(const_cast<char*>(extra.data()));
+        hd.extra_len = (uInt)extra.size();
+        deflateSetHeader(&zs, &hd);
+    } else if (level == 6) {   // one flavour with a file name in the header
+        hd.name = reinterpret_cast<Bytef*>(const_cast<char*>(name.c_str()));
+        deflateSetHeader(&zs, &hd);
+    }
+    std::string out(deflateBound(&zs, (uLong)body.size()) + 64 + extra.size(), '\0');
+    zs.next_in = reinterpret_cast<Bytef*>(const_cast<char*>(body.data()));
+    zs.avail_in = (uInt)body.size();
+    zs.next_out = reinterpret_cast<Bytef*>(&out[0]);
+    zs.avail_out = (uInt)out.size();
+    deflate(&zs, Z_FINISH);
+    out.resize(out.size() - zs.avail_out);
+    deflateEnd(&zs);
+    return out;
+}
+
+static std::string genome_text(size_t nbases, unsigned seed, bool repeats) {
+    std::string body;
+    body.reserve(nbases + nbases / 60 + 64);
+    unsigned x = seed;
+    size_t col = 0;
+    for (size_t j = 0; j < nbases; ++j) {
+        if (j % 200000 == 0) {
+            if (col) body += '\n';
+            body += ">contig" + std::to_string(j) + " synthetic\n";
+            col = 0;
+        }
+        x = x * 1664525u + 1013904223u;
+        char c = "ACGT"[(x >> 24) & 3];
+        if (repeats && (j / 3000) % 3 == 0) c = "ACGTTTGACA"[j % 10];          // tandem repeats: long matches, far references
+        if ((x >> 12) % 977 == 0) c = 'N';
+        if ((j / 5000) % 7 == 0) c = (char)(c | 0x20);
+        body += c;
+        if (++col == 60) body += '\n', col = 0;
+    }
+    body += '\n';
+    return body;
+}
+
+static void check_parallel_inflate() {
+    const std::string big = genome_text(6000000, 7u, true), rnd = genome_text(3000000, 99u, false);
+    int accepted = 0;
+    for (int level : {1, 6, 9})
+        for (const std::string* body : {&big, &rnd})
+            for (int threads : {2, 5}) {
+                const std::string gz = gz_member(*body, level);
+                TestBuf out;
+                // 128 KiB pieces: ~10-20 pieces per member, every one of them decoded without its history
+                const int rc = dd::gunzip_member_parallel(reinterpret_cast<const uint8_t*>(gz.data()), gz.size(), out, threads, (size_t)128 << 10);
+                CHECK(rc == 1 || rc == 0, "parallel gunzip rc %d", rc);
+                if (rc == 1) {
+                    ++accepted;
+                    CHECK(out.len == body->size() && memcmp(out.p, body->data(), body->size()) == 0, "level %d threads %d: parallel gunzip differs from the input",
+                          level, threads);
+                }
+            }
+    CHECK(accepted >= 10, "the parallel decoder declined %d of 12 ordinary members", 12 - accepted);
+    {   // fixed-Huffman and stored blocks (Z_FIXED; level 0): legal streams the block finder must not start in, decoded all the same
+        for (int flavour = 0; flavour < 2; ++flavour) {
+            const std::string gz = flavour ? gz_member(rnd, 0) : gz_member(rnd, 6, Z_FIXED);
+            TestBuf out;
+            const int rc = dd::gunzip_member_parallel(reinterpret_cast<const uint8_t*>(gz.data()), gz.size(), out, 4, (size_t)128 << 10);
+            CHECK(rc == 0 || (rc == 1 && out.len == rnd.size() && memcmp(out.p, rnd.data(), rnd.size()) == 0), "flavour %d: rc %d", flavour, rc);
+        }
+    }
+    {   // damage, truncation, two members, binary content: never a wrong answer, never a crash -- "not applicable" at worst
+        const std::string gz = gz_member(big, 1);
+        for (int kind = 0; kind < 6; ++kind) {
+            std::string bad = gz;
+            if (kind == 0) bad[bad.size() / 3] ^= 0x10;
+            else if (kind == 1) bad.resize(bad.size() * 2 / 3);
+            else if (kind == 2) bad += gz;                       // two members: the serial path's business
+            else if (kind == 3) bad[bad.size() - 6] ^= 0x01;     // wrong CRC
+            else if (kind == 4) bad[bad.size() - 2] ^= 0x01;     // wrong ISIZE
+            else bad += std::string(100, '\0');
+            TestBuf out;
+            const int rc = dd::gunzip_member_parallel(reinterpret_cast<const uint8_t*>(bad.data()), bad.size(), out, 4, (size_t)128 << 10);
+            CHECK(rc == 0 || (rc == 1 && out.len == big.size() && memcmp(out.p, big.data(), big.size()) == 0), "damage kind %d accepted as rc %d with other bytes", kind, rc);
+            CHECK(!(rc == 1 && kind <= 4), "damage kind %d went unnoticed", kind);
+        }
+        std::string binary(4000000, '\0');
+        unsigned x = 5;
+        for (char& c : binary) x = x * 1664525u + 1013904223u, c = (char)(x >> 24);
+        const std::string bz = gz_member(binary, 1);
+        TestBuf out;
+        const int rc = dd::gunzip_member_parallel(reinterpret_cast<const uint8_t*>(bz.data()), bz.size(), out, 4, (size_t)128 << 10);
+        CHECK(rc == 0 || (rc == 1 && out.len == binary.size() && memcmp(out.p, binary.data(), binary.size()) == 0), "binary member: rc %d", rc);
+    }
+    {   // BGZF: 64 KiB blocks, each a member with a 'BC' extra field that says its compressed size, + the empty EOF block
+        std::string file;
+        const size_t blk = 65280;
+        for (size_t a = 0; a <= big.size(); a += blk) {
+            const std::string part = a < big.size() ? big.substr(a, blk) : std::string();
+            std::string extra("BC\x02\x00\x00\x00", 6);
+            std::string m = gz_member(part, 5, Z_DEFAULT_STRATEGY, extra);
+            const size_t bsize = m.size() - 1;
+            m[16] = (char)(bsize & 0xff);       // BSIZE sits at offset 16 of a BGZF block header
+            m[17] = (char)(bsize >> 8);
+            file += m;
+        }
+        auto member = [](const uint8_t* src, size_t len, uint8_t* dst, size_t cap, size_t* used, size_t* made) {
+            return dd::zlib_gunzip_member(src, len, dst, cap, used, made);
+        };
+        TestBuf out;
+        int rc = dd::gunzip_bgzf_parallel(reinterpret_cast<const uint8_t*>(file.data()), file.size(), out, 5, member);
+        CHECK(rc == 1 && out.len == big.size() && memcmp(out.p, big.data(), big.size()) == 0, "BGZF: rc %d", rc);
+        std::string cut = file.substr(0, file.size() - 40);       // a block cut short
+        TestBuf out2;
+        rc = dd::gunzip_bgzf_parallel(reinterpret_cast<const uint8_t*>(cut.data()), cut.size(), out2, 3, member);
+        CHECK(rc == 0, "truncated BGZF accepted (rc %d)", rc);
+        std::string flip = file;
+        flip[file.size() / 2] ^= 0x40;
+        TestBuf out3;
+        rc = dd::gunzip_bgzf_parallel(reinterpret_cast<const uint8_t*>(flip.data()), flip.size(), out3, 3, member);
+        CHECK(rc == 0 || (rc == 1 && out3.len == big.size() && memcmp(out3.p, big.data(), big.size()) == 0), "damaged BGZF: rc %d with other bytes", rc);
+        const std::string plain = gz_member(rnd, 6);
+        TestBuf out4;
+        CHECK(dd::gunzip_bgzf_parallel(reinterpret_cast<const uint8_t*>(plain.data()), plain.size(), out4, 3, member) == 0, "a plain member taken for BGZF");
+    }
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
     dd::PlanKnobs base;
@@ -238,6 +384,7 @@ int main(int argc, char** argv) {
     check_plan(18, ragged, 2, 20, k2);
     check_loaders(argv[1]);
     check_gzip_edges(argv[1]);
+    check_parallel_inflate();
     if (failures) fprintf(stderr, "%d failure(s)\n", failures);
     else printf("sanitize_host: ok\n");
     return failures ? 1 : 0;
