@@ -18,6 +18,7 @@
 #pragma once
 #include <stdint.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <zlib.h>
 
 #include <stdio.h>
@@ -69,7 +70,26 @@ struct Huff {
     static constexpr int FAST = 10;
     uint16_t fast[1 << FAST];      // (symbol << 4) | length, 0 = longer code or invalid
     uint16_t count[16], symbol[320];
+    // literal/length codes only: two symbols at once where 11 bits hold two literal codes (DNA text under gzip -1 is
+    // ~2.2 bits per base, nearly all of them literals).  Entry: bits 0..4 = bits consumed, bits 5..6 = literals held
+    // (0: not a literal or a longer code -> decode() decides), bits 8..15 / 16..23 the literals.
+    static constexpr int PAIR = 11;
+    uint32_t pair[1 << PAIR];
     int maxlen = 0;
+    void build_pairs() {
+        for (uint32_t idx = 0; idx < (1u << PAIR); ++idx) {
+            const uint16_t e1 = fast[idx & ((1u << FAST) - 1)];
+            const int l1 = e1 & 15, s1 = e1 >> 4;
+            uint32_t v = 0;
+            if (e1 && s1 < 256) {
+                v = (uint32_t)l1 | (1u << 5) | ((uint32_t)s1 << 8);
+                const uint16_t e2 = fast[(idx >> l1) & ((1u << FAST) - 1)];
+                const int l2 = e2 & 15, s2 = e2 >> 4;
+                if (e2 && s2 < 256 && l1 + l2 <= PAIR) v = (uint32_t)(l1 + l2) | (2u << 5) | ((uint32_t)s1 << 8) | ((uint32_t)s2 << 16);
+            }
+            pair[idx] = v;
+        }
+    }
     // returns false when the lengths do not form a usable code (over-subscribed; incomplete unless `allow_incomplete`)
     bool build(const uint8_t* len, int n, bool allow_incomplete) {
         memset(count, 0, sizeof count);
@@ -196,11 +216,17 @@ struct SymBuf {
     ~SymBuf() { free(p); }
     bool room(size_t extra) {   // make sure `extra` more symbols fit
         if (len + extra <= cap) return true;
+        // 2 MiB-aligned, huge pages asked for: a piece's symbols are ~100 MB of fresh memory per thread
+        const size_t kHuge = (size_t)2 << 20;
         size_t want = std::max(cap * 2, len + extra + ((size_t)1 << 20));
-        uint16_t* q = static_cast<uint16_t*>(realloc(p, want * sizeof(uint16_t)));
-        if (!q) return false;
-        p = q;
-        cap = want;
+        want = (want * sizeof(uint16_t) + kHuge - 1) / kHuge * kHuge;
+        void* q = nullptr;
+        if (posix_memalign(&q, kHuge, want) != 0 || !q) return false;
+        (void)madvise(q, want, MADV_HUGEPAGE);
+        if (len) memcpy(q, p, len * sizeof(uint16_t));
+        free(p);
+        p = static_cast<uint16_t*>(q);
+        cap = want / sizeof(uint16_t);
         return true;
     }
 };
@@ -268,20 +294,30 @@ inline int decode_piece(const uint8_t* in, size_t n, uint64_t start, uint64_t st
                     b.drop(kDistExtra[ds]);
                 }
             } else {
+                codes.lit.build_pairs();
                 uint16_t* o = out->p;
                 size_t at = out->len, lim = out->cap;
                 const long long floor = known_start ? 0 : -32768;
                 for (;;) {
-                    if (at + 258 > lim) {   // one check per symbol covers the longest copy
-                        if (at > max_symbols) return -1;   // (a damaged stream can decode to anything: bounded, then refused)
+                    if (at + 260 > lim) {   // one check per step covers two literals or the longest copy
+                        if (at > max_symbols || b.over) return -1;   // (a damaged or truncated stream can decode to anything: bounded, then refused)
                         out->len = at;
                         if (!out->room(65536)) return -2;
                         o = out->p;
                         lim = out->cap;
                     }
+                    if (b.cnt < 32) b.refill();
+                    const uint32_t pe = codes.lit.pair[b.peek(Huff::PAIR)];
+                    if (pe) {
+                        o[at] = (uint16_t)((pe >> 8) & 0xff);
+                        o[at + 1] = (uint16_t)(pe >> 16);
+                        at += (pe >> 5) & 3;
+                        b.drop((int)(pe & 31));
+                        continue;
+                    }
                     const int s = codes.lit.decode(b);
                     if (s < 256) {
-                        if (s < 0 || b.over) return -1;
+                        if (s < 0) return -1;
                         o[at++] = (uint16_t)s;
                         continue;
                     }
@@ -309,6 +345,7 @@ inline int decode_piece(const uint8_t* in, size_t n, uint64_t start, uint64_t st
                     }
                     at += (size_t)len;
                 }
+                if (b.over) return -1;
                 produced = at;
                 out->len = at;
             }
@@ -438,8 +475,9 @@ inline int gunzip_bgzf_parallel(const uint8_t* in, size_t n, Buf& out, int nthre
 // 16-bit symbol buffers (2 bytes per output byte) stay bounded and are reused.  Returns 1 done, 0 not applicable (not
 // gzip, too small to be worth it, several members, no block start found, a piece that does not end where the next
 // begins, wrong ISIZE / CRC: the serial path decides), -1 out of memory.
+typedef uint32_t (*Crc32Fn)(uint32_t, const void*, size_t);   // libdeflate_crc32's signature; nullptr = zlib's crc32
 template <typename Buf>
-inline int gunzip_member_parallel(const uint8_t* in, size_t n, Buf& out, int nthreads, size_t min_piece = (size_t)4 << 20) {
+inline int gunzip_member_parallel(const uint8_t* in, size_t n, Buf& out, int nthreads, size_t min_piece = (size_t)4 << 20, Crc32Fn fast_crc = nullptr) {
     using namespace inflate_detail;
     const size_t hdr = gzip_header_len(in, n);
     if (!hdr || n < hdr + 8 + 2 * min_piece || nthreads < 2) return 0;
@@ -448,6 +486,7 @@ inline int gunzip_member_parallel(const uint8_t* in, size_t n, Buf& out, int nth
     const double t_begin = now();
     const size_t body_end = n - 8;   // if the file is ONE member, its trailer sits here (checked at the end)
     // pieces of 4 .. 16 MiB of compressed bytes, a multiple of the thread count of them when the member is large enough
+    // (a round of pieces ends at a barrier: 4 MiB pieces -- 16 rounds for a 3 Gbp genome -- measured 1.5x slower)
     size_t pieces = std::min<size_t>((body_end - hdr) / min_piece, std::max<size_t>((size_t)nthreads, (body_end - hdr) / (4 * min_piece)));
     if (pieces > (size_t)nthreads) pieces = pieces / (size_t)nthreads * (size_t)nthreads;
     if (pieces < 2) return 0;
@@ -551,11 +590,20 @@ inline int gunzip_member_parallel(const uint8_t* in, size_t n, Buf& out, int nth
                     dst[i] = (uint8_t)s[i];
                 }
             } else {
-                const uint8_t* w = win[(size_t)t].data();
-                for (size_t i = 0; i < m; ++i) dst[i] = s[i] < 256 ? (uint8_t)s[i] : w[s[i] - 256];
+                // one table for bytes and placeholders alike: no branch per symbol
+                std::vector<uint8_t> lut(256 + 32768);
+                for (int v = 0; v < 256; ++v) lut[(size_t)v] = (uint8_t)v;
+                memcpy(lut.data() + 256, win[(size_t)t].data(), 32768);
+                const uint8_t* L = lut.data();
+                for (size_t i = 0; i < m; ++i) dst[i] = L[s[i]];
             }
-            uint32_t k = (uint32_t)crc32(0L, Z_NULL, 0);
-            for (size_t a = 0; a < m; a += (size_t)1 << 30) k = (uint32_t)crc32(k, dst + a, (uInt)std::min<size_t>(m - a, (size_t)1 << 30));
+            uint32_t k;
+            if (fast_crc) {
+                k = fast_crc(0, dst, m);
+            } else {
+                k = (uint32_t)crc32(0L, Z_NULL, 0);
+                for (size_t a = 0; a < m; a += (size_t)1 << 30) k = (uint32_t)crc32(k, dst + a, (uInt)std::min<size_t>(m - a, (size_t)1 << 30));
+            }
             crcs[(size_t)t] = k;
         });
         if (bad.load()) return 0;

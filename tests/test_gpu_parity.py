@@ -376,6 +376,44 @@ def test_sketch_files_gz_and_plain(engine_factory, orc, tmp_path):
     assert eng.sketch_files([], 9, 14).shape == (0, 6, 1 << 12)
 
 
+def _bgzf(raw, level=1):
+    """bgzip's container: <= 64 KiB gzip members with a 'BC' extra subfield that holds the member's size - 1, + the empty EOF block"""
+    import zlib
+    out = bytearray()
+    for a in list(range(0, len(raw), 65280)) + [len(raw)]:
+        part = raw[a:a + 65280] if a < len(raw) else b""
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = c.compress(part) + c.flush()
+        out += (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + (len(body) + 25).to_bytes(2, "little") + body +
+                zlib.crc32(part).to_bytes(4, "little") + len(part).to_bytes(4, "little"))
+    return bytes(out)
+
+
+def test_large_gzip_files_are_inflated_in_parallel(engine_factory, orc, tmp_path, monkeypatch):
+    """One big .gz through dd_sketch_fasta / dd_sketch_files: a single gzip member cut at deflate block boundaries and
+    decoded piecewise without its history (dd_inflate.h), a BGZF file block by block, a realistic (repeat-rich: long,
+    far matches) genome too -- registers == the sketch of the uncompressed bytes, and == the serial decoder's."""
+    import zlib
+    eng = engine_factory(14, True)
+    cases = {"uniform": orc.synth_fasta(SEED, 0, 40_000_000, 7), "realistic": orc.synth_realistic(SEED, 1, 30_000_000)}
+    for name, fa in cases.items():
+        raw = fa.tobytes()
+        want = eng.sketch_buffer(fa, 19, 21)
+        for level in (1, 6):
+            co = zlib.compressobj(level, zlib.DEFLATED, 31)
+            p = tmp_path / f"{name}.{level}.fa.gz"
+            p.write_bytes(co.compress(raw) + co.flush())
+            assert p.stat().st_size > 2 * (4 << 20)            # large enough for the parallel path
+            assert np.array_equal(eng.sketch_fasta(str(p), 19, 21), want), (name, level)
+            assert np.array_equal(eng.sketch_files([str(p)], 19, 21)[0], want), (name, level)
+        b = tmp_path / f"{name}.bgzf.fa.gz"
+        b.write_bytes(_bgzf(raw))
+        assert np.array_equal(eng.sketch_fasta(str(b), 19, 21), want), name
+        assert np.array_equal(eng.sketch_files([str(b), str(tmp_path / f"{name}.1.fa.gz")], 19, 21)[1], want), name
+    monkeypatch.setenv("DD_NO_PARALLEL_GZIP", "1")
+    assert np.array_equal(eng.sketch_fasta(str(tmp_path / "uniform.1.fa.gz"), 19, 21), eng.sketch_buffer(cases["uniform"], 19, 21))
+
+
 def test_full_size_properties_cfg2(engine_factory, torch_cuda, orc):
     """BASELINE cfg 2 genome size (50 Mbp, k 4..40, log2m 14): too big for the oracle sweep, so check
     size-independent properties instead: sketch(whole) == max(sketch(records 0-1), sketch(records 2-4)),
