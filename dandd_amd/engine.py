@@ -355,6 +355,12 @@ class Engine:
         self._check(self._lib.dd_last_sketch_stats(self._ctx, C.byref(t), C.byref(u), C.byref(b)))
         return t.value, u.value, b.value
 
+    def warmup(self):
+        """One tiny sketch + cardinality: HIP loads a kernel module at its first launch, this makes the first launches
+        happen now (on whichever thread calls it) instead of inside the first real call."""
+        fa = np.frombuffer(b">w\n" + b"ACGTTGCAACGGTCA" * 16 + b"\n", dtype=np.uint8)
+        self.card_batch(self.sketch_buffer(fa, 15, 17))
+
     def synth_realistic_device(self, seed, genome_index, nbases, out_ptr):
         self._check(self._lib.dd_synth_realistic_device(self._ctx, int(seed), int(genome_index), int(nbases), C.c_void_p(int(out_ptr))))
 

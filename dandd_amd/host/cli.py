@@ -24,6 +24,14 @@ def tree_command(args):
         args.registers = 20
     ksweep = (int(args.mink), int(args.maxk)) if args.ksweep else None
     os.makedirs(args.outdir, exist_ok=True)
+    # a sketch directory with nothing in it: this run will sketch, so the GPU context is brought up beside the
+    # digests and directory walks instead of after them (a fully cached run never touches the GPU and starts none)
+    try:
+        cold = not any(e.is_dir() and any(os.scandir(e.path)) for e in os.scandir(args.sketchdir))
+    except OSError:
+        cold = True
+    if cold:
+        deltatree.prewarm_backend({"registers": int(args.registers), "canonicalize": args.canonicalize, "tool": tool})
     try:
         tree = deltatree.create_delta_tree(
             tag=args.tag, genomedir=args.genomedir, sketchdir=args.sketchdir, kstart=args.kstart,

@@ -39,18 +39,56 @@ def set_backend_factory(factory):
     _backends.clear()
 
 
-def backend_for(experiment):
+def _backend_key(experiment):
     exact = experiment.get("tool") == "kmc"
-    key = (int(experiment["registers"]), bool(experiment["canonicalize"]), exact)
+    return (int(experiment["registers"]), bool(experiment["canonicalize"]), exact)
+
+
+def _make_backend(key):
+    # both fail loudly without libdandd_hip.so / a gfx950 GPU; under torch.distributed.run every rank drives its own GPU
+    from .backend import HipBackend, HipExactBackend
+    cls = HipExactBackend if key[2] else HipBackend
+    return cls(log2m=key[0], canonical=key[1], device=int(os.environ.get("LOCAL_RANK", "0")))
+
+
+_prewarm = {}   # key -> (thread, result box)
+
+
+def prewarm_backend(experiment):
+    """Start creating the GPU backend of `experiment` on a thread of its own: loading libdandd_hip.so, HIP's first
+    use of the device and the first launch of every kernel module cost 0.25-0.35 s in a fresh process, during which a
+    one-shot `dandd` command has blake2b digests, directory walks and imports of its own to do (ctypes calls release
+    the GIL).  backend_for() picks the result up -- or the exception, which it re-raises."""
+    import threading
+    key = _backend_key(experiment)
+    if _backend_factory is not None or key in _backends or key in _prewarm:
+        return
+    box = []
+
+    def work():
+        try:
+            be = _make_backend(key)
+            if hasattr(be.engine, "warmup"):
+                be.engine.warmup()
+            box.append(be)
+        except BaseException as e:  # handed to the thread that asks for the backend
+            box.append(e)
+
+    t = threading.Thread(target=work, name="dandd-backend-prewarm")
+    _prewarm[key] = (t, box)
+    t.start()
+
+
+def backend_for(experiment):
+    key = _backend_key(experiment)
+    if key in _prewarm:
+        t, box = _prewarm.pop(key)
+        t.join()
+        if isinstance(box[0], BaseException):
+            raise box[0]
+        _backends[key] = box[0]
     if key not in _backends:
-        if _backend_factory is not None:
-            _backends[key] = _backend_factory(key[0], key[1])
-        else:
-            # both fail loudly without libdandd_hip.so / a gfx950 GPU; under torch.distributed.run
-            # every rank drives its own GPU
-            from .backend import HipBackend, HipExactBackend
-            cls = HipExactBackend if exact else HipBackend
-            _backends[key] = cls(log2m=key[0], canonical=key[1], device=int(os.environ.get("LOCAL_RANK", "0")))
+        _backends[key] = _backend_factory(key[0], key[1]) if _backend_factory is not None else _make_backend(key)
     return _backends[key]
 
 
