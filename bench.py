@@ -489,6 +489,7 @@ def main():
         slab, n = wl.regs, ng
         if gather:
             slab, n = ddist.allgather_leaves(wl.regs[:ng], ids if cfg["strong"] else list(range(ng)), n_sched), n_sched
+        wl.sched = (slab, n)      # (what the schedule ran on: the K2 roofline pass below reuses it, no second collective)
         if cfg["extra"] == "pairwise" and n:
             wl.pair = eng.pairwise_device(slab.data_ptr(), n, K)                 # all pairs x all k
         elif cfg["extra"] == "progressive" and n and orderings:
@@ -638,7 +639,7 @@ def main():
     # the K2 schedule of the config (all pairs / progressive) timed on its own, against its own roofline
     k2 = None
     if rank == 0 and cfg["extra"] and ng:
-        slab, n = (wl.regs, ng) if not gather else (ddist.allgather_leaves(wl.regs[:ng], ids if cfg["strong"] else list(range(ng)), n_sched), n_sched)
+        slab, n = wl.sched        # rank 0 alone from here on: no collective may be called
         run = (lambda: eng.pairwise_device(slab.data_ptr(), n, K)) if cfg["extra"] == "pairwise" else \
               (lambda: eng.progressive_device(slab.data_ptr(), n, K, orderings))
         run()

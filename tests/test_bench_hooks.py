@@ -74,10 +74,10 @@ def test_bench_two_ranks_on_one_gpu_matches_single_process(torch_cuda):
     common = ["--steps", "2", "--warmup", "1", "--mbp", "5", "--no-cpu-baseline", "--no-accuracy", "--no-secondary", "--no-ingest"]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common,
-                         env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+                         env=env, capture_output=True, text=True, timeout=240, cwd=ROOT)
     assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-4000:]
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--genomes", "20"] + common,
-                         env=dict(os.environ), capture_output=True, text=True, timeout=600, cwd=ROOT)
+                         env=dict(os.environ), capture_output=True, text=True, timeout=240, cwd=ROOT)
     assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-4000:]
     j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
     j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
@@ -94,7 +94,7 @@ def test_bench_config_presets_run(torch_cuda, config, extra):
     """The --config presets (BASELINE cfg 3 / 4 / 5 shapes, shrunk) produce a well-formed line: right k range, the
     extra schedule in the step, strong/weak scaling flag, finite throughput."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "1", "--warmup", "1",
-                        "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=240, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     want_k = {"cfg3": (2, 32), "cfg4share": (2, 32), "cfg5share": (4, 64)}[config]
@@ -113,7 +113,7 @@ def test_bench_cfg4_two_ranks_gathers_leaves_and_splits_orderings(torch_cuda):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "cfg4",
                         "--mbp", "1", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
-                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+                       env=env, capture_output=True, text=True, timeout=240, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["genomes_per_gpu"] == 15
@@ -133,9 +133,9 @@ def test_bench_world1_rccl_through_own_launcher(torch_cuda):
     common = ["--steps", "2", "--warmup", "1", "--mbp", "5", "--no-cpu-baseline", "--no-accuracy", "--no-secondary", "--no-ingest"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DD_BENCH_BACKEND", "DD_BENCH_SHARE_DEVICE")}
     plain = _line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common,
-                                 env=env, capture_output=True, text=True, timeout=600, cwd=ROOT))
+                                 env=env, capture_output=True, text=True, timeout=240, cwd=ROOT))
     forced = _line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist"] + common,
-                                  env=env, capture_output=True, text=True, timeout=600, cwd=ROOT))
+                                  env=env, capture_output=True, text=True, timeout=240, cwd=ROOT))
     assert plain["collectives"]["backend"] is None and plain["collectives"]["all_reduce_max_u8"] == 0
     c = forced["collectives"]
     assert c["backend"] == "nccl" and c["launcher"] == "bench.py self-spawn"
@@ -154,7 +154,7 @@ def test_bench_world1_rccl_allgather_of_leaves(torch_cuda):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DD_BENCH_BACKEND", "DD_BENCH_SHARE_DEVICE")}
     j = _line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--config", "cfg4share",
                               "--mbp", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
-                             env=env, capture_output=True, text=True, timeout=600, cwd=ROOT))
+                             env=env, capture_output=True, text=True, timeout=240, cwd=ROOT))
     assert j["collectives"]["backend"] == "nccl" and j["collectives"]["all_gather"] == 6     # 3 per step, 1 + 1 steps
     assert j["schedule"]["last_prefix_equals_root"] is True and j["schedule"]["genomes"] == 8
 
@@ -167,7 +167,7 @@ def test_bench_plain_gpus2_starts_its_own_ranks(torch_cuda):
     env.update(DD_BENCH_BACKEND="gloo", DD_BENCH_SHARE_DEVICE="1")
     j = _line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--mbp", "2",
                               "--no-cpu-baseline", "--no-accuracy", "--no-secondary", "--no-ingest"],
-                             env=env, capture_output=True, text=True, timeout=600, cwd=ROOT))
+                             env=env, capture_output=True, text=True, timeout=240, cwd=ROOT))
     assert j["n_gpus"] == 2 and len(j["gpus_active"]) == 2 and j["collectives"]["launcher"] == "bench.py self-spawn"
     assert j["collectives"]["all_reduce_max_u8"] == 2 and j["value"] > 0
 
@@ -179,6 +179,6 @@ def test_bench_without_enough_gpus_fails_loudly():
     if torch.cuda.device_count() >= 2:
         pytest.skip("this node really has two GPUs")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
-                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+                       env=env, capture_output=True, text=True, timeout=240, cwd=ROOT)
     assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert "wants cuda:1" in r.stderr
