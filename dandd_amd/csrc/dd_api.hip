@@ -1359,8 +1359,21 @@ int dd_progressive_device(dd_ctx* c, const uint8_t* leaf_dev, int n, int K, cons
     DD_HIP(hipEventRecord(c->stage_free, c->stream));
     {
         Span sp(c, DD_KERNEL_UNION);
-        dd::launch_progressive(leaf_dev, n, K, c->p, static_cast<const int32_t*>(c->ord.p), norder,
-                               static_cast<uint32_t*>(c->hist.p), c->stream);
+        // bit-plane AND-scan (dd_pscan.hip) where it applies; DD_PROGRESSIVE_STREAM=1 keeps the streaming kernel of
+        // dd_union.hip (one LDS atomic per register per prefix) for A/B runs and for the equality test
+        bool done = false;
+        if (dd::pscan_usable(n, norder, c->p) && !getenv("DD_PROGRESSIVE_STREAM")) {
+            if ((rc = c->gram.reserve(dd::pscan_scratch_bytes(n, K, c->p, norder)))) return rc;
+            dd::launch_register_range(leaf_dev, n, K, c->p, static_cast<uint32_t*>(c->gram.p), c->stream);
+            std::vector<uint32_t> rng((size_t)K * 2);   // (which thresholds exist decides the tile size: 296 bytes back to the host)
+            DD_HIP(hipMemcpyAsync(rng.data(), c->gram.p, rng.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            DD_HIP(hipStreamSynchronize(c->stream));
+            done = dd::launch_progressive_pscan(leaf_dev, n, K, c->p, static_cast<const int32_t*>(c->ord.p), norder, rng.data(), c->gram.p,
+                                                static_cast<uint32_t*>(c->hist.p), c->stream);
+        }
+        if (!done)
+            dd::launch_progressive(leaf_dev, n, K, c->p, static_cast<const int32_t*>(c->ord.p), norder,
+                                   static_cast<uint32_t*>(c->hist.p), c->stream);
     }
     DD_HIP(hipGetLastError());
     return estimates_from_hist(c, static_cast<const uint32_t*>(c->hist.p), njobs, card);

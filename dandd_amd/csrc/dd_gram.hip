@@ -334,6 +334,14 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const uint32_t* __rest
 
 }  // namespace
 
+// rng_dev[2k], rng_dev[2k+1] = smallest / largest register of k column k over the n sketches of the slab
+void launch_register_range(const uint8_t* leaf_dev, int n, int K, int p, uint32_t* rng_dev, hipStream_t st) {
+    const size_t m = (size_t)1 << p;
+    hipLaunchKernelGGL(gram_range_init_kernel, dim3((unsigned)((K + 63) / 64)), dim3(64), 0, st, rng_dev, K);
+    const int pieces = (int)((m + 65535) / 65536);
+    hipLaunchKernelGGL(gram_range_kernel, dim3((unsigned)((size_t)n * K * pieces)), dim3(256), 0, st, leaf_dev, K, p, pieces, rng_dev);
+}
+
 bool gram_usable(int n, int p) { return p >= 12 && n >= 2; }
 
 // thresholds a k column can need: registers live in 0 .. 64 - p + 1, thresholds vmin .. vmax - 1
@@ -371,9 +379,7 @@ void launch_pairwise_gram(const uint8_t* leaf_dev, int n, int K, int p, uint32_t
     uint32_t* rng = reinterpret_cast<uint32_t*>(base);
     uint32_t* part = reinterpret_cast<uint32_t*>(base + (((size_t)K * 2 * sizeof(uint32_t) + 255) & ~(size_t)255));
 
-    hipLaunchKernelGGL(gram_range_init_kernel, dim3((unsigned)((K + 63) / 64)), dim3(64), 0, st, rng, K);
-    const int pieces = (int)((m + 65535) / 65536);
-    hipLaunchKernelGGL(gram_range_kernel, dim3((unsigned)((size_t)n * K * pieces)), dim3(256), 0, st, leaf_dev, K, p, pieces, rng);
+    launch_register_range(leaf_dev, n, K, p, rng, st);
     // the diagonal super-block pairs (P, P), then the pairs P < Q; sp_fit of them per launch
     const int slots = gram_slots(p);
     const int len = gram_len(ns, K, p);

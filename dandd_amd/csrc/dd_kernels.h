@@ -183,6 +183,12 @@ bool gram_usable(int n, int log2m);
 size_t gram_scratch_bytes(int n, int K, int log2m, int* sp_per_launch);
 void launch_pairwise_gram(const uint8_t* leaf_dev, int n, int K, int log2m, uint32_t* hist_dev, void* scratch,
                           hipStream_t st);
+void launch_register_range(const uint8_t* leaf_dev, int n, int K, int log2m, uint32_t* rng_dev, hipStream_t st);
+// progressive unions as a bit-plane AND-scan (dd_pscan.hip); the streaming launch_progressive stays as the fallback
+bool pscan_usable(int n, int norder, int log2m);
+size_t pscan_scratch_bytes(int n, int K, int log2m, int norder);
+bool launch_progressive_pscan(const uint8_t* leaf_dev, int n, int K, int log2m, const int32_t* ord_dev, int norder, const uint32_t* rng_host,
+                              void* scratch, uint32_t* hist_dev, hipStream_t st);
 void launch_mle(const uint32_t* hist_dev, size_t njobs, int log2m, double* est_dev, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------

@@ -626,3 +626,31 @@ def test_sweep_parity_on_realistic_genome(engine_factory, orc, p, krange):
     eng = engine_factory(p, True)
     fa = orc.synth_realistic(SEED, 1, 3_000_000)
     _sweep_check(eng, orc, fa, krange[0], krange[1], True)
+
+
+@pytest.mark.parametrize("p,n,K,no", [(12, 2, 3, 1), (12, 7, 4, 10), (14, 30, 5, 10), (14, 33, 2, 3), (16, 64, 2, 2), (18, 12, 2, 9),
+                                       (20, 30, 3, 10), (20, 8, 2, 17)])
+def test_progressive_pscan_equals_streaming_kernel(engine_factory, torch_cuda, orc, monkeypatch, p, n, K, no):
+    """dd_progressive_device through the bit-plane AND-scan (dd_pscan.hip) == the streaming running-max kernel
+    (DD_PROGRESSIVE_STREAM=1, dd_union.hip) for every (ordering, prefix, k), as doubles -- more than 32 leaves (the
+    64-prefix instantiation), more orderings than one launch holds, degenerate and full threshold ranges, repeated
+    leaves inside an ordering -- and == the oracle's estimator on the running byte-max for sampled prefixes."""
+    torch = torch_cuda
+    eng = engine_factory(p, True)
+    rng = np.random.default_rng(7000 * p + 10 * n + no)
+    slab = _random_slab(rng, n, K, p, "corners")
+    ords = np.stack([rng.permutation(n) for _ in range(no)]).astype(np.int32)
+    if no > 1 and n > 2:
+        ords[-1, 1] = ords[-1, 0]            # a leaf twice in a row: the prefix does not change
+    dev = torch.from_numpy(slab).cuda()
+    scan = eng.progressive_device(dev.data_ptr(), n, K, ords)
+    monkeypatch.setenv("DD_PROGRESSIVE_STREAM", "1")
+    stream = eng.progressive_device(dev.data_ptr(), n, K, ords)
+    monkeypatch.delenv("DD_PROGRESSIVE_STREAM")
+    bad = np.argwhere(scan != stream)
+    assert bad.size == 0, f"{len(bad)} of {scan.size} entries differ, first (o, j, k) = {bad[0]}: scan {scan[tuple(bad[0])]} stream {stream[tuple(bad[0])]}"
+    for _ in range(5):
+        o, j, k = int(rng.integers(no)), int(rng.integers(n)), int(rng.integers(K))
+        run = slab[ords[o, :j + 1], k].max(axis=0)
+        want = orc.card(run, p)
+        assert scan[o, j, k] == want or (np.isinf(want) and np.isinf(scan[o, j, k])), (o, j, k)
