@@ -6,7 +6,8 @@
 //
 // The streaming kernel (dd_union.hip: progressive_kernel) keeps U_j in registers and pays one LDS atomic per register
 // per prefix -- 4.7 cycles per wave-wide ds_add_u32 whatever the bytes are (scripts/ubench_lds_atomic.hip): a 1.4 ms
-// floor for 10 orderings x 30 prefixes x 37 k of 2^20 registers, 3.1 ms measured.  Here the cumulative histogram is
+// floor for 10 orderings x 30 prefixes x 37 k of 2^20 registers, 3.15 ms measured (2.5 ms through this file).  Here the
+// cumulative histogram is
 // counted instead: U_j[r] <= v  <=>  every leaf of the prefix has leaf[r] <= v, so with the bit planes
 //         B_g,v = { r : leaf_g[r] <= v }          (one bit per register)
 // F_o,j(v) = popcount(B_o0,v & B_o1,v & .. & B_oj,v): a running AND along the ordering and one popcount per prefix --
@@ -16,7 +17,9 @@
 // One workgroup per (k, register range); per tile of 32 D registers:
 //   convert   every thread takes (leaf g, 32 registers): the 32 bytes are bit-sliced into six planes (two
 //             instructions per byte-dword and bit), and each needed threshold's plane is eq(vmin) | .. | eq(v), five
-//             ANDs of planes or their complements per threshold; planes go to LDS as [g][d][threshold]
+//             ANDs of planes or their complements per threshold; planes go to LDS as [g][threshold][d] (rows of D + 4
+//             words: a lane's 16-byte reads and its neighbours' then fall on different banks; rows of D words with their
+//             16-byte chunks rotated by the threshold measured 67 % conflict cycles against 39 %)
 //   scan      one LANE per chain (ordering, threshold): for each of the D plane words P = ~0, then for every prefix
 //             P &= plane[o_j][d][t], count_j += popcount(P) -- the counts stay in the lane's registers across all
 //             tiles of the range, so nothing is reduced until the very end.
@@ -24,6 +27,8 @@
 // Exact integers throughout; tests/test_gpu_parity.py checks every cardinality against the streaming kernel's.
 #include "dd_common.h"
 #include "dd_kernels.h"
+
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -46,19 +51,20 @@ DD_D void bit_slice(const uint32_t (&w)[8], uint32_t (&pl)[6]) {
     }
 }
 
-// NMAX: prefixes held in registers (n <= NMAX)
-template <int NMAX>
+// NMAX: prefixes held in registers (n <= NMAX); UPT: (leaf, 32 registers) units a thread converts per tile
+template <int NMAX, int UPT>
 __global__ __launch_bounds__(PS_THREADS) void pscan_kernel(const uint8_t* __restrict__ leaf, int n, int K, int p,
                                                            const int32_t* __restrict__ ord, int no, const uint32_t* __restrict__ rng,
                                                            int RR, int tiles_per_range, int D, int chain_pitch,
                                                            uint32_t* __restrict__ part) {
-    extern __shared__ uint32_t lds[];            // planes [g][d][T], then the orderings [no][n] as bytes
+    extern __shared__ uint32_t lds[];            // planes [g][t][DP], then the orderings [no][n] as bytes
     const int k = blockIdx.x / RR, rr = blockIdx.x % RR;
     const int vmin = (int)rng[2 * k], vmax = (int)rng[2 * k + 1];
     const int T = vmax - vmin;                   // thresholds vmin .. vmax-1
     if (T <= 0) return;                          // every register of the column equal: F is 0 below it, m from it on
+    const int DP = D + 4;                        // words per (leaf, threshold) row: 16 consecutive rows start on 16 different banks
     uint32_t* planes = lds;
-    uint8_t* ord_s = reinterpret_cast<uint8_t*>(lds + (size_t)n * D * T);
+    uint8_t* ord_s = reinterpret_cast<uint8_t*>(lds + (size_t)n * T * DP);
     for (int i = threadIdx.x; i < no * n; i += PS_THREADS) ord_s[i] = (uint8_t)ord[i];
     __syncthreads();
     // this lane's chain
@@ -68,29 +74,35 @@ __global__ __launch_bounds__(PS_THREADS) void pscan_kernel(const uint8_t* __rest
     uint32_t base[NMAX], cnt[NMAX];
 #pragma unroll
     for (int j = 0; j < NMAX; ++j) {
-        base[j] = j < n ? (uint32_t)((int)ord_s[o * n + j] * D * T + t) : 0u;
+        // (prefixes beyond n repeat the last leaf: the scan below runs all NMAX steps without a branch -- a branch per
+        // step kept every LDS read from being issued before the previous one was used: 13.8 ms instead of ~1 --, and
+        // their counts are never stored)
+        base[j] = (uint32_t)(((int)ord_s[o * n + (j < n ? j : n - 1)] * T + t) * DP);
         cnt[j] = 0;
     }
     const int units = n * D;                     // (leaf, 32 registers) pairs of a tile
     const size_t tile_regs = (size_t)32 * D;
-    const size_t reg0 = ((size_t)rr * tiles_per_range) * tile_regs;
-    constexpr int UPT = 4;                       // units per thread at most (units <= UPT * PS_THREADS: the host's choice of D)
+    // ranges of tiles_total / RR tiles, the remainder spread over the first ranges
+    const int tiles_total = tiles_per_range;     // (argument reused: all tiles of a row)
+    const int tile0 = (int)(((long long)tiles_total * rr) / RR), ntiles = (int)(((long long)tiles_total * (rr + 1)) / RR) - tile0;
+    const size_t reg0 = (size_t)tile0 * tile_regs;
     uint4 cur[UPT][2], nxt[UPT][2];
     auto load = [&](uint4 (&dst)[UPT][2], int tile) {
 #pragma unroll
         for (int q = 0; q < UPT; ++q) {
-            const int u = (int)threadIdx.x + q * PS_THREADS;
-            if (u < units) {
-                const int g = u / D, d = u % D;
-                const uint8_t* src = leaf + (((size_t)g * K + k) << p) + reg0 + (size_t)tile * tile_regs + (size_t)d * 32;
-                dst[q][0] = gload16(src);
-                dst[q][1] = gload16(src + 16);
-            }
+            // (threads past the last unit load the last unit again: with every load unconditional the compiler can count
+            // them, and waits for the current tile's bytes with the next tile's loads still in flight)
+            int u = (int)threadIdx.x + q * PS_THREADS;
+            u = u < units ? u : units - 1;
+            const int g = u / D, d = u % D;
+            const uint8_t* src = leaf + (((size_t)g * K + k) << p) + reg0 + (size_t)tile * tile_regs + (size_t)d * 32;
+            dst[q][0] = gload16(src);
+            dst[q][1] = gload16(src + 16);
         }
     };
     load(cur, 0);
-    for (int tile = 0; tile < tiles_per_range; ++tile) {
-        if (tile + 1 < tiles_per_range) load(nxt, tile + 1);
+    for (int tile = 0; tile < ntiles; ++tile) {
+        load(nxt, tile + 1 < ntiles ? tile + 1 : tile);
         // ---- convert: bytes -> threshold planes
 #pragma unroll
         for (int q = 0; q < UPT; ++q) {
@@ -101,7 +113,7 @@ __global__ __launch_bounds__(PS_THREADS) void pscan_kernel(const uint8_t* __rest
                 bit_slice(w, x);
 #pragma unroll
                 for (int b = 0; b < 6; ++b) nx[b] = ~x[b];
-                uint32_t* dst = planes + (size_t)u * T;      // [g][d][.]: u = g * D + d
+                uint32_t* dst = planes + (size_t)(u / D) * T * DP + (u % D);   // [g][.][d]
                 uint32_t le = 0;
 #pragma unroll
                 for (int v = 0; v < 64; ++v) {
@@ -110,7 +122,7 @@ __global__ __launch_bounds__(PS_THREADS) void pscan_kernel(const uint8_t* __rest
 #pragma unroll
                         for (int b = 1; b < 6; ++b) eq &= ((v >> b) & 1) ? x[b] : nx[b];
                         le |= eq;
-                        dst[v - vmin] = le;
+                        dst[(v - vmin) * DP] = le;
                     }
                 }
             }
@@ -118,15 +130,34 @@ __global__ __launch_bounds__(PS_THREADS) void pscan_kernel(const uint8_t* __rest
         __syncthreads();
         // ---- scan: running AND along the ordering, one popcount per prefix
         if (chain) {
-            for (int d = 0; d < D; ++d) {
-                uint32_t P = ~0u;
+            // four plane words per 16-byte read, four running ANDs side by side; the reads of the next eight prefixes
+            // are in flight while the current eight are ANDed and counted (two register sets, the loop unrolled in pairs)
+            uint4 xa[8], xb[8];
+            auto fetch = [&](uint4 (&x)[8], int j0, int d) {
+                const uint32_t col = (uint32_t)d;
 #pragma unroll
-                for (int j = 0; j < NMAX; ++j) {
-                    if (j < n) {
-                        P &= planes[base[j] + (uint32_t)(d * T)];
-                        cnt[j] += (uint32_t)__popc(P);
-                    }
+                for (int i = 0; i < 8; ++i) x[i] = *reinterpret_cast<const uint4*>(planes + base[(j0 + i) & (NMAX - 1)] + col);
+            };
+            uint32_t P0 = ~0u, P1 = ~0u, P2 = ~0u, P3 = ~0u;
+            auto fold = [&](const uint4 (&x)[8], int j0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    P0 &= x[i].x, P1 &= x[i].y, P2 &= x[i].z, P3 &= x[i].w;
+                    cnt[j0 + i] += (uint32_t)(__popc(P0) + __popc(P1)) + (uint32_t)(__popc(P2) + __popc(P3));
                 }
+            };
+            static_assert(NMAX == 32, "the scan is unrolled for 32 prefixes");
+            fetch(xa, 0, 0);
+            for (int d = 0; d < D; d += 4) {
+                P0 = P1 = P2 = P3 = ~0u;
+                fetch(xb, 8, d);
+                fold(xa, 0);
+                fetch(xa, 16, d);
+                fold(xb, 8);
+                fetch(xb, 24, d);
+                fold(xa, 16);
+                fetch(xa, 0, d + 4 < D ? d + 4 : d);   // (the last one is read again and dropped)
+                fold(xb, 24);
             }
         }
         __syncthreads();
@@ -174,51 +205,60 @@ __global__ __launch_bounds__(256) void pscan_finish_kernel(const uint32_t* __res
 // fit 128 KiB of LDS and its (leaf, word) units fit four per thread
 static int pscan_words(int n, int T) {
     int D = 32;
-    while (D > 1 && ((size_t)n * D * T * 4 > ((size_t)128 << 10) || n * D > 4 * PS_THREADS)) D >>= 1;
+    while (D > 4 && ((size_t)n * (D + 4) * T * 4 > ((size_t)150 << 10) || n * D > PS_THREADS)) D >>= 1;   // one (leaf, word) unit per thread
     return D;
 }
 
-bool pscan_usable(int n, int no, int p) { return p >= 12 && n >= 2 && n <= 64 && no >= 1; }
+// n <= 32: a lane keeps one count and one LDS offset per prefix in registers; longer orderings take the streaming
+// kernel.  log2m >= 19: below that the streaming kernel is the faster one (10 orderings x 30 prefixes x 37 k, same box:
+// 0.10 / 0.22 / 0.34 / 0.70 ms against 0.17 / 0.26 / 0.41 / 0.72 at log2m 15 / 16 / 17 / 18; 1.57 / 3.15 against
+// 1.30 / 2.50 at 19 / 20) -- DD_PROGRESSIVE_PSCAN=1 takes this path from log2m 12 on (tests).
+bool pscan_usable(int n, int no, int p) {
+    return p >= (getenv("DD_PROGRESSIVE_PSCAN") ? 12 : 19) && n >= 2 && n <= 32 && no >= 1;
+}
 
 // scratch: the range pairs of every k, then the partial counts [k][range][prefix][chain]
 size_t pscan_scratch_bytes(int n, int K, int p, int no) {
-    const size_t pitch = ((size_t)std::min(no, 8) * (size_t)(64 - p + 1) + 63) / 64 * 64;
+    const size_t pitch = PS_THREADS;
+    (void)no;
     return (((size_t)K * 2 * sizeof(uint32_t) + 255) & ~(size_t)255) + (size_t)K * 64 * (size_t)n * pitch * sizeof(uint32_t);
 }
 
 // rng_host: the (min, max) pairs gram_range_kernel left at the start of `scratch`, read back by the caller (K pairs).
-// Orderings are taken eight at a time (8 x 45 thresholds at most = 360 chains <= 512 lanes).  hist_dev is written
+// Orderings are taken as many at a time as have their chains in the 512 lanes of a workgroup.  hist_dev is written
 // in full.  Returns false when a column's thresholds do not fit (the caller falls back to the streaming kernel).
 bool launch_progressive_pscan(const uint8_t* leaf_dev, int n, int K, int p, const int32_t* ord_dev, int norder, const uint32_t* rng_host,
                               void* scratch, uint32_t* hist_dev, hipStream_t st) {
     int Tmax = 1;
     for (int k = 0; k < K; ++k) Tmax = std::max(Tmax, (int)rng_host[2 * k + 1] - (int)rng_host[2 * k]);
-    const int group = 8;
-    if (Tmax * std::min(norder, group) > PS_THREADS) return false;
+    // as many orderings per launch as have their chains in one workgroup's lanes, shared out evenly over the launches
+    const int fit = PS_THREADS / Tmax;
+    if (fit < 1) return false;
+    const int launches = (norder + fit - 1) / fit;
+    const int group = (norder + launches - 1) / launches;
     const int D = pscan_words(n, Tmax);
-    const size_t lds_bytes = (size_t)n * D * Tmax * 4 + (((size_t)group * n + 15) & ~(size_t)15);
-    if (lds_bytes > ((size_t)150 << 10)) return false;
+    const size_t lds_bytes = (size_t)n * (D + 4) * Tmax * 4 + (((size_t)group * n + 15) & ~(size_t)15);
+    if (lds_bytes > ((size_t)158 << 10)) return false;
     const size_t m = (size_t)1 << p;
     const int tiles = (int)(m / ((size_t)32 * D));
-    // register ranges: ~4 workgroups per CU over all k, at least 8 tiles each
-    int RR = 1;
-    while (RR < 64 && K * RR < 1024 && tiles / (RR * 2) >= 8) RR *= 2;
-    const int tiles_per_range = tiles / RR;
+    // register ranges: four rounds of one workgroup per CU over all k (just under, never just over), at least 4 tiles each
+    int RR = std::max(1, std::min(64, (4 * 256) / K));
+    while (RR > 1 && tiles / RR < 4) --RR;
+    const int tiles_per_range = tiles;    // (the kernel cuts [0, tiles) into RR ranges itself)
     uint8_t* base = static_cast<uint8_t*>(scratch);
     const uint32_t* rng = reinterpret_cast<const uint32_t*>(base);
     uint32_t* part = reinterpret_cast<uint32_t*>(base + (((size_t)K * 2 * sizeof(uint32_t) + 255) & ~(size_t)255));
-    const int pitch = (int)(((size_t)std::min(norder, group) * (size_t)(64 - p + 1) + 63) / 64 * 64);
+    const int pitch = PS_THREADS;
     for (int o0 = 0; o0 < norder; o0 += group) {
         const int no = std::min(group, norder - o0);
-        if (n <= 32) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pscan_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            hipLaunchKernelGGL(pscan_kernel<32>, dim3((unsigned)(K * RR)), dim3(PS_THREADS), lds_bytes, st, leaf_dev, n, K, p, ord_dev + (size_t)o0 * n, no,
-                               rng, RR, tiles_per_range, D, pitch, part);
-        } else {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pscan_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            hipLaunchKernelGGL(pscan_kernel<64>, dim3((unsigned)(K * RR)), dim3(PS_THREADS), lds_bytes, st, leaf_dev, n, K, p, ord_dev + (size_t)o0 * n, no,
-                               rng, RR, tiles_per_range, D, pitch, part);
-        }
+#define DD_PSCAN_LAUNCH(NMAX, UPT)                                                                                                             \
+    do {                                                                                                                                      \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pscan_kernel<NMAX, UPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+        hipLaunchKernelGGL((pscan_kernel<NMAX, UPT>), dim3((unsigned)(K * RR)), dim3(PS_THREADS), lds_bytes, st, leaf_dev, n, K, p,            \
+                           ord_dev + (size_t)o0 * n, no, rng, RR, tiles_per_range, D, pitch, part);                                           \
+    } while (0)
+        DD_PSCAN_LAUNCH(32, 1);
+#undef DD_PSCAN_LAUNCH
         const size_t jobs = (size_t)no * n * K;
         hipLaunchKernelGGL(pscan_finish_kernel, dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0, st, part, n, K, p, no, rng, RR, pitch,
                            hist_dev + (size_t)o0 * n * K * 64);

@@ -629,7 +629,7 @@ def test_sweep_parity_on_realistic_genome(engine_factory, orc, p, krange):
 
 
 @pytest.mark.parametrize("p,n,K,no", [(12, 2, 3, 1), (12, 7, 4, 10), (14, 30, 5, 10), (14, 33, 2, 3), (16, 64, 2, 2), (18, 12, 2, 9),
-                                       (20, 30, 3, 10), (20, 8, 2, 17)])
+                                       (19, 32, 2, 4), (20, 30, 3, 10), (20, 8, 2, 17)])
 def test_progressive_pscan_equals_streaming_kernel(engine_factory, torch_cuda, orc, monkeypatch, p, n, K, no):
     """dd_progressive_device through the bit-plane AND-scan (dd_pscan.hip) == the streaming running-max kernel
     (DD_PROGRESSIVE_STREAM=1, dd_union.hip) for every (ordering, prefix, k), as doubles -- more than 32 leaves (the
@@ -643,7 +643,9 @@ def test_progressive_pscan_equals_streaming_kernel(engine_factory, torch_cuda, o
     if no > 1 and n > 2:
         ords[-1, 1] = ords[-1, 0]            # a leaf twice in a row: the prefix does not change
     dev = torch.from_numpy(slab).cuda()
+    monkeypatch.setenv("DD_PROGRESSIVE_PSCAN", "1")      # (the library takes this path from log2m 19 on by itself)
     scan = eng.progressive_device(dev.data_ptr(), n, K, ords)
+    monkeypatch.delenv("DD_PROGRESSIVE_PSCAN")
     monkeypatch.setenv("DD_PROGRESSIVE_STREAM", "1")
     stream = eng.progressive_device(dev.data_ptr(), n, K, ords)
     monkeypatch.delenv("DD_PROGRESSIVE_STREAM")
