@@ -98,7 +98,9 @@ double dd_ertl_mle(const uint32_t hist[64], int log2m);
  * Replaces the flat prefix unions of DeltaTree.sketch_ordering
  * (lib/huffman_dandd.py:644-663): for ordering o and prefix length j,
  * card[o][j-1][kk] = |union of leaf[ord[o][0..j-1]]| at k = kmin+kk, computed as a
- * running byte-max (max is associative, so it equals the flat union bit for bit). */
+ * running byte-max (max is associative, so it equals the flat union bit for bit) -- or, from
+ * log2m 19 on and for n <= 32, as a running AND of threshold bit planes with a popcount per prefix
+ * (dd_pscan.hip): the same integers.  Register bytes must be <= 63. */
 int dd_progressive(dd_ctx *, const uint8_t *leaf /*[n][K][m]*/, int n, int K,
                    const int32_t *orderings /*[norder][n]*/, int norder,
                    double *card /*[norder][n][K]*/);
@@ -108,7 +110,9 @@ int dd_progressive_device(dd_ctx *, const uint8_t *leaf_dev, int n, int K,
 /* ---- all-pairs unions ------------------------------------------------------------
  * Replaces the 2-way unions of DeltaTree.pairwise_spiders (lib/huffman_dandd.py:666-695):
  * card[i][j][kk] for i<j is |leaf_i U leaf_j|; card[i][i][kk] is |leaf_i|; the lower
- * triangle mirrors the upper. */
+ * triangle mirrors the upper.  From log2m 12 on the histograms behind the estimates are counted as int8
+ * Gram matrices on the matrix cores (dd_gram.hip; F_ij(v) = sum_r [a_ir <= v][a_jr <= v]): the same
+ * integers as the byte-max + histogram kernel.  Register bytes must be <= 63. */
 int dd_pairwise(dd_ctx *, const uint8_t *leaf /*[n][K][m]*/, int n, int K,
                 double *card /*[n][n][K]*/);
 int dd_pairwise_device(dd_ctx *, const uint8_t *leaf_dev, int n, int K, double *card);
