@@ -6,7 +6,7 @@
 //
 // The streaming kernel (dd_union.hip: progressive_kernel) keeps U_j in registers and pays one LDS atomic per register
 // per prefix -- 4.7 cycles per wave-wide ds_add_u32 whatever the bytes are (scripts/ubench_lds_atomic.hip): a 1.4 ms
-// floor for 10 orderings x 30 prefixes x 37 k of 2^20 registers, 3.15 ms measured (2.5 ms through this file).  Here the
+// floor for 10 orderings x 30 prefixes x 37 k of 2^20 registers, 3.15 ms measured (2.1 ms through this file).  Here the
 // cumulative histogram is
 // counted instead: U_j[r] <= v  <=>  every leaf of the prefix has leaf[r] <= v, so with the bit planes
 //         B_g,v = { r : leaf_g[r] <= v }          (one bit per register)
@@ -52,8 +52,12 @@ DD_D void bit_slice(const uint32_t (&w)[8], uint32_t (&pl)[6]) {
 }
 
 // NMAX: prefixes held in registers (n <= NMAX); UPT: (leaf, 32 registers) units a thread converts per tile
+// At most 128 registers (four reads in flight, the ordering's leaves as bytes, the running store pointer): two
+// workgroups share a CU and hide each other's barriers and LDS latencies, and the host picks tiles small enough for two
+// workgroups' planes.  (One workgroup of 237 registers per CU with the next eight reads in flight during the fold of
+// the current eight measured 2.43 ms where this form takes 2.11.)
 template <int NMAX, int UPT>
-__global__ __launch_bounds__(PS_THREADS) void pscan_kernel(const uint8_t* __restrict__ leaf, int n, int K, int p,
+__global__ __launch_bounds__(PS_THREADS, 4) void pscan_kernel(const uint8_t* __restrict__ leaf, int n, int K, int p,
                                                            const int32_t* __restrict__ ord, int no, const uint32_t* __restrict__ rng,
                                                            int RR, int tiles_per_range, int D, int chain_pitch,
                                                            uint32_t* __restrict__ part) {
@@ -71,22 +75,23 @@ __global__ __launch_bounds__(PS_THREADS) void pscan_kernel(const uint8_t* __rest
     const int c = threadIdx.x;
     const bool chain = c < no * T;
     const int o = chain ? c / T : 0, t = chain ? c % T : 0;
-    uint32_t base[NMAX], cnt[NMAX];
+    uint32_t cnt[NMAX], gp[NMAX / 4];            // the ordering's leaves as bytes, four to a register
+    const uint32_t tDP = (uint32_t)(t * DP), rowDP = (uint32_t)(T * DP);
 #pragma unroll
-    for (int j = 0; j < NMAX; ++j) {
-        // (prefixes beyond n repeat the last leaf: the scan below runs all NMAX steps without a branch -- a branch per
-        // step kept every LDS read from being issued before the previous one was used: 13.8 ms instead of ~1 --, and
-        // their counts are never stored)
-        base[j] = (uint32_t)(((int)ord_s[o * n + (j < n ? j : n - 1)] * T + t) * DP);
-        cnt[j] = 0;
+    for (int j = 0; j < NMAX / 4; ++j) {
+        gp[j] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gp[j] |= (uint32_t)ord_s[o * n + (4 * j + i < n ? 4 * j + i : n - 1)] << (8 * i);
     }
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) cnt[j] = 0;
     const int units = n * D;                     // (leaf, 32 registers) pairs of a tile
     const size_t tile_regs = (size_t)32 * D;
     // ranges of tiles_total / RR tiles, the remainder spread over the first ranges
     const int tiles_total = tiles_per_range;     // (argument reused: all tiles of a row)
     const int tile0 = (int)(((long long)tiles_total * rr) / RR), ntiles = (int)(((long long)tiles_total * (rr + 1)) / RR) - tile0;
     const size_t reg0 = (size_t)tile0 * tile_regs;
-    uint4 cur[UPT][2], nxt[UPT][2];
+    uint4 cur[UPT][2];
     auto load = [&](uint4 (&dst)[UPT][2], int tile) {
 #pragma unroll
         for (int q = 0; q < UPT; ++q) {
@@ -102,7 +107,6 @@ __global__ __launch_bounds__(PS_THREADS) void pscan_kernel(const uint8_t* __rest
     };
     load(cur, 0);
     for (int tile = 0; tile < ntiles; ++tile) {
-        load(nxt, tile + 1 < ntiles ? tile + 1 : tile);
         // ---- convert: bytes -> threshold planes
 #pragma unroll
         for (int q = 0; q < UPT; ++q) {
@@ -111,6 +115,7 @@ __global__ __launch_bounds__(PS_THREADS) void pscan_kernel(const uint8_t* __rest
                 const uint32_t w[8] = {cur[q][0].x, cur[q][0].y, cur[q][0].z, cur[q][0].w, cur[q][1].x, cur[q][1].y, cur[q][1].z, cur[q][1].w};
                 uint32_t x[6], nx[6];
                 bit_slice(w, x);
+                if (UPT == 1) load(cur, tile + 1 < ntiles ? tile + 1 : tile);   // (the bytes are sliced: their registers take the next tile's)
 #pragma unroll
                 for (int b = 0; b < 6; ++b) nx[b] = ~x[b];
                 uint32_t* dst = planes + (size_t)(u / D) * T * DP + (u % D);   // [g][.][d]
@@ -122,7 +127,8 @@ __global__ __launch_bounds__(PS_THREADS) void pscan_kernel(const uint8_t* __rest
 #pragma unroll
                         for (int b = 1; b < 6; ++b) eq &= ((v >> b) & 1) ? x[b] : nx[b];
                         le |= eq;
-                        dst[(v - vmin) * DP] = le;
+                        *dst = le;
+                        dst += DP;           // (a running pointer: 64 precomputed row addresses would be hoisted out of the tile loop)
                     }
                 }
             }
@@ -130,42 +136,26 @@ __global__ __launch_bounds__(PS_THREADS) void pscan_kernel(const uint8_t* __rest
         __syncthreads();
         // ---- scan: running AND along the ordering, one popcount per prefix
         if (chain) {
-            // four plane words per 16-byte read, four running ANDs side by side; the reads of the next eight prefixes
-            // are in flight while the current eight are ANDed and counted (two register sets, the loop unrolled in pairs)
-            uint4 xa[8], xb[8];
-            auto fetch = [&](uint4 (&x)[8], int j0, int d) {
-                const uint32_t col = (uint32_t)d;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) x[i] = *reinterpret_cast<const uint4*>(planes + base[(j0 + i) & (NMAX - 1)] + col);
-            };
-            uint32_t P0 = ~0u, P1 = ~0u, P2 = ~0u, P3 = ~0u;
-            auto fold = [&](const uint4 (&x)[8], int j0) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    P0 &= x[i].x, P1 &= x[i].y, P2 &= x[i].z, P3 &= x[i].w;
-                    cnt[j0 + i] += (uint32_t)(__popc(P0) + __popc(P1)) + (uint32_t)(__popc(P2) + __popc(P3));
-                }
-            };
-            static_assert(NMAX == 32, "the scan is unrolled for 32 prefixes");
-            fetch(xa, 0, 0);
             for (int d = 0; d < D; d += 4) {
-                P0 = P1 = P2 = P3 = ~0u;
-                fetch(xb, 8, d);
-                fold(xa, 0);
-                fetch(xa, 16, d);
-                fold(xb, 8);
-                fetch(xb, 24, d);
-                fold(xa, 16);
-                fetch(xa, 0, d + 4 < D ? d + 4 : d);   // (the last one is read again and dropped)
-                fold(xb, 24);
+                uint32_t P0 = ~0u, P1 = ~0u, P2 = ~0u, P3 = ~0u;
+#pragma unroll
+                for (int j0 = 0; j0 < NMAX; j0 += 4) {
+                    uint4 xs[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        uint32_t g = (gp[j0 >> 2] >> (8 * i)) & 0xffu;
+                        asm volatile("" : "+v"(g));   // (keeps the 32 row offsets from being hoisted into 32 registers again)
+                        xs[i] = *reinterpret_cast<const uint4*>(planes + g * rowDP + tDP + (uint32_t)d);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        P0 &= xs[i].x, P1 &= xs[i].y, P2 &= xs[i].z, P3 &= xs[i].w;
+                        cnt[j0 + i] += (uint32_t)(__popc(P0) + __popc(P1)) + (uint32_t)(__popc(P2) + __popc(P3));
+                    }
+                }
             }
         }
         __syncthreads();
-#pragma unroll
-        for (int q = 0; q < UPT; ++q) {
-            cur[q][0] = nxt[q][0];
-            cur[q][1] = nxt[q][1];
-        }
     }
     if (chain) {
         uint32_t* out = part + ((size_t)k * RR + rr) * (size_t)n * chain_pitch + c;
@@ -203,18 +193,18 @@ __global__ __launch_bounds__(256) void pscan_finish_kernel(const uint32_t* __res
 
 // plane words per tile row: the largest power of two for which the planes of a tile (n leaves x D words x T thresholds)
 // fit 128 KiB of LDS and its (leaf, word) units fit four per thread
-static int pscan_words(int n, int T) {
+static int pscan_words(int n, int T, size_t lds_limit) {
     int D = 32;
-    while (D > 4 && ((size_t)n * (D + 4) * T * 4 > ((size_t)150 << 10) || n * D > PS_THREADS)) D >>= 1;   // one (leaf, word) unit per thread
+    while (D > 4 && ((size_t)n * (D + 4) * T * 4 > lds_limit || n * D > PS_THREADS)) D >>= 1;   // one (leaf, word) unit per thread
     return D;
 }
 
-// n <= 32: a lane keeps one count and one LDS offset per prefix in registers; longer orderings take the streaming
-// kernel.  log2m >= 19: below that the streaming kernel is the faster one (10 orderings x 30 prefixes x 37 k, same box:
-// 0.10 / 0.22 / 0.34 / 0.70 ms against 0.17 / 0.26 / 0.41 / 0.72 at log2m 15 / 16 / 17 / 18; 1.57 / 3.15 against
-// 1.30 / 2.50 at 19 / 20) -- DD_PROGRESSIVE_PSCAN=1 takes this path from log2m 12 on (tests).
+// n <= 32: a lane keeps one count per prefix in registers; longer orderings take the streaming kernel.  log2m >= 18:
+// below that the streaming kernel is the faster one (10 orderings x 30 prefixes x 37 k, same box: 0.10 / 0.22 / 0.34 ms
+// against 0.17 / 0.21 / 0.35 at log2m 15 / 16 / 17; 0.70 / 1.57 / 3.15 against 0.61 / 1.07 / 2.11 at 18 / 19 / 20) --
+// DD_PROGRESSIVE_PSCAN=1 takes this path from log2m 12 on (tests).
 bool pscan_usable(int n, int no, int p) {
-    return p >= (getenv("DD_PROGRESSIVE_PSCAN") ? 12 : 19) && n >= 2 && n <= 32 && no >= 1;
+    return p >= (getenv("DD_PROGRESSIVE_PSCAN") ? 12 : 18) && n >= 2 && n <= 32 && no >= 1;
 }
 
 // scratch: the range pairs of every k, then the partial counts [k][range][prefix][chain]
@@ -236,13 +226,13 @@ bool launch_progressive_pscan(const uint8_t* leaf_dev, int n, int K, int p, cons
     if (fit < 1) return false;
     const int launches = (norder + fit - 1) / fit;
     const int group = (norder + launches - 1) / launches;
-    const int D = pscan_words(n, Tmax);
+    const int D = pscan_words(n, Tmax, (size_t)76 << 10);   // two workgroups' planes per CU
     const size_t lds_bytes = (size_t)n * (D + 4) * Tmax * 4 + (((size_t)group * n + 15) & ~(size_t)15);
     if (lds_bytes > ((size_t)158 << 10)) return false;
     const size_t m = (size_t)1 << p;
     const int tiles = (int)(m / ((size_t)32 * D));
-    // register ranges: four rounds of one workgroup per CU over all k (just under, never just over), at least 4 tiles each
-    int RR = std::max(1, std::min(64, (4 * 256) / K));
+    // register ranges: four rounds of two workgroups per CU over all k (just under, never just over), at least 4 tiles each
+    int RR = std::max(1, std::min(64, (8 * 256) / K));
     while (RR > 1 && tiles / RR < 4) --RR;
     const int tiles_per_range = tiles;    // (the kernel cuts [0, tiles) into RR ranges itself)
     uint8_t* base = static_cast<uint8_t*>(scratch);

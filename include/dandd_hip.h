@@ -99,7 +99,7 @@ double dd_ertl_mle(const uint32_t hist[64], int log2m);
  * (lib/huffman_dandd.py:644-663): for ordering o and prefix length j,
  * card[o][j-1][kk] = |union of leaf[ord[o][0..j-1]]| at k = kmin+kk, computed as a
  * running byte-max (max is associative, so it equals the flat union bit for bit) -- or, from
- * log2m 19 on and for n <= 32, as a running AND of threshold bit planes with a popcount per prefix
+ * log2m 18 on and for n <= 32, as a running AND of threshold bit planes with a popcount per prefix
  * (dd_pscan.hip): the same integers.  Register bytes must be <= 63. */
 int dd_progressive(dd_ctx *, const uint8_t *leaf /*[n][K][m]*/, int n, int K,
                    const int32_t *orderings /*[norder][n]*/, int norder,
