@@ -616,10 +616,11 @@ def main():
             # block boundaries and the pieces are decoded in parallel without their history (dd_inflate.h); the serial
             # decoder (libdeflate, one thread) beside it
             try:
-                big = ingest_probe(eng, 1, 400_000_000, 24, kmin, kmax, torch, gz=True, reps=4)
+                big_nb = max(40_000_000, 8 * nb)     # 400 Mbp for the headline workload
+                big = ingest_probe(eng, 1, big_nb, 24, kmin, kmax, torch, gz=True, reps=4)
                 os.environ["DD_NO_PARALLEL_GZIP"] = "1"
                 try:
-                    ser = ingest_probe(eng, 1, 400_000_000, 24, kmin, kmax, torch, gz=True, reps=3)
+                    ser = ingest_probe(eng, 1, big_nb, 24, kmin, kmax, torch, gz=True, reps=3)
                 finally:
                     del os.environ["DD_NO_PARALLEL_GZIP"]
                 big["serial_decoder_value"] = ser["value"]

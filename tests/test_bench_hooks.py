@@ -182,3 +182,34 @@ def test_bench_without_enough_gpus_fails_loudly():
                        env=env, capture_output=True, text=True, timeout=240, cwd=ROOT)
     assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert "wants cuda:1" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_headline_line_has_every_object(torch_cuda):
+    """The driver's command shape on a shrunk workload (3 x 2 Mbp): the ONE line bench.py prints carries the contract's
+    keys and every object the headline run adds -- roofline (with the VALU bound's source when the workload is the
+    profiled one: here it is not, so traffic is null), cpu_baseline with its stages, accuracy_vs_exact, the secondary
+    steps (log2m 16 / 20, small genomes, realistic genomes), ingest (plain, small files, gzip, one big gzip parallel
+    and serial) -- and nothing in it is an error entry."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--genomes", "3", "--mbp", "2",
+                        "--cpu-sample-mbp", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    j = _line(r)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline", "accuracy_vs_exact", "secondary", "ingest", "gpus_active", "collectives"):
+        assert key in j, key
+    assert j["metric"].startswith("Gbp/s") and j["unit"] == "Gbp/s" and j["dtype"] == "u64" and j["vs_baseline"] is None
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "weak" and j["higher_is_better"] is True
+    rf = j["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1 and rf["traffic"] is None and rf["valu_bound"] is None
+    cb = j["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and set(cb["stages_s"]) == {"stage1_leaf_sketches", "leaf_cards", "stage2_progressive_unions_and_cards",
+                                                                              "stage3_nway_union_and_card"}
+    assert cb["stage1_only_value"] >= cb["value"] >= cb["with_stage2_value"] > 0
+    assert j["accuracy_vs_exact"]["sketches"] == 4 and abs(j["accuracy_vs_exact"]["card_rel_err_mean_signed"]) < 0.02
+    assert set(j["secondary"]) == {"log2m16", "log2m20", "log2m20_64x5Mbp", "realistic_log2m14", "realistic_log2m20"}
+    assert all("error" not in v and v["value"] > 0 for v in j["secondary"].values())
+    ing = j["ingest"]
+    assert ing["value"] > 0 and ing["best_value"] >= ing["value"]
+    for sub in ("small_files", "gzip_files", "one_big_gzip_file"):
+        assert "error" not in ing[sub] and ing[sub]["value"] > 0, sub
+    assert ing["one_big_gzip_file"]["serial_decoder_value"] > 0
