@@ -47,6 +47,17 @@ struct Bits {
         cnt -= skip;
     }
     inline void refill() {
+        if (pos + 8 <= n) {
+            // eight bytes at once: the bits above `cnt` that do not make a whole byte are ORed in again, identically, by
+            // the next refill (the stream position only advances by whole bytes)
+            uint64_t w;
+            memcpy(&w, p + pos, 8);
+            buf |= w << cnt;
+            const int bytes = (63 - cnt) >> 3;
+            pos += (size_t)bytes;
+            cnt += bytes * 8;
+            return;
+        }
         while (cnt <= 56) {
             if (pos < n) buf |= (uint64_t)p[pos] << cnt;
             else if (pos > n + 8) { over = true; }
@@ -75,6 +86,22 @@ struct Huff {
     // (0: not a literal or a longer code -> decode() decides), bits 8..15 / 16..23 the literals.
     static constexpr int PAIR = 11;
     uint32_t pair[1 << PAIR];
+    // one lookup per symbol for everything else a FAST-bit code can be: bits 0..3 code length, bits 4..6 kind (0 = longer
+    // code / invalid, 1 literal, 2 end of block, 3 length or distance), bits 7..10 extra bits, bits 11.. base (or the literal)
+    uint32_t info[1 << FAST];
+    void build_info(const uint16_t* base, const uint8_t* extra, int first, int nsym) {   // symbols first .. first+nsym-1 carry (base, extra)
+        for (uint32_t idx = 0; idx < (1u << FAST); ++idx) {
+            const uint16_t e = fast[idx];
+            const int l = e & 15, sym = e >> 4;
+            uint32_t v = 0;
+            if (e) {
+                if (first && sym < 256) v = (uint32_t)l | (1u << 4) | ((uint32_t)sym << 11);
+                else if (first && sym == 256) v = (uint32_t)l | (2u << 4);
+                else if (sym >= first && sym < first + nsym) v = (uint32_t)l | (3u << 4) | ((uint32_t)extra[sym - first] << 7) | ((uint32_t)base[sym - first] << 11);
+            }
+            info[idx] = v;
+        }
+    }
     int maxlen = 0;
     void build_pairs() {
         for (uint32_t idx = 0; idx < (1u << PAIR); ++idx) {
@@ -295,6 +322,8 @@ inline int decode_piece(const uint8_t* in, size_t n, uint64_t start, uint64_t st
                 }
             } else {
                 codes.lit.build_pairs();
+                codes.lit.build_info(kLenBase, kLenExtra, 257, 29);
+                codes.dist.build_info(kDistBase, kDistExtra, 0, 30);
                 uint16_t* o = out->p;
                 size_t at = out->len, lim = out->cap;
                 const long long floor = known_start ? 0 : -32768;
@@ -315,20 +344,46 @@ inline int decode_piece(const uint8_t* in, size_t n, uint64_t start, uint64_t st
                         b.drop((int)(pe & 31));
                         continue;
                     }
-                    const int s = codes.lit.decode(b);
-                    if (s < 256) {
-                        if (s < 0) return -1;
-                        o[at++] = (uint16_t)s;
-                        continue;
+                    // (after the refill above >= 32 bits are in hand: a length code with its extra bits takes <= 20 of them)
+                    int len;
+                    const uint32_t li = codes.lit.info[b.peek(Huff::FAST)];
+                    if (li) {
+                        b.drop((int)(li & 15));
+                        const uint32_t kind = (li >> 4) & 7;
+                        if (kind == 1) {
+                            o[at++] = (uint16_t)(li >> 11);
+                            continue;
+                        }
+                        if (kind == 2) break;
+                        const int ex = (int)((li >> 7) & 15);
+                        len = (int)(li >> 11) + (int)b.peek(ex);
+                        b.drop(ex);
+                    } else {
+                        const int s = codes.lit.decode(b);
+                        if (s < 256) {
+                            if (s < 0) return -1;
+                            o[at++] = (uint16_t)s;
+                            continue;
+                        }
+                        if (s == 256) break;
+                        if (s > 285) return -1;
+                        if (b.cnt < 32) b.refill();
+                        len = kLenBase[s - 257] + (int)b.take(kLenExtra[s - 257]);
                     }
-                    if (s == 256) break;
-                    if (s > 285) return -1;
                     if (b.cnt < 32) b.refill();
-                    const int len = kLenBase[s - 257] + (int)b.take(kLenExtra[s - 257]);
-                    const int ds = codes.dist.decode(b);
-                    if (ds < 0 || ds > 29) return -1;
-                    if (b.cnt < 16) b.refill();
-                    const int dist = kDistBase[ds] + (int)b.take(kDistExtra[ds]);
+                    int dist;
+                    const uint32_t di = codes.dist.info[b.peek(Huff::FAST)];
+                    if (di) {
+                        b.drop((int)(di & 15));
+                        const int ex = (int)((di >> 7) & 15);
+                        dist = (int)(di >> 11) + (int)b.peek(ex);
+                        b.drop(ex);
+                    } else {
+                        const int ds = codes.dist.decode(b);
+                        if (ds < 0 || ds > 29) return -1;
+                        if (b.cnt < 16) b.refill();
+                        dist = kDistBase[ds] + (int)b.take(kDistExtra[ds]);
+                    }
                     const long long from = (long long)at - dist;
                     if (from < floor) return -1;
                     if (from >= 0) {

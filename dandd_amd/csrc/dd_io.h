@@ -141,7 +141,7 @@ inline int read_gzip_whole(const char* path, FileBuf& out, int par = 1) {
     }
     // the compressed bytes are only ever read: map the file (page cache / tmpfs pages, no copy); read() as a fallback
     bool mapped = true;
-    uint8_t* in = static_cast<uint8_t*>(mmap(nullptr, n, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0));
+    uint8_t* in = static_cast<uint8_t*>(mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0));   // (not MAP_POPULATE: one thread would fill the page table that the decoding threads fill in parallel)
     size_t have = n;
     if (in == MAP_FAILED) {
         mapped = false;
