@@ -197,16 +197,16 @@ class HipExactBackend:
 
     def card(self, path):
         db = self._read(path)
-        files = None
         if db.get("distinct") is not None:
             # a database answers on its own -- unless its genomes are where they were and are no longer the files
             # the count was made from
             try:
-                files = [self._find(m) for m in db["members"]]
+                for m in db["members"]:
+                    self._find(m)
             except FileNotFoundError as e:
                 if "recorded" in str(e):     # found, but replaced by another file: the cached count is stale
                     raise
-                return float(db["distinct"])  # moved away altogether: nothing to compare with
+                # moved away altogether: nothing to compare with
             return float(db["distinct"])
         files = [self._find(m) for m in db["members"]]
         for m, f in zip(db["members"], files):
