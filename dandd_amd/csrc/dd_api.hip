@@ -139,7 +139,7 @@ struct dd_ctx {
     HostBuf pipe_out[2];
     hipEvent_t pipe_h2d[2] = {nullptr, nullptr}, pipe_done[2] = {nullptr, nullptr}, pipe_d2h[2] = {nullptr, nullptr};
     hipStream_t side[8] = {};  // k classes of a small call run side by side
-    hipEvent_t side_done[8] = {}, side_go = nullptr;
+    hipEvent_t side_done[8] = {}, side_go = nullptr, side_stagger = nullptr;
     bool side_ready = false;
     int ingest_calls = 0;
     // HBM the record streams of one log2m >= 17 call may take: a sixth of the device (48 GiB of 288), 16 GiB at least
@@ -319,6 +319,7 @@ void dd_destroy(dd_ctx* c) {
             (void)hipEventDestroy(c->side_done[i]);
         }
         (void)hipEventDestroy(c->side_go);
+        (void)hipEventDestroy(c->side_stagger);
     }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->out_stream) (void)hipStreamDestroy(c->out_stream);
@@ -349,6 +350,26 @@ int dd_synchronize(dd_ctx* c) {
 }
 
 // ------------------------------------------------------------------------------ sketch
+// The side streams the k classes of a call run on.  DD_SIDE_PRIO (experiments): one digit per stream, 0 = the
+// device's highest queue priority, 1 = normal, 2 = lowest.
+static int ensure_side_streams(dd_ctx* c) {
+    if (c->side_ready) return DD_OK;
+    int lo = 0, hi = 0;  // (numerically: hi <= lo)
+    DD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    const char* prio = getenv("DD_SIDE_PRIO");
+    const size_t np = prio ? strlen(prio) : 0;
+    for (int i = 0; i < 8; ++i) {
+        int pr = (lo + hi) / 2;
+        if ((size_t)i < np) pr = prio[i] == '0' ? hi : (prio[i] == '2' ? lo : pr);
+        DD_HIP(hipStreamCreateWithPriority(&c->side[i], hipStreamNonBlocking, pr));
+        DD_HIP(hipEventCreateWithFlags(&c->side_done[i], hipEventDisableTiming));
+    }
+    DD_HIP(hipEventCreateWithFlags(&c->side_go, hipEventDisableTiming));
+    DD_HIP(hipEventCreateWithFlags(&c->side_stagger, hipEventDisableTiming));
+    c->side_ready = true;
+    return DD_OK;
+}
+
 int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* nbytes, int ngenomes,
                      int kmin, int kmax, uint8_t* regs_dev) {
     if (check_ctx(c)) return DD_EINVAL;
@@ -554,14 +575,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     for (const dd::SweepClass& sc : classes)
         if (sc.plan.mode != dd::kBucketMode) lds_jobs += sc.jobs.size(), ++lds_classes;
     const bool side = lds_classes > 1 && (lds_jobs < 12000 || getenv("DD_SIDE_ALWAYS")) && !getenv("DD_NO_SIDE_STREAMS");
-    if (side && !c->side_ready) {
-        for (int i = 0; i < 8; ++i) {
-            DD_HIP(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
-            DD_HIP(hipEventCreateWithFlags(&c->side_done[i], hipEventDisableTiming));
-        }
-        DD_HIP(hipEventCreateWithFlags(&c->side_go, hipEventDisableTiming));
-        c->side_ready = true;
-    }
+    if (side && (rc = ensure_side_streams(c))) return rc;
     const bool side_b = bplan && !getenv("DD_NO_SIDE_STREAMS");  // log2m >= 18: see below
     // (launches that run side by side are timed as ONE span on the caller's stream: per-launch spans would overlap)
     std::unique_ptr<Span> phase((side || side_b) ? new Span(c, DD_KERNEL_SWEEP) : nullptr);
@@ -605,18 +619,17 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         const unsigned unit = unit_env ? (unsigned)std::max(1, std::min(16, atoi(unit_env))) * 64u : 256u;
         const int presorted = bplan->nb_log2 >= 1 && !getenv("DD_NO_PRESORT") ? 1 : 0;
         const dd::ScatterParams sp{rows_dev, K, bplan->logg, bplan->cap_chunks, unit, bplan->nb_log2, presorted};
-        if (side_b && !c->side_ready) {
-            for (int i = 0; i < 8; ++i) {
-                DD_HIP(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
-                DD_HIP(hipEventCreateWithFlags(&c->side_done[i], hipEventDisableTiming));
-            }
-            DD_HIP(hipEventCreateWithFlags(&c->side_go, hipEventDisableTiming));
-            c->side_ready = true;
-        }
+        if (side_b && (rc = ensure_side_streams(c))) return rc;
         // Every k class is a pipeline of its own -- scatter(e), sort(e), replay(e), scatter(e+1) ... over its own rows
         // -- so each gets a side stream: the tails of one class's launches are filled by the others' work.
         if (side_b) DD_HIP(hipEventRecord(c->side_go, st));
         int lane_b = 0;
+        // The class pipelines start one first-epoch scatter apart (class i + 1's first scatter waits for class i's):
+        // a class's replay (HBM reads, LDS compare-and-swaps) then runs beside the next class's scatter (VALU issue)
+        // instead of every scatter running beside every other and the replays likewise.  64 x 5 Mbp at log2m 20:
+        // 33.4 -> 31.7 ms; 10 x 50 Mbp and log2m 18 unchanged (profiles/r03_bucket_path.txt).
+        const bool stagger = side_b && !getenv("DD_NO_BUCKET_STAGGER");
+        int staggered = 0;
         for (size_t i = 0; i < classes.size(); ++i) {
             const dd::SweepClass& sc = classes[i];
             hipStream_t ks = st;
@@ -646,9 +659,11 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
                 if (j1 == j0) continue;
                 Span span(c, DD_KERNEL_SWEEP, !side_b);
                 const bool first = e == 0 && !getenv("DD_BUCKET_NO_FIRST");
+                if (stagger && e == 0 && staggered++) DD_HIP(hipStreamWaitEvent(ks, c->side_stagger, 0));
                 dd::launch_scatter(reinterpret_cast<const dd::SweepGenome*>(tdev),
                                    reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]) + j0, (int)(j1 - j0),
                                    sc.kclass, sc.plan, sp, ks, first);
+                if (stagger && e == 0) DD_HIP(hipEventRecord(c->side_stagger, ks));
                 dd::launch_replay(rows_dev, ngenomes, K, sc.kfirst - kmin, sc.klast - sc.kfirst + 1, *bplan, ks, first && presorted);
                 blocks += (int)(j1 - j0);
             }
