@@ -110,13 +110,16 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
     // seen), each later one is as long as everything before it -- the filter's bounds rise by about
     // one per doubling -- up to the length whose worst case (every update survives) fits the HBM budget.
     const bool bucket_mode = global_regs && knobs.buckets && knobs.filter;
-    const int bucket_nk = 1;  // ks per scatter job (two were measured slower: dd_sweep.hip)
+    // ks per FILTERED scatter job (the first epoch's jobs always hold one).  1; DD_BUCKET_NK=2 for A/B runs only: two
+    // were measured slower both at one workgroup per CU and, with 16 KiB filters, at two (profiles/r03_bucket_path.txt)
+    const int bucket_nk_knob = getenv("DD_BUCKET_NK") && atoi(getenv("DD_BUCKET_NK")) == 2 ? 2 : 1;
     const int bucket_probe = knobs.bucket_probe >= 0 ? knobs.bucket_probe : 1;
     const int bucket_fbits = knobs.bucket_fbits ? knobs.bucket_fbits : 4;  // measured: 4-bit entries win at log2m 18, 19 and 20
+    const int bucket_nk = (bucket_probe && bucket_fbits == 4) ? bucket_nk_knob : 1;  // (the only two-k kernels built)
     // a 64 KiB filter: 2^(p-16) registers per byte-wide entry, half as many per 4-bit entry
     int bucket_logg = knobs.bucket_logg ? knobs.bucket_logg - 1 : std::max(1, p - 16 - (bucket_fbits == 4 ? 1 : 0));
     // (a knob that asks for more filter than a workgroup can hold gets the finest one that fits; 16 bytes at least)
-    while ((m >> bucket_logg) * bucket_fbits / 8 + (kThreads / 64) * 1024 > (size_t)sweep_max_lds_bytes()) ++bucket_logg;
+    while (bucket_nk * ((m >> bucket_logg) * bucket_fbits / 8 + (kThreads / 64) * 1024) > (size_t)sweep_max_lds_bytes()) ++bucket_logg;
     while (bucket_logg > 0 && (m >> bucket_logg) * bucket_fbits / 8 < 16) --bucket_logg;
     const int nb_log2 = std::max(0, p - 16);  // index tiles of 64 KiB
     std::vector<size_t> epoch_edge;           // epoch e covers tiles [epoch_edge[e], epoch_edge[e+1])
@@ -203,13 +206,14 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
                 // ~16 jobs per resident workgroup slot; a job reloads its rows' filters, so not below 2 tiles
                 // once the epoch is long enough to allow it
                 const size_t slots = knobs.bucket_slots;  // (2048 .. 16384 measured: 8192 is best at log2m 18 and 20)
-                const size_t tpj = std::max<size_t>(std::min<size_t>(2, t_hi - t_lo), (tile_rows / bucket_nk + slots - 1) / slots);
+                const int nk_e = (e == 0 && !getenv("DD_BUCKET_NO_FIRST")) ? 1 : bucket_nk;
+                const size_t tpj = std::max<size_t>(std::min<size_t>(2, t_hi - t_lo), (tile_rows / nk_e + slots - 1) / slots);
                 std::vector<std::vector<SweepJob>> per_xcd(8);
                 int row = 0;
                 for (int g = 0; g < ngenomes; ++g) {
                     const size_t nt = std::min(tiles_of(nbytes[g]), t_hi);
-                    for (int q = 0; q < nks; q += bucket_nk, ++row) {  // one or two consecutive ks per job
-                        const int nkj = std::min(bucket_nk, nks - q);
+                    for (int q = 0; q < nks; q += nk_e, ++row) {  // one or two consecutive ks per job
+                        const int nkj = std::min(nk_e, nks - q);
                         size_t nj = 0;
                         for (size_t t0 = t_lo; t0 < nt; t0 += tpj, ++nj)
                             per_xcd[knobs.xcd_affinity ? row % 8 : 0].push_back(make_job(g, ka + q, nkj, kmin, t0, std::min(nt, t0 + tpj)));

@@ -1171,10 +1171,11 @@ DD_D void scatter_update(const Scatter& s, uint32_t& waiting, uint32_t& waiting2
     }
 }
 
-// NK = ks per job.  Only NK = 1 is instantiated: two consecutive ks per job (shared token loads and window
-// push, 7 of the ~50 VALU instructions of an update; two 64 KiB filters = one workgroup per CU) measured
-// SLOWER on MI355X -- 35.1 / 40.7 / 49.4 ms against 28.2 / 33.2 / 43.3 at log2m 18 / 19 / 20
-// (profiles/r02_bucket_path.txt); the code path is kept for the record.
+// NK = ks per job.  NK = 1 is what runs: two consecutive ks per job (shared token loads and window push, 7 of the
+// ~50 VALU instructions of an update) measured SLOWER on MI355X both with two 64 KiB filters = one workgroup per CU
+// (35.1 / 40.7 / 49.4 ms against 28.2 / 33.2 / 43.3 at log2m 18 / 19 / 20, profiles/r02_bucket_path.txt) and with
+// two 16 KiB filters at two workgroups per CU (29.2 against 27.4 ms at log2m 20, profiles/r03_bucket_path.txt).
+// NK = 2 is instantiated for nibble filter + row probe only and reached through DD_BUCKET_NK=2 (A/B runs, tests).
 template <int KC, bool CANON, bool NIB, bool PROBE, int NK, bool FIRST = false>
 __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __restrict__ genomes,
                                                       const SweepJob* __restrict__ jobs, int p, ScatterParams sp) {
@@ -1632,9 +1633,18 @@ void launch_scatter(const SweepGenome* genomes, const SweepJob* jobs, int njobs,
         if (plan.probe) DD_SCATTER_NN(KC, CN, NB, true); \
         else DD_SCATTER_NN(KC, CN, NB, false);  \
     } while (0)
+#define DD_SCATTER_TWO(KC, CN)                                                                          \
+    do {                                                                                                \
+        auto kern = scatter_kernel<KC, CN, true, true, 2>;                                              \
+        static std::atomic<unsigned long long> attr_done{0};                                            \
+        allow_full_lds(reinterpret_cast<const void*>(kern), attr_done);                                 \
+        hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3((unsigned)plan.threads), (size_t)plan.lds_bytes, st, \
+                           genomes, jobs, plan.log2m, sp);                                              \
+    } while (0)
 #define DD_SCATTER(KC, CN)                      \
     do {                                        \
-        if (plan.fbits == 4) DD_SCATTER_N(KC, CN, true); \
+        if (plan.nk_job == 2) DD_SCATTER_TWO(KC, CN); \
+        else if (plan.fbits == 4) DD_SCATTER_N(KC, CN, true); \
         else DD_SCATTER_N(KC, CN, false);       \
     } while (0)
 #define DD_SCATTER_KC(CN)                       \
@@ -1648,6 +1658,7 @@ void launch_scatter(const SweepGenome* genomes, const SweepJob* jobs, int njobs,
     else DD_SCATTER_KC(false);
 #undef DD_SCATTER_KC
 #undef DD_SCATTER
+#undef DD_SCATTER_TWO
 #undef DD_SCATTER_N
 #undef DD_SCATTER_NN
 }

@@ -95,6 +95,8 @@ BUCKET_KNOBS = {
     "sort_kernel_only": {"DD_NO_PRESORT": "1", "DD_BUCKET_E0": "2"},  # first-epoch chunks sorted by sort_chunks_kernel, not by the scatter
     "single_blocks": {"DD_BUCKET_UNIT": "1", "DD_BUCKET_E0": "1"},    # one 64-record block per reservation
     "packed_cursors": {"DD_CURSOR_STRIDE": "4"},                      # row cursors 4 bytes apart
+    "two_ks_per_job": {"DD_BUCKET_NK": "2", "DD_BUCKET_E0": "1"},      # filtered scatter jobs of two consecutive ks (A/B knob)
+    "two_ks_small_filter": {"DD_BUCKET_NK": "2", "DD_BUCKET_LOGG": "5", "DD_BUCKET_E0": "1", "DD_BUCKET_EMAX": "2"},
     "unstaggered": {"DD_NO_BUCKET_STAGGER": "1", "DD_BUCKET_E0": "1"},  # every class's first scatter at once (round 2's order)
     "side_priorities": {"DD_SIDE_PRIO": "201", "DD_BUCKET_E0": "1"},  # class pipelines on streams of different priority
 }
