@@ -140,7 +140,6 @@ struct dd_ctx {
     hipEvent_t pipe_h2d[2] = {nullptr, nullptr}, pipe_done[2] = {nullptr, nullptr}, pipe_d2h[2] = {nullptr, nullptr};
     hipStream_t side[8] = {};  // k classes of a small call run side by side
     hipEvent_t side_done[8] = {}, side_go = nullptr, side_stagger = nullptr;
-    bool side_ready = false;
     int ingest_calls = 0;
     // HBM the record streams of one log2m >= 17 call may take: a sixth of the device (48 GiB of 288), 16 GiB at least
     size_t bucket_budget = (size_t)16 << 30;
@@ -313,11 +312,12 @@ void dd_destroy(dd_ctx* c) {
         for (hipEvent_t e : {c->pipe_h2d[i], c->pipe_done[i], c->pipe_d2h[i]})
             if (e) (void)hipEventDestroy(e);
     }
-    if (c->side_ready) {
-        for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 8; ++i)
+        if (c->side[i]) {
             (void)hipStreamDestroy(c->side[i]);
             (void)hipEventDestroy(c->side_done[i]);
         }
+    if (c->side_go) {
         (void)hipEventDestroy(c->side_go);
         (void)hipEventDestroy(c->side_stagger);
     }
@@ -350,23 +350,27 @@ int dd_synchronize(dd_ctx* c) {
 }
 
 // ------------------------------------------------------------------------------ sketch
-// The side streams the k classes of a call run on.  DD_SIDE_PRIO (experiments): one digit per stream, 0 = the
-// device's highest queue priority, 1 = normal, 2 = lowest.
-static int ensure_side_streams(dd_ctx* c) {
-    if (c->side_ready) return DD_OK;
-    int lo = 0, hi = 0;  // (numerically: hi <= lo)
-    DD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+// The side streams the k classes of a call run on: `n` of them (at most 8), made when first asked for -- a stream
+// costs 2 ms to create (4 with a priority) and as much again to destroy, which a one-shot process pays in full.
+// DD_SIDE_PRIO (experiments): one digit per stream, 0 = the device's highest queue priority, 1 = normal, 2 = lowest.
+static int ensure_side_streams(dd_ctx* c, int n) {
+    if (!c->side_go) {
+        DD_HIP(hipEventCreateWithFlags(&c->side_go, hipEventDisableTiming));
+        DD_HIP(hipEventCreateWithFlags(&c->side_stagger, hipEventDisableTiming));
+    }
     const char* prio = getenv("DD_SIDE_PRIO");
     const size_t np = prio ? strlen(prio) : 0;
-    for (int i = 0; i < 8; ++i) {
-        int pr = (lo + hi) / 2;
-        if ((size_t)i < np) pr = prio[i] == '0' ? hi : (prio[i] == '2' ? lo : pr);
-        DD_HIP(hipStreamCreateWithPriority(&c->side[i], hipStreamNonBlocking, pr));
+    for (int i = 0; i < std::min(n, 8); ++i) {
+        if (c->side[i]) continue;
+        if ((size_t)i < np && (prio[i] == '0' || prio[i] == '2')) {
+            int lo = 0, hi = 0;  // (numerically: hi <= lo)
+            DD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            DD_HIP(hipStreamCreateWithPriority(&c->side[i], hipStreamNonBlocking, prio[i] == '0' ? hi : lo));
+        } else {
+            DD_HIP(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+        }
         DD_HIP(hipEventCreateWithFlags(&c->side_done[i], hipEventDisableTiming));
     }
-    DD_HIP(hipEventCreateWithFlags(&c->side_go, hipEventDisableTiming));
-    DD_HIP(hipEventCreateWithFlags(&c->side_stagger, hipEventDisableTiming));
-    c->side_ready = true;
     return DD_OK;
 }
 
@@ -575,7 +579,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     for (const dd::SweepClass& sc : classes)
         if (sc.plan.mode != dd::kBucketMode) lds_jobs += sc.jobs.size(), ++lds_classes;
     const bool side = lds_classes > 1 && (lds_jobs < 12000 || getenv("DD_SIDE_ALWAYS")) && !getenv("DD_NO_SIDE_STREAMS");
-    if (side && (rc = ensure_side_streams(c))) return rc;
+    if (side && (rc = ensure_side_streams(c, lds_classes))) return rc;
     const bool side_b = bplan && !getenv("DD_NO_SIDE_STREAMS");  // log2m >= 18: see below
     // (launches that run side by side are timed as ONE span on the caller's stream: per-launch spans would overlap)
     std::unique_ptr<Span> phase((side || side_b) ? new Span(c, DD_KERNEL_SWEEP) : nullptr);
@@ -619,7 +623,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         const unsigned unit = unit_env ? (unsigned)std::max(1, std::min(16, atoi(unit_env))) * 64u : 256u;
         const int presorted = bplan->nb_log2 >= 1 && !getenv("DD_NO_PRESORT") ? 1 : 0;
         const dd::ScatterParams sp{rows_dev, K, bplan->logg, bplan->cap_chunks, unit, bplan->nb_log2, presorted};
-        if (side_b && (rc = ensure_side_streams(c))) return rc;
+        if (side_b && (rc = ensure_side_streams(c, (int)classes.size()))) return rc;
         // Every k class is a pipeline of its own -- scatter(e), sort(e), replay(e), scatter(e+1) ... over its own rows
         // -- so each gets a side stream: the tails of one class's launches are filled by the others' work.
         if (side_b) DD_HIP(hipEventRecord(c->side_go, st));
