@@ -772,7 +772,11 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
     // (log2m >= 17: the scatter/sort/replay path runs epoch by epoch over all rows of a launch and wants many rows)
     // (Batches that grow -- 64, 128, 256 MB -- were measured against fixed 128 MB ones once the job tables of several
     // batch shapes could be kept: 20.6-22.9 ms against 19.1 for 10 x 50 Mbp.  Fixed it is.)
-    const size_t kBatchBytes = (size_t)(getenv("DD_BATCH_MB") ? std::max(1, atoi(getenv("DD_BATCH_MB"))) : (c->p >= 17 ? 512 : 128)) << 20;
+    // (a context's FIRST call at log2m >= 17 keeps to 128 MB: the record areas and the pinned register staging are
+    // allocated for a batch's rows, and hipMalloc + hipHostMalloc of a 512 MB batch's 5.5 GB + 0.4 GB cost a one-shot
+    // `dandd tree -r 20` 0.23 s against 0.06 s; a long-lived context grows them on its second call)
+    const size_t kBatchBytes = (size_t)(getenv("DD_BATCH_MB") ? std::max(1, atoi(getenv("DD_BATCH_MB")))
+                                        : (c->p >= 17 ? (c->ingest_calls == 0 ? 128 : 512) : 128)) << 20;
     // (at most 256 files per launch: the loaders' window is two batches of host buffers of 2 MiB at least; with 64,
     // a thousand 100 kbp plasmids took 23 launches of ~3 ms each)
     const size_t kMaxBatchFiles = getenv("DD_BATCH_FILES") ? (size_t)std::max(1, atoi(getenv("DD_BATCH_FILES"))) : 256;

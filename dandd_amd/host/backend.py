@@ -56,9 +56,9 @@ def write_sketch_file(path, regs, log2m, k, canonical, fmt=None):
     fmt = fmt or sketch_format()
     tmp = f"{path}.{os.getpid()}.tmp"  # per process: ranks of a multi-GPU run share the sketch directory
     if fmt == "native":
-        with open(tmp, "wb") as f:
+        with open(tmp, "wb", buffering=0) as f:  # (two plain write(2) calls; no copy of the registers)
             f.write(_HDR.pack(MAGIC, log2m, k, 1 if canonical else 0, 0))
-            f.write(regs.tobytes())
+            f.write(memoryview(regs).cast("B"))
     else:
         head = _DASH.pack(0, 0, _ERTL_MLE, _ERTL_JOINT_MLE, 1, log2m, 0.0)
         if fmt == "dashing":
@@ -226,10 +226,56 @@ class HipBackend:
     name = "hip"
 
     def __init__(self, log2m, canonical=True, device=0):
+        from collections import OrderedDict
         from ..engine import Engine  # raises EngineError when the library or the GPU is missing
         self.log2m = int(log2m)
         self.canonical = bool(canonical)
         self.engine = Engine(device=device, log2m=self.log2m, canonical=self.canonical)
+        # Registers of the sketch files this process wrote or read last, so that a tree does not read back from
+        # the sketch directory what it stored a moment ago (at log2m 20 a 10-genome, 37-k tree wrote 370 MiB and
+        # read 780 MiB of it again).  The FILES stay the contract (cache hits, other ranks, later runs); an entry is
+        # only trusted while its file is still there with the size it was written with.
+        self._recent = OrderedDict()  # path -> (registers, k, file size)
+        self._recent_bytes = 0
+        self._recent_limit = int(os.environ.get("DANDD_SKETCH_CACHE_MB", "1024")) << 20
+
+    def _remember(self, path, regs, k):
+        if self._recent_limit <= 0:
+            return
+        old = self._recent.pop(path, None)
+        if old is not None:
+            self._recent_bytes -= old[0].nbytes
+        try:
+            size = os.path.getsize(path)
+        except OSError:
+            return
+        self._recent[path] = (regs, int(k), size)
+        self._recent_bytes += regs.nbytes
+        while self._recent_bytes > self._recent_limit and self._recent:
+            _, (r, _, _) = self._recent.popitem(last=False)
+            self._recent_bytes -= r.nbytes
+
+    def _store(self, path, regs, k):
+        write_sketch_file(path, regs, self.log2m, k, self.canonical)
+        self._remember(path, regs, k)
+
+    def _load(self, path):
+        """-> (registers, log2m, k, canonical) of a sketch file: from memory when this process handled it last."""
+        hit = self._recent.get(path)
+        if hit is not None:
+            try:
+                same = os.path.getsize(path) == hit[2]
+            except OSError:
+                same = False
+            if same:
+                self._recent.move_to_end(path)
+                return hit[0], self.log2m, hit[1], self.canonical
+            self._recent_bytes -= hit[0].nbytes
+            del self._recent[path]
+        out = read_sketch_file(path)
+        if out[1] == self.log2m:
+            self._remember(path, out[0], out[2])
+        return out
 
     def describe(self, op, **kw):
         """The string stored where the reference stores its shell command line."""
@@ -243,24 +289,33 @@ class HipBackend:
         kmin, kmax = min(ks), max(ks)
         regs = self.engine.sketch_fasta(fasta, kmin, kmax)  # ONE pass over the FASTA for all ks
         for k, out in zip(ks, out_paths):
-            write_sketch_file(out, regs[k - kmin], self.log2m, k, self.canonical)
+            self._store(out, regs[k - kmin], k)
 
     def leaf_many(self, fastas, kmin, kmax, path_of):
         """Sketch MANY FASTAs over [kmin, kmax] through the ingestion pipeline (loader threads read and
-        inflate ahead of the GPU) and store every (fasta, k) sketch at path_of(fasta_index, k)."""
+        inflate ahead of the GPU) and store every (fasta, k) sketch at path_of(fasta_index, k).
+        -> {path: cardinality} of every sketch stored, from ONE batched histogram + estimate launch (the reference
+        asks `dashing card` for each file in a process of its own, lib/sketch_classes.py:306-321; the caller puts
+        these where it would have cached those answers)."""
         regs = self.engine.sketch_files(list(fastas), kmin, kmax)
-        for i in range(len(fastas)):
+        n, K = len(fastas), kmax - kmin + 1
+        est = self.engine.card_batch(regs.reshape(n * K, -1)).reshape(n, K) if n else None
+        cards = {}
+        for i in range(n):
             for k in range(kmin, kmax + 1):
-                write_sketch_file(path_of(i, k), regs[i, k - kmin], self.log2m, k, self.canonical)
+                path = path_of(i, k)
+                self._store(path, regs[i, k - kmin], k)
+                cards[path] = float(est[i, k - kmin])
+        return cards
 
     def union(self, in_paths, out_path):
-        parts = [read_sketch_file(p) for p in in_paths]
+        parts = [self._load(p) for p in in_paths]
         k = parts[0][2]
         merged = self.engine.union([r for r, _, _, _ in parts])
-        write_sketch_file(out_path, merged, self.log2m, k, self.canonical)
+        self._store(out_path, merged, k)
 
     def card(self, path):
-        regs, log2m, _, _ = read_sketch_file(path)
+        regs, log2m, _, _ = self._load(path)
         if log2m != self.log2m:
             raise ValueError(f"{path}: log2m {log2m} does not match the backend's {self.log2m}")
         return float(self.engine.card(regs))
@@ -273,7 +328,7 @@ class HipBackend:
         slab = np.empty((n, K, 1 << self.log2m), dtype=np.uint8)
         for i, row in enumerate(leaf_paths):
             for kk, p in enumerate(row):
-                slab[i, kk] = read_sketch_file(p)[0]
+                slab[i, kk] = self._load(p)[0]
         return slab
 
     def pairwise_cards(self, leaf_paths):

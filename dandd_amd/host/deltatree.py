@@ -511,7 +511,11 @@ class DeltaTree:
                 todo.append(leaf.fastas[0])
                 templates.append(tmpl)
         if todo and (world > 1 or len(todo) > 1):
-            be.leaf_many(todo, lo, hi, lambda i, k: templates[i].with_k(k))
+            cards = be.leaf_many(todo, lo, hi, lambda i, k: templates[i].with_k(k))
+            # (the product backend estimates every sketch of the batch in one launch: its answers go where
+            # individual_card would have put them one file at a time; an empty sketch's 0 is left for that path)
+            if cards:
+                self.speciesinfo.cardkey.update({p: c for p, c in cards.items() if c > 0})
         return len(todo)
 
     def presketch_range(self, lo, hi):
