@@ -234,8 +234,8 @@ class HipBackend:
         # Registers of the sketch files this process wrote or read last, so that a tree does not read back from
         # the sketch directory what it stored a moment ago (at log2m 20 a 10-genome, 37-k tree wrote 370 MiB and
         # read 780 MiB of it again).  The FILES stay the contract (cache hits, other ranks, later runs); an entry is
-        # only trusted while its file is still there with the size it was written with.
-        self._recent = OrderedDict()  # path -> (registers, k, file size)
+        # only trusted while its file is still there with the size and modification time it had then.
+        self._recent = OrderedDict()  # path -> (registers, k, (file size, mtime))
         self._recent_bytes = 0
         self._recent_limit = int(os.environ.get("DANDD_SKETCH_CACHE_MB", "1024")) << 20
 
@@ -246,10 +246,10 @@ class HipBackend:
         if old is not None:
             self._recent_bytes -= old[0].nbytes
         try:
-            size = os.path.getsize(path)
+            st = os.stat(path)
         except OSError:
             return
-        self._recent[path] = (regs, int(k), size)
+        self._recent[path] = (regs, int(k), (st.st_size, st.st_mtime_ns))
         self._recent_bytes += regs.nbytes
         while self._recent_bytes > self._recent_limit and self._recent:
             _, (r, _, _) = self._recent.popitem(last=False)
@@ -264,7 +264,8 @@ class HipBackend:
         hit = self._recent.get(path)
         if hit is not None:
             try:
-                same = os.path.getsize(path) == hit[2]
+                st = os.stat(path)
+                same = (st.st_size, st.st_mtime_ns) == hit[2]
             except OSError:
                 same = False
             if same:

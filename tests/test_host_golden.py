@@ -421,3 +421,44 @@ def _schedule_walk(host, tmp_path, sweep, plain_factory, hooked_factory):
         strip = lambda rows: sorted(tuple(sorted((k, v) for k, v in r.items() if k not in ("sketchloc",))) for r in rows)
         assert strip(plain[f]) == strip(hooked[f]), f
     assert sorted(r["sketchbase"] for r in db_plain) == sorted(r["sketchbase"] for r in db_hooked)
+
+
+@pytest.mark.gpu
+def test_backend_keeps_written_sketches_and_batch_cards(tmp_path, torch_cuda):
+    """HipBackend.leaf_many: the cardinalities it returns are the ones `card` gives file by file, the registers of
+    a stored sketch are served from memory only while the file on disk is the one that was written, and a cache
+    of zero bytes (DANDD_SKETCH_CACHE_MB=0) changes nothing but the reads."""
+    import numpy as np
+    from dandd_amd.host.backend import HipBackend, read_sketch_file, write_sketch_file
+    rng = np.random.default_rng(5)
+    fastas = []
+    for g in range(3):
+        p = os.path.join(str(tmp_path), f"g{g}.fasta")
+        with open(p, "wb") as f:
+            f.write(b">g\n" + rng.choice(np.frombuffer(b"ACGT", np.uint8), size=20000 + 7000 * g).tobytes() + b"\n")
+        fastas.append(p)
+    be = HipBackend(12, True)
+    path_of = lambda i, k: os.path.join(str(tmp_path), f"s{i}.w.{k}.spacing.12.hll")
+    cards = be.leaf_many(fastas, 9, 13, path_of)
+    assert len(cards) == 15 and all(c > 0 for c in cards.values())
+    for path, c in cards.items():
+        regs = read_sketch_file(path)[0]
+        assert c == be.engine.card(regs) == be.card(path)
+        assert np.array_equal(be._load(path)[0], regs)
+    # a file replaced behind the backend's back is read again, a removed one is an error as it always was
+    victim = path_of(0, 9)
+    other = read_sketch_file(path_of(2, 13))[0]
+    os.utime(victim, ns=(1, 1))
+    write_sketch_file(victim, other, 12, 9, True)
+    assert be.card(victim) == be.engine.card(other) != cards[victim]
+    os.remove(victim)
+    with pytest.raises(OSError):
+        be.card(victim)
+    # unions come out the same with and without the memory
+    be.union([path_of(0, 11), path_of(1, 11), path_of(2, 11)], os.path.join(str(tmp_path), "u11.hll"))
+    be2 = HipBackend(12, True)
+    be2._recent_limit = 0
+    be2.union([path_of(0, 11), path_of(1, 11), path_of(2, 11)], os.path.join(str(tmp_path), "v11.hll"))
+    assert not be2._recent
+    assert np.array_equal(read_sketch_file(os.path.join(str(tmp_path), "u11.hll"))[0], read_sketch_file(os.path.join(str(tmp_path), "v11.hll"))[0])
+    assert be.card(os.path.join(str(tmp_path), "u11.hll")) == be2.card(os.path.join(str(tmp_path), "v11.hll"))
