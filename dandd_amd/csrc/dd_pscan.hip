@@ -6,7 +6,7 @@
 //
 // The streaming kernel (dd_union.hip: progressive_kernel) keeps U_j in registers and pays one LDS atomic per register
 // per prefix -- 4.7 cycles per wave-wide ds_add_u32 whatever the bytes are (scripts/ubench_lds_atomic.hip): a 1.4 ms
-// floor for 10 orderings x 30 prefixes x 37 k of 2^20 registers, 3.15 ms measured (2.1 ms through this file).  Here the
+// floor for 10 orderings x 30 prefixes x 37 k of 2^20 registers, 3.15 ms measured (1.8 ms through this file).  Here the
 // cumulative histogram is
 // counted instead: U_j[r] <= v  <=>  every leaf of the prefix has leaf[r] <= v, so with the bit planes
 //         B_g,v = { r : leaf_g[r] <= v }          (one bit per register)
@@ -37,6 +37,13 @@ namespace {
 
 constexpr int PS_THREADS = 512;
 
+// 16 bytes at an absolute LDS byte address (ds_read_b128 with `words` as its immediate offset)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+DD_D uint4 lds_read16(uint32_t byte_addr, int words) {
+    const u32x4 v = *((const __attribute__((address_space(3))) u32x4*)(uintptr_t)byte_addr + words / 4);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // the six bit planes of 32 registers (8 dwords of 4 bytes): bit i + 8 q of plane b = bit b of byte q of dword i
 DD_D void bit_slice(const uint32_t (&w)[8], uint32_t (&pl)[6]) {
 #pragma unroll
@@ -52,16 +59,19 @@ DD_D void bit_slice(const uint32_t (&w)[8], uint32_t (&pl)[6]) {
 }
 
 // NMAX: prefixes held in registers (n <= NMAX); UPT: (leaf, 32 registers) units a thread converts per tile
-// At most 128 registers (four reads in flight, the ordering's leaves as bytes, the running store pointer): two
-// workgroups share a CU and hide each other's barriers and LDS latencies, and the host picks tiles small enough for two
-// workgroups' planes.  (One workgroup of 237 registers per CU with the next eight reads in flight during the fold of
-// the current eight measured 2.43 ms where this form takes 2.11.)
-template <int NMAX, int UPT>
+// At most 128 registers (the next prefix's reads in flight, the ordering's leaves as bytes, the running store pointer):
+// two workgroups share a CU and hide each other's barriers and LDS latencies, and the host picks tiles small enough
+// for two workgroups' planes.  (One workgroup of 237 registers per CU with the next eight reads in flight during the
+// fold of the current eight measured 2.43 ms where the d-major two-workgroup form took 2.11 and this one takes 1.82.)
+// DG: 16-byte groups of plane words a lane folds per prefix before it moves to the next prefix (one row address per DG
+// reads).
+template <int NMAX, int UPT, int DG>
 __global__ __launch_bounds__(PS_THREADS, 4) void pscan_kernel(const uint8_t* __restrict__ leaf, int n, int K, int p,
                                                            const int32_t* __restrict__ ord, int no, const uint32_t* __restrict__ rng,
                                                            int RR, int tiles_per_range, int D, int chain_pitch,
                                                            uint32_t* __restrict__ part) {
     extern __shared__ uint32_t lds[];            // planes [g][t][DP], then the orderings [no][n] as bytes
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)lds != 0u) __builtin_trap();  // (the scan reads at absolute LDS addresses)
     const int k = blockIdx.x / RR, rr = blockIdx.x % RR;
     const int vmin = (int)rng[2 * k], vmax = (int)rng[2 * k + 1];
     const int T = vmax - vmin;                   // thresholds vmin .. vmax-1
@@ -135,23 +145,58 @@ __global__ __launch_bounds__(PS_THREADS, 4) void pscan_kernel(const uint8_t* __r
         }
         __syncthreads();
         // ---- scan: running AND along the ordering, one popcount per prefix
+        // Prefix-major over chunks of DG 16-byte groups: a prefix's row address is computed once per chunk and its DG
+        // reads carry their word offsets as immediates (the d-major form paid the byte extraction, a 64-bit multiply-add
+        // and a move per READ: 14 instructions per (prefix, four words) where this takes 9 + 3 / DG); the next prefix's
+        // reads are issued before the current one's words are folded; every count is one chain of v_bcnt accumulations.
         if (chain) {
-            for (int d = 0; d < D; d += 4) {
-                uint32_t P0 = ~0u, P1 = ~0u, P2 = ~0u, P3 = ~0u;
+            for (int d0 = 0; d0 < D; d0 += 4 * DG) {
+                uint32_t P[4 * DG];
 #pragma unroll
-                for (int j0 = 0; j0 < NMAX; j0 += 4) {
-                    uint4 xs[4];
+                for (int i = 0; i < 4 * DG; ++i) P[i] = ~0u;
+                // (rows are read at their absolute LDS byte address -- the kernel's only LDS is the dynamic array, which
+                // then starts at 0, checked at the top -- so a row's address is ONE 24-bit multiply-add, full rate, where
+                // pointer arithmetic took a quarter-rate v_mul_lo_u32, a shift and an add)
+                const uint32_t at0 = 4u * (tDP + (uint32_t)d0), row_bytes = 4u * rowDP;
+                auto row = [&](int j) {
+                    uint32_t g = (gp[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                    asm volatile("" : "+v"(g));   // (keeps the 32 row offsets from being hoisted into 32 registers again)
+                    return __umul24(g, row_bytes) + at0;
+                };
+                constexpr bool PF = true;
+                uint4 nxt[DG];
+                if (PF) {
+                    const uint32_t r0 = row(0);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        uint32_t g = (gp[j0 >> 2] >> (8 * i)) & 0xffu;
-                        asm volatile("" : "+v"(g));   // (keeps the 32 row offsets from being hoisted into 32 registers again)
-                        xs[i] = *reinterpret_cast<const uint4*>(planes + g * rowDP + tDP + (uint32_t)d);
+                    for (int q = 0; q < DG; ++q) nxt[q] = lds_read16(r0, 4 * q);
+                }
+#pragma unroll
+                for (int j = 0; j < NMAX; ++j) {
+                    uint4 xs[DG];
+                    if (PF) {
+#pragma unroll
+                        for (int q = 0; q < DG; ++q) xs[q] = nxt[q];
+                        if (j + 1 < NMAX) {
+                            const uint32_t r1 = row(j + 1);
+#pragma unroll
+                            for (int q = 0; q < DG; ++q) nxt[q] = lds_read16(r1, 4 * q);
+                        }
+                    } else {
+                        const uint32_t r0 = row(j);
+#pragma unroll
+                        for (int q = 0; q < DG; ++q) xs[q] = lds_read16(r0, 4 * q);
                     }
+                    uint32_t cj = cnt[j];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        P0 &= xs[i].x, P1 &= xs[i].y, P2 &= xs[i].z, P3 &= xs[i].w;
-                        cnt[j0 + i] += (uint32_t)(__popc(P0) + __popc(P1)) + (uint32_t)(__popc(P2) + __popc(P3));
+                    for (int q = 0; q < DG; ++q) {
+                        P[4 * q] &= xs[q].x, P[4 * q + 1] &= xs[q].y, P[4 * q + 2] &= xs[q].z, P[4 * q + 3] &= xs[q].w;
+                        // (v_bcnt_u32_b32 adds its count to an accumulator operand; written as C the compiler turns the
+                        // chain into a tree of counts-from-zero and v_add3s, half an instruction more per word)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cj) : "v"(P[4 * q + i]));
                     }
+                    cnt[j] = cj;
+                    __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler gathers the reads of many prefixes and spills)
                 }
             }
         }
@@ -241,13 +286,16 @@ bool launch_progressive_pscan(const uint8_t* leaf_dev, int n, int K, int p, cons
     const int pitch = PS_THREADS;
     for (int o0 = 0; o0 < norder; o0 += group) {
         const int no = std::min(group, norder - o0);
-#define DD_PSCAN_LAUNCH(NMAX, UPT)                                                                                                             \
+#define DD_PSCAN_LAUNCH(NMAX, UPT, DG)                                                                                                         \
     do {                                                                                                                                      \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pscan_kernel<NMAX, UPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
-        hipLaunchKernelGGL((pscan_kernel<NMAX, UPT>), dim3((unsigned)(K * RR)), dim3(PS_THREADS), lds_bytes, st, leaf_dev, n, K, p,            \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pscan_kernel<NMAX, UPT, DG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+        hipLaunchKernelGGL((pscan_kernel<NMAX, UPT, DG>), dim3((unsigned)(K * RR)), dim3(PS_THREADS), lds_bytes, st, leaf_dev, n, K, p,        \
                            ord_dev + (size_t)o0 * n, no, rng, RR, tiles_per_range, D, pitch, part);                                           \
     } while (0)
-        DD_PSCAN_LAUNCH(32, 1);
+        // (D = 4, 8, 16 or 32 plane words per row: one or two 16-byte groups per chunk of the scan; four groups -- 16
+        // running ANDs beside the 32 counts -- spill)
+        if (D >= 8) DD_PSCAN_LAUNCH(32, 1, 2);
+        else DD_PSCAN_LAUNCH(32, 1, 1);
 #undef DD_PSCAN_LAUNCH
         const size_t jobs = (size_t)no * n * K;
         hipLaunchKernelGGL(pscan_finish_kernel, dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0, st, part, n, K, p, no, rng, RR, pitch,
