@@ -52,9 +52,6 @@ def _load_tree(path):
 
 def progressive_command(args):
     tree = _load_tree(args.delta_tree)
-    # (the orderings are drawn afresh on every run, so their unions are new work for the GPU practically always:
-    # its context comes up beside the host-side set-up, as in `tree`)
-    deltatree.prewarm_backend(tree.experiment)
     if not args.tag:
         args.tag = tree.speciesinfo.tag
     outfile = tree.make_prefix(tag=args.tag, label=f"progu{args.norderings}", outdir=args.outdir)
@@ -84,8 +81,6 @@ def kij_command(args):
     if not args.tag:
         args.tag = tree.speciesinfo.tag
     outfile = tree.make_prefix(tag=args.tag, label=args.label, outdir=args.outdir)
-    if not os.path.exists(outfile + ".kij.csv"):  # (a first run over these genomes: the pair unions are new work)
-        deltatree.prewarm_backend(tree.experiment)
     if args.flist_loc:
         with open(args.flist_loc) as f:
             wanted = {line.strip() for line in f}

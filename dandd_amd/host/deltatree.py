@@ -54,21 +54,23 @@ def _make_backend(key):
 _prewarm = {}   # key -> (thread, result box)
 
 
-def prewarm_backend(experiment):
+def prewarm_backend(experiment, first_launches=True):
     """Start creating the GPU backend of `experiment` on a thread of its own: loading libdandd_hip.so, HIP's first
     use of the device and the first launch of every kernel module cost 0.25-0.35 s in a fresh process, during which a
     one-shot `dandd` command has blake2b digests, directory walks and imports of its own to do (ctypes calls release
-    the GIL).  backend_for() picks the result up -- or the exception, which it re-raises."""
+    the GIL).  backend_for() picks the result up -- or the exception, which it re-raises.  (Measured on `tree` over
+    10 x 50 Mbp, four alternating runs: 0.68 s with / 0.66 s without at log2m 14, 0.82 / 0.85 at log2m 20 -- within the
+    box's noise; in `progressive` and `kij`, whose host-side set-up is short, it cost 0.05-0.1 s and is not used.)"""
     import threading
     key = _backend_key(experiment)
-    if _backend_factory is not None or key in _backends or key in _prewarm:
+    if _backend_factory is not None or key in _backends or key in _prewarm or os.environ.get("DANDD_NO_PREWARM") == "1":
         return
     box = []
 
     def work():
         try:
             be = _make_backend(key)
-            if hasattr(be.engine, "warmup"):
+            if first_launches and hasattr(be.engine, "warmup"):   # (the sketching kernels: a command that will sketch)
                 be.engine.warmup()
             box.append(be)
         except BaseException as e:  # handed to the thread that asks for the backend
