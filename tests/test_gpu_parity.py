@@ -632,13 +632,14 @@ def test_sweep_parity_on_realistic_genome(engine_factory, orc, p, krange):
     _sweep_check(eng, orc, fa, krange[0], krange[1], True)
 
 
-@pytest.mark.parametrize("p,n,K,no", [(12, 2, 3, 1), (12, 7, 4, 10), (14, 30, 5, 10), (14, 33, 2, 3), (16, 64, 2, 2), (18, 12, 2, 9),
-                                       (19, 32, 2, 4), (20, 30, 3, 10), (20, 8, 2, 17)])
+@pytest.mark.parametrize("p,n,K,no", [(12, 2, 3, 1), (12, 7, 4, 10), (14, 30, 5, 10), (14, 32, 3, 4), (14, 33, 2, 3), (16, 64, 2, 2),
+                                       (18, 12, 2, 9), (19, 32, 2, 4), (20, 30, 3, 10), (20, 8, 2, 17)])
 def test_progressive_pscan_equals_streaming_kernel(engine_factory, torch_cuda, orc, monkeypatch, p, n, K, no):
     """dd_progressive_device through the bit-plane AND-scan (dd_pscan.hip) == the streaming running-max kernel
     (DD_PROGRESSIVE_STREAM=1, dd_union.hip) for every (ordering, prefix, k), as doubles -- more than 32 leaves (the
     64-prefix instantiation), more orderings than one launch holds, degenerate and full threshold ranges, repeated
-    leaves inside an ordering -- and == the oracle's estimator on the running byte-max for sampled prefixes."""
+    leaves inside an ordering, plane rows of 4 (n = 32 with 51 thresholds), 8 and 32 words, i.e. both forms of the
+    prefix-major scan -- and == the oracle's estimator on the running byte-max for sampled prefixes."""
     torch = torch_cuda
     eng = engine_factory(p, True)
     rng = np.random.default_rng(7000 * p + 10 * n + no)
