@@ -1592,6 +1592,8 @@ void launch_scatter(const SweepGenome* genomes, const SweepJob* jobs, int njobs,
                     const ScatterParams& sp, hipStream_t st, bool first_epoch) {
     if (njobs <= 0) return;
     if (first_epoch) {
+        // (DD_FIRST_LDS_KB, experiments: more dynamic LDS than the kernel needs = fewer workgroups per CU)
+        const size_t first_lds_floor = getenv("DD_FIRST_LDS_KB") ? (size_t)atoi(getenv("DD_FIRST_LDS_KB")) << 10 : 0;
         // every register of the call is still zero: the unfiltered form (no filter, no queues; rows of several index
         // tiles get their chunks sorted on the way out: 4 KiB + 256 B of LDS per wave)
 #define DD_FIRST(KC, CN)                                                                                                           \
@@ -1601,7 +1603,7 @@ void launch_scatter(const SweepGenome* genomes, const SweepJob* jobs, int njobs,
             static std::atomic<unsigned long long> attr_done{0};                                                                   \
             allow_full_lds(reinterpret_cast<const void*>(kern), attr_done);                                                        \
             hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3((unsigned)plan.threads),                                          \
-                               (size_t)(plan.threads / 64) * (kChunkRecords * 4 + 256), st, genomes, jobs, plan.log2m, sp);         \
+                               std::max((size_t)(plan.threads / 64) * (kChunkRecords * 4 + 256), first_lds_floor), st, genomes, jobs, plan.log2m, sp); \
         } else {                                                                                                                   \
             hipLaunchKernelGGL((scatter_kernel<KC, CN, false, false, 1, true>), dim3((unsigned)njobs), dim3((unsigned)plan.threads), 0, \
                                st, genomes, jobs, plan.log2m, sp);                                                                 \
