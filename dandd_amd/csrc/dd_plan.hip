@@ -121,7 +121,9 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
     // (a knob that asks for more filter than a workgroup can hold gets the finest one that fits; 16 bytes at least)
     while (bucket_nk * ((m >> bucket_logg) * bucket_fbits / 8 + (kThreads / 64) * 1024) > (size_t)sweep_max_lds_bytes()) ++bucket_logg;
     while (bucket_logg > 0 && (m >> bucket_logg) * bucket_fbits / 8 < 16) --bucket_logg;
-    const int nb_log2 = std::max(0, p - 16);  // index tiles of 64 KiB
+    // index tiles of 64 KiB (DD_BUCKET_TILE_LOG2=17: 128 KiB, one replay workgroup per CU, segments twice as long -- A/B)
+    const int tile_log2 = getenv("DD_BUCKET_TILE_LOG2") ? std::max(16, std::min(17, atoi(getenv("DD_BUCKET_TILE_LOG2")))) : 16;
+    const int nb_log2 = std::max(0, p - tile_log2);
     std::vector<size_t> epoch_edge;           // epoch e covers tiles [epoch_edge[e], epoch_edge[e+1])
     size_t epoch_longest = 0, bucket_row_tokens = 0;
     if (bucket_mode) {

@@ -97,6 +97,7 @@ BUCKET_KNOBS = {
     "packed_cursors": {"DD_CURSOR_STRIDE": "4"},                      # row cursors 4 bytes apart
     "two_ks_per_job": {"DD_BUCKET_NK": "2", "DD_BUCKET_E0": "1"},      # filtered scatter jobs of two consecutive ks (A/B knob)
     "two_ks_small_filter": {"DD_BUCKET_NK": "2", "DD_BUCKET_LOGG": "5", "DD_BUCKET_E0": "1", "DD_BUCKET_EMAX": "2"},
+    "big_tiles": {"DD_BUCKET_TILE_LOG2": "17", "DD_BUCKET_E0": "1"},    # 128 KiB index tiles: one replay workgroup per CU (A/B knob)
     "unstaggered": {"DD_NO_BUCKET_STAGGER": "1", "DD_BUCKET_E0": "1"},  # every class's first scatter at once (round 2's order)
     "side_priorities": {"DD_SIDE_PRIO": "201", "DD_BUCKET_E0": "1"},  # class pipelines on streams of different priority
 }
