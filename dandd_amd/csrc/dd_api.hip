@@ -621,7 +621,9 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         // tail of one overlaps the body of another), then one sort + replay over all rows
         const char* unit_env = getenv("DD_BUCKET_UNIT");
         const unsigned unit = unit_env ? (unsigned)std::max(1, std::min(16, atoi(unit_env))) * 64u : 256u;
-        const int presorted = bplan->nb_log2 >= 1 && !getenv("DD_NO_PRESORT") ? 1 : 0;
+        // first-epoch chunks leave the scatter sorted by index tile: 2 = one 16 384-record chunk per workgroup and 16
+        // updates (round 4), 1 = every wave its own 1024-record chunks (DD_FIRST_WG=0), 0 = sorted by a pass of their own
+        const int presorted = bplan->nb_log2 >= 1 && !getenv("DD_NO_PRESORT") ? ((getenv("DD_FIRST_WG") && atoi(getenv("DD_FIRST_WG")) == 0) ? 1 : 2) : 0;
         const dd::ScatterParams sp{rows_dev, K, bplan->logg, bplan->cap_chunks, unit, bplan->nb_log2, presorted};
         if (side_b && (rc = ensure_side_streams(c, (int)classes.size()))) return rc;
         // Every k class is a pipeline of its own -- scatter(e), sort(e), replay(e), scatter(e+1) ... over its own rows
@@ -668,7 +670,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
                                    reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]) + j0, (int)(j1 - j0),
                                    sc.kclass, sc.plan, sp, ks, first);
                 if (stagger && e == 0) DD_HIP(hipEventRecord(c->side_stagger, ks));
-                dd::launch_replay(rows_dev, ngenomes, K, sc.kfirst - kmin, sc.klast - sc.kfirst + 1, *bplan, ks, first && presorted);
+                dd::launch_replay(rows_dev, ngenomes, K, sc.kfirst - kmin, sc.klast - sc.kfirst + 1, *bplan, ks, first ? presorted : 0);
                 blocks += (int)(j1 - j0);
             }
             if (side_b) {

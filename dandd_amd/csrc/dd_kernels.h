@@ -146,13 +146,15 @@ struct ScatterParams {
     unsigned cap_chunks;
     unsigned unit;              // records a wave reserves per atomic add on the row's cursor (multiple of 64)
     int nb_log2;                // index tiles per row (log2)
-    int presorted;              // first-epoch scatter sorts its chunks by index tile itself (rows of several tiles)
+    int presorted;              // first-epoch scatter sorts its chunks by index tile itself (rows of several tiles): 1 = every
+                                // wave its own 1024-record chunks, 2 = the workgroup's 16 384-record chunks (one per 16 updates)
 };
 void launch_scatter(const SweepGenome* genomes_dev, const SweepJob* jobs_dev, int njobs, int kclass,
                     const SweepPlan& plan, const ScatterParams& sp, hipStream_t st, bool first_epoch);
 // sort + replay + cursor reset of rows k0 .. k0+nks-1 (indices into a genome's K rows) of every genome
+// (presorted: the form of the chunks the scatter left, ScatterParams::presorted; 0 = unsorted: the sort pass runs first)
 void launch_replay(const BucketRow* rows_dev, int ngenomes, int K, int k0, int nks, const SweepPlan& plan, hipStream_t st,
-                   bool presorted = false);
+                   int presorted = 0);
 int sweep_max_lds_bytes();
 // small-k class: jobs carry ks <= kBitmapMaxK; records k-mer presence in genome.bitmap
 // (kfirst..klast: the ks of the class; the LDS image covers exactly their bitmaps)

@@ -1301,6 +1301,221 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
     }
 }
 
+// ---- first epoch, WORKGROUP chunks (round 4) ------------------------------------------------------------
+// The 16 waves of a first-epoch workgroup fill their 4 KiB collection areas in lockstep: every update adds 64
+// entries (null ones included) to each, so after every 16 updates the workgroup holds exactly 16 384 records and
+// sends them out as ONE chunk sorted by index tile -- the segment of an index tile is then 16 times as long as in a
+// wave's own 1024-record chunk (4 KiB instead of 256 B at log2m 20), and the replay reads it with 16-byte loads.
+//   LDS: [wave][1024] records | two count tables [wave][16] used alternately | [wave][16] placement offsets | slot
+//   per update : record to the wave's area, one LDS atomic on the wave's (tile, copy) counter -- as before
+//   per round  : ONE workgroup barrier; every wave then reads all 256 counts of the round in (tile, wave, copy)
+//                order (four per lane), scans them across the wave, keeps the 16 offsets that are its own, and
+//                places its records with returning atomics on those -- no second barrier: the next round counts
+//                into the other table, which each wave clears (its own 16 entries) right after the barrier, when
+//                every wave is known to have finished reading it.
+//   per job    : ONE atomic add on the row's cursor reserves the chunks of all its rounds (4 per tile).
+// A wave whose segments all lie behind the end of the stream still takes part in the four rounds of the tile.
+constexpr uint32_t kWgChunkRecords = 16u * kChunkRecords;
+constexpr uint32_t kWgAreaBytes = 16u * kChunkRecords * 4u;          // 64 KiB: the waves' collection areas
+constexpr uint32_t kWgTableBytes = 16u * 16u * 4u;                   // one count table
+constexpr uint32_t kWgOffsets = kWgAreaBytes + 2u * kWgTableBytes;   // placement offsets [wave][16]
+constexpr uint32_t kWgPosSlot = kWgOffsets + kWgTableBytes;          // the job's first record position
+constexpr uint32_t kWgLdsBytes = kWgPosSlot + 16u;
+
+// a wave-uniform value that arrived through a vector load (a table entry): moved to scalar registers
+DD_D uint64_t uniform64(uint64_t v) {
+    // (the builtin returns int: without the casts the low half would be sign-extended over the high one)
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)), lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+    return ((uint64_t)hi << 32) | lo;
+}
+template <typename T>
+DD_D T* uniform_ptr(T* q) { return reinterpret_cast<T*>(uniform64(reinterpret_cast<uint64_t>(q))); }
+
+struct ScatterWg {
+    uint32_t* area;
+    uint32_t* fill;
+    uint16_t* seg;
+    uint8_t* regs;
+    uint32_t cap_records;
+    int nb_log2, tshift, cshift;
+};
+// one round's records of the workgroup leave as a sorted chunk at record position `pos` of the row's stream;
+// `have` = 1024 for a wave that hashed this round, 0 for one that is beyond the stream
+DD_D void scatter_flush_wg(const ScatterWg& s, uint32_t wave, uint32_t tbl, uint32_t done, uint32_t have) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t queue = wave * (kChunkRecords * 4u);
+    const uint32_t mine = kWgAreaBytes + tbl * kWgTableBytes, other = kWgAreaBytes + (tbl ^ 1u) * kWgTableBytes;
+    const uint32_t off = kWgOffsets + wave * 64u;
+    __syncthreads();  // every count of this round is in; nobody reads the other table any more
+    if (lane < 16u) lds32(other + wave * 64u + 4u * lane) = 0;
+    const uint32_t pos = lds32(kWgPosSlot) + done;
+    if (pos + kWgChunkRecords > s.cap_records) {
+        // the stream is full: the records go to their registers directly (exact, slow, rare)
+        if (have) {
+#pragma unroll 1
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t e = lds32(queue + 4u * ((uint32_t)i * 64u + lane));
+                if (e >> 24) {
+                    uint8_t* a = s.regs + (e & 0xFFFFFFu);
+                    (void)cas_raise<RegsGlobal>(a, RegsGlobal::load32(a), e >> 24);
+                }
+            }
+        }
+        return;
+    }
+    // keys 4 lane .. 4 lane + 3 in (tile, wave, copy) order; a wave's counter j = tile << cshift | copy
+    // (key -> table entry computed twice rather than kept: the kernel has 64 VGPRs)
+    const uint32_t cmask = (1u << s.cshift) - 1u;
+    auto entry = [&](uint32_t key, uint32_t& w, uint32_t& slot) {
+        w = (key >> s.cshift) & 15u;
+        slot = ((key >> (4 + s.cshift)) << s.cshift) | (key & cmask);
+    };
+    uint32_t cnt[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t w, slot;
+        entry(4u * lane + (uint32_t)j, w, slot);
+        cnt[j] = lds32(mine + w * 64u + 4u * slot);
+    }
+    uint32_t at = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    {
+        const uint32_t sum = at;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(at, d);
+            if (lane >= (uint32_t)d) at += up;
+        }
+        if (wave == 0u && lane == 63u) gstore4(s.fill + pos / kChunkRecords, at);  // the chunk's non-null records
+        at -= sum;
+    }
+    const uint32_t chunk = pos / kChunkRecords;  // (tables are indexed by 1024-record chunk: this one owns 16 entries)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t w, slot;
+        entry(4u * lane + (uint32_t)j, w, slot);
+        if (w == wave) lds32(off + 4u * slot) = at;
+        if (wave == 0u && w == 0u && (slot & cmask) == 0u)
+            ((DD_GLOBAL uint16_t*)s.seg)[(size_t)chunk * 16u + (slot >> s.cshift)] = (uint16_t)at;
+        at += cnt[j];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (have) {
+        const uint32_t copy = lane & cmask;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t e = lds32(queue + 4u * ((uint32_t)i * 64u + lane));
+            if (e >> 24) gstore4(s.area + pos + atomicAdd(&lds32(off + 4u * ((((e & 0xFFFFFFu) >> s.tshift) << s.cshift) | copy)), 1u), e);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int KC, bool CANON>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KC == 2 ? 4 : 8, 8))) void scatter_first_wg_kernel(const SweepGenome* __restrict__ genomes,
+                                                               const SweepJob* __restrict__ jobs, int p, ScatterParams sp) {
+    const SweepJob job = jobs[blockIdx.x];
+    if (job.tile_begin >= job.tile_end) return;  // filler of the XCD-affine order
+    lds_starts_at_zero();
+    const SweepGenome g = genomes[job.genome];
+    const int k = job.kfirst;
+    const unsigned long long ntok = uniform64(gload8u(g.ntok));
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+
+    struct TileIn {
+        uint4 hc, sc;
+        uint2 hb, sb;
+        bool live;
+    };
+    auto fetch = [&](unsigned tile, TileIn& t) {
+        const unsigned long long seg = (unsigned long long)tile * blockDim.x + threadIdx.x;
+        t.live = tile < job.tile_end && seg * kSegTokens < ntok;
+        t.hc = make_uint4(0, 0, 0, 0);
+        t.hb = make_uint2(~0u, ~0u);
+        t.sc = make_uint4(0, 0, 0, 0);
+        t.sb = make_uint2(~0u, ~0u);
+        if (!t.live) return;
+        if (seg > 0) {
+            t.hc = gload16(g.codes + (seg - 1) * 4);
+            t.hb = gload8(g.bad + (seg - 1) * 2);
+        }
+        t.sc = gload16(g.codes + seg * 4);
+        t.sb = gload8(g.bad + seg * 2);
+    };
+    TileIn next;
+    fetch(job.tile_begin, next);
+
+    const BucketRow row = sp.rows[(size_t)job.genome * sp.K + job.krow];
+    ScatterWg s;
+    s.area = uniform_ptr(row.area);
+    s.fill = uniform_ptr(row.fill);
+    s.seg = uniform_ptr(row.seg);
+    s.regs = uniform_ptr(row.regs);
+    s.cap_records = sp.cap_chunks * kChunkRecords;
+    s.nb_log2 = sp.nb_log2;
+    s.tshift = p - sp.nb_log2;
+    s.cshift = 4 - sp.nb_log2;
+    // the chunks of every round of the job in one reservation; the position is first read behind a barrier
+    if (threadIdx.x == 0) lds32(kWgPosSlot) = gadd32(row.cursor, (job.tile_end - job.tile_begin) * 4u * kWgChunkRecords);
+    if (lane < 32u) lds32(kWgAreaBytes + (lane >> 4) * kWgTableBytes + wave * 64u + 4u * (lane & 15u)) = 0;
+    __builtin_amdgcn_wave_barrier();
+
+    const uint32_t queue = wave * (kChunkRecords * 4u) + 4u * lane;
+    const uint32_t copy = lane & ((1u << s.cshift) - 1u);
+    const int tile_sh = 32 - sp.nb_log2;  // hash high word >> tile_sh = index tile
+    uint32_t tbl = 0, done = 0;
+    for (unsigned tile = job.tile_begin; tile < job.tile_end; ++tile) {
+        const TileIn in = next;
+        fetch(tile + 1, next);
+        if (!__any(in.live)) {
+            // nothing to hash for this wave, but the workgroup's four rounds of the tile need its barriers
+#pragma unroll 1
+            for (int w = 0; w < 4; ++w) {
+                scatter_flush_wg(s, wave, tbl, done, 0u);
+                tbl ^= 1u;
+                done += kWgChunkRecords;
+            }
+            continue;
+        }
+        const uint4 hc = in.hc, sc = in.sc;
+        const uint2 hb = in.hb, sb = in.sb;
+        Windows<KC == 1 ? 5 : (KC == 3 ? 6 : KC)> win;
+        win.prime(hc);
+        auto update = [&](uint32_t cnt_base, int i, bool valid) {
+            const Probe q = probe(win.template hash<CANON>(k), p);
+            const uint32_t rec = valid ? (q.hi >> (32 - p)) | (rho_of(q, p) << 24) : 0u;
+            lds32(queue + 256u * (uint32_t)i) = rec;
+            if (valid) atomicAdd(&lds32(cnt_base + (((q.hi >> tile_sh) << s.cshift) << 2)), 1u);
+        };
+        const bool clean = __all((hb.x | hb.y | sb.x | sb.y) == 0u);
+        int run = hb.y ? __builtin_clz(hb.y) : 32 + (hb.x ? __builtin_clz(hb.x) : 32);
+#pragma unroll 1
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t cbase = kWgAreaBytes + tbl * kWgTableBytes + wave * 64u + 4u * copy;
+            // (the round's code word picked by selects: a register array indexed by the loop counter would go to scratch,
+            // and unrolling the four rounds quadruples the kernel)
+            const uint32_t cwd = w == 0 ? sc.x : (w == 1 ? sc.y : (w == 2 ? sc.z : sc.w));
+            if (clean) {
+#pragma unroll 1
+                for (int i = 0; i < 16; ++i) {
+                    win.push((cwd >> (2 * i)) & 3u);
+                    update(cbase, i, true);
+                }
+            } else {
+                const uint32_t bw = ((w & 2) ? sb.y : sb.x) >> ((w & 1) * 16);
+#pragma unroll 1
+                for (int i = 0; i < 16; ++i) {
+                    run = ((bw >> i) & 1u) ? 0 : run + 1;
+                    win.push((cwd >> (2 * i)) & 3u);
+                    update(cbase, i, run >= k);
+                }
+            }
+            scatter_flush_wg(s, wave, tbl, done, kChunkRecords);
+            tbl ^= 1u;
+            done += kWgChunkRecords;
+        }
+    }
+}
+
 // Between scatter and replay when a row has more than one index tile (log2m >= 17): every chunk of every
 // stream is sorted by index tile in place (one wave per chunk: LDS counting sort), null records dropped,
 // and the start of each tile's segment is noted in seg[chunk][tile].  A replay workgroup then reads only
@@ -1369,6 +1584,10 @@ __global__ __launch_bounds__(256) void sort_chunks_kernel(const BucketRow* __res
 // CU.  A wave takes every 16th chunk of the row's stream, U at a time, and reads only the segment of its
 // own tile (all of a chunk when the row is a single tile and nothing was sorted); segment headers, records
 // and the LDS work of three consecutive steps overlap.
+// BIG: the stream holds the first epoch's WORKGROUP chunks (scatter_first_wg_kernel: 16 384 records each, segment table and
+// fill count at the entries of the chunk's first 1024 records): a wave takes every 16th of them and streams its tile's
+// segment -- 4 KiB on average at log2m 20 -- with 16-byte loads, two 1 KiB pieces per step and the next step's in flight.
+template <bool BIG>
 __global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restrict__ rows, RowSet rs, int p, int logg,
                                                      int nb_log2, uint32_t cap_chunks, int fbits) {
     lds_starts_at_zero();
@@ -1395,6 +1614,91 @@ __global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restric
     };
     constexpr int U = 4;
     const DD_GLOBAL uint16_t* seg = (const DD_GLOBAL uint16_t*)row.seg;
+    // U records of a lane in three sweeps -- all register words read, all first compare-and-swaps issued, then the
+    // (rare) retries -- instead of read / compare / CAS record by record: the LDS round trips of one lane's records
+    // overlap (an LDS atomic orders every later LDS access of the wave behind it, so the record-by-record form ran
+    // them back to back; while the registers are still filling, half the records raise one).  A word changed in
+    // between -- by a neighbour, or by this lane's previous record -- fails its CAS and is retried from the value
+    // that came back.
+    auto apply_u = [&](const uint32_t (&e)[U]) {
+        uint32_t wd[U];
+        uint32_t retry = 0;  // bit i: record i's first CAS found another value than the one read
+#pragma unroll
+        for (int i = 0; i < U; ++i) wd[i] = RegsLds::load32(e[i] & (tile - 1u));
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const uint32_t a = e[i] & (tile - 1u), rho = e[i] >> 24, sh = RegsLds::shift(a), cur = (wd[i] >> sh) & 0xFFu;
+            if (rho > cur) {
+                const uint32_t prev = RegsLds::cas32(a, wd[i], wd[i] + ((rho - cur) << sh));
+                if (prev != wd[i]) retry |= 1u << i;
+                wd[i] = prev;
+            }
+        }
+        if (__any(retry != 0u)) {
+#pragma unroll
+            for (int i = 0; i < U; ++i)
+                if ((retry >> i) & 1u) (void)cas_raise<RegsLds>(e[i] & (tile - 1u), wd[i], e[i] >> 24);
+        }
+    };
+    if (BIG) {
+        const uint32_t nbig = nrec / kWgChunkRecords;  // (a chunk the capacity cut short went to the registers directly)
+        struct Piece {
+            uint4 a, b;
+            uint32_t i, st, en;  // wave-uniform: lane 0's first record of `a`, the segment's bounds; en = 0: nothing
+        };
+        auto header = [&](uint32_t C, uint32_t& st, uint32_t& en) {
+            st = en = 0;
+            if (C < nbig) {
+                st = seg[(size_t)C * 256u + b];
+                en = b + 1u < nb ? (uint32_t)seg[(size_t)C * 256u + b + 1u] : gload4(row.fill + (size_t)C * 16u);
+            }
+        };
+        uint32_t C = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        uint32_t st, en, st1, en1, st2, en2;
+        header(C, st, en);
+        header(C + 16u, st1, en1);
+        header(C + 32u, st2, en2);
+        st = __builtin_amdgcn_readfirstlane(st);
+        en = __builtin_amdgcn_readfirstlane(en);
+        uint32_t i = st & ~3u;
+        auto issue = [&](Piece& P) {
+            P.i = i, P.st = st, P.en = C < nbig ? en : 0u;
+            const uint32_t* base = row.area + (size_t)C * kWgChunkRecords;
+            const uint32_t ia = i + 4u * lane, ib = ia + 256u;
+            P.a = P.b = make_uint4(0, 0, 0, 0);
+            if (ia < P.en) P.a = gload16(base + ia);  // (a quad may straddle the segment's end: still inside the chunk)
+            if (ib < P.en) P.b = gload16(base + ib);
+            i += 512u;
+            if (C < nbig && i >= en) {  // on to this wave's next chunk; its header was fetched two chunks ago
+                C += 16u;
+                st = __builtin_amdgcn_readfirstlane(st1);
+                en = __builtin_amdgcn_readfirstlane(en1);
+                st1 = st2, en1 = en2;
+                header(C + 32u, st2, en2);
+                i = st & ~3u;
+            }
+        };
+        Piece cur, nxt;
+        bool more = C < nbig;
+        issue(cur);
+        while (more) {
+            more = C < nbig;
+            issue(nxt);
+            uint32_t ea[U] = {cur.a.x, cur.a.y, cur.a.z, cur.a.w}, eb[U] = {cur.b.x, cur.b.y, cur.b.z, cur.b.w};
+            if (!(cur.i >= cur.st && cur.i + 512u <= cur.en)) {
+                // a piece that holds an end of the segment: records of the neighbouring tiles (or beyond) are nulled
+                const uint32_t d = cur.i + 4u * lane - cur.st, len = cur.en - cur.st;
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    ea[j] = d + (uint32_t)j < len ? ea[j] : 0u;
+                    eb[j] = d + 256u + (uint32_t)j < len ? eb[j] : 0u;
+                }
+            }
+            apply_u(ea);
+            apply_u(eb);
+            cur = nxt;
+        }
+    } else {
     struct Head {
         uint32_t st[U], en[U];
     };
@@ -1437,40 +1741,16 @@ __global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restric
         h1 = h2;
         heads(c + 2u * step, h2);      // headers two steps ahead
         records(c + step, h1, v1);     // records one step ahead
-        // The 2U records of the step in three sweeps -- all register words read, all first compare-and-swaps
-        // issued, then the (rare) retries -- instead of read / compare / CAS record by record: the LDS round trips
-        // of one lane's records overlap (an LDS atomic orders every later LDS access of the wave behind it, so
-        // the record-by-record form ran them back to back; while the registers are still filling, half the
-        // records raise one).  A word changed in between -- by a neighbour, or by this lane's previous record --
-        // fails its CAS and is retried from the value that came back.
-        // (U at a time: all 2U together need 75+ VGPRs, and above 64 only one 1024-thread workgroup fits a CU)
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            uint32_t wd[U];
-            uint32_t retry = 0;  // bit i: record i's first CAS found another value than the one read
-#pragma unroll
-            for (int i = 0; i < U; ++i) wd[i] = RegsLds::load32((half ? v0.r1[i] : v0.r0[i]) & (tile - 1u));
-#pragma unroll
-            for (int i = 0; i < U; ++i) {
-                const uint32_t e = half ? v0.r1[i] : v0.r0[i];
-                const uint32_t a = e & (tile - 1u), rho = e >> 24, sh = RegsLds::shift(a), cur = (wd[i] >> sh) & 0xFFu;
-                if (rho > cur) {
-                    const uint32_t prev = RegsLds::cas32(a, wd[i], wd[i] + ((rho - cur) << sh));
-                    if (prev != wd[i]) retry |= 1u << i;
-                    wd[i] = prev;
-                }
-            }
-            if (__any(retry != 0u)) {
-#pragma unroll
-                for (int i = 0; i < U; ++i)
-                    if ((retry >> i) & 1u) (void)cas_raise<RegsLds>((half ? v0.r1[i] : v0.r0[i]) & (tile - 1u), wd[i], (half ? v0.r1[i] : v0.r0[i]) >> 24);
-            }
-        }
+        // The 2U records of the step, U at a time (apply_u; all 2U together need 75+ VGPRs, and above 64 only one
+        // 1024-thread workgroup fits a CU)
+        apply_u(v0.r0);
+        apply_u(v0.r1);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t* base = row.area + (size_t)(c + 16u * u) * kChunkRecords;
             for (uint32_t i = h0.st[u] + 128u + lane; i < h0.en[u]; i += 64u) apply(gload4(base + i));  // longer than twice the expected size
         }
+    }
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < (tile >> 4); i += blockDim.x) gstore16(tile_g + (size_t)i * 16, l4[i]);
@@ -1598,7 +1878,12 @@ void launch_scatter(const SweepGenome* genomes, const SweepJob* jobs, int njobs,
         // tiles get their chunks sorted on the way out: 4 KiB + 256 B of LDS per wave)
 #define DD_FIRST(KC, CN)                                                                                                           \
     do {                                                                                                                           \
-        if (sp.presorted) {                                                                                                        \
+        if (sp.presorted == 2) {                                                                                                   \
+            auto kern = scatter_first_wg_kernel<KC, CN>;                                                                           \
+            static std::atomic<unsigned long long> attr_done{0};                                                                   \
+            allow_full_lds(reinterpret_cast<const void*>(kern), attr_done);                                                        \
+            hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3(1024), std::max((size_t)kWgLdsBytes, first_lds_floor), st, genomes, jobs, plan.log2m, sp); \
+        } else if (sp.presorted) {                                                                                                        \
             auto kern = scatter_kernel<KC, CN, true, false, 1, true>;                                                              \
             static std::atomic<unsigned long long> attr_done{0};                                                                   \
             allow_full_lds(reinterpret_cast<const void*>(kern), attr_done);                                                        \
@@ -1665,7 +1950,7 @@ void launch_scatter(const SweepGenome* genomes, const SweepJob* jobs, int njobs,
 #undef DD_SCATTER_NN
 }
 
-void launch_replay(const BucketRow* rows, int ngenomes, int K, int k0, int nks, const SweepPlan& plan, hipStream_t st, bool presorted) {
+void launch_replay(const BucketRow* rows, int ngenomes, int K, int k0, int nks, const SweepPlan& plan, hipStream_t st, int presorted) {
     const RowSet rs{K, k0, nks, ngenomes * nks};
     if (rs.nrows <= 0) return;
     const size_t tile = (size_t)1 << (plan.log2m - plan.nb_log2);
@@ -1675,10 +1960,16 @@ void launch_replay(const BucketRow* rows, int ngenomes, int K, int k0, int nks, 
         hipLaunchKernelGGL(sort_chunks_kernel, dim3((unsigned)rs.nrows * wgs_per_row), dim3(256), 0, st, rows, rs, plan.log2m,
                            plan.nb_log2, plan.cap_chunks, wgs_per_row);
     }
-    static std::atomic<unsigned long long> attr_done{0};
-    allow_full_lds(reinterpret_cast<const void*>(replay_kernel), attr_done);
-    hipLaunchKernelGGL(replay_kernel, dim3(blocks), dim3(1024), tile, st, rows, rs, plan.log2m, plan.logg, plan.nb_log2,
-                       plan.cap_chunks, plan.fbits);
+    static std::atomic<unsigned long long> attr_done[2] = {{0}, {0}};
+    if (presorted == 2) {  // the first epoch's workgroup chunks
+        allow_full_lds(reinterpret_cast<const void*>(replay_kernel<true>), attr_done[1]);
+        hipLaunchKernelGGL(replay_kernel<true>, dim3(blocks), dim3(1024), tile, st, rows, rs, plan.log2m, plan.logg, plan.nb_log2,
+                           plan.cap_chunks, plan.fbits);
+    } else {
+        allow_full_lds(reinterpret_cast<const void*>(replay_kernel<false>), attr_done[0]);
+        hipLaunchKernelGGL(replay_kernel<false>, dim3(blocks), dim3(1024), tile, st, rows, rs, plan.log2m, plan.logg, plan.nb_log2,
+                           plan.cap_chunks, plan.fbits);
+    }
     hipLaunchKernelGGL(reset_cursors_kernel, dim3((unsigned)(rs.nrows + 255) / 256), dim3(256), 0, st, rows, rs);
 }
 

@@ -100,6 +100,9 @@ BUCKET_KNOBS = {
     "big_tiles": {"DD_BUCKET_TILE_LOG2": "17", "DD_BUCKET_E0": "1"},    # 128 KiB index tiles: one replay workgroup per CU (A/B knob)
     "unstaggered": {"DD_NO_BUCKET_STAGGER": "1", "DD_BUCKET_E0": "1"},  # every class's first scatter at once (round 2's order)
     "side_priorities": {"DD_SIDE_PRIO": "201", "DD_BUCKET_E0": "1"},  # class pipelines on streams of different priority
+    "wave_chunks": {"DD_FIRST_WG": "0", "DD_BUCKET_E0": "2"},          # first epoch: every wave its own 1024-record chunks (round 3's form)
+    "wg_chunks_tight": {"DD_BUCKET_CAP": "40", "DD_BUCKET_E0": "3"},    # workgroup chunks (16 384 records) against a 40-chunk stream: two fit, the rest overflow
+    "wg_chunks_big_tiles": {"DD_BUCKET_TILE_LOG2": "17", "DD_BUCKET_E0": "3"},
 }
 
 
