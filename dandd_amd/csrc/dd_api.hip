@@ -623,7 +623,9 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         const unsigned unit = unit_env ? (unsigned)std::max(1, std::min(16, atoi(unit_env))) * 64u : 256u;
         // first-epoch chunks leave the scatter sorted by index tile: 2 = one 16 384-record chunk per workgroup and 16
         // updates (round 4), 1 = every wave its own 1024-record chunks (DD_FIRST_WG=0), 0 = sorted by a pass of their own
-        const int presorted = bplan->nb_log2 >= 1 && !getenv("DD_NO_PRESORT") ? ((getenv("DD_FIRST_WG") && atoi(getenv("DD_FIRST_WG")) == 0) ? 1 : 2) : 0;
+        // (DD_FIRST_WG: 3 = binned tiles of tokens, the default; 2 = 16 384-record sorted chunks; 0 = per-wave chunks)
+        const int first_wg = getenv("DD_FIRST_WG") ? atoi(getenv("DD_FIRST_WG")) : 3;
+        const int presorted = bplan->nb_log2 >= 1 && !getenv("DD_NO_PRESORT") ? (first_wg == 0 ? 1 : (first_wg == 2 ? 2 : 3)) : 0;
         const dd::ScatterParams sp{rows_dev, K, bplan->logg, bplan->cap_chunks, unit, bplan->nb_log2, presorted};
         if (side_b && (rc = ensure_side_streams(c, (int)classes.size()))) return rc;
         // Every k class is a pipeline of its own -- scatter(e), sort(e), replay(e), scatter(e+1) ... over its own rows

@@ -147,7 +147,8 @@ struct ScatterParams {
     unsigned unit;              // records a wave reserves per atomic add on the row's cursor (multiple of 64)
     int nb_log2;                // index tiles per row (log2)
     int presorted;              // first-epoch scatter sorts its chunks by index tile itself (rows of several tiles): 1 = every
-                                // wave its own 1024-record chunks, 2 = the workgroup's 16 384-record chunks (one per 16 updates)
+                                // wave its own 1024-record chunks, 2 = the workgroup's 16 384-record chunks (one per 16 updates),
+                                // 3 = every tile of tokens binned: 16 fixed regions of 4480 records, counts in seg[chunk][16]
 };
 void launch_scatter(const SweepGenome* genomes_dev, const SweepJob* jobs_dev, int njobs, int kclass,
                     const SweepPlan& plan, const ScatterParams& sp, hipStream_t st, bool first_epoch);

@@ -246,8 +246,9 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
             // (no epoch at all when every genome of the call is empty: epoch_edge is {0} then)
             const size_t first_tokens = nepochs ? (epoch_edge[1] - epoch_edge[0]) * kTileTokens : 0;
             const size_t per_row = std::min(std::max(first_tokens, 4 * m), bucket_row_tokens);
+            // (the first epoch's binned tiles take 70 chunks of stream per tile of tokens, not 64: dd_sweep.hip)
             sc.plan.cap_chunks = (unsigned)(knobs.bucket_cap_chunks ? knobs.bucket_cap_chunks
-                                                : per_row / 1024 + max_jobs_row_epoch * (kThreads / 64) + 16);
+                                                : (per_row + per_row / 8) / 1024 + max_jobs_row_epoch * (kThreads / 64) + 16);
             sc.plan.logg = bucket_logg;
             sc.plan.fbits = bucket_fbits;
             sc.plan.nk_job = bucket_nk;

@@ -1516,6 +1516,129 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KC == 2 ? 
     }
 }
 
+// ---- first epoch, BINNED tiles of tokens (round 4, what runs) ----------------------------------------------------
+// Sorting 16 384 records per workgroup still costs two LDS atomics per record (count, then place) plus the pass over
+// the collection area: 2.4 of the 4.5 ms of a class-0 launch over 64 x 5 Mbp at log2m 20, against 2.1 ms of hashing
+// (timing-only builds, profiles/r04_bucket_path.txt).  A record's index tile is the top bits of a hash, so the 65 536
+// records a workgroup makes of one tile of tokens spread over the 16 bins (index tile x copy) as evenly as coin flips
+// do: 4096 per bin, sigma 62.  So every bin of a chunk gets a FIXED region of kBinCap = 4480 records (+ 6 sigma) in
+// the row's stream, a record's slot is ONE returning LDS atomic on the workgroup's counter of its bin, and the record
+// goes straight from the hash to its slot -- no collection area, no counting pass, no placement pass, one workgroup
+// barrier per 64 updates (the counters of odd and even tiles alternate; wave 0 saves and clears a tile's counters
+// behind the barrier while the others already fill the next tile's).  A bin that should ever overflow sends the
+// record to its register by compare-and-swap (exact; ~3e-10 per bin).  The replay reads a bin's records -- 16 KiB
+// in one piece -- with 16-byte loads.  Stream space: 70 instead of 64 chunks of 1024 records per tile of tokens.
+constexpr uint32_t kBinCap = 4480;                        // records per (chunk, bin): a multiple of 64
+constexpr uint32_t kBinChunkRecords = 16u * kBinCap;      // 71 680 = 70 x 1024: stream space of one tile of tokens
+constexpr uint32_t kBinPosSlot = 128u;                    // LDS: counters [2][16] at 0, the job's position behind them
+constexpr uint32_t kBinLdsBytes = 256u;
+
+template <int KC, bool CANON>
+__global__ __launch_bounds__(1024) void scatter_first_bin_kernel(
+    const SweepGenome* __restrict__ genomes, const SweepJob* __restrict__ jobs, int p, ScatterParams sp) {
+    const SweepJob job = jobs[blockIdx.x];
+    if (job.tile_begin >= job.tile_end) return;  // filler of the XCD-affine order
+    lds_starts_at_zero();
+    const SweepGenome g = genomes[job.genome];
+    const int k = job.kfirst;
+    const unsigned long long ntok = uniform64(gload8u(g.ntok));
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+
+    struct TileIn {
+        uint4 hc, sc;
+        uint2 hb, sb;
+        bool live;
+    };
+    auto fetch = [&](unsigned tile, TileIn& t) {
+        const unsigned long long seg = (unsigned long long)tile * blockDim.x + threadIdx.x;
+        t.live = tile < job.tile_end && seg * kSegTokens < ntok;
+        t.hc = make_uint4(0, 0, 0, 0);
+        t.hb = make_uint2(~0u, ~0u);
+        t.sc = make_uint4(0, 0, 0, 0);
+        t.sb = make_uint2(~0u, ~0u);
+        if (!t.live) return;
+        if (seg > 0) {
+            t.hc = gload16(g.codes + (seg - 1) * 4);
+            t.hb = gload8(g.bad + (seg - 1) * 2);
+        }
+        t.sc = gload16(g.codes + seg * 4);
+        t.sb = gload8(g.bad + seg * 2);
+    };
+    TileIn next;
+    fetch(job.tile_begin, next);
+
+    const BucketRow row = sp.rows[(size_t)job.genome * sp.K + job.krow];
+    uint32_t* const area = uniform_ptr(row.area);
+    uint16_t* const counts = uniform_ptr(row.seg);  // [chunk][16]: records in each bin
+    uint8_t* const regs = uniform_ptr(row.regs);
+    const uint32_t cap_records = sp.cap_chunks * kChunkRecords;
+    const int cshift = 4 - sp.nb_log2, tile_sh = 32 - sp.nb_log2;
+    if (threadIdx.x < 32u) lds32(4u * threadIdx.x) = 0;
+    if (threadIdx.x == 0) lds32(kBinPosSlot) = gadd32(row.cursor, (job.tile_end - job.tile_begin) * kBinChunkRecords);
+    __syncthreads();
+    const uint32_t pos0 = __builtin_amdgcn_readfirstlane(lds32(kBinPosSlot));
+    const uint32_t copy = lane & ((1u << cshift) - 1u);
+
+    for (unsigned tile = job.tile_begin; tile < job.tile_end; ++tile) {
+        const TileIn in = next;
+        fetch(tile + 1, next);
+        const uint32_t t = tile - job.tile_begin;
+        const uint32_t ctr = (t & 1u) * 64u;
+        const uint32_t cpos = pos0 + t * kBinChunkRecords;
+        const bool room = cpos + kBinChunkRecords <= cap_records;  // else: the stream is full, records go to the registers (exact, slow, rare)
+        if (__any(in.live)) {
+            const uint4 hc = in.hc, sc = in.sc;
+            const uint2 hb = in.hb, sb = in.sb;
+            const uint32_t cw[4] = {sc.x, sc.y, sc.z, sc.w};
+            uint32_t* const bins = area + cpos + copy * kBinCap;  // this lane's copy of bin 0 of the chunk
+            Windows<KC == 1 ? 5 : (KC == 3 ? 6 : KC)> win;
+            win.prime(hc);
+            auto update = [&](bool valid) {
+                const Probe q = probe(win.template hash<CANON>(k), p);
+                if (!valid) return;
+                const uint32_t rec = (q.hi >> (32 - p)) | (rho_of(q, p) << 24);
+                const uint32_t bin0 = (q.hi >> tile_sh) << cshift;  // + copy = the bin
+                uint32_t slot = kBinCap;
+                if (room) slot = atomicAdd(&lds32(ctr + ((bin0 | copy) << 2)), 1u);
+                if (__builtin_expect(slot < kBinCap, 1)) {
+                    gstore4(bins + bin0 * kBinCap + slot, rec);
+                } else {
+                    uint8_t* a = regs + (rec & 0xFFFFFFu);
+                    (void)cas_raise<RegsGlobal>(a, RegsGlobal::load32(a), rec >> 24);
+                }
+            };
+            if (__all((hb.x | hb.y | sb.x | sb.y) == 0u)) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+#pragma unroll 1
+                    for (int i = 0; i < 16; ++i) {
+                        win.push((cw[w] >> (2 * i)) & 3u);
+                        update(true);
+                    }
+                }
+            } else {
+                int run = hb.y ? __builtin_clz(hb.y) : 32 + (hb.x ? __builtin_clz(hb.x) : 32);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const uint32_t bw = ((w & 2) ? sb.y : sb.x) >> ((w & 1) * 16);
+#pragma unroll 1
+                    for (int i = 0; i < 16; ++i) {
+                        run = ((bw >> i) & 1u) ? 0 : run + 1;
+                        win.push((cw[w] >> (2 * i)) & 3u);
+                        update(run >= k);
+                    }
+                }
+            }
+        }
+        __syncthreads();  // the tile's records are placed and counted; the other parity's counters are clear
+        if (wave == 0u && lane < 16u) {
+            const uint32_t c = lds32(ctr + 4u * lane);
+            lds32(ctr + 4u * lane) = 0;
+            if (room) ((DD_GLOBAL uint16_t*)counts)[(size_t)(cpos / kBinChunkRecords) * 16u + lane] = (uint16_t)(c < kBinCap ? c : kBinCap);
+        }
+    }
+}
+
 // Between scatter and replay when a row has more than one index tile (log2m >= 17): every chunk of every
 // stream is sorted by index tile in place (one wave per chunk: LDS counting sort), null records dropped,
 // and the start of each tile's segment is noted in seg[chunk][tile].  A replay workgroup then reads only
@@ -1584,10 +1707,13 @@ __global__ __launch_bounds__(256) void sort_chunks_kernel(const BucketRow* __res
 // CU.  A wave takes every 16th chunk of the row's stream, U at a time, and reads only the segment of its
 // own tile (all of a chunk when the row is a single tile and nothing was sorted); segment headers, records
 // and the LDS work of three consecutive steps overlap.
-// BIG: the stream holds the first epoch's WORKGROUP chunks (scatter_first_wg_kernel: 16 384 records each, segment table and
+// FORM 2: the stream holds the first epoch's WORKGROUP chunks (scatter_first_wg_kernel: 16 384 records each, segment table and
 // fill count at the entries of the chunk's first 1024 records): a wave takes every 16th of them and streams its tile's
 // segment -- 4 KiB on average at log2m 20 -- with 16-byte loads, two 1 KiB pieces per step and the next step's in flight.
-template <bool BIG>
+// FORM 3: the first epoch's binned tiles (scatter_first_bin_kernel): chunk C = 16 bins of kBinCap records' room, counts in
+// seg[C][16]; unit u = (chunk, copy of this tile's bin); the 512-record pieces of a unit go round the 16 waves, so every
+// wave has a 2 KiB piece in flight while it applies the previous one.
+template <int FORM>
 __global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restrict__ rows, RowSet rs, int p, int logg,
                                                      int nb_log2, uint32_t cap_chunks, int fbits) {
     lds_starts_at_zero();
@@ -1640,7 +1766,49 @@ __global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restric
                 if ((retry >> i) & 1u) (void)cas_raise<RegsLds>(e[i] & (tile - 1u), wd[i], e[i] >> 24);
         }
     };
-    if (BIG) {
+    if (FORM == 3) {
+        const int cshift = 4 - nb_log2;
+        const uint32_t nunits = (nrec / kBinChunkRecords) << cshift;
+        const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        struct Piece {
+            uint4 a, b;
+            uint32_t off, cnt;  // wave-uniform: the piece's first record within its bin, the bin's records
+        };
+        auto header = [&](uint32_t u) -> uint32_t {  // records in unit u's bin
+            return u < nunits ? (uint32_t)seg[(size_t)(u >> cshift) * 16u + ((b << cshift) | (u & ((1u << cshift) - 1u)))] : 0u;
+        };
+        auto issue = [&](uint32_t u, uint32_t cnt, Piece& P) {
+            P.off = ((wave - u) & 15u) * 512u;
+            P.cnt = __builtin_amdgcn_readfirstlane(cnt);
+            P.a = P.b = make_uint4(0, 0, 0, 0);
+            if (P.off >= P.cnt) return;
+            const uint32_t* base = row.area + (size_t)(u >> cshift) * kBinChunkRecords + ((b << cshift) | (u & ((1u << cshift) - 1u))) * kBinCap + P.off;
+            if (P.off + 4u * lane < P.cnt) P.a = gload16(base + 4u * lane);  // (a quad may straddle the bin's last record: still inside its region)
+            if (P.off + 256u + 4u * lane < P.cnt) P.b = gload16(base + 256u + 4u * lane);
+        };
+        uint32_t c0 = header(0), c1 = header(1), c2 = header(2);
+        Piece cur, nxt;
+        issue(0, c0, cur);
+        for (uint32_t u = 0; u < nunits; ++u) {
+            issue(u + 1u, c1, nxt);
+            c1 = c2;
+            c2 = header(u + 3u);
+            if (cur.off < cur.cnt) {
+                uint32_t ea[U] = {cur.a.x, cur.a.y, cur.a.z, cur.a.w}, eb[U] = {cur.b.x, cur.b.y, cur.b.z, cur.b.w};
+                if (cur.off + 512u > cur.cnt) {  // the bin's last piece: what lies behind its last record is nulled
+                    const uint32_t d = cur.off + 4u * lane;
+#pragma unroll
+                    for (int j = 0; j < U; ++j) {
+                        ea[j] = d + (uint32_t)j < cur.cnt ? ea[j] : 0u;
+                        eb[j] = d + 256u + (uint32_t)j < cur.cnt ? eb[j] : 0u;
+                    }
+                }
+                apply_u(ea);
+                apply_u(eb);
+            }
+            cur = nxt;
+        }
+    } else if (FORM == 2) {
         const uint32_t nbig = nrec / kWgChunkRecords;  // (a chunk the capacity cut short went to the registers directly)
         struct Piece {
             uint4 a, b;
@@ -1878,7 +2046,10 @@ void launch_scatter(const SweepGenome* genomes, const SweepJob* jobs, int njobs,
         // tiles get their chunks sorted on the way out: 4 KiB + 256 B of LDS per wave)
 #define DD_FIRST(KC, CN)                                                                                                           \
     do {                                                                                                                           \
-        if (sp.presorted == 2) {                                                                                                   \
+        if (sp.presorted == 3) {                                                                                                   \
+            auto kern = scatter_first_bin_kernel<KC, CN>;                                                                          \
+            hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3(1024), std::max((size_t)kBinLdsBytes, first_lds_floor), st, genomes, jobs, plan.log2m, sp); \
+        } else if (sp.presorted == 2) {                                                                                            \
             auto kern = scatter_first_wg_kernel<KC, CN>;                                                                           \
             static std::atomic<unsigned long long> attr_done{0};                                                                   \
             allow_full_lds(reinterpret_cast<const void*>(kern), attr_done);                                                        \
@@ -1960,16 +2131,17 @@ void launch_replay(const BucketRow* rows, int ngenomes, int K, int k0, int nks, 
         hipLaunchKernelGGL(sort_chunks_kernel, dim3((unsigned)rs.nrows * wgs_per_row), dim3(256), 0, st, rows, rs, plan.log2m,
                            plan.nb_log2, plan.cap_chunks, wgs_per_row);
     }
-    static std::atomic<unsigned long long> attr_done[2] = {{0}, {0}};
-    if (presorted == 2) {  // the first epoch's workgroup chunks
-        allow_full_lds(reinterpret_cast<const void*>(replay_kernel<true>), attr_done[1]);
-        hipLaunchKernelGGL(replay_kernel<true>, dim3(blocks), dim3(1024), tile, st, rows, rs, plan.log2m, plan.logg, plan.nb_log2,
-                           plan.cap_chunks, plan.fbits);
-    } else {
-        allow_full_lds(reinterpret_cast<const void*>(replay_kernel<false>), attr_done[0]);
-        hipLaunchKernelGGL(replay_kernel<false>, dim3(blocks), dim3(1024), tile, st, rows, rs, plan.log2m, plan.logg, plan.nb_log2,
-                           plan.cap_chunks, plan.fbits);
-    }
+    static std::atomic<unsigned long long> attr_done[3] = {{0}, {0}, {0}};
+#define DD_REPLAY(FORM, SLOT)                                                                                                   \
+    do {                                                                                                                        \
+        allow_full_lds(reinterpret_cast<const void*>(replay_kernel<FORM>), attr_done[SLOT]);                                    \
+        hipLaunchKernelGGL(replay_kernel<FORM>, dim3(blocks), dim3(1024), tile, st, rows, rs, plan.log2m, plan.logg, plan.nb_log2, \
+                           plan.cap_chunks, plan.fbits);                                                                        \
+    } while (0)
+    if (presorted == 3) DD_REPLAY(3, 2);       // the first epoch's binned tiles
+    else if (presorted == 2) DD_REPLAY(2, 1);  // ... or its workgroup chunks
+    else DD_REPLAY(0, 0);
+#undef DD_REPLAY
     hipLaunchKernelGGL(reset_cursors_kernel, dim3((unsigned)(rs.nrows + 255) / 256), dim3(256), 0, st, rows, rs);
 }
 
