@@ -580,7 +580,11 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         if (sc.plan.mode != dd::kBucketMode) lds_jobs += sc.jobs.size(), ++lds_classes;
     const bool side = lds_classes > 1 && (lds_jobs < 12000 || getenv("DD_SIDE_ALWAYS")) && !getenv("DD_NO_SIDE_STREAMS");
     if (side && (rc = ensure_side_streams(c, lds_classes))) return rc;
-    const bool side_b = bplan && !getenv("DD_NO_SIDE_STREAMS");  // log2m >= 18: see below
+    // log2m >= 17, see below.  A call whose only epoch is the unfiltered first one (many small genomes: 64 x 5 Mbp at
+    // log2m 20) runs its classes one after the other instead: its scatter (returning LDS atomics, 4-byte stores) and
+    // its replay (HBM reads at 5 TB/s) each have the chip to themselves then -- 24.4 -> 22.9 ms with round 4's kernels
+    // (profiles/r04_bucket_path.txt); calls with filtered epochs keep the side streams (26.8 against 24.9 ms without).
+    const bool side_b = bplan && (bplan->nepochs > 1 || getenv("DD_SIDE_ALWAYS")) && !getenv("DD_NO_SIDE_STREAMS");
     // (launches that run side by side are timed as ONE span on the caller's stream: per-launch spans would overlap)
     std::unique_ptr<Span> phase((side || side_b) ? new Span(c, DD_KERNEL_SWEEP) : nullptr);
     if (side) DD_HIP(hipEventRecord(c->side_go, st));
@@ -636,7 +640,9 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         // a class's replay (HBM reads, LDS compare-and-swaps) then runs beside the next class's scatter (VALU issue)
         // instead of every scatter running beside every other and the replays likewise.  64 x 5 Mbp at log2m 20:
         // 33.4 -> 31.7 ms; 10 x 50 Mbp and log2m 18 unchanged (profiles/r03_bucket_path.txt).
-        const bool stagger = side_b && !getenv("DD_NO_BUCKET_STAGGER");
+        // (round 4: with the first epoch binned straight from the hash the stagger LOSES -- 64 x 5 Mbp 25.6 against 24.4 ms,
+        // 10 x 50 Mbp 25.6 against 24.9 at log2m 20, equal at 18 -- and is off; DD_BUCKET_STAGGER=1 brings it back)
+        const bool stagger = side_b && getenv("DD_BUCKET_STAGGER") && atoi(getenv("DD_BUCKET_STAGGER")) == 1;
         int staggered = 0;
         for (size_t i = 0; i < classes.size(); ++i) {
             const dd::SweepClass& sc = classes[i];

@@ -1593,6 +1593,8 @@ __global__ __launch_bounds__(1024) void scatter_first_bin_kernel(
             uint32_t* const bins = area + cpos + copy * kBinCap;  // this lane's copy of bin 0 of the chunk
             Windows<KC == 1 ? 5 : (KC == 3 ? 6 : KC)> win;
             win.prime(hc);
+            // (deferring a record's store until the next update's atomic is out, so that the slot's LDS round trip overlaps a
+            // hash, and unrolling the token loop by two were both measured: no difference -- the loop is not waiting there)
             auto update = [&](bool valid) {
                 const Probe q = probe(win.template hash<CANON>(k), p);
                 if (!valid) return;

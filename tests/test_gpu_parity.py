@@ -98,11 +98,14 @@ BUCKET_KNOBS = {
     "two_ks_per_job": {"DD_BUCKET_NK": "2", "DD_BUCKET_E0": "1"},      # filtered scatter jobs of two consecutive ks (A/B knob)
     "two_ks_small_filter": {"DD_BUCKET_NK": "2", "DD_BUCKET_LOGG": "5", "DD_BUCKET_E0": "1", "DD_BUCKET_EMAX": "2"},
     "big_tiles": {"DD_BUCKET_TILE_LOG2": "17", "DD_BUCKET_E0": "1"},    # 128 KiB index tiles: one replay workgroup per CU (A/B knob)
-    "unstaggered": {"DD_NO_BUCKET_STAGGER": "1", "DD_BUCKET_E0": "1"},  # every class's first scatter at once (round 2's order)
+    "staggered": {"DD_BUCKET_STAGGER": "1", "DD_BUCKET_E0": "1"},       # class pipelines one first-epoch scatter apart (round 3's order)
+    "one_epoch_side_streams": {"DD_SIDE_ALWAYS": "1"},                  # a single-epoch call on side streams all the same
     "side_priorities": {"DD_SIDE_PRIO": "201", "DD_BUCKET_E0": "1"},  # class pipelines on streams of different priority
+    "wg_sorted_chunks": {"DD_FIRST_WG": "2", "DD_BUCKET_E0": "3"},    # first epoch: the workgroup's 16 384-record sorted chunks (A/B knob)
     "wave_chunks": {"DD_FIRST_WG": "0", "DD_BUCKET_E0": "2"},          # first epoch: every wave its own 1024-record chunks (round 3's form)
-    "wg_chunks_tight": {"DD_BUCKET_CAP": "40", "DD_BUCKET_E0": "3"},    # workgroup chunks (16 384 records) against a 40-chunk stream: two fit, the rest overflow
-    "wg_chunks_big_tiles": {"DD_BUCKET_TILE_LOG2": "17", "DD_BUCKET_E0": "3"},
+    "bins_tight": {"DD_BUCKET_CAP": "150", "DD_BUCKET_E0": "3"},       # binned first epoch (70 chunks of stream per tile of tokens) against a 150-chunk stream: two tiles fit, the third overflows
+    "wg_chunks_tight": {"DD_FIRST_WG": "2", "DD_BUCKET_CAP": "40", "DD_BUCKET_E0": "3"},
+    "bins_big_tiles": {"DD_BUCKET_TILE_LOG2": "17", "DD_BUCKET_E0": "3"},
 }
 
 
