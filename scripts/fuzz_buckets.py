@@ -46,7 +46,7 @@ for it in range(n_cfg):
     if rng.integers(0, 4) == 0:
         os.environ["DD_SIDE_ALWAYS"] = "1"
     if rng.integers(0, 5) == 0:
-        os.environ["DD_BUCKET_TILE_LOG2", "DD_FIRST_WG"] = "17"
+        os.environ["DD_BUCKET_TILE_LOG2"] = "17"
     if rng.integers(0, 3) == 0:
         os.environ["DD_FIRST_WG"] = str(int(rng.choice([0, 2])))
     canon = bool(rng.integers(0, 2))
