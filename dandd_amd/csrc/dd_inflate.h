@@ -513,8 +513,9 @@ inline int gunzip_bgzf_parallel(const uint8_t* in, size_t n, Buf& out, int nthre
             if (i0 >= blks.size() || bad.load()) return;
             for (size_t i = i0; i < std::min(blks.size(), i0 + 64); ++i) {
                 size_t used = 0, made = 0;
+                // (a member must also END where its BSIZE says: bytes left over inside a block are not a clean BGZF file)
                 if (!inflate_member(in + blks[i].in_off, blks[i].in_len, out.p + blks[i].out_off, blks[i].out_len, &used, &made) ||
-                    made != blks[i].out_len) {
+                    made != blks[i].out_len || used != blks[i].in_len) {
                     bad.store(1);
                     return;
                 }
@@ -593,14 +594,17 @@ inline int gunzip_member_parallel(const uint8_t* in, size_t n, Buf& out, int nth
                 status.store(-2);
                 return;
             }
-            // (text inflates 3-5x; a piece that claims more than 256x is either damaged or so repetitive that the serial
-            // decoder is the better tool: "not applicable")
+            // (text inflates 3-5x; a piece that claims more than 32x, or more than the whole member's ISIZE, is either
+            // damaged or so repetitive that the serial decoder -- which needs the output buffer only, not two bytes of
+            // symbol per output byte and thread -- is the better tool: "not applicable")
+            size_t max_symbols = packed * 32 + ((size_t)1 << 20);
+            if ((size_t)want_size >= n) max_symbols = std::min(max_symbols, (size_t)want_size + 1);  // (ISIZE is modulo 2^32: one smaller than the file has wrapped)
             const int rc = decode_piece(in, body_end, st[c], c + 1 < np ? st[c + 1] : 0, c == 0, 0, &sym[(size_t)t], &res[(size_t)t],
-                                        packed * 256 + ((size_t)1 << 20));
+                                        max_symbols);
             if (rc) status.store(rc);
         });
         t_decode += now() - ta;
-        if (status.load() == -2) return -1;
+        // (a symbol buffer that could not grow is "not applicable" too: the serial path decides, with the output buffer alone)
         if (status.load()) return 0;
         // a piece ends exactly where the next was found to start; only the very last sees the final block
         std::vector<size_t> off(cnt + 1, total);

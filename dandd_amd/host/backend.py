@@ -56,9 +56,13 @@ def write_sketch_file(path, regs, log2m, k, canonical, fmt=None):
     fmt = fmt or sketch_format()
     tmp = f"{path}.{os.getpid()}.tmp"  # per process: ranks of a multi-GPU run share the sketch directory
     if fmt == "native":
-        with open(tmp, "wb", buffering=0) as f:  # (two plain write(2) calls; no copy of the registers)
-            f.write(_HDR.pack(MAGIC, log2m, k, 1 if canonical else 0, 0))
-            f.write(memoryview(regs).cast("B"))
+        with open(tmp, "wb", buffering=0) as f:  # (plain write(2) calls; no copy of the registers)
+            # a raw write may be short (disk filling, NFS, a signal): loop until every byte is out, or let the
+            # OS error surface -- a truncated temp file must never be renamed into the sketch cache
+            for piece in (_HDR.pack(MAGIC, log2m, k, 1 if canonical else 0, 0), regs):
+                mv = memoryview(piece).cast("B")
+                while len(mv):
+                    mv = mv[f.write(mv):]
     else:
         head = _DASH.pack(0, 0, _ERTL_MLE, _ERTL_JOINT_MLE, 1, log2m, 0.0)
         if fmt == "dashing":
@@ -113,6 +117,10 @@ def convert_main(argv):
     return 2
 
 
+class StaleGenome(FileNotFoundError):
+    """A member's file is where it was recorded, but is not the file it was: another size."""
+
+
 class HipExactBackend:
     """`--exact`: the KMC branch of the reference (lib/sketch_classes.py:377-465), which counts
     distinct canonical k-mers exactly.  A "database" here is a small JSON file listing the FASTAs it
@@ -164,8 +172,9 @@ class HipExactBackend:
     @staticmethod
     def _find(member):
         """The file a member stands for: DANDD_GENOMEDIR first (a moved collection), then where it was seen.
-        A candidate of another size is not that genome."""
-        tried = []
+        A candidate of another size is not that genome: StaleGenome when one was found, plain FileNotFoundError
+        when there is no file of that name at all."""
+        tried, replaced = [], False
         for d in [os.environ.get("DANDD_GENOMEDIR"), member.get("dir")]:
             if not d:
                 continue
@@ -174,9 +183,11 @@ class HipExactBackend:
                 if member.get("size") is None or os.path.getsize(cand) == member["size"]:
                     return cand
                 tried.append(f"{cand} ({os.path.getsize(cand)} bytes, recorded {member['size']})")
+                replaced = True
             else:
                 tried.append(cand)
-        raise FileNotFoundError(f"{member['name']}: not found as recorded -- tried {tried} (set DANDD_GENOMEDIR to where the genomes are now)")
+        kind = StaleGenome if replaced else FileNotFoundError
+        raise kind(f"{member['name']}: not found as recorded -- tried {tried} (set DANDD_GENOMEDIR to where the genomes are now)")
 
     def leaf(self, fasta, ks, out_paths):
         full = os.path.abspath(fasta)
@@ -198,15 +209,16 @@ class HipExactBackend:
     def card(self, path):
         db = self._read(path)
         if db.get("distinct") is not None:
-            # a database answers on its own -- unless its genomes are where they were and are no longer the files
-            # the count was made from
-            try:
-                for m in db["members"]:
+            # a database answers on its own (like a KMC database once its FASTAs are gone) -- unless a genome is
+            # where it was and is no longer the file the count was made from: that raises StaleGenome, the caller
+            # deletes the database or restores the file
+            for m in db["members"]:
+                try:
                     self._find(m)
-            except FileNotFoundError as e:
-                if "recorded" in str(e):     # found, but replaced by another file: the cached count is stale
+                except StaleGenome:
                     raise
-                # moved away altogether: nothing to compare with
+                except FileNotFoundError:
+                    pass  # moved away altogether: nothing to compare with
             return float(db["distinct"])
         files = [self._find(m) for m in db["members"]]
         for m, f in zip(db["members"], files):
@@ -249,6 +261,10 @@ class HipBackend:
             st = os.stat(path)
         except OSError:
             return
+        if regs.base is not None:
+            # a row of a [n][K][m] slab: kept as a view it would pin the whole slab for as long as ANY of its rows is
+            # cached, and DANDD_SKETCH_CACHE_MB would bound nothing (64 x 31 x 1 MiB: 2 GiB alive behind a 1 GiB limit)
+            regs = regs.copy()
         self._recent[path] = (regs, int(k), (st.st_size, st.st_mtime_ns))
         self._recent_bytes += regs.nbytes
         while self._recent_bytes > self._recent_limit and self._recent:
