@@ -56,6 +56,20 @@ CONFIGS = {
 }
 
 
+def rank_shards(cfg, world):
+    """Which genomes of a config each rank holds, and the FASTA bytes that puts into its HBM: the plan main() follows
+    (strong scaling: dandd_amd.dist.shard_by_weight over equal sizes; weak: every rank its own cfg['genomes'])."""
+    from dandd_amd import dist as ddist
+    from dandd_amd.engine import synth_size
+    nb = int(cfg["mbp"] * 1e6)
+    if cfg["strong"]:
+        plan = ddist.shard_by_weight([nb] * cfg["genomes"], world)
+    else:
+        plan = [list(range(r * cfg["genomes"], (r + 1) * cfg["genomes"])) for r in range(world)]
+    per = synth_size(nb, cfg["nrec"])
+    return plan, [len(ids) * per for ids in plan]
+
+
 def usable_cpus():
     """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (the GPU
     boxes show 256 logical CPUs behind a 16-CPU quota; counting 256 would oversubscribe 16x)."""
@@ -457,12 +471,9 @@ def main():
     nb = int(cfg["mbp"] * 1e6)
     kmin, kmax, p = cfg["kmin"], cfg["kmax"], args.log2m
     K, m = kmax - kmin + 1, 1 << p
-    if cfg["strong"]:   # the job's genomes sharded over the ranks (equal sizes: round robin by weight)
-        ids = ddist.shard_by_weight([nb] * cfg["genomes"], world)[rank]
-        total_genomes = cfg["genomes"]
-    else:               # every rank brings its own genomes
-        ids = list(range(rank * cfg["genomes"], (rank + 1) * cfg["genomes"]))
-        total_genomes = cfg["genomes"] * world
+    # strong: the job's genomes sharded over the ranks (equal sizes: round robin by weight); weak: every rank brings its own
+    ids = rank_shards(cfg, world)[0][rank]
+    total_genomes = cfg["genomes"] if cfg["strong"] else cfg["genomes"] * world
     eng = Engine(device=local_rank, log2m=p, canonical=True)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     wl = Workload(torch, eng, ids, nb, cfg["nrec"], kmin, kmax)

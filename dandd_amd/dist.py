@@ -120,6 +120,16 @@ def gather_rows(rows, mine, n_total, device=None):
     return full.cpu().numpy()
 
 
+def allgather_geometry(n_total, world, K, m, most_held=0):
+    """Sizes of allgather_leaves' exchange, without a process group: every rank sends ONE padded [rows][K][m] uint8 slab
+    (rows = the largest shard, at least ceil(n_total / world) + 1) and receives `world` of them next to the job's whole
+    [n_total][K][m] slab.  -> dict(rows, sent_bytes, received_bytes, full_bytes, peak_bytes)."""
+    rows = max((n_total + world - 1) // world + 1, int(most_held))
+    sent = rows * K * m
+    return {"rows": rows, "sent_bytes": sent, "received_bytes": world * sent, "full_bytes": n_total * K * m,
+            "peak_bytes": sent + world * sent + n_total * K * m}
+
+
 def allgather_leaves(leaves, mine, n_total):
     """Every rank's leaf slabs (uint8 [len(mine)][K][m], genomes `mine` of the job) -> the job's whole
     [n_total][K][m] slab on every rank, in genome order: what `progressive` and `kij` need before their
@@ -134,10 +144,10 @@ def allgather_leaves(leaves, mine, n_total):
         full[torch.tensor(list(mine), device=leaves.device, dtype=torch.long)] = leaves
         return full
     world = dist.get_world_size()
-    most = (n_total + world - 1) // world + 1  # shards differ by at most one genome in count when sizes are equal; pad generously
     counts = [torch.zeros(1, dtype=torch.int64, device=leaves.device) for _ in range(world)]
     dist.all_gather(counts, torch.tensor([len(mine)], dtype=torch.int64, device=leaves.device))
-    most = max(most, max(int(c.item()) for c in counts))
+    # (shards differ by at most one genome in count when sizes are equal; padded generously: allgather_geometry)
+    most = allgather_geometry(n_total, world, K, m, max(int(c.item()) for c in counts))["rows"]
     ids = torch.full((most,), -1, dtype=torch.int64, device=leaves.device)
     ids[:len(mine)] = torch.tensor(list(mine), dtype=torch.int64, device=leaves.device)
     padded = torch.zeros((most, K, m), dtype=torch.uint8, device=leaves.device)

@@ -10,13 +10,14 @@ nb = int(float(sys.argv[2])) if len(sys.argv) > 2 else 50_000_000
 kmin = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 kmax = int(sys.argv[4]) if len(sys.argv) > 4 else 40
 p = int(sys.argv[5]) if len(sys.argv) > 5 else 14
+nrec = int(sys.argv[6]) if len(sys.argv) > 6 else 5
 eng = Engine(0, p, True)
 K = kmax - kmin + 1
 bufs = []
 for g in range(ng):
-    n = synth_size(nb, 5)
+    n = synth_size(nb, nrec)
     b = torch.empty(n + 16, dtype=torch.uint8, device="cuda")
-    eng.synth_fasta_device(0xD4ADD, g, nb, 5, b.data_ptr())
+    eng.synth_fasta_device(0xD4ADD, g, nb, nrec, b.data_ptr())
     bufs.append((b, n))
 regs = torch.empty((ng, K, 1 << p), dtype=torch.uint8, device="cuda")
 eng.synchronize()

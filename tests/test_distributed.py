@@ -32,6 +32,32 @@ def test_shard_plan_is_balanced_and_deterministic():
     assert shard_by_weight([], 4) == [[], [], [], []]
 
 
+def test_cfg5_and_cfg4_launch_geometry_on_eight_and_four_gpus():
+    """Row (e) stays launch-ready without a node to run it on: the plans `bench.py --config cfg5 --gpus 8` and
+    `--config cfg4 --gpus 4` would follow, checked for size on the CPU.  BASELINE cfg 5: 100 x 3 Gbp over 8 GPUs ->
+    13 / 12 genomes per rank, every genome on exactly one rank, <= 40 GB of FASTA per rank (288 GB of HBM each).
+    BASELINE cfg 4: 30 x 250 Mbp, k 2-32, 4 GPUs, DandD's default log2m 20: the padded slab a rank sends into the
+    all-gather of leaf sketches stays <= 2 GB (and the whole exchange far inside one GPU's memory)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from dandd_amd.dist import allgather_geometry
+    plan, fasta_bytes = bench.rank_shards(bench.CONFIGS["cfg5"], 8)
+    assert sorted(i for ids in plan for i in ids) == list(range(100))
+    assert sorted(len(ids) for ids in plan) == [12] * 4 + [13] * 4
+    assert max(fasta_bytes) <= 40e9 and min(fasta_bytes) >= 36e9
+    assert plan == bench.rank_shards(bench.CONFIGS["cfg5"], 8)[0]          # every rank computes the same plan
+    # a rank's share is what `--config cfg5share` benchmarks on one GPU
+    assert bench.CONFIGS["cfg5share"]["genomes"] == max(len(ids) for ids in plan)
+    cfg4 = bench.CONFIGS["cfg4"]
+    plan4, _ = bench.rank_shards(cfg4, 4)
+    assert sorted(len(ids) for ids in plan4) == [7, 7, 8, 8]
+    K = cfg4["kmax"] - cfg4["kmin"] + 1
+    geo = allgather_geometry(cfg4["genomes"], 4, K, 1 << 20, max(len(ids) for ids in plan4))
+    assert geo["rows"] == 9 and geo["sent_bytes"] == 9 * K * (1 << 20) <= 2e9
+    assert geo["full_bytes"] == 30 * K * (1 << 20) and geo["peak_bytes"] < 3e9
+    assert allgather_geometry(cfg4["genomes"], 4, K, 1 << 14)["sent_bytes"] < 5e6   # log2m 14: 4.6 MB per rank
+
+
 def test_two_rank_gloo_sweep_matches_single_process(orc, tmp_path):
     kmin, kmax, p = 9, 13, 10
     fastas = []
