@@ -471,9 +471,51 @@ struct Windows<6> {
     }
 };
 
+// The 128-bit class as four 32-bit words per window (see Windows<5>): used by the scatter kernels, whose push is paid per
+// (token, k) -- with u64 members the compiler spent 16 instructions on a push (two 64-bit copies, shift / or pairs,
+// and the funnel shifts that take the words apart again at the hash), this form 12.
+template <>
+struct Windows<7> {
+    uint32_t f0 = 0, f1 = 0, f2 = 0, f3 = 0;  // forward window, low .. high word
+    uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;  // reverse complement, top-aligned in 128 bits
+    DD_D void prime(const uint4& hc) {
+        f0 = pairrev32(hc.w);
+        f1 = pairrev32(hc.z);
+        f2 = pairrev32(hc.y);
+        f3 = pairrev32(hc.x);
+        r3 = ~hc.w;
+        r2 = ~hc.z;
+        r1 = ~hc.y;
+        r0 = ~hc.x;
+    }
+    DD_D void push(uint32_t c) {
+        f3 = __builtin_amdgcn_alignbit(f3, f2, 30);
+        f2 = __builtin_amdgcn_alignbit(f2, f1, 30);
+        f1 = __builtin_amdgcn_alignbit(f1, f0, 30);
+        f0 = (f0 << 2) | c;
+        r0 = __builtin_amdgcn_alignbit(r1, r0, 2);
+        r1 = __builtin_amdgcn_alignbit(r2, r1, 2);
+        r2 = __builtin_amdgcn_alignbit(r3, r2, 2);
+        r3 = (r3 >> 2) | ((3u - c) << 30);
+    }
+    template <bool CANON>
+    DD_D uint64_t hash(int k) const {  // 49 <= k <= 64, as Windows<2>
+        const int hb = 2 * k - 96;  // bits of the k-mer in the top word, 2..32
+        const uint32_t mh = (hb == 32) ? ~0u : ((1u << hb) - 1u);
+        const uint64_t ah = pack64(f3 & mh, f2);
+        const uint64_t al = pack64(f1, f0);
+        if (!CANON) return wang64_fast<false>(fold128(ah, al));
+        const uint32_t s = 128u - 2u * (uint32_t)k;  // 0..30
+        const uint64_t bh = pack64(r3 >> s, __builtin_amdgcn_alignbit(r3, r2, s));
+        const uint64_t bl = pack64(__builtin_amdgcn_alignbit(r2, r1, s), __builtin_amdgcn_alignbit(r1, r0, s));
+        const bool f_lt = (ah < bh) | ((ah == bh) & (al < bl));  // bitwise: no exec-mask short circuit
+        return wang64_fast<false>(fold128(f_lt ? ah : bh, f_lt ? al : bl));
+    }
+};
+
 // every k of the group for the token just pushed
-template <int KC, bool CANON, bool CHECK, typename MakeRegs>
-DD_D void sweep_token(const Windows<KC>& win, int run, int kfirst, int nk, int p, const MakeRegs& slot) {
+template <int KC, bool CANON, bool CHECK, typename Win, typename MakeRegs>
+DD_D void sweep_token(const Win& win, int run, int kfirst, int nk, int p, const MakeRegs& slot) {
     // The loop counter stays wave-uniform in both variants (k-dependent masks and shifts are then
     // scalar); in the CHECK variant lanes whose run is too short for k are simply predicated off.
     int j = 0;
@@ -576,7 +618,9 @@ __global__ __launch_bounds__(1024) void sweep_kernel(const SweepGenome* __restri
         const uint4 hc = cur.hc, sc = cur.sc;
         const uint2 hb = cur.hb, sb = cur.sb;
         const uint32_t cw[4] = {sc.x, sc.y, sc.z, sc.w};
-        Windows<KC> win;
+        // (the 128-bit class as 32-bit words, Windows<7>: 1.6 % at log2m 16, 0.6 % at 14 on k 49..64; the 64- and 96-bit
+        // classes measure equal to slightly slower in that form here, where one push serves several ks, and keep u64 members)
+        Windows<KC == 2 ? 7 : KC> win;
         win.prime(hc);
         if (__all((hb.x | hb.y | sb.x | sb.y) == 0u)) {
             // No BREAK within 128 tokens of any lane of the wave (the common case away from
@@ -1255,7 +1299,7 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
         const uint4 hc = in.hc, sc = in.sc;
         const uint2 hb = in.hb, sb = in.sb;
         const uint32_t cw[4] = {sc.x, sc.y, sc.z, sc.w};
-        Windows<KC == 1 ? 5 : (KC == 3 ? 6 : KC)> win;
+                Windows<KC == 1 ? 5 : (KC == 3 ? 6 : (KC == 2 ? 7 : KC))> win;
         win.prime(hc);
         if (__all((hb.x | hb.y | sb.x | sb.y) == 0u)) {
 #pragma unroll
@@ -1478,7 +1522,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KC == 2 ? 
         }
         const uint4 hc = in.hc, sc = in.sc;
         const uint2 hb = in.hb, sb = in.sb;
-        Windows<KC == 1 ? 5 : (KC == 3 ? 6 : KC)> win;
+                Windows<KC == 1 ? 5 : (KC == 3 ? 6 : (KC == 2 ? 7 : KC))> win;
         win.prime(hc);
         auto update = [&](uint32_t cnt_base, int i, bool valid) {
             const Probe q = probe(win.template hash<CANON>(k), p);
@@ -1591,7 +1635,7 @@ __global__ __launch_bounds__(1024) void scatter_first_bin_kernel(
             const uint2 hb = in.hb, sb = in.sb;
             const uint32_t cw[4] = {sc.x, sc.y, sc.z, sc.w};
             uint32_t* const bins = area + cpos + copy * kBinCap;  // this lane's copy of bin 0 of the chunk
-            Windows<KC == 1 ? 5 : (KC == 3 ? 6 : KC)> win;
+                    Windows<KC == 1 ? 5 : (KC == 3 ? 6 : (KC == 2 ? 7 : KC))> win;
             win.prime(hc);
             // (deferring a record's store until the next update's atomic is out, so that the slot's LDS round trip overlaps a
             // hash, and unrolling the token loop by two were both measured: no difference -- the loop is not waiting there)
