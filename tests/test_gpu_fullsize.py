@@ -327,7 +327,59 @@ def test_default_registers_whole_genome_3gbp(engine_factory, torch_cuda, orc):
         assert bad.size == 0, f"1 Gbp, log2m 20, k={k}: {bad.size} registers differ, first idx {bad[0]}: got {got[bad[0]]} want {want[bad[0]]}"
 
 
-@pytest.mark.parametrize("p", [14, 20])
+@pytest.mark.parametrize("p", [18, 20])
+def test_many_small_genomes_at_default_registers(engine_factory, torch_cuda, orc, p):
+    """A bacterial collection at DandD's defaults (cfg 3's genomes, -r 20): 64 x 5 Mbp in ONE call.  At log2m 20 the only
+    epoch is the unfiltered first one (4.8 tokens per register): every update is a record, binned straight into its index
+    tile's region of the row's stream (16 bins of 4480 per tile of tokens), the classes run back to back.  Rows of five
+    genomes against the oracle for one k of the 32-, 64- and 96-bit classes; the whole slab twice."""
+    torch = torch_cuda
+    eng = engine_factory(p, True)
+    ng, nb, kmin, kmax = 64, 5_000_000, 10, 40
+    K = kmax - kmin + 1
+    bufs, sizes = _device_genomes(torch, eng, [(g, nb, 5) for g in range(ng)])
+    regs = torch.empty((ng, K, eng.m), dtype=torch.uint8, device="cuda")
+    eng.sketch_device([b.data_ptr() for b in bufs], sizes, kmin, kmax, regs.data_ptr())
+    eng.synchronize()
+    for g, k in ((0, 12), (7, 16), (21, 17), (40, 31), (63, 40)):
+        got = regs[g, k - kmin].cpu().numpy()
+        want = orc.sketch(_host(bufs[g], sizes[g]), k, p, True)
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, f"log2m {p}, genome {g}, k={k}: {bad.size} registers differ, first idx {bad[0]}: got {got[bad[0]]} want {want[bad[0]]}"
+    again = torch.empty_like(regs)
+    eng.sketch_device([b.data_ptr() for b in bufs], sizes, kmin, kmax, again.data_ptr())
+    eng.synchronize()
+    assert torch.equal(regs, again)
+
+
+@pytest.mark.parametrize("p", [15, 16, 17])
+def test_cfg2_genome_between_the_register_regimes(engine_factory, torch_cuda, orc, p):
+    """The register counts between the two regimes that had full-size parity (14: several ks per LDS group; 18, 20:
+    scatter + replay), on the 50 Mbp BASELINE genome: log2m 15 (two ks per 80 KiB group), 16 -- where the metric's
+    accuracy clause is met: ONE k per group, the window push unshared -- and 17, the first size whose registers live in
+    HBM (two 64 KiB index tiles per row, first epoch binned).  One k of every kernel class (small-k sets, 32-, 64-,
+    96- and 128-bit windows) against the oracle, bit for bit, plus determinism of the whole slab."""
+    torch = torch_cuda
+    eng = engine_factory(p, True)
+    bufs, sizes = _device_genomes(torch, eng, [(0, 50_000_000, 5)])
+    kmin, kmax = 8, 52
+    K = kmax - kmin + 1
+    regs = torch.empty((1, K, eng.m), dtype=torch.uint8, device="cuda")
+    eng.sketch_device([bufs[0].data_ptr()], sizes, kmin, kmax, regs.data_ptr())
+    eng.synchronize()
+    fa = _host(bufs[0], sizes[0])
+    for k in (8, 13, 27, 41, 52):
+        got = regs[0, k - kmin].cpu().numpy()
+        want = orc.sketch(fa, k, p, True)
+        bad = np.flatnonzero(got != want)
+        assert bad.size == 0, f"log2m {p}, k={k}: {bad.size} registers differ, first idx {bad[0]}: got {got[bad[0]]} want {want[bad[0]]}"
+    again = torch.empty_like(regs)
+    eng.sketch_device([bufs[0].data_ptr()], sizes, kmin, kmax, again.data_ptr())
+    eng.synchronize()
+    assert torch.equal(regs, again)
+
+
+@pytest.mark.parametrize("p", [14, 16, 20])
 def test_cfg5_share_as_benchmarked(engine_factory, torch_cuda, p):
     """BASELINE cfg 5, one GPU's share exactly as `bench.py --config cfg5share` runs it: 13 x 3 Gbp (39.5 GB of
     FASTA) in ONE dd_sketch_device call, k 4..64 (K = 61).  Rows of the first and the last genome == their own
