@@ -228,35 +228,116 @@ def cpu_baseline(nbases, nrec, kmin, kmax, log2m, ngenomes=4):
     }
 
 
-def load_counters(cfg, kmin, kmax, p):
-    """profiles/r03_k1_counters_p<P>.json (scripts/profile_r03.sh: rocprofv3 --pmc passes over this very workload), or None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", f"r03_k1_counters_p{p}.json")) as f:
-            cj = json.load(f)
-        w = cj["workload"]
-        if (w["genomes"], w["mbp"], w["kmin"], w["kmax"], w["log2m"]) == (cfg["genomes"], cfg["mbp"], kmin, kmax, p):
-            return cj
-    except (OSError, KeyError, ValueError):
-        pass
+def load_counters(genomes, mbp, kmin, kmax, p):
+    """The committed rocprofv3 passes over this very workload -- profiles/r04_k1_counters_*.json (scripts/profile_r04.sh:
+    FETCH_SIZE, WRITE_SIZE, SQ and TCC in separate --pmc passes, round-4 kernels) -- or None when no file matches."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_k1_counters_*.json"))):
+        try:
+            with open(path) as f:
+                cj = json.load(f)
+            w = cj["workload"]
+            if (w["genomes"], w["mbp"], w["kmin"], w["kmax"], w["log2m"]) == (genomes, mbp, kmin, kmax, p):
+                cj["_file"] = "profiles/" + os.path.basename(path)
+                return cj
+        except (OSError, KeyError, ValueError):
+            pass
     return None
 
 
-def valu_bound(kmin, kmax, updates_per_s, counters):
+def isa_table():
+    """profiles/r04_isa_classes.json: instruction classes of K1's hot loops, counted by scripts/isa_classes.py in the ISA of
+    the shipped build and priced with the measured issue costs (profiles/r01_ubench_issue_costs.txt)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_isa_classes.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def issue_model(counters, kernel_s_per_step):
+    """valu_bound.frac_of_mix: the SIMD time the step's K1 instructions need at their measured issue cost, over the SIMD
+    time the step had.  Per kernel: SQ_INSTS_VALU of the committed counter file x the mean ns per instruction of THAT
+    kernel's hot loop in the ISA table (its cheap / dear mix; kernels without an entry -- replay, sort, the small-k
+    classes -- are priced at the mean of the two classes); summed and divided by 1024 SIMDs x the K1 time of a step."""
+    isa = isa_table()
+    if not counters or not isa or kernel_s_per_step <= 0:
+        return None
+    costs = isa["issue_costs"]
+    by_prefix = {}
+    for name, ent in isa["kernels"].items():
+        m = __import__("re").match(r"([a-z_]+)<(\d)", name)
+        if m:
+            ns = (ent["valu_cheap_per_update"] * costs["cheap_ns"] + ent["valu_dear_per_update"] * costs["dear_ns"]) / ent["valu_per_update"]
+            by_prefix[(m.group(1), m.group(2))] = (ns, ent["cheap_fraction"])
+    default_ns = 0.5 * (costs["cheap_ns"] + costs["dear_ns"])
+    busy_ns, rows = 0.0, {}
+    k1 = ("sweep_kernel", "bitmap", "scatter", "sort_chunks", "replay", "bigmap")
+    for name, ent in counters["kernels"].items():
+        if not name.startswith(k1) or "sq_insts_valu" not in ent:
+            continue
+        m = __import__("re").match(r"([a-z_]+)<(\d)", name)
+        key = (m.group(1), m.group(2)) if m else None
+        if key and key[0] == "scatter_first_wg_kernel":
+            key = ("scatter_first_bin_kernel", key[1])
+        ns, cheap = by_prefix.get(key, (default_ns, None))
+        busy_ns += ent["sq_insts_valu"] * ns
+        rows[name] = {"valu_wave_instr": ent["sq_insts_valu"], "ns_per_instr": ns, "cheap_fraction_of_hot_loop": cheap}
+    frac = busy_ns * 1e-9 / (1024.0 * kernel_s_per_step)
+    return {"frac_of_mix": frac, "simd_busy_ms_per_step": busy_ns * 1e-6 / 1024.0, "kernel_ms_per_step": kernel_s_per_step * 1e3,
+            "cheap_ns": costs["cheap_ns"], "dear_ns": costs["dear_ns"], "by_kernel": rows,
+            "from": "profiles/r04_isa_classes.json (scripts/isa_classes.py over the shipped build's ISA) x " + counters.get("_file", "the counter file") +
+                    " (SQ_INSTS_VALU per kernel and step); kernels that overlap on side streams (log2m >= 17) share the step's SIMD time"}
+
+
+def valu_bound(kmin, kmax, updates_per_s, counters, kernel_s_per_step=0.0):
     """The bound that actually binds K1: VALU issue.  Instructions per (token, k) are SQ_INSTS_VALU of the K1 kernels of
     one step divided by the step's wave-updates, read from the committed counter file (never a table in this script);
     a wave64 instruction occupies a SIMD-32 for 2 cycles at best, so the chip retires at most 256 CU x 4 SIMD x 2.4 GHz / 2
-    wave instructions per second (= 78.6 T lane-ops/s).  None when no counter file matches the workload."""
+    wave instructions per second (= 78.6 T lane-ops/s): `frac`.  `frac_of_mix` prices the same instructions at the issue
+    cost of their class instead (issue_model).  None when no counter file matches the workload."""
     if not counters:
         return None
     ipu = counters["k1_valu_instr_per_update"]
     achieved = updates_per_s * ipu  # lane-instructions per second
-    return {"valu_instr_per_update": ipu, "by_class": counters.get("valu_per_update_by_class"),
-            "achieved_lane_instr_per_s": achieved, "peak_lane_instr_per_s": VALU_PEAK_LANEOPS, "frac": achieved / VALU_PEAK_LANEOPS,
-            "instr_counts_from": f"profiles/r03_k1_counters_p{counters['workload']['log2m']}.json (SQ_INSTS_VALU of every K1 kernel of a step / "
-                                 "(bases x K / 64); scripts/profile_r03.sh)",
-            "note": "peak assumes every instruction is in the 2-cycle class; two thirds of K1's are in the 4-cycle class on gfx950 "
-                    "(64-bit shifts/adds, v_mad_u64_u32, v_mul_lo, v_cmp, v_ffbh): against that mix the log2m <= 16 kernels run at "
-                    "~98 % of issue (DESIGN.md section 4)"}
+    out = {"valu_instr_per_update": ipu, "by_class": counters.get("valu_per_update_by_class"),
+           "achieved_lane_instr_per_s": achieved, "peak_lane_instr_per_s": VALU_PEAK_LANEOPS, "frac": achieved / VALU_PEAK_LANEOPS,
+           "instr_counts_from": f"{counters.get('_file')} (SQ_INSTS_VALU of every K1 kernel of a step / (bases x K / 64); scripts/profile_r04.sh)"}
+    model = issue_model(counters, kernel_s_per_step)
+    if model:
+        out["frac_of_mix"] = model["frac_of_mix"]
+        out["issue_model"] = model
+    return out
+
+
+def k1_roofline(ng, nbytes, nb, K, m, p, kmin, kmax, sweep_ms, sweep_n, steps, genomes, mbp):
+    """The `roofline` object of one K1 configuration: algorithmic bytes over the HIP-event time of the step's K1 launches
+    against 8 TB/s, the counter-file traffic, and the VALU-issue bound -- for the headline and for every secondary line."""
+    counters = load_counters(genomes, mbp, kmin, kmax, p)
+    alg_bytes = ng * nbytes + ng * K * m
+    s_per_step = sweep_ms / 1e3 / steps
+    achieved = alg_bytes / s_per_step / 1e9
+    updates_per_s = ng * nb * K / s_per_step
+    return {
+        "bound": "hbm",
+        "kernel": "K1: sweep_kernel launches of one step" + (" (scatter + sort + replay at log2m >= 17; the first epoch binned straight from the hash)" if p >= 17 else ""),
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": counters["k1_bytes_per_step"]["total"] if counters else None,
+        "traffic_from": (f"{counters['_file']} (separate FETCH_SIZE / WRITE_SIZE passes of scripts/profile_r04.sh; fetch "
+                         f"{counters['k1_bytes_per_step']['fetch']:.4g} B = 2 x FETCH_SIZE, write {counters['k1_bytes_per_step']['write']:.4g} B)") if counters else None,
+        "traffic_note": "K1 bytes per step = 2 x FETCH_SIZE + WRITE_SIZE of separate PMC passes.  log2m <= 16: above the algorithmic bytes "
+                        "because each k-group re-reads the 3-bit token stream and every job merges its LDS registers into the slab "
+                        "(~230 GB/s, irrelevant to a VALU-bound kernel).  log2m >= 17: the record streams (written by scatter, read "
+                        "and rewritten by sort, read by replay) and the register tiles replay loads and stores per epoch",
+        "algorithmic_bytes_per_step": alg_bytes,
+        "kernel_ms_per_step": sweep_ms / steps,
+        "launches_per_step": sweep_n / steps,
+        "avg_launch_ms": sweep_ms / max(1, sweep_n),
+        "register_updates_per_s": updates_per_s,
+        "valu_lane_ops_peak": VALU_PEAK_LANEOPS,
+        "valu_bound": valu_bound(kmin, kmax, updates_per_s, counters, s_per_step),
+        "note": "integer-VALU bound (hash per (base,k)); see DESIGN.md for ops/update and the VALU fraction",
+    }
 
 
 class Workload:
@@ -557,12 +638,17 @@ def main():
                 for _ in range(2):
                     w2.step(ddist)
                 torch.cuda.synchronize()
+                e2.timing_enable(True)
+                e2.timing_reset()
                 t1 = time.perf_counter()
                 for _ in range(3):
                     _, _, card2 = w2.step(ddist)
                 torch.cuda.synchronize()
                 d2 = (time.perf_counter() - t1) / 3
-                entry = {"why": why, "value": ng * nb / d2 / 1e9, "unit": "Gbp/s", "ms_per_step": d2 * 1e3, "steps": 3}
+                sw2 = e2.timing_read(KERNEL_SWEEP)
+                e2.timing_enable(False)
+                entry = {"why": why, "value": ng * nb / d2 / 1e9, "unit": "Gbp/s", "ms_per_step": d2 * 1e3, "steps": 3,
+                         "roofline": k1_roofline(ng, nbytes, nb, K, 1 << p2, p2, kmin, kmax, sw2[0], sw2[1], 3, cfg["genomes"], cfg["mbp"])}
                 if p2 == 16 and not args.no_accuracy:
                     entry["accuracy_vs_exact"] = accuracy_block(w2, card2, "log2m 16, same genomes and k range")
                 sec[f"log2m{p2}"] = entry
@@ -578,13 +664,18 @@ def main():
                 for _ in range(2):
                     w3.step(ddist)
                 torch.cuda.synchronize()
+                e3.timing_enable(True)
+                e3.timing_reset()
                 t1 = time.perf_counter()
                 for _ in range(3):
                     w3.step(ddist)
                 torch.cuda.synchronize()
                 d3 = (time.perf_counter() - t1) / 3
+                sw3 = e3.timing_read(KERNEL_SWEEP)
+                e3.timing_enable(False)
                 sec["log2m20_64x5Mbp"] = {"why": "many small genomes at DandD's default -r 20", "value": 64 * 5_000_000 / d3 / 1e9,
-                                          "unit": "Gbp/s", "ms_per_step": d3 * 1e3, "steps": 3}
+                                          "unit": "Gbp/s", "ms_per_step": d3 * 1e3, "steps": 3,
+                                          "roofline": k1_roofline(64, w3.nbytes, 5_000_000, K, 1 << 20, 20, kmin, kmax, sw3[0], sw3[1], 3, 64, 5.0)}
                 del w3
                 e3.close()
                 torch.cuda.empty_cache()
@@ -640,14 +731,9 @@ def main():
             except Exception as e:
                 extras["ingest"]["one_big_gzip_file"] = {"error": f"{type(e).__name__}: {e}"}
 
-    # HBM-side traffic of K1 per step: PMC counters cannot be read from inside this process, so the number comes from the
-    # committed rocprofv3 passes over this very workload (profiles/r03_k1_counters_p<P>.json, scripts/profile_r03.sh) and
-    # is only reported when this run's workload is the profiled one.
-    counters = load_counters(cfg, kmin, kmax, p)
-    traffic = counters["k1_bytes_per_step"]["total"] if counters else None
-    traffic_src = (f"profiles/r03_k1_counters_p{p}.json (round-3 kernels; separate FETCH_SIZE / WRITE_SIZE passes of scripts/profile_r03.sh; "
-                   f"fetch {counters['k1_bytes_per_step']['fetch']:.4g} B = 2 x FETCH_SIZE, write {counters['k1_bytes_per_step']['write']:.4g} B)") if counters else None
-
+    # (HBM-side traffic of K1 per step: PMC counters cannot be read from inside this process, so the number comes from the
+    # committed rocprofv3 passes over this very workload -- k1_roofline / load_counters -- and is only reported when this
+    # run's workload is a profiled one)
     # the K2 schedule of the config (all pairs / progressive) timed on its own, against its own roofline
     k2 = None
     if rank == 0 and cfg["extra"] and ng:
@@ -661,39 +747,64 @@ def main():
             run()
         k2_ms = eng.timing_read(KERNEL_UNION)[0] / 3
         eng.timing_enable(False)
+        path = eng.last_k2_path()     # which device form ran (dd_last_k2_path): never assumed from log2m or n here
         hist_bytes = 256
-        if cfg["extra"] == "pairwise":
-            lo = slab[:n].amin(dim=(0, 2)).cpu().numpy().astype(int)
-            hi = slab[:n].amax(dim=(0, 2)).cpu().numpy().astype(int)
-            thresholds = [int(b - a) for a, b in zip(lo, hi)]
+        lo = slab[:n].amin(dim=(0, 2)).cpu().numpy().astype(int)
+        hi = slab[:n].amax(dim=(0, 2)).cpu().numpy().astype(int)
+        thresholds = [int(b - a) for a, b in zip(lo, hi)]        # per k: the register values between which a threshold says something
+
+        def k2_traffic(tag):
+            for rnd in ("r04", "r03"):
+                try:
+                    with open(os.path.join(ROOT, "profiles", f"{rnd}_k2_counters_{tag}_p{p}.json")) as f:
+                        kj = json.load(f)
+                    if (kj["workload"]["genomes"], kj["workload"]["K"], kj["workload"]["log2m"]) == (n, K, p) and kj["workload"].get("path", path) == path:
+                        return kj["bytes_per_launch"]["total"], f"profiles/{rnd}_k2_counters_{tag}_p{p}.json"
+                except (OSError, KeyError, ValueError):
+                    pass
+            return None, None
+
+        if cfg["extra"] == "pairwise" and path == "pairwise_gram":
             ns = (n + 63) // 64
             blocks = ns * 3 + ns * (ns - 1) // 2 * 4                      # 32 x 32 blocks per (k, threshold, 32 registers)
-            stream_env = bool(os.environ.get("DD_PAIRWISE_STREAM"))
             mfma = sum(thresholds) * (m // 32) * blocks
             tops = 2.0 * 32 * 32 * 32 * mfma / (k2_ms / 1e3) / 1e12
-            k2 = {"bound": "mfma", "kernel": "gram_kernel + range + finish + mle (dd_gram.hip: all pairs as int8 Gram matrices, v_mfma_i32_32x32x32_i8)"
-                  if not stream_env else "pairwise_kernel (streaming, DD_PAIRWISE_STREAM=1)",
+            k2 = {"bound": "mfma", "path": path,
+                  "kernel": "gram_kernel + range + finish + mle (dd_gram.hip: all pairs as int8 Gram matrices, v_mfma_i32_32x32x32_i8)",
                   "achieved": tops, "peak": 5000.0, "unit": "TOP/s", "frac": tops / 5000.0,
                   "peak_note": "int8 dense = 2 x the bf16 dense peak of MI355X_MICROARCH.md (2.5 PF) at 2.4 GHz; the chip holds ~2.06 GHz under this load",
                   "ms": k2_ms, "pairs": n * (n + 1) // 2, "thresholds_per_k": thresholds,
                   "useful_fraction_of_blocks": (n * (n + 1) / 2) / (blocks * 1024.0),
-                  "compulsory_bytes": n * K * m + n * (n + 1) // 2 * K * hist_bytes,
-                  "traffic": None, "traffic_from": None}
-            try:
-                with open(os.path.join(ROOT, "profiles", f"r03_k2_counters_cfg3_p{p}.json")) as f:
-                    kj = json.load(f)
-                if (kj["workload"]["genomes"], kj["workload"]["K"], kj["workload"]["log2m"]) == (n, K, p):
-                    k2["traffic"], k2["traffic_from"] = kj["bytes_per_launch"]["total"], f"profiles/r03_k2_counters_cfg3_p{p}.json"
-            except (OSError, KeyError, ValueError):
-                pass
+                  "compulsory_bytes": n * K * m + n * (n + 1) // 2 * K * hist_bytes}
+            k2["traffic"], k2["traffic_from"] = k2_traffic("cfg3")
+        elif cfg["extra"] == "progressive" and path == "progressive_pscan":
+            # bit-plane scan: every (ordering, threshold) chain reads its 32 bytes of plane per prefix and 256 registers
+            # from LDS -- that read stream is what the kernel is made of: priced against the LDS
+            lds_bytes = float(len(orderings)) * n * sum(thresholds) * (m // 8)
+            lds_peak = 128.0 * 256 * 2.4e9 / 1e9                         # 128 B per clock and CU, 256 CUs, 2.4 GHz: GB/s
+            gbs = lds_bytes / (k2_ms / 1e3) / 1e9
+            k2 = {"bound": "lds", "path": path,
+                  "kernel": "pscan_kernel + register range + finish + mle (dd_pscan.hip: running AND of threshold bit planes, one popcount per prefix)",
+                  "achieved": gbs, "peak": lds_peak, "unit": "GB/s", "frac": gbs / lds_peak, "ms": k2_ms,
+                  "lds_bytes_read": lds_bytes, "thresholds_per_k": thresholds,
+                  "algorithmic_bytes": len(orderings) * n * K * hist_bytes + n * K * m,
+                  "note": "achieved = plane bytes the chains read from LDS (orderings x prefixes x thresholds x m / 8) over the launch time; peak = "
+                          "ds_read_b128 rate of MI355X_MICROARCH.md (128 B/clk/CU).  HBM sees the leaf slab once (n x K x m) plus the histograms",
+                  "pmc": "profiles/r03_k2_pscan_pmc_p20.txt (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 39-42 %: the gap to the roof)"}
+            k2["traffic"], k2["traffic_from"] = k2_traffic("cfg4share" if n == 8 else "cfg4")
         else:
-            nbytes_alg = len(orderings) * n * K * m + len(orderings) * n * K * hist_bytes
+            stream_pairs = cfg["extra"] == "pairwise"
+            units = n * (n + 1) // 2 if stream_pairs else len(orderings) * n
+            nbytes_alg = units * K * m * (2 if stream_pairs else 1) + units * K * hist_bytes
             gbs = nbytes_alg / (k2_ms / 1e3) / 1e9
-            k2 = {"bound": "hbm", "kernel": "progressive_kernel (running byte-max along every ordering, one LDS histogram per prefix)",
+            k2 = {"bound": "hbm", "path": path,
+                  "kernel": "pairwise_kernel (streaming: byte-max of two rows, one LDS histogram per pair)" if stream_pairs else
+                            "progressive_kernel (running byte-max along every ordering, one LDS histogram per prefix)",
                   "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "ms": k2_ms,
-                  "algorithmic_bytes": nbytes_alg, "traffic": None,
-                  "note": "bytes = one new leaf row read per (ordering, prefix, k) + the histograms written; the kernel is bound by one LDS atomic "
-                          "per register per prefix, not by HBM (DESIGN.md, K2)"}
+                  "algorithmic_bytes": nbytes_alg,
+                  "note": "bytes = the rows read per (pair | ordering, prefix) and k + the histograms written; the kernel is bound by one LDS atomic "
+                          "per register per unit, not by HBM (DESIGN.md, K2)"}
+            k2["traffic"], k2["traffic_from"] = k2_traffic(("cfg3" if stream_pairs else ("cfg4share" if n == 8 else "cfg4")))
 
     # BASELINE cfg 5's accuracy clause ("delta within 1 % of exact on a subsample"): genome 0 of the share, exact
     # distinct k-mers (GPU sort + distinct, in passes) at the HLL's argmax-k and its neighbours and at k = 31 and kmax
@@ -714,10 +825,6 @@ def main():
         steps = args.steps
         total_bases = total_genomes * nb * steps
         # algorithmic bytes of one step on one GPU: FASTA read once + registers written once
-        alg_bytes = ng * nbytes + ng * K * m
-        sweep_s_per_step = sweep_ms / 1e3 / steps
-        achieved_gbs = alg_bytes / sweep_s_per_step / 1e9
-        updates_per_s = ng * nb * K / sweep_s_per_step
         out = {
             "metric": "Gbp/s sketched over k-sweep",
             "value": total_bases / dt / 1e9,
@@ -744,28 +851,7 @@ def main():
                 "genomes_per_gpu": ng, "bases_per_genome": nb, "kmin": kmin, "kmax": kmax, "log2m": p,
                 "parallelism": f"genomes sharded over {world} GPU(s)" + ("; RCCL max all-reduce of the root" if use_group else ""),
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "K1: sweep_kernel launches of one step" + (" (scatter + sort + replay at log2m >= 17)" if p >= 17 else ""),
-                "achieved": achieved_gbs,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved_gbs / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_from": traffic_src,
-                "traffic_note": "K1 bytes per step = 2 x FETCH_SIZE + WRITE_SIZE of separate PMC passes.  log2m <= 16: above the algorithmic bytes "
-                                "because each k-group re-reads the 3-bit token stream and every job merges its LDS registers into the slab "
-                                "(~230 GB/s, irrelevant to a VALU-bound kernel).  log2m >= 17: the record streams (written by scatter, read "
-                                "and rewritten by sort, read by replay) and the register tiles replay loads and stores per epoch",
-                "algorithmic_bytes_per_step": alg_bytes,
-                "kernel_ms_per_step": sweep_ms / steps,
-                "launches_per_step": sweep_n / steps,
-                "avg_launch_ms": sweep_ms / max(1, sweep_n),
-                "register_updates_per_s": updates_per_s,
-                "valu_lane_ops_peak": VALU_PEAK_LANEOPS,
-                "valu_bound": valu_bound(kmin, kmax, updates_per_s, counters),
-                "note": "integer-VALU bound (hash per (base,k)); see DESIGN.md for ops/update and the VALU fraction",
-            },
+            "roofline": k1_roofline(ng, nbytes, nb, K, m, p, kmin, kmax, sweep_ms, sweep_n, steps, cfg["genomes"], cfg["mbp"]),
             "other_kernels_ms_per_step": {"pack_K0": pack_ms / steps, "union_hist_K2": union_ms / steps},
             "roofline_k2": k2,
             # the HBM-bound kernel of the path: FASTA bytes read once + 3 bits per base written

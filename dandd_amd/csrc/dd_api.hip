@@ -147,6 +147,7 @@ struct dd_ctx {
     // stats of the last sketch call
     uint64_t st_tokens = 0, st_updates = 0;
     int st_blocks = 0;
+    int k2_path = 0;  // DD_K2_*: what the last progressive / pairwise call ran
 };
 
 namespace {
@@ -1404,6 +1405,7 @@ int dd_progressive_device(dd_ctx* c, const uint8_t* leaf_dev, int n, int K, cons
             done = dd::launch_progressive_pscan(leaf_dev, n, K, c->p, static_cast<const int32_t*>(c->ord.p), norder, rng.data(), c->gram.p,
                                                 static_cast<uint32_t*>(c->hist.p), c->stream);
         }
+        c->k2_path = done ? DD_K2_PROGRESSIVE_PSCAN : DD_K2_PROGRESSIVE_STREAM;
         if (!done)
             dd::launch_progressive(leaf_dev, n, K, c->p, static_cast<const int32_t*>(c->ord.p), norder,
                                    static_cast<uint32_t*>(c->hist.p), c->stream);
@@ -1436,6 +1438,7 @@ int dd_pairwise_device(dd_ctx* c, const uint8_t* leaf_dev, int n, int K, double*
     // kernel of dd_union.hip (one LDS atomic per register per pair) for A/B runs and for the equality test
     const bool gram = dd::gram_usable(n, c->p) && !getenv("DD_PAIRWISE_STREAM");
     if (gram && (rc = c->gram.reserve(dd::gram_scratch_bytes(n, K, c->p, nullptr)))) return rc;
+    c->k2_path = gram ? DD_K2_PAIRWISE_GRAM : DD_K2_PAIRWISE_STREAM;
     {
         Span sp(c, DD_KERNEL_UNION);
         if (gram) {
@@ -1518,6 +1521,11 @@ int dd_last_sketch_stats(dd_ctx* c, uint64_t* tokens, uint64_t* updates, int* sw
     if (updates) *updates = c->st_updates;
     if (sweep_blocks) *sweep_blocks = c->st_blocks;
     return DD_OK;
+}
+
+int dd_last_k2_path(dd_ctx* c) {
+    if (check_ctx(c)) return DD_EINVAL;
+    return c->k2_path;
 }
 
 // --------------------------------------------------------------------------- synthetic

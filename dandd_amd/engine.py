@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdandd_hip.so")
 
 KERNEL_PACK, KERNEL_SWEEP, KERNEL_UNION = 0, 1, 2
-ABI_VERSION = 2   # include/dandd_hip.h: DD_ABI_VERSION
+ABI_VERSION = 3   # include/dandd_hip.h: DD_ABI_VERSION
 
 EXPORTS = [
     "dd_abi_version", "dd_last_error", "dd_create", "dd_destroy", "dd_set_stream", "dd_synchronize",
@@ -26,7 +26,7 @@ EXPORTS = [
     "dd_card", "dd_card_batch", "dd_card_batch_device", "dd_hist_batch_device", "dd_ertl_mle",
     "dd_progressive", "dd_progressive_device", "dd_pairwise", "dd_pairwise_device",
     "dd_exact_count", "dd_exact_count_device",
-    "dd_timing_enable", "dd_timing_read", "dd_timing_reset", "dd_last_sketch_stats",
+    "dd_timing_enable", "dd_timing_read", "dd_timing_reset", "dd_last_sketch_stats", "dd_last_k2_path",
     "dd_synth_size", "dd_synth_fasta_device", "dd_synth_realistic_size", "dd_synth_realistic_device", "dd_plan_sweep",
 ]
 
@@ -124,6 +124,8 @@ def load_library(path=None):
     lib.dd_timing_reset.argtypes = [vp]
     lib.dd_last_sketch_stats.restype = i32
     lib.dd_last_sketch_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(i32)]
+    lib.dd_last_k2_path.restype = i32
+    lib.dd_last_k2_path.argtypes = [vp]
     lib.dd_synth_size.restype = sz
     lib.dd_synth_size.argtypes = [u64, i32]
     lib.dd_synth_fasta_device.restype = i32
@@ -354,6 +356,15 @@ class Engine:
         t, u, b = C.c_uint64(), C.c_uint64(), C.c_int()
         self._check(self._lib.dd_last_sketch_stats(self._ctx, C.byref(t), C.byref(u), C.byref(b)))
         return t.value, u.value, b.value
+
+    K2_PATHS = {0: None, 1: "progressive_stream", 2: "progressive_pscan", 3: "pairwise_stream", 4: "pairwise_gram"}
+
+    def last_k2_path(self):
+        """Which device form the last progressive / pairwise call took (include/dandd_hip.h: DD_K2_*)."""
+        rc = self._lib.dd_last_k2_path(self._ctx)
+        if rc < 0:
+            self._check(rc)
+        return self.K2_PATHS[rc]
 
     def warmup(self):
         """One tiny sketch + cardinality: HIP loads a kernel module at its first launch, this makes the first launches

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 2
+#define DD_ABI_VERSION 3
 
 #define DD_OK 0
 #define DD_EINVAL (-1)   /* bad argument */
@@ -142,6 +142,15 @@ int dd_timing_reset(dd_ctx *);
 /* per-call statistics of the last dd_sketch_* call: tokens (bases + breaks) packed,
  * register updates issued (tokens x K upper bound), number of sweep workgroups */
 int dd_last_sketch_stats(dd_ctx *, uint64_t *tokens, uint64_t *updates, int *sweep_blocks);
+/* which kernels the last dd_progressive* / dd_pairwise* call of the context ran (ABI 3): the union schedules of
+ * lib/huffman_dandd.py:644-695 have two device forms each, picked by register count and set sizes -- a benchmark
+ * line must name the one that ran, not the one its author expected */
+#define DD_K2_NONE 0
+#define DD_K2_PROGRESSIVE_STREAM 1 /* progressive_kernel: running byte-max, one LDS histogram per prefix  */
+#define DD_K2_PROGRESSIVE_PSCAN 2  /* pscan_kernel: running AND of threshold bit planes (log2m >= 18, n <= 32) */
+#define DD_K2_PAIRWISE_STREAM 3    /* pairwise_kernel: one LDS atomic per register per pair */
+#define DD_K2_PAIRWISE_GRAM 4      /* gram_kernel: int8 Gram matrices on the matrix cores (log2m >= 12) */
+int dd_last_k2_path(dd_ctx *);
 
 /* ---- synthetic FASTA on the device (bench / tests) ----------
  * Byte-identical to oracle/dd_oracle.c:orc_synth_fasta for the same arguments. */

@@ -29,6 +29,7 @@ int main(void) {
         return 17;
     }
     if (!strlen(dd_last_error())) return 18;
+    if (dd_last_k2_path(NULL) >= 0) return 19; /* ABI 3: a query on no context is an error code, not a path */
     printf("abi_consumer: ok (%ld jobs)\n", n);
     return 0;
 }

@@ -102,6 +102,47 @@ def test_bench_config_presets_run(torch_cuda, config, extra):
     assert j["scaling"] == ("strong" if config == "cfg3" else "weak") and j["value"] > 0 and np.isfinite(j["delta_root"])
     assert config in j["config"]["workload"] and j["roofline"]["kernel_ms_per_step"] > 0
     assert "accuracy_vs_exact" not in j and "secondary" not in j      # only the headline config carries those
+    # the K2 object names the device form that RAN (dd_last_k2_path), on the roof that form is bound by
+    k2 = j["roofline_k2"]
+    if config == "cfg3":
+        assert k2["path"] == "pairwise_gram" and k2["bound"] == "mfma" and "gram_kernel" in k2["kernel"]
+    elif config == "cfg4share":
+        assert k2["path"] == "progressive_stream" and k2["bound"] == "hbm" and "progressive_kernel" in k2["kernel"]   # log2m 14
+    else:
+        assert k2 is None
+
+
+@pytest.mark.gpu
+def test_bench_progressive_line_names_the_bit_plane_scan_at_log2m_20(torch_cuda):
+    """From log2m 18 on (n <= 32) dd_progressive_device runs the bit-plane AND-scan: the line must say pscan_kernel and
+    price it against the LDS read rate -- round 3's line named progressive_kernel on the HBM roof for a kernel that had not run."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "cfg4share", "--steps", "1", "--warmup", "1", "--mbp", "2",
+                        "--log2m", "20", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    k2 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["roofline_k2"]
+    assert k2["path"] == "progressive_pscan" and k2["bound"] == "lds" and "pscan_kernel" in k2["kernel"]
+    assert k2["unit"] == "GB/s" and k2["peak"] == pytest.approx(128 * 256 * 2.4) and 0 < k2["frac"] < 1 and k2["lds_bytes_read"] > 0
+
+
+def test_committed_counter_files_feed_the_issue_model():
+    """bench.py's valu_bound is computed from COMMITTED evidence only: profiles/r04_k1_counters_*.json (PMC passes) and
+    profiles/r04_isa_classes.json (instruction classes of the hot loops in the shipped ISA x measured issue costs).
+    On the CPU: the files load for the headline workload, for DandD's default registers, for the small-genome
+    regime and for the cfg 5 share; the log2m 14 kernels come out at 90-105 % of issue for their own instruction mix."""
+    sys.path.insert(0, ROOT)
+    import bench
+    isa = bench.isa_table()
+    assert isa and {"sweep_kernel<0, true, 0>", "sweep_kernel<1, true, 0>", "sweep_kernel<3, true, 0>", "sweep_kernel<2, true, 0>"} <= set(isa["kernels"])
+    assert 2.2 < isa["issue_costs"]["cheap_cycles"] < 2.7 and 4.0 < isa["issue_costs"]["dear_cycles"] < 4.5
+    for args in ((10, 50.0, 4, 40, 14), (10, 50.0, 4, 40, 16), (10, 50.0, 4, 40, 20), (64, 5.0, 4, 40, 20),
+                 (13, 3000.0, 4, 64, 14), (13, 3000.0, 4, 64, 16), (13, 3000.0, 4, 64, 20)):
+        c = bench.load_counters(*args)
+        assert c is not None and c["k1_bytes_per_step"]["total"] > 0 and c["k1_valu_instr_per_update"] > 10, args
+    c14 = bench.load_counters(10, 50.0, 4, 40, 14)
+    k1_ms = sum(v.get("ms_per_step_in_pmc_run", 0.0) for k, v in c14["kernels"].items() if k.startswith(("sweep_kernel", "bitmap")))
+    vb = bench.valu_bound(4, 40, 10 * 50e6 * 37 / (k1_ms / 1e3), c14, k1_ms / 1e3)
+    assert 0.45 < vb["frac"] < 0.6 and 0.9 < vb["frac_of_mix"] < 1.05, (vb["frac"], vb["frac_of_mix"])
+    assert bench.load_counters(3, 2.0, 4, 40, 14) is None
 
 
 @pytest.mark.gpu
@@ -201,6 +242,13 @@ def test_bench_headline_line_has_every_object(torch_cuda):
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "weak" and j["higher_is_better"] is True
     rf = j["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1 and rf["traffic"] is None and rf["valu_bound"] is None
+    # every secondary K1 line carries its own roofline; the small-genome one is a fixed workload with committed counters
+    for name in ("log2m16", "log2m20", "log2m20_64x5Mbp"):
+        r2 = j["secondary"][name]["roofline"]
+        assert r2["bound"] == "hbm" and 0 < r2["frac"] < 1 and r2["kernel_ms_per_step"] > 0, name
+    small = j["secondary"]["log2m20_64x5Mbp"]["roofline"]
+    assert small["traffic"] > 50e9 and "r04_k1_counters_64x5_p20.json" in small["traffic_from"]
+    assert 0 < small["valu_bound"]["frac_of_mix"] < 1.2 and small["valu_bound"]["issue_model"]["by_kernel"]
     cb = j["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and set(cb["stages_s"]) == {"stage1_leaf_sketches", "leaf_cards", "stage2_progressive_unions_and_cards",
                                                                               "stage3_nway_union_and_card"}
