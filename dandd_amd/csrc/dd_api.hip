@@ -704,6 +704,13 @@ int dd_sketch_buffer(dd_ctx* c, const uint8_t* fasta, size_t nbytes, int kmin, i
     DeviceGuard guard(c->device);
     const size_t K = (size_t)(kmax - kmin + 1), m = (size_t)1 << c->p;
     int rc;
+    // (FASTQ in a host buffer: resolved into the FASTA K0 reads, as the file paths do -- dd_io.h)
+    FileBuf fq;
+    if (dd::has_plus_line(fasta, nbytes)) {
+        if (!fq.reserve(nbytes + 16)) return fail(DD_ENOMEM, "out of host memory");
+        fq.len = nbytes = dd::fastq_to_fasta(fasta, nbytes, fq.p);
+        fasta = fq.p;
+    }
     if ((rc = c->fasta.reserve(nbytes + 16))) return rc;
     if ((rc = c->regs.reserve(K * m))) return rc;
     if (nbytes) DD_HIP(hipMemcpyAsync(c->fasta.p, fasta, nbytes, hipMemcpyHostToDevice, c->stream));
@@ -915,10 +922,19 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
                 if (!ok) err = std::string("read error on ") + paths[it.file];
                 if (f) fclose(f);
             }
+            bool last;
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (!ok && sl.ok) sl.ok = false, sl.err = err;
-                if (--sl.pieces_left == 0) sl.done = true;
+                last = --sl.pieces_left == 0;
+            }
+            if (last) {
+                // a plain file read in pieces is whole now: FASTQ records are resolved before K0 sees the bytes (dd_io.h;
+                // read_fasta_file has done the same for the files that came through zlib)
+                if (it.len && ok && !dd::normalize_records(fb)) ok = false, err = std::string("out of host memory reading ") + paths[it.file];
+                std::lock_guard<std::mutex> lk(mu);
+                if (!ok && sl.ok) sl.ok = false, sl.err = err;
+                sl.done = true;
             }
             cv.notify_all();
         }

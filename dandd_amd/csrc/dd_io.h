@@ -221,8 +221,99 @@ inline int read_gzip_whole(const char* path, FileBuf& out, int par = 1) {
     return rc;
 }
 
-// Whole FASTA file into memory; gzip (any number of members) or plain, decided by zlib itself.
+inline bool read_file_bytes(const char* path, FileBuf& out, std::string& err, int par);
+
+// ---- FASTQ ---------------------------------------------------------------------------------------------------------
+// `dashing sketch` reads its inputs through klib's kseq.h, which takes FASTA and FASTQ alike
+// (/root/reference/lib/sketch_classes.py:358-365 hands it whatever the species directory holds).  K0's line machine
+// knows kseq's FASTA rules; a FASTQ record's quality text is a length-counted field that a parallel tokenizer cannot
+// delimit, so buffers that hold a '+' line are rewritten on the host -- by kseq's own state machine, as recalled
+// (oracle/POLICIES.md P10) -- into the FASTA K0 reads: one ">" line and one sequence line per record.
+inline bool has_plus_line(const uint8_t* p, size_t n) {
+    if (n && p[0] == '+') return true;
+    for (const uint8_t* q = p; n && (q = static_cast<const uint8_t*>(memchr(q, '+', (size_t)(p + n - q)))) != nullptr; ++q)
+        if (q > p && q[-1] == '\n') return true;
+    return false;
+}
+// src[0..n) -> dst (at least n + 2 bytes; may be src itself: the output never runs ahead of the input by more than two
+// bytes, which memmove tolerates); returns the bytes written
+inline size_t fastq_to_fasta(const uint8_t* src, size_t n, uint8_t* dst) {
+    size_t i = 0, o = 0;
+    bool have_header = false;  // kseq's last_char: the next record's header character has been consumed
+    for (;;) {
+        if (!have_header) {
+            while (i < n && src[i] != '>' && src[i] != '@') ++i;
+            if (i >= n) break;
+            ++i;
+        }
+        have_header = false;
+        while (i < n && src[i] != '\n') ++i;
+        const bool header_closed = i < n;
+        if (i < n) ++i;
+        // (in place: everything read so far is at least as long as what goes out, except for a header cut short by the
+        // end of the buffer -- hence the two bytes of slack)
+        dst[o++] = '>';
+        if (header_closed || i < n) dst[o++] = '\n';
+        size_t seq_len = 0;
+        int c = -1;
+        while (i < n) {
+            c = src[i];
+            if (c == '>' || c == '+' || c == '@') break;
+            if (c == '\n') {
+                ++i;
+                c = -1;
+                continue;
+            }
+            size_t e = i;
+            while (e < n && src[e] != '\n') ++e;
+            size_t len = e - i;
+            if (len && src[e - 1] == '\r' && seq_len + len > 1) --len;  // one '\r' in front of the line end goes
+            memmove(dst + o, src + i, len);
+            // (sequence lines are joined: a '>' or '@' that was in the middle of a line must not end up at a line start)
+            o += len;
+            seq_len += len;
+            i = e < n ? e + 1 : e;
+            c = -1;
+        }
+        if (seq_len) dst[o++] = '\n';
+        if (i >= n) break;
+        if (c == '>' || c == '@') {
+            ++i;
+            have_header = true;
+            continue;
+        }
+        while (i < n && src[i] != '\n') ++i;  // the rest of the '+' line
+        if (i < n) ++i;
+        size_t qual_len = 0;
+        while (i < n && qual_len < seq_len) {
+            size_t e = i;
+            while (e < n && src[e] != '\n') ++e;
+            size_t len = e - i;
+            if (len && src[e - 1] == '\r' && qual_len + len > 1) --len;
+            qual_len += len;
+            i = e < n ? e + 1 : e;
+        }
+    }
+    return o;
+}
+// a file's bytes as K0 wants them; false: out of memory
+inline bool normalize_records(FileBuf& fb) {
+    if (!has_plus_line(fb.p, fb.len)) return true;
+    if (!fb.reserve(fb.len + 16)) return false;
+    fb.len = fastq_to_fasta(fb.p, fb.len, fb.p);
+    return true;
+}
+
+// Whole FASTA (or FASTQ) file into memory; gzip (any number of members) or plain, decided by zlib itself.
 inline bool read_fasta_file(const char* path, FileBuf& out, std::string& err, int par = 1) {
+    if (!read_file_bytes(path, out, err, par)) return false;
+    if (!normalize_records(out)) {
+        err = std::string("out of host memory reading ") + path;
+        return false;
+    }
+    return true;
+}
+inline bool read_file_bytes(const char* path, FileBuf& out, std::string& err, int par) {
     const int fast = read_gzip_whole(path, out, par);
     if (fast == 1) return true;
     if (fast < 0) {

@@ -26,9 +26,9 @@ constexpr int kPackBytesPerThread = 64;
 constexpr int kPackChunk = kPackThreads * kPackBytesPerThread;  // 16 KiB of FASTA per K0 workgroup
 constexpr int kSegTokens = 64;                 // tokens per K1 thread segment
 
-// scratch for one K0 run over n bytes: 4 x int64 per chunk
+// scratch for one K0 run over n bytes: 4 x int64 per chunk, + one for the position of the first header character
 inline size_t pack_chunks(size_t n) { return (n + kPackChunk - 1) / kPackChunk; }
-inline size_t pack_scratch_bytes(size_t n) { return (pack_chunks(n) + 1) * 4 * sizeof(long long); }
+inline size_t pack_scratch_bytes(size_t n) { return ((pack_chunks(n) + 1) * 4 + 2) * sizeof(long long); }
 // capacity (in u32 words) of the code / bad arrays for an n-byte FASTA (tokens <= n)
 inline size_t codes_words(size_t n) { return ((n + 63) / 64 + 1) * 4; }
 inline size_t bad_words(size_t n) { return ((n + 63) / 64 + 1) * 2; }

@@ -4,7 +4,12 @@
 // bonsai's 2-bit encoder; command built at /root/reference/lib/sketch_classes.py:351-366):
 // headers and newlines are dropped, A/C/G/T (either case) become 0..3, every other byte and
 // every record boundary becomes a BREAK that resets the k-mer windows.  The oracle's
-// statement of the same rules is oracle/dd_oracle.c:orc_tokenize.
+// statement of the same rules is oracle/dd_oracle.c:orc_records + orc_tokenize.
+// Record rules (kseq's FASTA rules as recalled, oracle/POLICIES.md P10): everything before the FIRST '>' or '@' of the
+// buffer (anywhere, not only at a line start) is skipped -- pack_first finds it, the bytes in front of it read as
+// newlines --; a line that starts with '>' or '@' is a header line; a '\r' right in front of a line end (or of the end of
+// the buffer) is dropped, any other '\r' is an ambiguous byte.  FASTQ records ('+' lines, quality text) are resolved on
+// the host before the bytes get here (dd_io.h: fastq_to_fasta; dd_sketch_device takes FASTA).
 //
 // The only state that crosses a byte is "am I inside a header line" (1 bit).  A span of bytes
 // acts on that bit as IDENTITY (no newline and no line start in it), or as a CONSTANT (it contains a
@@ -44,10 +49,12 @@ struct Bytes16 {
     DD_D uint32_t at(int i) const { return (w[i >> 2] >> ((i & 3) * 8)) & 0xFFu; }
 };
 
-// 16 bytes; bytes at or beyond n read as '\r' (emits nothing, changes nothing)
-DD_D Bytes16 load16(const uint8_t* fa, size_t n, size_t pos) {
+// 16 bytes; bytes at or beyond n, and bytes in front of the buffer's first header character (`first`), read as '\n':
+// outside a header line a newline emits nothing, inside one it closes the line -- a header that the end of the buffer
+// cuts short still yields its record's BREAK -- and what follows it is a line start.
+DD_D Bytes16 load16(const uint8_t* fa, size_t n, size_t pos, size_t first) {
     Bytes16 b;
-    if (pos + 16 <= n) {
+    if (pos + 16 <= n && pos >= first) {
         const uint4 v = gload16(fa + pos);
         b.w[0] = v.x; b.w[1] = v.y; b.w[2] = v.z; b.w[3] = v.w;
     } else {
@@ -57,7 +64,7 @@ DD_D Bytes16 load16(const uint8_t* fa, size_t n, size_t pos) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 size_t p = pos + 4 * j + i;
-                uint32_t c = p < n ? fa[p] : (uint32_t)'\r';
+                uint32_t c = (p < n && p >= first) ? fa[p] : (uint32_t)'\n';
                 w |= c << (8 * i);
             }
             b.w[j] = w;
@@ -77,8 +84,9 @@ struct LineState {
 };
 
 // Tokens of 16 bytes.  PACK: also assemble them (codes: token j at bits 2j..2j+1, bad: bit j).
+// (`after`: the byte behind the 16 -- a '\r' is dropped only in front of a line end)
 template <bool PACK>
-DD_D int scan16(const Bytes16& b, LineState& s, uint32_t& codes, uint32_t& bad) {
+DD_D int scan16(const Bytes16& b, uint32_t after, LineState& s, uint32_t& codes, uint32_t& bad) {
     int cnt = 0;
     if (PACK) {
         codes = 0;
@@ -87,7 +95,7 @@ DD_D int scan16(const Bytes16& b, LineState& s, uint32_t& codes, uint32_t& bad) 
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const uint32_t c = b.at(i);
-        if (s.ls) s.hdr = (c == '>');
+        if (s.ls) s.hdr = (c == '>' || c == '@');
         if (c == '\n') {
             if (s.hdr) {  // one BREAK per header line
                 if (PACK) bad |= 1u << cnt;
@@ -99,7 +107,8 @@ DD_D int scan16(const Bytes16& b, LineState& s, uint32_t& codes, uint32_t& bad) 
             s.seen_nl = true;
         } else {
             s.ls = false;
-            if (!(s.hdr || c == '\r')) {
+            const bool cr_at_eol = c == '\r' && (i < 15 ? b.at(i < 15 ? i + 1 : 15) : after) == '\n';
+            if (!(s.hdr || cr_at_eol)) {
                 if (PACK) {
                     const uint32_t code = base_code(c);
                     codes |= (code & 3u) << (2 * cnt);
@@ -159,6 +168,7 @@ DD_D SpanBits span_bits(const Bytes16 (&b)[SUB]) {
 // run ONE pass of the byte machine (entered as "not in a header").
 struct ThreadSpan {
     Bytes16 b[SUB];
+    uint32_t after;   // the byte behind the span ('\n' at the end of the buffer)
     SpanBits bits;
     bool line_start;  // first byte is the first of a line (the incoming bit is then irrelevant)
     bool plain;       // bits.plain and the whole span lies inside the file
@@ -166,13 +176,21 @@ struct ThreadSpan {
     int t0, t1;       // tokens if entered outside / inside a header line
 };
 
-DD_D ThreadSpan load_span(const uint8_t* fa, size_t n, size_t pos) {
+DD_D ThreadSpan load_span(const uint8_t* fa, size_t n, size_t pos, size_t first) {
     ThreadSpan t;
 #pragma unroll
-    for (int j = 0; j < SUB; ++j) t.b[j] = load16(fa, n, pos + 16 * j);
-    t.line_start = (pos == 0) || (pos - 1 < n ? *(const DD_GLOBAL uint8_t*)(fa + pos - 1) == '\n' : false);
+    for (int j = 0; j < SUB; ++j) t.b[j] = load16(fa, n, pos + 16 * j, first);
+    t.line_start = (pos <= first) || (pos - 1 < n ? *(const DD_GLOBAL uint8_t*)(fa + pos - 1) == '\n' : false);
     t.bits = span_bits(t.b);
     t.plain = t.bits.plain && pos + kPackBytesPerThread <= n;
+    // a byte that is not A/C/G/T at a line start may be a header's '@' ('>' and '+' are outside the plain range anyway):
+    // such a span takes the byte machine (lines that start inside an N run do too: a few per genome)
+    if (t.plain) {
+        const uint64_t starts = (pack_u64(t.bits.nl[1], t.bits.nl[0]) << 1) | (t.line_start ? 1ull : 0ull);
+        if (pack_u64(t.bits.bad[1], t.bits.bad[0]) & starts) t.plain = false;
+    }
+    t.after = '\n';
+    if (!t.plain && pos + kPackBytesPerThread < n) t.after = *(const DD_GLOBAL uint8_t*)(fa + pos + kPackBytesPerThread);
     if (pos >= n) {  // tail of the last chunk
         t.kind = KIND_ID;
         t.t0 = t.t1 = 0;
@@ -190,7 +208,7 @@ DD_D ThreadSpan load_span(const uint8_t* fa, size_t n, size_t pos) {
         LineState s{false, t.line_start, false, 0, 0};
         uint32_t d0, d1;
 #pragma unroll
-        for (int j = 0; j < SUB; ++j) (void)scan16<false>(t.b[j], s, d0, d1);
+        for (int j = 0; j < SUB; ++j) (void)scan16<false>(t.b[j], j + 1 < SUB ? t.b[j + 1 < SUB ? j + 1 : j].at(0) : t.after, s, d0, d1);
         t.kind = (s.seen_nl || t.line_start) ? (s.hdr ? KIND_C1 : KIND_C0) : KIND_ID;
         t.t0 = s.pre + s.rest;
         t.t1 = t.line_start ? t.t0 : s.rest + (s.seen_nl ? 1 : 0);
@@ -257,11 +275,37 @@ DD_D int block_incl_sum(int v, int* sm /*[NW]*/, int* total) {
 
 // scratch layout of one genome: four arrays of (nchunks + 1) int64
 struct Scratch {
-    long long *kind_in, *cnt0, *cnt1, *slot;
+    long long *kind_in, *cnt0, *cnt1, *slot, *first;
     DD_D explicit Scratch(const PackGenome& g)
         : kind_in(g.scratch), cnt0(g.scratch + (g.nchunks + 1)), cnt1(g.scratch + 2 * (g.nchunks + 1)),
-          slot(g.scratch + 3 * (g.nchunks + 1)) {}
+          slot(g.scratch + 3 * (g.nchunks + 1)), first(g.scratch + 4 * (g.nchunks + 1)) {}
 };
+
+// ---------------------------------------------------------------------------------------
+// grid = genomes: position of the buffer's first '>' or '@' (n if there is none: kseq then finds no record and the
+// sketch stays empty).  A well-formed file has it at byte 0 and the loop ends in its first round.
+__global__ __launch_bounds__(1024) void pack_first(const PackGenome* __restrict__ tab) {
+    __shared__ unsigned long long found;
+    const PackGenome G = tab[blockIdx.x];
+    const Scratch S(G);
+    if (threadIdx.x == 0) found = ~0ull;
+    __syncthreads();
+    for (size_t base = 0; base < G.n; base += 1024u * 16u) {
+        const size_t pos = base + (size_t)threadIdx.x * 16u;
+        if (pos < G.n) {
+            const Bytes16 b = load16(G.fa, G.n, pos, 0);
+#pragma unroll
+            for (int i = 15; i >= 0; --i) {
+                const uint32_t c = b.at(i);
+                if ((c == '>' || c == '@') && pos + i < G.n) atomicMin(&found, (unsigned long long)(pos + i));
+            }
+        }
+        __syncthreads();
+        if (found != ~0ull) break;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *S.first = (long long)(found == ~0ull ? G.n : found);
+}
 
 // ---------------------------------------------------------------------------------------
 // grid = (max chunks over the batch, genomes)
@@ -271,7 +315,7 @@ __global__ __launch_bounds__(T) void pack_stats(const PackGenome* __restrict__ t
     const size_t c = blockIdx.x;
     if (c >= G.nchunks) return;
     const size_t pos = c * (size_t)kPackChunk + (size_t)threadIdx.x * kPackBytesPerThread;
-    const ThreadSpan t = load_span(G.fa, G.n, pos);
+    const ThreadSpan t = load_span(G.fa, G.n, pos, (size_t)gload8u(Scratch(G).first));
     const Incoming in = propagate(t.kind, false, sm);
     int t0, t1;  // tokens if the CHUNK is entered outside / inside a header
     if (in.determined || t.line_start) {
@@ -377,7 +421,7 @@ __global__ __launch_bounds__(T) void pack_write(const PackGenome* __restrict__ t
     const Scratch SC(G);
     const TokenStream out = G.out;
     const size_t pos = c * (size_t)kPackChunk + (size_t)threadIdx.x * kPackBytesPerThread;
-    const ThreadSpan t = load_span(G.fa, G.n, pos);
+    const ThreadSpan t = load_span(G.fa, G.n, pos, (size_t)gload8u(SC.first));
     const Incoming in = propagate(t.kind, SC.kind_in[c] != 0, sm);
     const int cnt = in.hdr ? t.t1 : t.t0;
     int total;
@@ -438,7 +482,7 @@ __global__ __launch_bounds__(T) void pack_write(const PackGenome* __restrict__ t
 #pragma unroll
             for (int j = 0; j < SUB; ++j) {
                 uint32_t pc, pb;
-                const int n16 = scan16<true>(t.b[j], s, pc, pb);
+                const int n16 = scan16<true>(t.b[j], j + 1 < SUB ? t.b[j + 1 < SUB ? j + 1 : j].at(0) : t.after, s, pc, pb);
                 if (n16) {
                     const int wi = (int)((tk >> 4) - cw0), sh = (int)(tk & 15) * 2;
                     if (pc << sh) atomicOr(&lcodes[cidx(wi)], pc << sh);
@@ -477,6 +521,7 @@ __global__ __launch_bounds__(T) void pack_write(const PackGenome* __restrict__ t
 void launch_pack_batch(const PackGenome* tab_dev, int ngenomes, size_t max_chunks, hipStream_t st) {
     if (ngenomes <= 0) return;
     const dim3 grid((unsigned)max_chunks, (unsigned)ngenomes);
+    hipLaunchKernelGGL(pack_first, dim3((unsigned)ngenomes), dim3(1024), 0, st, tab_dev);
     if (max_chunks) hipLaunchKernelGGL(pack_stats, grid, dim3(T), 0, st, tab_dev);
     hipLaunchKernelGGL(pack_scan, dim3((unsigned)ngenomes), dim3(1024), 0, st, tab_dev);
     if (max_chunks) hipLaunchKernelGGL(pack_write, grid, dim3(T), 0, st, tab_dev);

@@ -14,33 +14,14 @@
 
 typedef unsigned __int128 u128;
 
-/* ------------------------------------------------------------------ hash */
+/* ============================================================== POLICY BLOCK
+ * Every assumption about what `dashing` does that could not be checked against a Dashing binary or its source
+ * (RECALL) is ONE definition in this block; oracle/POLICIES.md lists them with the product
+ * lines that implement the same rule and the known-answer vectors that would change.  A mismatch found the day a
+ * binary is available (bench.py diffs its registers against this oracle, bench.py:dashing_baseline) is a one-line
+ * change here plus the matching line of the kernels. */
 
-/* Thomas Wang 64-bit mix == sketch::hash::WangHash.
- * KATs: wang(0)=0x77cfa1eef01bca90 wang(1)=0x5bca7c69b794f8ce */
-uint64_t orc_wang64(uint64_t key) {
-    key = (~key) + (key << 21);
-    key = key ^ (key >> 24);
-    key = (key + (key << 3)) + (key << 8); /* * 265 */
-    key = key ^ (key >> 14);
-    key = (key + (key << 2)) + (key << 4); /* * 21 */
-    key = key ^ (key >> 28);
-    key = key + (key << 31);
-    return key;
-}
-
-uint64_t orc_fold128(uint64_t hi, uint64_t lo) { return lo ^ (hi * 0x9E3779B97F4A7C15ull); }
-
-/* sketch::hll::hllbase_t::add: index = top p bits, rho = leading
- * zeros of the remaining q=64-p bits (with a sentinel) + 1. */
-void orc_idx_rho(uint64_t h, int p, uint32_t *idx, uint8_t *rho) {
-    uint64_t w = ((h << 1) | 1) << (p - 1);
-    *idx = (uint32_t)(h >> (64 - p));
-    *rho = (uint8_t)(__builtin_clzll(w) + 1);
-}
-
-/* ------------------------------------------------------------- tokenizer */
-
+/* P1  2-bit code table: A/a 0, C/c 1, G/g 2, T/t 3; every other byte is ambiguous and resets the k-mer window */
 static const int8_t *code_lut(void) {
     static int8_t lut[256];
     static int init = 0;
@@ -54,54 +35,143 @@ static const int8_t *code_lut(void) {
     }
     return lut;
 }
+/* P3  canonical form: the smaller of the k-mer and its reverse complement as unsigned integers, no XOR mask;
+ * P4  the all-T 32-mer (every bit set: bonsai's "ambiguous" marker) is an ordinary k-mer */
+static inline uint64_t pol_canonical64(uint64_t fw, uint64_t rc) { return rc < fw ? rc : fw; }
+static inline u128 pol_canonical128(u128 fw, u128 rc) { return rc < fw ? rc : fw; }
+/* P5  hash of a k-mer (k <= 32): Thomas Wang's 64-bit mix == sketch::hash::WangHash.
+ * KATs: wang(0)=0x77cfa1eef01bca90 wang(1)=0x5bca7c69b794f8ce */
+uint64_t orc_wang64(uint64_t key) {
+    key = (~key) + (key << 21);
+    key = key ^ (key >> 24);
+    key = (key + (key << 3)) + (key << 8); /* * 265 */
+    key = key ^ (key >> 14);
+    key = (key + (key << 2)) + (key << 4); /* * 21 */
+    key = key ^ (key >> 28);
+    key = key + (key << 31);
+    return key;
+}
+/* P5b k in 33..64 has no Dashing analogue (/root/reference/lib/huffman_dandd.py:109): the 128-bit canonical k-mer is
+ * folded to 64 bits before the same hash.  Engine-defined, not a RECALL. */
+uint64_t orc_fold128(uint64_t hi, uint64_t lo) { return lo ^ (hi * 0x9E3779B97F4A7C15ull); }
+static inline uint64_t pol_hash(uint64_t hi, uint64_t lo, int k) { return orc_wang64(k <= 32 ? lo : orc_fold128(hi, lo)); }
+/* P6  register index = the TOP p bits of the hash;  P7  rho = leading zeros of the remaining 64 - p bits, counted
+ * with a sentinel bit behind them, + 1: in [1, 64 - p + 1]   (sketch::hll::hllbase_t::add) */
+static inline uint32_t pol_index(uint64_t h, int p) { return (uint32_t)(h >> (64 - p)); }
+static inline uint8_t pol_rho(uint64_t h, int p) { return (uint8_t)(__builtin_clzll(((h << 1) | 1) << (p - 1)) + 1); }
+/* P8  Ertl's ML estimator stops at a relative step of 1e-2 / sqrt(m) (dashing's default ERTL_MLE) */
+static inline double pol_mle_relerr(uint64_t m) { return 1e-2 / sqrt((double)m); }
+/* P10 record rules: kseq's (below, orc_records) */
+/* ======================================================== end of POLICY BLOCK */
 
-size_t orc_tokenize(const uint8_t *fa, size_t n, uint8_t *out) {
-    const int8_t *lut = code_lut();
-    size_t nt = 0;
-    int line_start = 1, in_header = 0;
-    for (size_t i = 0; i < n; ++i) {
-        uint8_t c = fa[i];
-        if (c == '\n') {
-            if (in_header) { /* one BREAK per header line */
-                if (out) out[nt] = 4;
-                ++nt;
+void orc_idx_rho(uint64_t h, int p, uint32_t *idx, uint8_t *rho) {
+    *idx = pol_index(h, p);
+    *rho = pol_rho(h, p);
+}
+
+/* ----------------------------------------------------------------- records */
+
+/* P10  The sequence text of a FASTA / FASTQ buffer as klib's kseq.h reads it (Dashing parses its inputs with kseq;
+ * RECALL of kseq_read):
+ *   - everything before the first '>' or '@' (anywhere, not only at a line start) is skipped;
+ *   - the rest of that line is the header (name + comment);
+ *   - the following lines are sequence until a line STARTS with '>', '@' or '+' (or the input ends); empty lines are
+ *     skipped; the line terminator is dropped, and so is ONE '\r' in front of it;
+ *   - a line starting with '>' or '@' starts the next record;
+ *   - a line starting with '+' makes the record a FASTQ record: the rest of that line is skipped, then whole lines are
+ *     read as quality until they hold at least as many characters as the sequence; the reader then looks for the next
+ *     '>' or '@' ANYWHERE in what follows (kseq's last_char = 0).
+ * Output: the sequence bytes of every record verbatim (a '\r' inside a line, digits, anything), each record CLOSED by
+ * one '\n' -- a byte that cannot occur in sequence text -- so that the encoder sees one BREAK per record.  `out` needs
+ * n + 1 bytes at most (NULL: count only).  Returns the number of bytes written. */
+size_t orc_records(const uint8_t *fa, size_t n, uint8_t *out) {
+    size_t i = 0, o = 0;
+    int have_header = 0; /* kseq's last_char: the header character of the next record has been consumed */
+    for (;;) {
+        if (!have_header) {
+            while (i < n && fa[i] != '>' && fa[i] != '@') ++i;
+            if (i >= n) break;
+            ++i; /* the header character */
+        }
+        have_header = 0;
+        while (i < n && fa[i] != '\n') ++i; /* name and comment */
+        if (i < n) ++i;
+        size_t seq_len = 0;
+        int c = -1; /* the character that ended the sequence part; -1: end of input */
+        while (i < n) {
+            c = fa[i];
+            if (c == '>' || c == '+' || c == '@') break;
+            if (c == '\n') { /* empty line */
+                ++i;
+                c = -1;
+                continue;
             }
-            in_header = 0;
-            line_start = 1;
+            size_t e = i;
+            while (e < n && fa[e] != '\n') ++e;
+            size_t len = e - i;
+            /* kseq drops one trailing '\r' of the accumulated sequence (if it is longer than one character) */
+            if (len && fa[e - 1] == '\r' && seq_len + len > 1) --len;
+            if (out) memcpy(out + o, fa + i, len);
+            o += len;
+            seq_len += len;
+            i = e < n ? e + 1 : e;
+            c = -1;
+        }
+        if (out) out[o] = '\n';
+        ++o;
+        if (i >= n) break;
+        if (c == '>' || c == '@') {
+            ++i;
+            have_header = 1;
             continue;
         }
-        if (line_start && c == '>') in_header = 1;
-        line_start = 0;
-        if (in_header || c == '\r') continue;
-        if (out) out[nt] = (uint8_t)lut[c];
-        ++nt;
+        /* c == '+': FASTQ.  Skip the rest of the '+' line, then quality lines until they cover the sequence. */
+        while (i < n && fa[i] != '\n') ++i;
+        if (i < n) ++i;
+        size_t qual_len = 0;
+        while (i < n && qual_len < seq_len) {
+            size_t e = i;
+            while (e < n && fa[e] != '\n') ++e;
+            size_t len = e - i;
+            if (len && fa[e - 1] == '\r' && qual_len + len > 1) --len;
+            qual_len += len;
+            i = e < n ? e + 1 : e;
+        }
     }
-    return nt;
+    return o;
+}
+
+/* ------------------------------------------------------------- tokenizer */
+
+/* Token values 0..3 = A,C,G,T; 4 = BREAK: an ambiguous byte of a record's sequence, or the end of a record (one per
+ * record, so windows never span records). */
+size_t orc_tokenize(const uint8_t *fa, size_t n, uint8_t *out) {
+    const int8_t *lut = code_lut();
+    uint8_t *seq = (uint8_t *)malloc(n + 1);
+    if (!seq) abort();
+    const size_t m = orc_records(fa, n, seq);
+    if (out)
+        for (size_t i = 0; i < m; ++i) out[i] = (uint8_t)lut[seq[i]];  /* ('\n', the record mark, is ambiguous like any other) */
+    free(seq);
+    return m;
 }
 
 /* ---------------------------------------------------------------- sketch */
 
-/* k-mer stream of bonsai's unspaced/unwindowed encoder (A.1): rolling forward
- * window, rolling reverse-complement window, canonical = min(fw, rc). */
+/* k-mer stream of bonsai's unspaced/unwindowed encoder (A.1) over kseq's records: rolling forward window, rolling
+ * reverse-complement window, canonical form by policy P3. */
 typedef void (*kmer_fn)(void *ctx, uint64_t hi, uint64_t lo);
 
 static void for_each_kmer(const uint8_t *fa, size_t n, int k, int canonical, kmer_fn fn, void *ctx) {
     const int8_t *lut = code_lut();
     const u128 mask = (k == 64) ? ~(u128)0 : (((u128)1 << (2 * k)) - 1);
+    uint8_t *seq = (uint8_t *)malloc(n + 1);
+    if (!seq) abort();
+    const size_t m = orc_records(fa, n, seq);
     u128 fw = 0, rc = 0;
-    int run = 0, line_start = 1, in_header = 0;
-    for (size_t i = 0; i < n; ++i) {
-        uint8_t ch = fa[i];
-        if (ch == '\n') {
-            if (in_header) run = 0;
-            in_header = 0;
-            line_start = 1;
-            continue;
-        }
-        if (line_start && ch == '>') in_header = 1;
-        line_start = 0;
-        if (in_header || ch == '\r') continue;
-        int c = lut[ch];
+    int run = 0;
+    for (size_t i = 0; i < m; ++i) {
+        int c = lut[seq[i]];
         if (c > 3) {
             run = 0;
             continue;
@@ -109,10 +179,11 @@ static void for_each_kmer(const uint8_t *fa, size_t n, int k, int canonical, kme
         fw = ((fw << 2) | (u128)c) & mask;
         rc = (rc >> 2) | ((u128)(3 - c) << (2 * (k - 1)));
         if (++run >= k) {
-            u128 x = (canonical && rc < fw) ? rc : fw;
+            u128 x = canonical ? pol_canonical128(fw, rc) : fw;
             fn(ctx, (uint64_t)(x >> 64), (uint64_t)x);
         }
     }
+    free(seq);
 }
 
 struct hll_ctx {
@@ -122,34 +193,26 @@ struct hll_ctx {
 
 static void hll_add(void *vctx, uint64_t hi, uint64_t lo) {
     struct hll_ctx *c = (struct hll_ctx *)vctx;
-    uint64_t x = (c->k <= 32) ? lo : orc_fold128(hi, lo);
-    uint32_t idx;
-    uint8_t rho;
-    orc_idx_rho(orc_wang64(x), c->p, &idx, &rho);
+    const uint64_t h = pol_hash(hi, lo, c->k);
+    const uint32_t idx = pol_index(h, c->p);
+    const uint8_t rho = pol_rho(h, c->p);
     if (rho > c->regs[idx]) c->regs[idx] = rho;
 }
 
-/* Same stream as for_each_kmer, k <= 32, 64-bit windows, everything inlined:
- * this is the loop a tuned single-threaded `dashing sketch` job spends its time
- * in, so it is also what bench.py times as the CPU baseline. */
+/* Same stream as for_each_kmer, k <= 32, 64-bit windows, everything inlined: this is the loop a tuned single-threaded
+ * `dashing sketch` job spends its time in (kseq copies a record's sequence out, the encoder runs over the copy), so it is
+ * also what bench.py times as the CPU baseline. */
 static void sketch64(const uint8_t *fa, size_t n, int k, int p, int canonical, uint8_t *regs) {
     const int8_t *lut = code_lut();
     const uint64_t mask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1);
-    const int rsh = 2 * (k - 1), q = 64 - p;
+    const int rsh = 2 * (k - 1);
+    uint8_t *seq = (uint8_t *)malloc(n + 1);
+    if (!seq) abort();
+    const size_t m = orc_records(fa, n, seq);
     uint64_t fw = 0, rc = 0;
-    int run = 0, line_start = 1, in_header = 0;
-    for (size_t i = 0; i < n; ++i) {
-        uint8_t ch = fa[i];
-        if (ch == '\n') {
-            if (in_header) run = 0;
-            in_header = 0;
-            line_start = 1;
-            continue;
-        }
-        if (line_start && ch == '>') in_header = 1;
-        line_start = 0;
-        if (in_header || ch == '\r') continue;
-        int c = lut[ch];
+    int run = 0;
+    for (size_t i = 0; i < m; ++i) {
+        int c = lut[seq[i]];
         if (c > 3) {
             run = 0;
             continue;
@@ -157,13 +220,13 @@ static void sketch64(const uint8_t *fa, size_t n, int k, int p, int canonical, u
         fw = ((fw << 2) | (uint64_t)c) & mask;
         rc = (rc >> 2) | ((uint64_t)(3 - c) << rsh);
         if (++run >= k) {
-            uint64_t x = (canonical && rc < fw) ? rc : fw;
-            uint64_t h = orc_wang64(x);
-            uint32_t idx = (uint32_t)(h >> q);
-            uint8_t rho = (uint8_t)(__builtin_clzll(((h << 1) | 1) << (p - 1)) + 1);
+            const uint64_t h = pol_hash(0, canonical ? pol_canonical64(fw, rc) : fw, k);
+            const uint32_t idx = pol_index(h, p);
+            const uint8_t rho = pol_rho(h, p);
             if (rho > regs[idx]) regs[idx] = rho;
         }
     }
+    free(seq);
 }
 
 int orc_sketch(const uint8_t *fa, size_t n, int k, int p, int canonical, uint8_t *regs) {
@@ -230,7 +293,7 @@ double orc_ertl_mle(const uint32_t c[64], int p) {
     double b = z + ldexp((double)c[q + 1], -q);
     double x = (b <= 1.5 * a) ? mprime / (0.5 * b + a) : (mprime / b) * log1p(b / a);
     double dx = x, gprev = 0.0;
-    const double relerr = 1e-2 / sqrt((double)m);
+    const double relerr = pol_mle_relerr(m);
     while (dx > x * relerr) {
         int kappam1;
         frexp(x, &kappam1);

@@ -48,12 +48,13 @@ uint64_t orc_fold128(uint64_t hi, uint64_t lo);
 /* idx = h >> (64-p); rho = clz64(((h<<1)|1) << (p-1)) + 1  in [1, 64-p+1] */
 void orc_idx_rho(uint64_t h, int p, uint32_t *idx, uint8_t *rho);
 
-/* ---- FASTA -> token stream (A.1) ----
- * Token values 0..3 = A,C,G,T (case-insensitive); 4 = BREAK (non-ACGT byte, or
- * one BREAK per header line so windows never span records).  '\n' and '\r'
- * emit nothing.  A line whose first byte is '>' is a header line.  Bytes
- * before the first header are treated as sequence (kseq would skip them).
- * Returns the number of tokens; out may be NULL to count only. */
+/* ---- FASTA / FASTQ -> records -> token stream (A.1; policy P10 of POLICIES.md) ----
+ * orc_records: the sequence text of every record as klib's kseq.h reads it (everything before the first '>' or '@' is
+ * skipped; a line starting with '>' / '@' is a header, one starting with '+' opens FASTQ quality lines; one '\r' in
+ * front of a line end is dropped), each record closed by one '\n'.  out: n + 1 bytes, or NULL to count only.
+ * orc_tokenize: token values 0..3 = A,C,G,T (case-insensitive); 4 = BREAK (any other sequence byte, and one at the end
+ * of every record so windows never span records).  Returns the number of tokens; out may be NULL to count only. */
+size_t orc_records(const uint8_t *fa, size_t n, uint8_t *out);
 size_t orc_tokenize(const uint8_t *fa, size_t n, uint8_t *out);
 
 /* ---- one `dashing sketch -k K -S p [--no-canon]` job: max-merges into regs[2^p] ---- */

@@ -33,6 +33,8 @@ def _bind(lib):
     lib.orc_fold128.argtypes = [C.c_uint64, C.c_uint64]
     lib.orc_idx_rho.restype = None
     lib.orc_idx_rho.argtypes = [C.c_uint64, C.c_int, C.POINTER(C.c_uint32), u8p]
+    lib.orc_records.restype = C.c_size_t
+    lib.orc_records.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
     lib.orc_tokenize.restype = C.c_size_t
     lib.orc_tokenize.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
     lib.orc_sketch.restype = C.c_int
@@ -95,6 +97,15 @@ def idx_rho(h, p):
     idx, rho = C.c_uint32(), C.c_uint8()
     lib().orc_idx_rho(C.c_uint64(h), p, C.byref(idx), C.byref(rho))
     return idx.value, rho.value
+
+
+def records(fa):
+    """Sequence strings of the records of a FASTA / FASTQ buffer, kseq's rules (orc_records) -> list of bytes"""
+    a = np.ascontiguousarray(fa, dtype=np.uint8)
+    out = np.empty(a.size + 1, dtype=np.uint8)
+    n = lib().orc_records(a.ctypes.data, a.size, out.ctypes.data)
+    body = out[:n].tobytes()
+    return body.split(b"\n")[:-1] if n else []
 
 
 def tokenize(fa):

@@ -12,7 +12,7 @@ from oracle import dd_oracle as orc
 n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 engines = {}
-alph = [np.frombuffer(b"ACGT", np.uint8), np.frombuffer(b"ACGTacgtN", np.uint8), np.frombuffer(b"ACGTACGTACGTRYKMn-* 0>", np.uint8)]
+alph = [np.frombuffer(b"ACGT", np.uint8), np.frombuffer(b"ACGTacgtN", np.uint8), np.frombuffer(b"ACGTACGTACGTRYKMn-* 0>@\r", np.uint8)]
 KNOBS = ["DD_BUCKET_E0", "DD_BUCKET_EMAX", "DD_BUCKET_CAP", "DD_BUCKET_LOGG", "DD_BUCKET_FBITS", "DD_NO_XCD_AFFINITY", "DD_GLOBAL_FROM_P", "DD_BIGMAP_ANY_SIZE", "DD_NO_PRESORT", "DD_BUCKET_UNIT", "DD_BUCKET_NK", "DD_BUCKET_STAGGER", "DD_SIDE_ALWAYS", "DD_BUCKET_TILE_LOG2", "DD_FIRST_WG"]
 t0 = time.time()
 for it in range(n_cfg):

@@ -11,7 +11,14 @@ sys.path.insert(0, os.path.dirname(HERE))
 import pyref  # noqa: E402
 
 rnd = random.Random(20261002)
-kat = {"wang64": [], "idx_rho": [], "fold128": [], "sketch": [], "mle": []}
+kat = {"wang64": [], "idx_rho": [], "fold128": [], "sketch": [], "mle": [], "records": []}
+# record rules (kseq's, as recalled: POLICIES.md P10): input -> the sequence string of every record
+for text in ["", ">h\n", ">h", "ACGT", "ACGTNNACGT\n>late\nGGCC\n", "junk junk >h1 comment\nACGT\nTTGA\n\n>h2\nCC\n",
+             ">a\r\nACGTAC\r\nGTACGG\r\n", ">a\nAC\rGT\nAA\r\r\nC\n", ">a\nACGT>ACGT\n@b also a header\nTTTT\n",
+             "@r1\nACGTACGT\n+\nIIIIIIII\n@r2\nGGCCA\n+r2\nII@>I\n", "@r1\nACGT\nACGT\n+\nIIII\nII@I\n@r2\nTT\n+\n>I\n",
+             "@r1\nACGT\n+\nII\n", ">x\nACGT\n+\nACGT\nGGGG>y\nCC\n", "@q\nAC\n+\n@@\n@q2\nGG\n+\n>>\n>f\nTTA\n",
+             "\n\n>x\n\nACG\n\nT\n", ">only\n\n\n", "@", "+\nACGT\n>z\nAC\n"]:
+    kat["records"].append([text, [r.decode("latin-1") for r in pyref.records(text.encode("latin-1"))]])
 for x in [0, 1, 2, 0xDEADBEEF, 2**32, 2**63, 2**64 - 1] + [rnd.getrandbits(64) for _ in range(40)]:
     kat["wang64"].append([hex(x), hex(pyref.wang64(x))])
 for _ in range(40):

@@ -16,6 +16,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <random>
 #include <vector>
 
 #include "dd_io.h"
@@ -209,6 +210,30 @@ static void check_gzip_edges(const std::string& dir) {
     CHECK(!bad_ok || fb.size() != body.size() || memcmp(fb.data(), body.data(), body.size()) != 0, "damaged gzip read back as if intact");
 }
 
+// ---- dd_io.h: FASTQ records rewritten as FASTA, in place ----------------------------------------------------------------
+// random text over the characters the record rules care about: the in-place form (exactly as large a buffer as the input
+// plus the two bytes of slack the function asks for, so ASan sees any overrun) must equal the out-of-place form, never
+// grow by more than two bytes and leave no line that starts with '+'
+static void fastq_rewrite_cases() {
+    std::mt19937 rng(20261004);
+    const char alphabet[] = "ACGTacgtN>@+\n\n\n\r I#";
+    for (int it = 0; it < 20000; ++it) {
+        const size_t n = rng() % 96;
+        std::string in(n, 'A');
+        for (auto& c : in) c = alphabet[rng() % (sizeof alphabet - 1)];
+        std::vector<uint8_t> out(n + 2), inplace(n + 2);
+        const size_t m = dd::fastq_to_fasta(reinterpret_cast<const uint8_t*>(in.data()), n, out.data());
+        memcpy(inplace.data(), in.data(), n);
+        const size_t m2 = dd::fastq_to_fasta(inplace.data(), n, inplace.data());
+        CHECK(m <= n + 2 && m == m2 && memcmp(out.data(), inplace.data(), m) == 0, "FASTQ rewrite: in place differs from out of place");
+        CHECK(!dd::has_plus_line(out.data(), m), "FASTQ rewrite: a '+' line survived");
+        // (a second pass may still shorten it: a '\r' that survived at the end of a record's sequence now stands in front of
+        // a line end -- where it is an ambiguous byte behind the record's last k-mer either way)
+        std::vector<uint8_t> again(m + 2);
+        CHECK(dd::fastq_to_fasta(out.data(), m, again.data()) <= m, "FASTQ rewrite: a second pass grew the buffer");
+    }
+}
+
 // ---- dd_inflate.h: a gzip member decoded in pieces without their history, BGZF blocks in parallel -------------------
 struct TestBuf {   // the part of FileBuf the decoders use
     uint8_t* p = nullptr;
@@ -385,6 +410,7 @@ int main(int argc, char** argv) {
     check_loaders(argv[1]);
     check_gzip_edges(argv[1]);
     check_parallel_inflate();
+    fastq_rewrite_cases();
     if (failures) fprintf(stderr, "%d failure(s)\n", failures);
     else printf("sanitize_host: ok\n");
     return failures ? 1 : 0;

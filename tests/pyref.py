@@ -31,22 +31,67 @@ def fold128(hi, lo):
 CODE = {ord("A"): 0, ord("a"): 0, ord("C"): 1, ord("c"): 1, ord("G"): 2, ord("g"): 2, ord("T"): 3, ord("t"): 3}
 
 
+def records(fa: bytes):
+    """The sequence strings of a FASTA / FASTQ buffer, read the way klib's kseq.h reads it (character by character, as
+    kseq_read does with ks_getc / ks_getuntil): what is in front of the first '>' or '@' is skipped; name and comment run to
+    the end of the line; sequence lines follow until a line starts with '>', '@' or '+'; a '+' line opens quality lines,
+    read until they are as long as the sequence, after which the reader again looks for '>' or '@' anywhere."""
+    out, i, n = [], 0, len(fa)
+    last_char = 0
+    while True:
+        if last_char == 0:
+            while i < n and fa[i] not in (62, 64):      # '>' '@'
+                i += 1
+            if i >= n:
+                return out
+            i += 1
+        last_char = 0
+        while i < n and fa[i] != 10:                    # header line
+            i += 1
+        i += 1
+        seq = bytearray()
+        c = -1
+        while i < n:
+            c = fa[i]
+            i += 1
+            if c in (62, 43, 64):                       # '>' '+' '@'
+                break
+            if c == 10:
+                c = -1
+                continue
+            seq.append(c)
+            while i < n and fa[i] != 10:                # the rest of the line
+                seq.append(fa[i])
+                i += 1
+            i += 1
+            if len(seq) > 1 and seq[-1] == 13:          # KS_SEP_LINE: one trailing '\r' goes
+                seq.pop()
+            c = -1
+        out.append(bytes(seq))
+        if c in (62, 64):
+            last_char = c
+            continue
+        if c != 43:
+            return out
+        while i < n and fa[i] != 10:                    # rest of the '+' line
+            i += 1
+        i += 1
+        qual = bytearray()
+        while i < n and len(qual) < len(seq):
+            while i < n and fa[i] != 10:
+                qual.append(fa[i])
+                i += 1
+            i += 1
+            if len(qual) > 1 and qual[-1] == 13:
+                qual.pop()
+
+
 def tokenize(fa: bytes):
-    """-> list of tokens 0..3 / 4 (BREAK); same rules as oracle orc_tokenize."""
+    """-> list of tokens 0..3 / 4 (BREAK: an ambiguous sequence byte, and one at the end of every record)"""
     out = []
-    line_start, in_header = True, False
-    for c in fa:
-        if c == 10:
-            if in_header:
-                out.append(4)
-            in_header, line_start = False, True
-            continue
-        if line_start and c == ord(">"):
-            in_header = True
-        line_start = False
-        if in_header or c == 13:
-            continue
-        out.append(CODE.get(c, 4))
+    for seq in records(fa):
+        out.extend(CODE.get(c, 4) for c in seq)
+        out.append(4)
     return out
 
 

@@ -64,6 +64,15 @@ RAGGED = {
     "gt_midline": b">a\nACGTAGCTAG>CTAGGATCGATCGATTGACG\nACGT>ACGTAGCATCGATCGA\n",
     "blank_lines": b">a\n\n\nACGTAGCTAGCTAGC\n\nTAGGATCGATCGATTGACG\n\n",
     "poly": b">a\n" + b"A" * 100 + b"\n" + b"T" * 100 + b"\n" + b"ACGT" * 30 + b"\n",
+    # kseq's record rules (oracle/POLICIES.md P10): text in front of the first header is skipped (also when the '>' is not at a
+    # line start), '@' at a line start is a header too, only a '\r' in front of a line end is dropped, a headerless buffer
+    # holds no record at all ("no_header" above), FASTQ records are resolved on the host
+    "junk_before_header": b"some text\nACGTACGTAGCTAGCATCGATCGAT\nmore >rec1 comment\nACGTAGCTAGCTAGGATCGATCGATTGACG\nTTGACCAGTAGCAT\n",
+    "late_header": b"N" * 700 + b"\n" + b"ACGT" * 50 + b"\n" * 3 + b">x\n" + b"ACGTTGCATGCCGATAGCTAGCTAGCATGCATCGAT" * 4 + b"\n",
+    "at_headers": b">a\nACGTAGCTAGCTAGGATCGATCG\n@b looks like FASTQ\nTTGACGATCGATGCAGCAGCATCGAC\n@c\nGGGATCGAGCTAGCATCGAC\n",
+    "cr_midline": b">a\nACGTAGCTAG\rCTAGGATCGATCGATTGACG\r\r\nACGTACGTAGCATCGATCGA\r\n",
+    "fastq": b"@r1 desc\nACGTAGCTAGCTAGGATCGATCGATTGACG\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIIIII\n@r2\nTTGACGATCGATGCAGCAGCATCGACNACGT\n+r2\nII@>IIIIIIIIIIIIIIIIIIIIIIIIIII\n",
+    "fastq_multiline": b"@r1\nACGTAGCTAGCTAGG\nATCGATCGATTGACG\n+\nIIIIIIIIIIIIIII\n@IIIIIIIIIIIIII\n@r2\nGGCATGCATGCATCAGT\n+\n>IIIIIIIIIIIIIIII\n>fa\nTTGACCATGACATG\n",
 }
 
 

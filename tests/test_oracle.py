@@ -50,11 +50,18 @@ def test_golden_kat_file(orc):
         assert nz == {int(k): v for k, v in case["nonzero"].items()}
     for case in kat["mle"]:
         assert orc.ertl_mle(np.array(case["hist"], dtype=np.uint32), case["p"]) == case["estimate"]
+    for text, want in kat["records"]:      # kseq's record rules (POLICIES.md P10): FASTA, FASTQ, junk in front, CRLF
+        got = orc.records(np.frombuffer(text.encode("latin-1"), dtype=np.uint8))
+        assert [r.decode("latin-1") for r in got] == want, repr(text)
 
 
 RAGGED = [
     b"", b">h\n", b">h", b"ACGT", b"ACGTNNACGTTTGA\n", b">a\nACGTACGTAC\nGGTTAACC\n>b desc\nTTGACCAGT\n",
     b">a\r\nACGTAC\r\nGTACGG\r\n", b">a\nacgtnACGT>ACGT\n\n\nAC\n", b"\n\n>x\n\nACGTAGCTAGCAT\n", b">a\nA\n>b\nC\n>c\nG\n",
+    # kseq's record rules: text in front of the first header, '@' headers, FASTQ (also multi-line, also with '@' / '>' in the
+    # quality), a '\r' inside a line, a '+' line in a FASTA file
+    b"junk >h1 c\nACGTTGCA\nAC\n", b"ACGTACGTAGCTAGCTAGCATCG\n", b"@r1\nACGTTGCAAC\n+\nIIIIIIIIII\n@r2\nGGCATGCAT\n+\nII@>IIIII\n",
+    b"@r1\nACGTTG\nCAACGT\n+\nIIIIII\nI@IIII\n>fa\nTTGACCA\n", b">a\nACGT\rTTGA\nACGTAC\r\r\nGT\n", b">x\nACGTTGCA\n+\nACGTTGCA\nGG>y\nCCATGG\n",
 ]
 
 
