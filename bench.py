@@ -110,16 +110,52 @@ def dashing_baseline(fa, nbases, ks, log2m, jobs, ncpu, exe):
         with ThreadPoolExecutor(max_workers=jobs) as ex:
             outs = list(ex.map(one, ks))
         dt = time.perf_counter() - t0
-        same, checked = [], [k for k in ks if k <= 32][:: max(1, len(ks) // 6)]
+        same, checked, diagnosis = [], [k for k in ks if k <= 32][:: max(1, len(ks) // 6)], {}
         for k in checked:
             regs = read_sketch_file(outs[ks.index(k)])[0]
-            same.append(bool(np.array_equal(regs, orc.sketch(fa, k, log2m, True))))
-        return {"value": nbases / dt / 1e9, "unit": "Gbp/s", "cores": min(jobs, len(ks)), "kind": "dashing",
-                "sample": f"1 synthetic genome x {nbases/1e6:g} Mbp, k {ks[0]}-{ks[-1]}, -S {log2m}: one `{exe} sketch` process per k, "
-                          f"{jobs} in flight on {ncpu} usable host CPUs, {dt:.1f} s wall",
-                "registers_equal_oracle": dict(zip(map(str, checked), same)), "registers_all_equal": all(same)}
+            ours = orc.sketch(fa, k, log2m, True)
+            same.append(bool(np.array_equal(regs, ours)))
+            if not same[-1]:
+                diagnosis[str(k)] = diagnose_register_mismatch(regs, ours, log2m, orc)
+        out = {"value": nbases / dt / 1e9, "unit": "Gbp/s", "cores": min(jobs, len(ks)), "kind": "dashing",
+               "sample": f"1 synthetic genome x {nbases/1e6:g} Mbp, k {ks[0]}-{ks[-1]}, -S {log2m}: one `{exe} sketch` process per k, "
+                         f"{jobs} in flight on {ncpu} usable host CPUs, {dt:.1f} s wall",
+               "registers_equal_oracle": dict(zip(map(str, checked), same)), "registers_all_equal": all(same)}
+        if diagnosis:
+            out["mismatch_diagnosis"] = diagnosis   # which RECALL policy of oracle/POLICIES.md the difference points at
+        return out
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+def diagnose_register_mismatch(theirs, ours, log2m, orc):
+    """Dashing's registers differ from the oracle's: which assumption of oracle/POLICIES.md does the difference point at?
+    Same non-empty registers with other values -> the rho rule (P7); the same multiset of values at other indices -> the
+    index bits (P6); statistically the same sketch (cardinalities within 3 sigma) -> the hash or its input (P3, P4, P5);
+    a different cardinality -> a different SET of k-mers: the code table or the record rules (P1, P2, P10)."""
+    theirs, ours = np.asarray(theirs, dtype=np.uint8), np.asarray(ours, dtype=np.uint8)
+    if theirs.shape != ours.shape:
+        return {"differing": None, "points_at": "P9 (container: another register count than -S asked for)"}
+    sigma = 1.04 / float(np.sqrt(1 << log2m))
+    ct, co = float(orc.card(theirs, log2m)), float(orc.card(ours, log2m))
+    rel = abs(ct - co) / max(co, 1.0)
+    d = {"differing": int((theirs != ours).sum()), "of": int(ours.size),
+         "same_support": bool(np.array_equal(theirs > 0, ours > 0)),
+         "same_histogram": bool(np.array_equal(np.bincount(theirs, minlength=64), np.bincount(ours, minlength=64))),
+         "card_dashing": ct, "card_oracle": co, "card_rel_diff_in_sigma": rel / sigma}
+    both = (theirs > 0) & (ours > 0)
+    shift = np.unique(theirs[both].astype(int) - ours[both].astype(int)) if both.any() else np.array([0])
+    if d["differing"] <= 0.01 * ours.size:
+        d["points_at"] = "a few registers only: P4 (the all-T 32-mer), P7's saturation case, or a damaged file"
+    elif d["same_histogram"]:
+        d["points_at"] = "P6 (which p bits of the hash index the register)"
+    elif d["same_support"] and shift.size == 1:
+        d["points_at"] = f"P7 (rho: sentinel / offset of the leading-zero count; every register is off by {int(shift[0])})"
+    elif rel < 3 * sigma:
+        d["points_at"] = "P3 / P5 (canonical form or hash: another but statistically equivalent sketch of the same k-mer set)"
+    else:
+        d["points_at"] = "P1 / P2 / P10 (another set of k-mers: code table, window reset, record rules)"
+    return d
 
 
 def cpu_baseline(nbases, nrec, kmin, kmax, log2m, ngenomes=4):

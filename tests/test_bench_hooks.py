@@ -33,7 +33,12 @@ while i < len(a):
     i += 1
 regs = orc.sketch(np.fromfile(fasta, dtype=np.uint8), k, S, True)
 if os.environ.get("SHIM_CORRUPT") and k == int(os.environ["SHIM_CORRUPT"]):
-    regs = regs.copy(); regs[5] += 1
+    mode = os.environ.get("SHIM_MODE", "one")
+    regs = regs.copy()
+    if mode == "one": regs[5] += 1
+    elif mode == "rho": regs[regs > 0] += 1                 # another sentinel / offset in the rho rule
+    elif mode == "index": regs = regs[::-1].copy()          # other bits of the hash as the index
+    elif mode == "hash": regs = orc.sketch(np.fromfile(fasta, dtype=np.uint8), k, S, False)   # another hash input (here: not canonical)
 write_sketch_file(os.path.join(prefix, os.path.basename(fasta) + ".w.%%d.spacing.%%d.hll" %% (k, S)), regs, S, k, True, fmt="dashing")
 '''
 
@@ -63,6 +68,12 @@ def test_cpu_baseline_uses_and_checks_a_dashing_on_path(tmp_path, monkeypatch):
     monkeypatch.setenv("SHIM_CORRUPT", "10")   # a Dashing whose registers differ must be reported, not hidden
     bad = bench.cpu_baseline(120_000, 2, 10, 13, 12)
     assert bad["kind"] == "dashing" and bad["registers_all_equal"] is False and bad["registers_equal_oracle"]["10"] is False
+    # ... and the line says which RECALL assumption (oracle/POLICIES.md) the difference points at
+    assert bad["mismatch_diagnosis"]["10"]["differing"] == 1 and bad["mismatch_diagnosis"]["10"]["same_support"]
+    for mode, policy in (("rho", "P7"), ("index", "P6"), ("hash", "P3 / P5")):
+        monkeypatch.setenv("SHIM_MODE", mode)
+        d = bench.cpu_baseline(120_000, 2, 10, 13, 12)["mismatch_diagnosis"]["10"]
+        assert d["points_at"].startswith(policy), (mode, d)
 
 
 @pytest.mark.gpu

@@ -3,6 +3,8 @@ fast per-k derivation used in the hot Python loops must produce exactly what the
 constructor produces (names, directories, catalog entries)."""
 import os
 
+import numpy as np
+
 import pytest
 
 from dandd_amd.host import store
@@ -87,6 +89,30 @@ def test_dashing_container_round_trip(tmp_path):
     assert backend.convert_main(["import", exported, back, "21"]) == 0
     r2, log2m, k, canon = backend.read_sketch_file(back)
     assert (log2m, k, canon) == (12, 21, True) and np.array_equal(r2, regs)
+
+
+def test_dashing_container_against_a_byte_level_fixture(tmp_path, monkeypatch):
+    """Row f2 (Dashing's `.hll` container) against bytes this package did not write: tests/golden/hll/recalled_p10*.hll
+    were built field by field by tests/golden/make_hll_fixture.py (no import of dandd_amd).  The reader takes the plain
+    and the gzip form and returns the fixture's registers; the writer reproduces the plain fixture byte for byte and a
+    gzip stream that inflates to it.  (The LAYOUT stays a recollection -- POLICIES.md P9; this pins it against drift.)"""
+    import gzip
+    from dandd_amd.host import backend
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hll")
+    want = np.frombuffer(open(os.path.join(gold, "recalled_p10.registers"), "rb").read(), dtype=np.uint8)
+    plain = open(os.path.join(gold, "recalled_p10.hll"), "rb").read()
+    assert len(plain) == 32 + 1024 and plain[32:] == want.tobytes()
+    for name in ("recalled_p10.hll", "recalled_p10.gz.hll"):
+        # the file NAME carries k (Dashing's container does not): give the fixture a DandD leaf name
+        leaf = tmp_path / f"g0.fasta.w.21.spacing.10.{'gz' if 'gz' in name else 'plain'}.hll"
+        leaf.write_bytes(open(os.path.join(gold, name), "rb").read())
+        regs, log2m, k, canon = backend.read_sketch_file(str(leaf))
+        assert (log2m, canon) == (10, True) and np.array_equal(regs, want)
+    out = tmp_path / "written.w.21.spacing.10.hll"
+    backend.write_sketch_file(str(out), want, 10, 21, True, fmt="dashing-plain")
+    assert out.read_bytes() == plain
+    backend.write_sketch_file(str(out), want, 10, 21, True, fmt="dashing")
+    assert out.read_bytes()[:2] == b"\x1f\x8b" and gzip.decompress(out.read_bytes()) == plain
 
 
 def test_exact_databases_identify_genomes_by_name_and_size(tmp_path, monkeypatch):
