@@ -448,8 +448,22 @@ def accuracy_block(wl, card, what):
     }
 
 
+def bgzf_bytes(raw, level=6):
+    """bgzip's container: gzip members of <= 64 KiB of text, each with its own size in a 'BC' extra field, + the empty EOF block"""
+    import zlib
+    out = bytearray()
+    for a in list(range(0, len(raw), 65280)) + [len(raw)]:
+        part = raw[a:a + 65280] if a < len(raw) else b""
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = c.compress(part) + c.flush()
+        out += (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + (len(body) + 25).to_bytes(2, "little") + body +
+                zlib.crc32(part).to_bytes(4, "little") + len(part).to_bytes(4, "little"))
+    return bytes(out)
+
+
 def ingest_probe(eng, ng, nb, nrec, kmin, kmax, torch, gz=False, reps=10):
-    """dd_sketch_files over FASTA files (tmpfs when there is one: a warm page cache), third call."""
+    """dd_sketch_files over FASTA files (tmpfs when there is one: a warm page cache), third call.
+    gz: False plain, True one gzip member per file (gzip -1), "bgzf" bgzip's blocked container (level 6)."""
     import zlib
     from dandd_amd.engine import synth_size
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
@@ -462,7 +476,10 @@ def ingest_probe(eng, ng, nb, nrec, kmin, kmax, torch, gz=False, reps=10):
             eng.synth_fasta_device(SEED, g, nb, nrec, buf.data_ptr())
             eng.synchronize()
             p = os.path.join(d, f"g{g:03d}.fasta" + (".gz" if gz else ""))
-            if gz:  # one gzip member, level 1 (what `gzip -1` writes)
+            if gz == "bgzf":
+                with open(p, "wb") as f:
+                    f.write(bgzf_bytes(buf[:n].cpu().numpy().tobytes()))
+            elif gz:  # one gzip member, level 1 (what `gzip -1` writes)
                 co = zlib.compressobj(1, zlib.DEFLATED, 31)
                 with open(p, "wb") as f:
                     f.write(co.compress(buf[:n].cpu().numpy().tobytes()) + co.flush())
@@ -479,7 +496,7 @@ def ingest_probe(eng, ng, nb, nrec, kmin, kmax, torch, gz=False, reps=10):
         _, wait, batches, nbytes = eng.last_ingest_stats()
         return {"value": ng * nb / med / 1e9, "unit": "Gbp/s", "ms": med * 1e3, "best_value": ng * nb / best / 1e9, "best_ms": best * 1e3,
                 "launches": batches, "fasta_MB": nbytes / 1e6,
-                "what": f"dd_sketch_files: {ng} x {nb/1e6:g} Mbp {'gzip -1' if gz else 'plain'} FASTA files in {base or 'the temp dir'} (warm page cache) -> "
+                "what": f"dd_sketch_files: {ng} x {nb/1e6:g} Mbp {'BGZF (bgzip -6; blocks inflated on the GPU, dd_ginflate.hip)' if gz == 'bgzf' else 'gzip -1' if gz else 'plain'} FASTA files in {base or 'the temp dir'} (warm page cache) -> "
                         f"pinned host buffers -> H2D on a copy stream overlapped with K0/K1 -> registers back to the host; "
                         f"k {kmin}-{kmax}; `value` = MEDIAN of calls {'4-' + str(reps) if reps > 4 else '2-' + str(reps)} on one context, best beside it "
                         f"(PCIe-inclusive: reported beside the headline `value`, never as it)"}
@@ -750,6 +767,17 @@ def main():
             extras["ingest"]["small_files"] = ingest_probe(eng, 64, 5_000_000, cfg["nrec"], kmin, kmax, torch)
             # ... and as most genome directories really are: .gz (host inflate: libdeflate or zlib, one thread per file)
             extras["ingest"]["gzip_files"] = ingest_probe(eng, ng, nb, cfg["nrec"], kmin, kmax, torch, gz=True)
+            # ... and bgzip'd (htslib's blocked gzip): independent <= 64 KiB members, inflated on the GPU (dd_ginflate.hip) -- the
+            # compressed bytes cross PCIe, the host only walks the block sizes; DD_NO_GPU_INFLATE=1 beside it = the host decoder
+            try:
+                extras["ingest"]["bgzf_files"] = ingest_probe(eng, ng, nb, cfg["nrec"], kmin, kmax, torch, gz="bgzf")
+                os.environ["DD_NO_GPU_INFLATE"] = "1"
+                try:
+                    extras["ingest"]["bgzf_files"]["host_decoder_value"] = ingest_probe(eng, ng, nb, cfg["nrec"], kmin, kmax, torch, gz="bgzf", reps=5)["value"]
+                finally:
+                    del os.environ["DD_NO_GPU_INFLATE"]
+            except Exception as e:
+                extras["ingest"]["bgzf_files"] = {"error": f"{type(e).__name__}: {e}"}
             # ... and ONE large .gz (a whole assembly as NCBI ships it: a single gzip member): its deflate stream is cut at
             # block boundaries and the pieces are decoded in parallel without their history (dd_inflate.h); the serial
             # decoder (libdeflate, one thread) beside it

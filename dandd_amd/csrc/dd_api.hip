@@ -137,6 +137,11 @@ struct dd_ctx {
     hipStream_t copy_stream = nullptr, out_stream = nullptr;  // H2D and D2H on streams of their own: an in-order stream would park batch b+1's upload behind batch b's results
     DevBuf pipe_fasta[2], pipe_regs[2];
     HostBuf pipe_out[2];
+    // BGZF files inflated on the device (dd_ginflate.hip): compressed bytes, block table and error count of a batch
+    DevBuf pipe_gz[2], pipe_jobs[2], pipe_err[2];
+    HostBuf pipe_jobs_host[2], pipe_err_host[2];
+    bool no_gpu_inflate = false;   // a block the device decoder refused: this context inflates on the host from now on
+    bool inflate_retry = false;    // ... and the call that met it is run again
     hipEvent_t pipe_h2d[2] = {nullptr, nullptr}, pipe_done[2] = {nullptr, nullptr}, pipe_d2h[2] = {nullptr, nullptr};
     hipStream_t side[8] = {};  // k classes of a small call run side by side
     hipEvent_t side_done[8] = {}, side_go = nullptr, side_stagger = nullptr;
@@ -310,6 +315,11 @@ void dd_destroy(dd_ctx* c) {
         c->pipe_fasta[i].release();
         c->pipe_regs[i].release();
         c->pipe_out[i].release();
+        c->pipe_gz[i].release();
+        c->pipe_jobs[i].release();
+        c->pipe_err[i].release();
+        c->pipe_jobs_host[i].release();
+        c->pipe_err_host[i].release();
         for (hipEvent_t e : {c->pipe_h2d[i], c->pipe_done[i], c->pipe_d2h[i]})
             if (e) (void)hipEventDestroy(e);
     }
@@ -762,9 +772,85 @@ static void parallel_copy(uint8_t* dst, const uint8_t* src, size_t n, int nthrea
     for (auto& t : th) t.join();
 }
 
+static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, int kmin, int kmax, uint8_t* regs, int nthreads);
+
 int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, int kmax, uint8_t* regs,
                     int nthreads) {
     if (check_ctx(c)) return DD_EINVAL;
+    c->inflate_retry = false;
+    int rc = sketch_files_impl(c, paths, nfiles, kmin, kmax, regs, nthreads);
+    if (rc != DD_OK && c->inflate_retry) {
+        // a BGZF block the device decoder would not take: the whole call again with every .gz inflated on the host, whose
+        // decoder either reads the file or says what is wrong with it
+        c->inflate_retry = false;
+        c->no_gpu_inflate = true;
+        rc = sketch_files_impl(c, paths, nfiles, kmin, kmax, regs, nthreads);
+    }
+    return rc;
+}
+
+// One BGZF file's blocks, found on the host (a walk over the 'BC' size fields: ~800 per 50 Mbp file); the blocks
+// themselves are inflated on the device.  false: not a BGZF file the device path takes (the host decoder reads it).
+struct BgzfBlock {
+    size_t in_off;
+    uint32_t in_len, out_len;
+    size_t out_off;
+};
+static bool bgzf_for_device(const char* path, FileBuf& fb, std::vector<BgzfBlock>& blks, size_t& out_size) {
+    using namespace dd::inflate_detail;
+    struct stat sb;
+    if (stat(path, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 28 || (size_t)sb.st_size > ((size_t)3 << 30)) return false;
+    FILE* f = fopen(path, "rb");
+    if (!f) return false;
+    uint8_t head[64];
+    const size_t got = fread(head, 1, sizeof head, f);
+    if (!bgzf_block_size(head, std::max<size_t>(got, 65536))) {   // (only the header is needed here; the size is checked in the walk)
+        fclose(f);
+        return false;
+    }
+    const size_t n = (size_t)sb.st_size;
+    fb.len = 0;
+    bool ok = fb.reserve(n + 16) && fseeko(f, 0, SEEK_SET) == 0 && fread(fb.p, 1, n, f) == n;
+    fclose(f);
+    if (!ok) return false;
+    blks.clear();
+    size_t p = 0, total = 0;
+    while (p < n) {
+        const size_t bs = bgzf_block_size(fb.p + p, n - p);
+        if (!bs) {
+            for (size_t q = p; q < n; ++q)
+                if (fb.p[q]) return false;   // (trailing zeros are tolerated, as gzread tolerates them)
+            break;
+        }
+        const uint8_t* t = fb.p + p + bs - 4;
+        const size_t isize = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+        if (isize > 65536) return false;
+        if (isize) blks.push_back(BgzfBlock{p, (uint32_t)bs, (uint32_t)isize, total});
+        total += isize;
+        p += bs;
+    }
+    if (blks.empty()) return false;
+    // FASTQ (reads, not assemblies) starts with '@' and needs the host's record pass (dd_io.h): look at the first block's text
+    {
+        uint8_t first[256];
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, 15 + 16) != Z_OK) return false;
+        zs.next_in = fb.p + blks[0].in_off;
+        zs.avail_in = blks[0].in_len;
+        zs.next_out = first;
+        zs.avail_out = sizeof first;
+        const int zr = inflate(&zs, Z_SYNC_FLUSH);
+        const size_t made = sizeof first - zs.avail_out;
+        inflateEnd(&zs);
+        if ((zr != Z_OK && zr != Z_STREAM_END) || !made || first[0] == '@' || dd::has_plus_line(first, made)) return false;
+    }
+    fb.len = n;
+    out_size = total;
+    return true;
+}
+
+static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, int kmin, int kmax, uint8_t* regs, int nthreads) {
     if (nfiles < 0 || (nfiles && (!paths || !regs))) return fail(DD_EINVAL, "null argument");
     if (kmin < 1 || kmax > 64 || kmin > kmax) return fail(DD_EINVAL, "k range %d..%d outside 1..64", kmin, kmax);
     for (int i = 0; i < nfiles; ++i)
@@ -779,13 +865,17 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
 
     // batch size in files: ~128 MB of FASTA per launch, judged by what is on disk (a .gz inflates ~4x)
     size_t disk_bytes = 0;
+    bool any_gz = false;
     for (int i = 0; i < nfiles; ++i) {
         struct stat sb;
         if (stat(paths[i], &sb) == 0 && sb.st_size > 0) {
             const size_t n = (size_t)sb.st_size, L = strlen(paths[i]);
-            disk_bytes += (L > 3 && strcmp(paths[i] + L - 3, ".gz") == 0) ? 4 * n : n;
+            const bool gz = L > 3 && strcmp(paths[i] + L - 3, ".gz") == 0;
+            any_gz |= gz;
+            disk_bytes += gz ? 4 * n : n;
         }
     }
+    const bool gpu_inflate = !c->no_gpu_inflate && !getenv("DD_NO_GPU_INFLATE");
     const size_t avg = std::max<size_t>(1, disk_bytes / (size_t)nfiles);
     // (log2m >= 17: the scatter/sort/replay path runs epoch by epoch over all rows of a launch and wants many rows)
     // (Batches that grow -- 64, 128, 256 MB -- were measured against fixed 128 MB ones once the job tables of several
@@ -793,8 +883,11 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
     // (a context's FIRST call at log2m >= 17 keeps to 128 MB: the record areas and the pinned register staging are
     // allocated for a batch's rows, and hipMalloc + hipHostMalloc of a 512 MB batch's 5.5 GB + 0.4 GB cost a one-shot
     // `dandd tree -r 20` 0.23 s against 0.06 s; a long-lived context grows them on its second call)
+    // (BGZF files inflated on the device: a launch of the inflate kernel takes as long as ONE block does -- 10 ms, the
+    // serial walk of a deflate stream by one wave -- whether it holds 1 block or the 3840 the chip keeps in flight, so
+    // those calls batch ~320 MB of text: five 50 Mbp files, one round of blocks)
     const size_t kBatchBytes = (size_t)(getenv("DD_BATCH_MB") ? std::max(1, atoi(getenv("DD_BATCH_MB")))
-                                        : (c->p >= 17 ? (c->ingest_calls == 0 ? 128 : 512) : 128)) << 20;
+                                        : (c->p >= 17 ? (c->ingest_calls == 0 ? 128 : 512) : (any_gz && gpu_inflate ? 320 : 128))) << 20;
     // (at most 256 files per launch: the loaders' window is two batches of host buffers of 2 MiB at least; with 64,
     // a thousand 100 kbp plasmids took 23 launches of ~3 ms each)
     const size_t kMaxBatchFiles = getenv("DD_BATCH_FILES") ? (size_t)std::max(1, atoi(getenv("DD_BATCH_FILES"))) : 256;
@@ -825,6 +918,9 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
         bool claimed = false, ready = false;  // a loader took the file's buffer / the buffer can be written to
         int pieces_left = 0;
         size_t plain_size = 0;                // > 0: not gzip, read in pieces by several loaders
+        bool dev_inflate = false;             // BGZF: the buffer holds the COMPRESSED file, the device inflates its blocks
+        size_t out_size = 0;                  // ... into this many bytes of text
+        std::vector<BgzfBlock> blks;
     };
     std::vector<Slot> slots(nfiles);
     // Work items in file order.  A plain file is cut into 8 MiB pieces that different loaders pread into the
@@ -915,7 +1011,8 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
                 cv.notify_all();
             }
             if (it.len == 0) {
-                ok = read_fasta_file(paths[it.file], fb, err, gz_par);
+                if (gpu_inflate && bgzf_for_device(paths[it.file], fb, sl.blks, sl.out_size)) sl.dev_inflate = true;
+                else ok = read_fasta_file(paths[it.file], fb, err, gz_par);
             } else if (ok && fb.cap >= sl.plain_size) {
                 FILE* f = fopen(paths[it.file], "rb");
                 ok = f && fseeko(f, (off_t)it.off, SEEK_SET) == 0 && fread(fb.p + it.off, 1, it.len, f) == it.len;
@@ -950,6 +1047,7 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
     struct InFlight {
         int first = 0, count = 0;   // files of the batch
         bool active = false;
+        bool inflated = false;      // some of its files were inflated on the device: the error count is looked at
     };
     InFlight fly[2];
     // hand a finished batch's results to the caller and its host buffers back to the pool
@@ -958,7 +1056,8 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
         if (!f.active) return DD_OK;
         f.active = false;
         const bool arrived = hipEventSynchronize(c->pipe_d2h[set]) == hipSuccess;
-        if (arrived)
+        const bool refused = arrived && f.inflated && *static_cast<const uint32_t*>(c->pipe_err_host[set].p) != 0;
+        if (arrived && !refused)
             parallel_copy(regs + (size_t)f.first * slab, static_cast<const uint8_t*>(c->pipe_out[set].p), (size_t)f.count * slab, nthreads);
         else
             (void)hipStreamSynchronize(c->copy_stream);  // nothing may still read the host buffers that go back below
@@ -969,6 +1068,10 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
         }
         cv.notify_all();
         // (a failed batch has still given its buffers back: the loaders must never wait for ever)
+        if (refused) {
+            c->inflate_retry = true;
+            return fail(DD_EIO, "ingestion pipeline: %u BGZF block(s) refused by the device decoder", *static_cast<const uint32_t*>(c->pipe_err_host[set].p));
+        }
         return arrived ? DD_OK : fail(DD_EHIP, "ingestion pipeline: D2H failed");
     };
     auto release_unsent = [&](int first, int count) {  // error path: the loaders must never wait for ever
@@ -1020,12 +1123,29 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
         const double ti = now();
         std::vector<size_t> sizes(count), offs(count);
         size_t tot = 0;
+        size_t gz_tot = 0, njobs = 0;
+        std::vector<size_t> gz_off(count, 0);
         for (int j = 0; j < count; ++j) {
-            sizes[j] = c->file_pool[slots[i + j].buf]->size();
+            const Slot& sj = slots[i + j];
+            sizes[j] = sj.dev_inflate ? sj.out_size : c->file_pool[sj.buf]->size();
             offs[j] = tot;
             tot += align_up(sizes[j] + 16, 256);
+            if (sj.dev_inflate) {
+                gz_off[j] = gz_tot;
+                gz_tot += align_up(c->file_pool[sj.buf]->size() + 16, 256);
+                njobs += sj.blks.size();
+            }
         }
         total_bytes += tot;
+        if (njobs && ((rc = c->pipe_gz[set].reserve(gz_tot + 16)) != DD_OK || (rc = c->pipe_jobs[set].reserve(njobs * sizeof(dd::InflateJob))) != DD_OK ||
+                      (rc = c->pipe_jobs_host[set].reserve(njobs * sizeof(dd::InflateJob))) != DD_OK || (rc = c->pipe_err[set].reserve(256)) != DD_OK ||
+                      (rc = c->pipe_err_host[set].reserve(256)) != DD_OK)) {
+            first_err = g_err;
+            release_unsent(i, count);
+            cv.notify_all();
+            i += count;
+            continue;
+        }
         // (growing a device buffer frees the old one: the compute stream may still read it for the batch before
         // last only if that batch has not been retired -- it has, above)
         if ((rc = c->pipe_fasta[set].reserve(tot + 16)) != DD_OK || (rc = c->pipe_regs[set].reserve((size_t)count * slab)) != DD_OK ||
@@ -1038,11 +1158,30 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
         }
         hipError_t e = hipSuccess;
         std::vector<const uint8_t*> ptrs(count);
+        dd::InflateJob* jobs_host = njobs ? static_cast<dd::InflateJob*>(c->pipe_jobs_host[set].p) : nullptr;
+        size_t nj = 0;
         for (int j = 0; j < count && e == hipSuccess; ++j) {
             ptrs[j] = static_cast<const uint8_t*>(c->pipe_fasta[set].p) + offs[j];
-            if (sizes[j])
-                e = hipMemcpyAsync(const_cast<uint8_t*>(ptrs[j]), c->file_pool[slots[i + j].buf]->data(), sizes[j],
-                                   hipMemcpyHostToDevice, c->copy_stream);
+            const Slot& sj = slots[i + j];
+            const FileBuf& fbj = *c->file_pool[sj.buf];
+            if (sj.dev_inflate) {
+                // the COMPRESSED file goes over PCIe (a quarter of the text); its blocks are inflated into ptrs[j] below
+                uint8_t* gz = static_cast<uint8_t*>(c->pipe_gz[set].p) + gz_off[j];
+                e = hipMemcpyAsync(gz, fbj.data(), fbj.size(), hipMemcpyHostToDevice, c->copy_stream);
+                for (const BgzfBlock& b : sj.blks)
+                    jobs_host[nj++] = dd::InflateJob{gz + b.in_off, b.in_len, b.out_len, const_cast<uint8_t*>(ptrs[j]) + b.out_off};
+            } else if (sizes[j]) {
+                e = hipMemcpyAsync(const_cast<uint8_t*>(ptrs[j]), fbj.data(), sizes[j], hipMemcpyHostToDevice, c->copy_stream);
+            }
+        }
+        if (njobs && e == hipSuccess) {
+            e = hipMemsetAsync(c->pipe_err[set].p, 0, 4, c->copy_stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(c->pipe_jobs[set].p, jobs_host, njobs * sizeof(dd::InflateJob), hipMemcpyHostToDevice, c->copy_stream);
+            if (e == hipSuccess) {
+                dd::launch_inflate_bgzf(static_cast<const dd::InflateJob*>(c->pipe_jobs[set].p), (int)njobs, static_cast<uint32_t*>(c->pipe_err[set].p), c->copy_stream);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(c->pipe_err_host[set].p, c->pipe_err[set].p, 4, hipMemcpyDeviceToHost, c->copy_stream);
         }
         if (e == hipSuccess) e = hipEventRecord(c->pipe_h2d[set], c->copy_stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->pipe_h2d[set], 0);
@@ -1069,6 +1208,7 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
             fly[set].first = i;
             fly[set].count = count;
             fly[set].active = true;
+            fly[set].inflated = njobs != 0;
             ++nbatches;
         }
         if (trace)

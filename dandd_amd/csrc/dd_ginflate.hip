@@ -1,0 +1,473 @@
+// dd_ginflate.hip -- BGZF blocks inflated on the GPU, straight into the FASTA buffer K0 reads.
+//
+// Real genome directories hold .fa.gz (/root/reference/lib/species_specifics.py:93) and every `dashing sketch` job of
+// the reference inflates its input again (lib/huffman_dandd.py:214-218: one process per k).  On the host ten 50 Mbp
+// .gz files at once are bound by the CPUs' aggregate inflate rate (3.8-5.6 Gbp/s on 16 cores, profiles/r03_ingest_gzip.txt)
+// while the kernels behind them run at 20-36 Gbp/s.  A BGZF file (bgzip, htslib) is a sequence of independent gzip
+// members of <= 64 KiB of text each, every one saying its own compressed size: they can be decoded anywhere, in any order.
+//
+// One wave per block.  A deflate stream is a serial thing -- every Huffman code starts where the previous one ended --
+// so the wave walks it in LOCKSTEP: all lanes hold the same bit buffer and look the same table entry up (LDS broadcasts),
+// and what a symbol makes is done by the lanes together: a match of length L is copied by L lanes at once, dynamic-code
+// tables are filled code by code with the replicas of a code spread over the lanes.
+// The block's TEXT lives where it is going -- the FASTA buffer in HBM --, not in LDS: a wave then needs 10 KiB of LDS (its
+// code tables and a ring of compressed input) instead of 76, sixteen waves share a CU instead of two, and the serial
+// chain of one block (table lookup -> table lookup -> copy, ~10^3 cycles per symbol with the round trips to L2) hides
+// behind fifteen others.  (The first form kept a 64 KiB image per wave in LDS: 5 ms per block with nothing to overlap,
+// 20 ms per 1600-block launch, slower than the host's sixteen threads; profiles/r04_bgzf.txt.)  A copy reads what earlier
+// symbols of the same wave stored: stores are awaited (vmcnt) only when the source reaches into the part of the text
+// that may still be in flight, and the bytes are read past the vector L1 (sc1).
+// Anything that is not a valid block -- bad code lengths, a distance before the block's start, a length that does not
+// match the member's ISIZE -- raises the launch's error count and the caller falls back to the host decoder
+// (dd_inflate.h), which words the error.  The member's CRC-32 is NOT checked here (ISIZE and the deflate structure are).
+#include "dd_common.h"
+#include "dd_kernels.h"
+
+#include <atomic>
+
+namespace dd {
+namespace {
+
+extern __shared__ __attribute__((aligned(16))) uint8_t g_lds[];
+
+constexpr uint32_t kLitInfo = 0;                  // u32[1024]: literal / length code table (10-bit lookup)
+constexpr uint32_t kDistInfo = kLitInfo + 4096u;  // u32[1024]: distance code table
+constexpr uint32_t kLitCount = kDistInfo + 4096u; // u16[16] + u16[288]: codes longer than 10 bits, puff-style
+constexpr uint32_t kLitSymbol = kLitCount + 32u;
+constexpr uint32_t kDistCount = kLitSymbol + 576u;
+constexpr uint32_t kDistSymbol = kDistCount + 32u;
+constexpr uint32_t kLens = kDistSymbol + 64u;     // u8[320]: code lengths while a table is built
+constexpr uint32_t kClInfo = kLens + 320u;        // u16[128]: code-length code table (7-bit lookup)
+constexpr uint32_t kInflateLds = (kClInfo + 256u + 15u) & ~15u;   // 9.25 KiB: seventeen one-wave workgroups per CU
+
+constexpr int FAST = 10;
+
+__constant__ uint16_t c_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ uint8_t c_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ uint16_t c_dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ uint8_t c_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+DD_D uint32_t& l32(uint32_t off) { return *reinterpret_cast<uint32_t*>(g_lds + off); }
+DD_D uint16_t& l16(uint32_t off) { return *reinterpret_cast<uint16_t*>(g_lds + off); }
+DD_D uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane(v); }
+DD_D uint64_t uni64(uint64_t v) { return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v); }
+DD_D uint32_t gload1(const uint8_t* p) { return *(const DD_GLOBAL uint8_t*)p; }
+DD_D uint32_t lane_value(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+
+// The wave's bit reader: every lane holds the same state.  The block's compressed words come through the lanes
+// themselves: lane j keeps word (window + j) of the input, a refill of the bit buffer is ONE v_readlane, and the next
+// window of 256 bytes is asked for (one coalesced load) when the current one is entered, a whole window ahead of need.
+// (Words taken from HBM as they were needed cost a memory round trip per 32 bits of input: 6.5 ms per block; a ring in
+// LDS costs eight instructions per word and 2 KiB per wave; profiles/r04_bgzf.txt.)
+struct WBits {
+    const uint32_t* w;     // the input as 4-byte aligned words
+    uint32_t wi;           // next word to put into `ahead`
+    uint32_t nwords;       // words that belong to the block (beyond: zeros)
+    uint32_t cur, nxt;     // this lane's word of the window that holds word wi, and of the one after it
+    uint64_t buf;
+    int cnt;
+    uint32_t ahead;        // W[wi - 1], already taken from the window
+    DD_D uint32_t fetch(uint32_t first) const {   // this lane's word of the 64 that start at `first`
+        const uint32_t i = first + (threadIdx.x & 63u);
+        return i < nwords ? gload4(w + i) : 0u;
+    }
+    DD_D uint32_t word() {   // W[wi++]
+        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(wi & 63u));
+        ++wi;
+        if ((wi & 63u) == 0u) {
+            cur = nxt;
+            nxt = fetch(wi + 64u);
+        }
+        return v;
+    }
+    DD_D void init(const uint8_t* p, uint32_t nbytes) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+        const uint32_t skip = (uint32_t)(a & 3u);
+        w = reinterpret_cast<const uint32_t*>(a - skip);
+        nwords = (skip + nbytes + 3u) / 4u;
+        cur = fetch(0);
+        nxt = fetch(64u);
+        wi = 0;
+        buf = word();
+        cnt = 32;
+        ahead = word();
+        buf >>= 8 * skip;
+        cnt -= 8 * (int)skip;
+        refill();
+    }
+    DD_D void refill() {   // from >= 0 valid bits to >= 32
+        buf |= (uint64_t)ahead << cnt;
+        cnt += 32;
+        ahead = word();
+    }
+    DD_D void need() { if (cnt <= 32) refill(); }   // more than 32 valid bits afterwards
+    DD_D uint32_t peek(int k) const { return (uint32_t)buf & ((1u << k) - 1u); }   // k <= 16
+    DD_D void drop(int k) { buf >>= k; cnt -= k; }
+    DD_D uint32_t take(int k) {
+        if (cnt < k) refill();
+        const uint32_t v = peek(k);
+        drop(k);
+        return v;
+    }
+    // bytes of the input consumed so far, counting a partly used byte as consumed
+    DD_D uint32_t bytes_used(const uint8_t* p) const {
+        const uintptr_t base = reinterpret_cast<uintptr_t>(w);
+        const uint64_t bits = (uint64_t)(wi - 1) * 32ull - (uint64_t)cnt;   // (`ahead` is read but not in the buffer)
+        return (uint32_t)((bits + 7ull) / 8ull - (reinterpret_cast<uintptr_t>(p) - base));
+    }
+};
+
+// A canonical Huffman code from the lengths at g_lds[kLens + first .. + n): info table (FAST-bit lookup) at `info`, the
+// puff-style count / symbol arrays at `cnt_off` / `sym_off` for longer codes.  kind: 0 literal/length tree, 1 distance tree.
+// Wave-uniform; returns false when the lengths are not a usable code.
+__device__ __noinline__ bool build_table(uint32_t first, int n, int kind, uint32_t info, uint32_t cnt_off, uint32_t sym_off) {
+    const uint32_t lane = threadIdx.x & 63u;
+    // count[l]: lanes 0..15 hold one length each
+    uint32_t mine = 0;
+    if (lane < 16u)
+        for (int i = 0; i < n; ++i) mine += (g_lds[kLens + first + i] == lane) ? 1u : 0u;
+    if (lane < 16u) l16(cnt_off + 2u * lane) = (uint16_t)mine;
+    for (uint32_t i = lane; i < (1u << FAST); i += 64u) l32(info + 4u * i) = 0;
+    __builtin_amdgcn_wave_barrier();
+    int left = 1, nonzero = 0;
+    // next canonical code and next index into symbol[] of each length: lane l keeps length l's pair
+    uint32_t my_code = 0, my_off = 0;
+    uint32_t c = 0, o = 0;
+    for (uint32_t l = 1; l <= 15u; ++l) {
+        const uint32_t cl = uni(l16(cnt_off + 2u * l));
+        left = (left << 1) - (int)cl;
+        if (left < 0) return false;
+        nonzero += (int)cl;
+        if (lane == l) my_code = c, my_off = o;
+        c = (c + cl) << 1;
+        o += cl;
+    }
+    if (nonzero == 0) return kind == 1;   // (a block of literals only may come with no distance code at all: RFC 1951, 3.2.7)
+    if (left > 0 && !(kind == 1 && nonzero == 1)) return false;   // incomplete: only a one-code distance tree may be
+    // every symbol in turn (uniform), its table replicas spread over the lanes
+    for (int i = 0; i < n; ++i) {
+        const uint32_t l = uni((uint32_t)g_lds[kLens + first + i]);
+        if (!l) continue;
+        const uint32_t cd = lane_value(my_code, l), at = lane_value(my_off, l);
+        if (lane == l) ++my_code, ++my_off;
+        if (lane == 0) l16(sym_off + 2u * at) = (uint16_t)i;
+        if (l > (uint32_t)FAST) continue;
+        uint32_t v;
+        if (kind == 0) {
+            if (i < 256) v = l | (1u << 4) | ((uint32_t)i << 11);
+            else if (i == 256) v = l | (2u << 4);
+            else if (i <= 285) v = l | (3u << 4) | ((uint32_t)c_len_extra[i - 257] << 7) | ((uint32_t)c_len_base[i - 257] << 11);
+            else v = 0;   // 286, 287: never valid in a stream
+        } else {
+            v = i <= 29 ? (l | (3u << 4) | ((uint32_t)c_dist_extra[i] << 7) | ((uint32_t)c_dist_base[i] << 11)) : 0u;
+        }
+        const uint32_t rev = __builtin_bitreverse32(cd) >> (32u - l);
+        for (uint32_t f = rev + (lane << l); f < (1u << FAST); f += 64u << l) l32(info + 4u * f) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return true;
+}
+
+// a code longer than FAST bits (or an invalid one), from the low bits of `bits`: walk the lengths, one bit at a time.
+// -> symbol << 4 | code length, or ~0u when there is no such code.  (The bit reader stays in the caller's registers:
+// handing it over by reference put it, and with it every shift of the hot loop, into scratch memory.)
+__device__ __noinline__ uint32_t decode_slow(uint64_t bits, uint32_t cnt_off, uint32_t sym_off) {
+    int code = 0, first = 0, index = 0;
+    for (int l = 1; l <= 15; ++l) {
+        code |= (int)(bits & 1ull);
+        bits >>= 1;
+        const int c = (int)uni(l16(cnt_off + 2u * (uint32_t)l));
+        if (code - c < first) return (uni(l16(sym_off + 2u * (uint32_t)(index + (code - first)))) << 4) | (uint32_t)l;
+        index += c;
+        first += c;
+        first <<= 1;
+        code <<= 1;
+    }
+    return ~0u;
+}
+
+}  // namespace
+
+// grid = blocks; one wave each.  `errors`: blocks that could not be decoded (the caller falls back to the host).
+__global__ __launch_bounds__(64) void inflate_bgzf_kernel(const InflateJob* __restrict__ jobs, uint32_t* __restrict__ errors) {
+    const InflateJob job = jobs[blockIdx.x];
+    const uint32_t lane = threadIdx.x & 63u;
+    bool ok = true;
+    const uint8_t* in = job.in;
+    const uint32_t n = job.in_len;
+    uint8_t* const out = job.out;
+    uint32_t at = 0;
+    // The text goes out 64 bytes at a time: every lane owns one byte of the batch [bstart, bstart + used) and knows where it
+    // comes from -- a literal, or an earlier position of the text --, so a batch of ~8 symbols costs ONE load and ONE
+    // (contiguous) store, and the serial chain pays a round trip to L2 per batch instead of per symbol.
+    uint32_t bstart = 0, used = 0;   // wave-uniform
+    uint32_t from = 0;               // this lane's byte: 0x80000000 | literal, or its source offset in the text
+    uint32_t safe = 0;               // text [0, safe) is known to have reached L2: stores issued since may still be in flight
+    auto flush = [&]() {
+        if (used) {
+            uint32_t v = from & 0xFFu;
+            if (lane < used && !(from >> 31)) v = gload1_fresh(out + from);
+            if (lane < used) out[bstart + lane] = (uint8_t)v;
+            bstart += used;
+            used = 0;
+        }
+    };
+    auto settle = [&](uint32_t src_end) {   // before text below src_end is read: everything stored so far has landed
+        if (src_end > safe) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            safe = bstart;
+        }
+    };
+    // gzip member header: 10 fixed bytes, FEXTRA (BGZF's 'BC' field lives there), then -- not in BGZF, but legal -- name, comment, CRC16
+    uint32_t hdr = 0;
+    if (n < 28u || uni(gload1(in)) != 0x1fu || uni(gload1(in + 1)) != 0x8bu || uni(gload1(in + 2)) != 8u) ok = false;
+    if (ok) {
+        const uint32_t flg = uni(gload1(in + 3));
+        hdr = 10;
+        if (flg & 4u) hdr += 2u + (uni(gload1(in + 10)) | (uni(gload1(in + 11)) << 8));
+        if (flg & (8u | 16u | 2u | 0xE0u)) ok = false;   // (name / comment / header CRC: bgzip writes none; the host decoder takes such files)
+        if (hdr + 8u > n) ok = false;
+    }
+    WBits b;
+    if (ok) {
+        b.init(in + hdr, n - hdr);
+        for (;;) {
+            const uint32_t bfinal = b.take(1), btype = b.take(2);
+            if (btype == 3u) { ok = false; break; }
+            if (btype == 0u) {
+                b.drop(b.cnt & 7);
+                const uint32_t len = b.take(16), nlen = b.take(16);
+                if ((len ^ nlen) != 0xffffu || at + len > job.out_len) { ok = false; break; }
+                // stored bytes: the reader's buffered bits first (whole bytes now), the rest straight from the input
+                const uint32_t used_in = b.bytes_used(in + hdr);   // bytes consumed up to the data's first byte (a byte boundary)
+                if (hdr + used_in + len + 8u > n) { ok = false; break; }
+                flush();
+                for (uint32_t i = lane; i < len; i += 64u) out[at + i] = (uint8_t)gload1(in + hdr + used_in + i);
+                bstart = at + len;
+                at += len;
+                b.init(in + hdr + used_in + len, n - hdr - used_in - len);
+            } else {
+                if (btype == 1u) {
+                    for (uint32_t i = lane; i < 320u; i += 64u) g_lds[kLens + i] = (uint8_t)(i < 144u ? 8 : i < 256u ? 9 : i < 280u ? 7 : i < 288u ? 8 : 5);
+                    __builtin_amdgcn_wave_barrier();
+                    if (!uni(build_table(0, 288, 0, kLitInfo, kLitCount, kLitSymbol)) || !uni(build_table(288, 30, 1, kDistInfo, kDistCount, kDistSymbol))) { ok = false; break; }
+                } else {
+                    const uint32_t hlit = b.take(5) + 257u, hdist = b.take(5) + 1u, hclen = b.take(4) + 4u;
+                    if (hlit > 286u || hdist > 30u) { ok = false; break; }
+                    // the code-length code: 19 lengths of 3 bits, a 7-bit table
+                    if (lane < 19u) g_lds[kLens + lane] = 0;
+                    __builtin_amdgcn_wave_barrier();
+                    for (uint32_t i = 0; i < hclen; ++i) {
+                        const uint32_t v = b.take(3);
+                        if (lane == 0) g_lds[kLens + c_cl_order[i]] = (uint8_t)v;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    {
+                        int left = 1;
+                        uint32_t mine = 0;   // lane l: how many of the 19 have length l, then its next code
+                        if (lane < 8u)
+                            for (int i = 0; i < 19; ++i) mine += ((uint32_t)g_lds[kLens + i] == lane) ? 1u : 0u;
+                        const uint32_t zeros = lane_value(mine, 0);
+                        uint32_t c = 0, my_code = 0;
+                        for (uint32_t l = 1; l <= 7u; ++l) {
+                            const uint32_t cl = lane_value(mine, l);
+                            left = (left << 1) - (int)cl;
+                            if (lane == l) my_code = c;
+                            c = (c + cl) << 1;
+                        }
+                        if (left != 0 && !(zeros == 18u && left > 0)) { ok = false; break; }   // (one code of one bit is tolerated, as zlib does)
+                        for (uint32_t i = lane; i < 128u; i += 64u) l16(kClInfo + 2u * i) = 0;
+                        __builtin_amdgcn_wave_barrier();
+                        for (int i = 0; i < 19; ++i) {
+                            const uint32_t l = uni((uint32_t)g_lds[kLens + i]);
+                            if (!l) continue;
+                            const uint32_t cd = lane_value(my_code, l);
+                            if (lane == l) ++my_code;
+                            const uint32_t rev = __builtin_bitreverse32(cd) >> (32u - l);
+                            for (uint32_t f = rev + (lane << l); f < 128u; f += 64u << l) l16(kClInfo + 2u * f) = (uint16_t)(l | ((uint32_t)i << 4));
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    // the literal/length and distance code lengths, run-length coded
+                    uint32_t i = 0, prev = 0;
+                    while (i < hlit + hdist) {
+                        b.need();
+                        const uint32_t e = uni(l16(kClInfo + 2u * b.peek(7)));
+                        if (!e) { ok = false; break; }
+                        b.drop((int)(e & 15u));
+                        const uint32_t s = e >> 4;
+                        uint32_t rep = 1, val = s;
+                        if (s == 16u) {
+                            if (!i) { ok = false; break; }
+                            val = prev;
+                            rep = 3u + b.take(2);
+                        } else if (s == 17u) {
+                            val = 0;
+                            rep = 3u + b.take(3);
+                        } else if (s == 18u) {
+                            val = 0;
+                            rep = 11u + b.take(7);
+                        }
+                        if (i + rep > hlit + hdist) { ok = false; break; }
+                        // (lengths of the two trees go to their own places: literal/length at 0.., distance at 288..)
+                        for (uint32_t r = lane; r < rep; r += 64u) {
+                            const uint32_t sym = i + r;
+                            g_lds[kLens + (sym < hlit ? sym : 288u + (sym - hlit))] = (uint8_t)val;
+                        }
+                        i += rep;
+                        prev = val;
+                    }
+                    if (!ok) break;
+                    __builtin_amdgcn_wave_barrier();
+                    if (uni((uint32_t)g_lds[kLens + 256u]) == 0u) { ok = false; break; }   // no end-of-block code
+                    if (!uni(build_table(0, (int)hlit, 0, kLitInfo, kLitCount, kLitSymbol)) || !uni(build_table(288, (int)hdist, 1, kDistInfo, kDistCount, kDistSymbol))) { ok = false; break; }
+                }
+                // the block's symbols.  (Every lane holds the same reader and batch state, and what comes out of memory or
+                // out of a call is said to be uniform where it is read: the bookkeeping then stays in scalar registers and
+                // its branches are scalar.  Left to itself the compiler ran all of it on the vector unit under exec masks,
+                // ~460 instructions per symbol; a wave issues one instruction in ~4 cycles and the waves of a CU share one
+                // scalar and four vector issue slots, so instructions per symbol is what a launch costs.)
+                for (;;) {
+                    b.need();   // > 32 bits: a literal/length code and its extra bits take <= 15 + 5
+                    const uint32_t li = uni(l32(kLitInfo + 4u * b.peek(FAST)));
+                    uint32_t kind = (li >> 4) & 7u, val, ex;
+                    if (kind == 1u) {
+                        // LITERALS, decoded side by side: lane i looks up the code that WOULD start at bit i of the buffer
+                        // and keeps its length if it is a literal's (0 otherwise); a scalar walk from bit 0 -- one v_readlane
+                        // per step -- marks the codes that really start there, and the marked lanes hand their literals to
+                        // the output batch.  The walk stops at the first code that is not a literal (or is longer than
+                        // the table's 10 bits): the one-symbol path takes that one.
+                        const uint32_t span = (uint32_t)b.cnt - (uint32_t)FAST;   // bit positions whose lookup lies inside the buffer (> 22)
+                        uint32_t e = 0;
+                        if (lane < span) e = l32(kLitInfo + 4u * ((uint32_t)(b.buf >> lane) & ((1u << FAST) - 1u)));
+                        const uint32_t step = ((e >> 4) & 7u) == 1u ? (e & 15u) : 0u;
+                        unsigned long long mark = 0;
+                        uint32_t pos = 0, nl = 0;
+                        const uint32_t room = 64u - used;
+                        do {
+                            const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)step, (int)pos);
+                            if (!st) break;
+                            mark |= 1ull << pos;
+                            pos += st;
+                            ++nl;
+                        } while (pos < span && nl < room);
+                        if (at + nl > job.out_len) { ok = false; break; }
+                        if ((mark >> lane) & 1ull) {
+                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mark >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mark, 0u));
+                            g_lds[kLens + rank] = (uint8_t)(e >> 11);
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane - used < nl) from = 0x80000000u | (uint32_t)g_lds[kLens + lane - used];
+                        __builtin_amdgcn_wave_barrier();
+                        used += nl;
+                        at += nl;
+                        b.drop((int)pos);
+                        if (used == 64u) flush();
+                        continue;
+                    }
+                    if (li) {
+                        b.drop((int)(li & 15u));
+                        ex = (li >> 7) & 15u;
+                        val = li >> 11;
+                    } else {   // a code longer than the table's 10 bits
+                        const uint32_t r = uni(decode_slow(b.buf, kLitCount, kLitSymbol));
+                        const uint32_t sy = r >> 4;
+                        if (r == ~0u || sy > 285u) { ok = false; break; }
+                        b.drop((int)(r & 15u));
+                        if (sy < 256u) {
+                            if (at >= job.out_len) { ok = false; break; }
+                            if (lane == used) from = 0x80000000u | sy;
+                            ++at;
+                            if (++used == 64u) flush();
+                            continue;
+                        }
+                        kind = sy == 256u ? 2u : 3u;
+                        ex = sy > 256u ? uni((uint32_t)c_len_extra[sy - 257u]) : 0u;
+                        val = sy > 256u ? uni((uint32_t)c_len_base[sy - 257u]) : 0u;
+                    }
+                    if (kind != 3u) {   // end of block (kind 0: a code the stream may not use)
+                        if (kind != 2u) ok = false;
+                        flush();
+                        break;
+                    }
+                    const uint32_t len = val + b.peek((int)ex);
+                    b.drop((int)ex);
+                    b.need();   // a distance code and its extra bits: <= 15 + 13
+                    const uint32_t di = uni(l32(kDistInfo + 4u * b.peek(FAST)));
+                    uint32_t dist;
+                    if (di) {
+                        b.drop((int)(di & 15u));
+                        const uint32_t dex = (di >> 7) & 15u;
+                        dist = (di >> 11) + b.peek((int)dex);
+                        b.drop((int)dex);
+                    } else {
+                        const uint32_t r = uni(decode_slow(b.buf, kDistCount, kDistSymbol));
+                        const uint32_t ds = r >> 4;
+                        if (r == ~0u || ds > 29u) { ok = false; break; }
+                        b.drop((int)(r & 15u));
+                        const uint32_t dex = uni((uint32_t)c_dist_extra[ds]);
+                        dist = uni((uint32_t)c_dist_base[ds]) + b.peek((int)dex);
+                        b.drop((int)dex);
+                    }
+                    if (dist > at || at + len > job.out_len) { ok = false; break; }
+                    // the copy: its bytes join the batch (several batches when it is long).  It reads the dist-byte pattern in
+                    // front of it; should that reach into the batch itself, the batch leaves first.
+                    const uint32_t pat = at - dist, pat_end = pat + (dist < len ? dist : len);
+                    if (pat_end > bstart) flush();
+                    settle(pat_end);
+                    at += len;
+                    auto place = [&](auto src_of) {
+                        uint32_t done = 0;
+                        do {
+                            const uint32_t room = 64u - used, left = len - done;
+                            const uint32_t take = left < room ? left : room;
+                            const uint32_t o = done + lane - used;   // this lane's offset inside the match (if it is one of the `take`)
+                            if (lane - used < take) from = pat + src_of(o);
+                            used += take;
+                            done += take;
+                            if (used == 64u) flush();
+                        } while (done < len);
+                    };
+                    if (dist >= len) place([](uint32_t o) { return o; });
+                    else if (dist == 1u) place([](uint32_t) { return 0u; });   // (a run of N, of one base)
+                    else place([&](uint32_t o) { return o % dist; });          // the pattern repeats inside the match
+                }
+                if (!ok) break;
+            }
+            if (bfinal) break;
+        }
+    }
+    // the member's trailer: CRC-32 (not checked), ISIZE
+    if (ok) {
+        const uint32_t used = b.bytes_used(in + hdr);
+        if (hdr + used + 8u > n) ok = false;
+        else {
+            const uint8_t* t = in + hdr + used + 4u;
+            const uint32_t isize = uni(gload1(t)) | (uni(gload1(t + 1)) << 8) | (uni(gload1(t + 2)) << 16) | (uni(gload1(t + 3)) << 24);
+            if (isize != at || at != job.out_len) ok = false;
+        }
+    }
+    if (!ok) {
+        if (lane == 0) atomicAdd(errors, 1u);
+        return;
+    }
+}
+
+size_t inflate_lds_bytes() { return kInflateLds; }
+
+void launch_inflate_bgzf(const InflateJob* jobs_dev, int njobs, uint32_t* errors_dev, hipStream_t st) {
+    if (njobs <= 0) return;
+    static std::atomic<unsigned long long> done{0};   // one bit per device: the attribute is per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_relaxed) & bit)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(inflate_bgzf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLds) != hipSuccess)
+            (void)hipGetLastError();
+        done.fetch_or(bit, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(inflate_bgzf_kernel, dim3((unsigned)njobs), dim3(64), kInflateLds, st, jobs_dev, errors_dev);
+}
+
+}  // namespace dd

@@ -217,6 +217,19 @@ hipError_t launch_exact_sort_count(uint64_t* lo, uint64_t* hi, uint64_t* lo_alt,
                                    int k, void* temp, size_t temp_bytes, unsigned long long* counters,
                                    hipStream_t st);
 
+// ---------------------------------------------------------------------------------------
+// BGZF blocks inflated on the device (dd_ginflate.hip): one wave per block, text straight into the FASTA buffer
+// ---------------------------------------------------------------------------------------
+struct InflateJob {
+    const uint8_t* in;          // the block: a whole gzip member (header, deflate data, CRC-32, ISIZE)
+    uint32_t in_len;
+    uint32_t out_len;           // its ISIZE (<= 65536)
+    uint8_t* out;               // where its text goes
+};
+size_t inflate_lds_bytes();
+// *errors_dev += blocks that did not decode (the caller falls back to the host decoder)
+void launch_inflate_bgzf(const InflateJob* jobs_dev, int njobs, uint32_t* errors_dev, hipStream_t st);
+
 // synthetic FASTA
 void launch_synth(uint64_t seed, int gi, uint64_t nbases, int nrec, uint8_t* out_dev, hipStream_t st);
 size_t synth_size(uint64_t nbases, int nrec);

@@ -396,17 +396,62 @@ def test_sketch_files_gz_and_plain(engine_factory, orc, tmp_path):
     assert eng.sketch_files([], 9, 14).shape == (0, 6, 1 << 12)
 
 
-def _bgzf(raw, level=1):
+def _bgzf(raw, level=1, strategy=0, block=65280):
     """bgzip's container: <= 64 KiB gzip members with a 'BC' extra subfield that holds the member's size - 1, + the empty EOF block"""
     import zlib
     out = bytearray()
-    for a in list(range(0, len(raw), 65280)) + [len(raw)]:
-        part = raw[a:a + 65280] if a < len(raw) else b""
-        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+    for a in list(range(0, len(raw), block)) + [len(raw)]:
+        part = raw[a:a + block] if a < len(raw) else b""
+        c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
         body = c.compress(part) + c.flush()
         out += (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + (len(body) + 25).to_bytes(2, "little") + body +
                 zlib.crc32(part).to_bytes(4, "little") + len(part).to_bytes(4, "little"))
     return bytes(out)
+
+
+def test_bgzf_files_are_inflated_on_the_device(engine_factory, orc, tmp_path, monkeypatch):
+    """dd_sketch_files over BGZF files: the compressed bytes cross PCIe and dd_ginflate.hip inflates the blocks into the FASTA
+    buffer K0 reads.  Every kind of deflate block -- dynamic codes at levels 1 / 6 / 9, fixed codes (Z_FIXED), stored
+    blocks (level 0), Huffman-only (no matches: an empty distance tree), run-length (distance 1 only), blocks of 1 byte and
+    of the full 64 KiB, repeat-rich text with long far matches -- gives the registers of the uncompressed bytes; a damaged
+    block makes the call fall back to the host decoder, which reports it."""
+    import zlib
+    eng = engine_factory(14, True)
+    uniform, real = orc.synth_fasta(SEED, 0, 3_000_000, 4).tobytes(), orc.synth_realistic(SEED, 1, 2_000_000).tobytes()
+    lowent = (b">x\n" + b"ACGT" * 20 + b"\n") * 20000        # 1.7 MB of one repeated line: maximal matches, overlapping copies
+    cases = []
+    for name, raw, kw in (("l1", uniform, dict(level=1)), ("l6", uniform, dict(level=6)), ("l9", real, dict(level=9)),
+                          ("fixed", uniform[:400_000], dict(level=6, strategy=zlib.Z_FIXED)), ("stored", uniform[:700_000], dict(level=0)),
+                          ("huff", uniform[:500_000], dict(level=6, strategy=zlib.Z_HUFFMAN_ONLY)), ("rle", real[:500_000], dict(level=6, strategy=zlib.Z_RLE)),
+                          ("tiny", uniform[:3000], dict(level=6, block=1)), ("full", uniform, dict(level=6, block=65536)), ("lowent", lowent, dict(level=9))):
+        path = tmp_path / f"{name}.fa.gz"
+        path.write_bytes(_bgzf(raw, **kw))
+        cases.append((name, str(path), np.frombuffer(raw, dtype=np.uint8)))
+    got = eng.sketch_files([p for _, p, _ in cases], 19, 21)
+    assert eng.last_ingest_stats()[2] >= 1
+    for (name, _, fa), regs in zip(cases, got):
+        assert np.array_equal(regs, eng.sketch_buffer(fa, 19, 21)), name
+    monkeypatch.setenv("DD_NO_GPU_INFLATE", "1")                 # the host decoder on the same files: same registers
+    assert np.array_equal(eng.sketch_files([p for _, p, _ in cases[:3]], 19, 21), got[:3])
+    monkeypatch.delenv("DD_NO_GPU_INFLATE")
+    # a block whose deflate data is damaged (its size fields intact): the device refuses it, the call is run again on the
+    # host, whose decoder either reproduces zlib's answer or raises -- never a silently different sketch
+    bad = bytearray(open(cases[1][1], "rb").read())
+    for off in range(20000, 20040):
+        bad[off] ^= 0x5A
+    (tmp_path / "bad.fa.gz").write_bytes(bytes(bad))
+    from dandd_amd.engine import EngineError
+    try:
+        regs = eng.sketch_files([str(tmp_path / "bad.fa.gz")], 19, 21)
+        try:
+            import gzip
+            assert np.array_equal(regs[0], eng.sketch_buffer(np.frombuffer(gzip.decompress(bytes(bad)), dtype=np.uint8), 19, 21))
+        except (OSError, EOFError, zlib.error):
+            raise AssertionError("a damaged BGZF file was sketched although zlib refuses it")
+    except EngineError:
+        pass
+    # (the context now inflates on the host; a fresh one takes the device path again)
+    assert np.array_equal(eng.sketch_files([cases[0][1]], 19, 21)[0], got[0])
 
 
 def test_large_gzip_files_are_inflated_in_parallel(engine_factory, orc, tmp_path, monkeypatch):
