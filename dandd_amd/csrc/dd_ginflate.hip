@@ -81,21 +81,27 @@ struct WBits {
         }
         return v;
     }
+    DD_D void seek(uint32_t q) {   // the next word() is W[q]
+        wi = q;
+        cur = fetch(q & ~63u);
+        nxt = fetch((q & ~63u) + 64u);
+    }
+    DD_D void start_at(uint32_t q, uint32_t r) {   // the reader stands at bit r (< 32) of W[q]
+        seek(q);
+        buf = word();
+        ahead = word();
+        buf >>= r;
+        cnt = 32 - (int)r;
+        refill();
+    }
     DD_D void init(const uint8_t* p, uint32_t nbytes) {
         const uintptr_t a = reinterpret_cast<uintptr_t>(p);
         const uint32_t skip = (uint32_t)(a & 3u);
         w = reinterpret_cast<const uint32_t*>(a - skip);
         nwords = (skip + nbytes + 3u) / 4u;
-        cur = fetch(0);
-        nxt = fetch(64u);
-        wi = 0;
-        buf = word();
-        cnt = 32;
-        ahead = word();
-        buf >>= 8 * skip;
-        cnt -= 8 * (int)skip;
-        refill();
+        start_at(0, 8u * skip);
     }
+    DD_D uint32_t bit_pos() const { return (wi - 1u) * 32u - (uint32_t)cnt; }   // bits of W consumed (`ahead` is read but not in the buffer)
     DD_D void refill() {   // from >= 0 valid bits to >= 32
         buf |= (uint64_t)ahead << cnt;
         cnt += 32;
@@ -203,20 +209,16 @@ __global__ __launch_bounds__(64) void inflate_bgzf_kernel(const InflateJob* __re
     // (contiguous) store, and the serial chain pays a round trip to L2 per batch instead of per symbol.
     uint32_t bstart = 0, used = 0;   // wave-uniform
     uint32_t from = 0;               // this lane's byte: 0x80000000 | literal, or its source offset in the text
-    uint32_t safe = 0;               // text [0, safe) is known to have reached L2: stores issued since may still be in flight
     auto flush = [&]() {
         if (used) {
             uint32_t v = from & 0xFFu;
+            // (what the batch copies was stored by earlier batches of this wave: they have landed before it is read --
+            // a batch ago they were issued, the wait is free -- and the bytes are read past the vector L1)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane < used && !(from >> 31)) v = gload1_fresh(out + from);
             if (lane < used) out[bstart + lane] = (uint8_t)v;
             bstart += used;
             used = 0;
-        }
-    };
-    auto settle = [&](uint32_t src_end) {   // before text below src_end is read: everything stored so far has landed
-        if (src_end > safe) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            safe = bstart;
         }
     };
     // gzip member header: 10 fixed bytes, FEXTRA (BGZF's 'BC' field lives there), then -- not in BGZF, but legal -- name, comment, CRC16
@@ -323,115 +325,168 @@ __global__ __launch_bounds__(64) void inflate_bgzf_kernel(const InflateJob* __re
                     if (uni((uint32_t)g_lds[kLens + 256u]) == 0u) { ok = false; break; }   // no end-of-block code
                     if (!uni(build_table(0, (int)hlit, 0, kLitInfo, kLitCount, kLitSymbol)) || !uni(build_table(288, (int)hdist, 1, kDistInfo, kDistCount, kDistSymbol))) { ok = false; break; }
                 }
-                // the block's symbols.  (Every lane holds the same reader and batch state, and what comes out of memory or
-                // out of a call is said to be uniform where it is read: the bookkeeping then stays in scalar registers and
-                // its branches are scalar.  Left to itself the compiler ran all of it on the vector unit under exec masks,
-                // ~460 instructions per symbol; a wave issues one instruction in ~4 cycles and the waves of a CU share one
-                // scalar and four vector issue slots, so instructions per symbol is what a launch costs.)
+                // THE BLOCK'S SYMBOLS, a window of 64 bit positions at a time.
+                // A wave issues one instruction in ~4-8 cycles and the waves of a CU share ONE scalar issue slot: a launch
+                // of thousands of blocks costs what its scalar instructions cost (the lockstep form -- one table lookup,
+                // one set of field extractions, one copy per symbol, all scalar -- ran ~100 scalar instructions per symbol:
+                // 5.7 ms per block alone, 13.7 ms for 3 880 blocks; profiles/r04_bgzf.txt).  So the lanes decode: lane i
+                // decodes the WHOLE symbol that would start at bit i of the window -- literal/length code, extra bits,
+                // distance code, extra bits: two table gathers --; a scalar walk from the symbol that really starts the
+                // window follows the chain (one v_readlane and a dozen scalar instructions per symbol) and gives every
+                // symbol on it its place in the output batch; then the lanes of the batch look their symbol up and note
+                // where their byte comes from.  Symbols the lanes cannot finish alone leave the walk to the one-symbol
+                // path below: codes longer than the tables' 10 bits, the end of the block, a match whose source may be
+                // inside the batch (distance < length + 64) or before the text's start, one that does not fit a batch.
+                uint32_t q, r, s0, s1, s2, s3, s4;   // the window: bit r of word W[q] = s0; s0..s4 = W[q .. q + 4]
+                {
+                    const uint32_t P = b.bit_pos();
+                    q = P >> 5;
+                    r = P & 31u;
+                    b.seek(q);
+                    s0 = b.word(), s1 = b.word(), s2 = b.word(), s3 = b.word(), s4 = b.word();
+                }
+                uint32_t osv = 0;   // a symbol's lane: the batch slot of its first byte
                 for (;;) {
-                    b.need();   // > 32 bits: a literal/length code and its extra bits take <= 15 + 5
-                    const uint32_t li = uni(l32(kLitInfo + 4u * b.peek(FAST)));
-                    uint32_t kind = (li >> 4) & 7u, val, ex;
-                    if (kind == 1u) {
-                        // LITERALS, decoded side by side: lane i looks up the code that WOULD start at bit i of the buffer
-                        // and keeps its length if it is a literal's (0 otherwise); a scalar walk from bit 0 -- one v_readlane
-                        // per step -- marks the codes that really start there, and the marked lanes hand their literals to
-                        // the output batch.  The walk stops at the first code that is not a literal (or is longer than
-                        // the table's 10 bits): the one-symbol path takes that one.
-                        const uint32_t span = (uint32_t)b.cnt - (uint32_t)FAST;   // bit positions whose lookup lies inside the buffer (> 22)
-                        uint32_t e = 0;
-                        if (lane < span) e = l32(kLitInfo + 4u * ((uint32_t)(b.buf >> lane) & ((1u << FAST) - 1u)));
-                        const uint32_t step = ((e >> 4) & 7u) == 1u ? (e & 15u) : 0u;
-                        unsigned long long mark = 0;
-                        uint32_t pos = 0, nl = 0;
-                        const uint32_t room = 64u - used;
-                        do {
-                            const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)step, (int)pos);
-                            if (!st) break;
-                            mark |= 1ull << pos;
-                            pos += st;
-                            ++nl;
-                        } while (pos < span && nl < room);
-                        if (at + nl > job.out_len) { ok = false; break; }
+                    // lane i: the 64 bits from bit r + i on
+                    const uint32_t t = lane + r, kq = t >> 5, sh = t & 31u;
+                    const uint32_t wa = kq == 0u ? s0 : (kq == 1u ? s1 : s2), wb = kq == 0u ? s1 : (kq == 1u ? s2 : s3), wc = kq == 0u ? s2 : (kq == 1u ? s3 : s4);
+                    const uint32_t x_lo = __builtin_amdgcn_alignbit(wb, wa, sh), x_hi = __builtin_amdgcn_alignbit(wc, wb, sh);
+                    const uint32_t e1 = l32(kLitInfo + 4u * (x_lo & ((1u << FAST) - 1u)));
+                    const uint32_t l1 = e1 & 15u, ex1 = (e1 >> 7) & 15u, kd = (e1 >> 4) & 7u;
+                    const uint32_t v1 = (e1 >> 11) + ((x_lo >> l1) & ((1u << ex1) - 1u));   // the literal, or the match's length
+                    const uint32_t t1 = l1 + ex1;
+                    const uint32_t y = (uint32_t)((((uint64_t)x_hi << 32) | x_lo) >> t1);
+                    const uint32_t e2 = l32(kDistInfo + 4u * (y & ((1u << FAST) - 1u)));
+                    const uint32_t l2 = e2 & 15u, ex2 = (e2 >> 7) & 15u;
+                    const uint32_t dv = (e2 >> 11) + ((y >> l2) & ((1u << ex2) - 1u));
+                    // bits 0..5: the symbol's length in bits; 6..14: bytes it makes; 0 = not for the walk
+                    uint32_t pk = 0;
+                    if (kd == 1u) pk = l1 | (1u << 6);
+                    else if (kd == 3u && e2 != 0u && dv >= v1 + 64u && dv <= at) pk = (t1 + l2 + ex2) | (v1 << 6);
+                    unsigned long long mark = 0, starts = 0;
+                    uint32_t pos = 0, outacc = 0, pks = 0;
+                    const uint32_t room = 64u - used;
+                    do {
+                        pks = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)pos);
+                        const uint32_t ol = pks >> 6;
+                        if (!pks || outacc + ol > room) break;
+                        const uint32_t slot = used + outacc;
+                        mark |= 1ull << pos;
+                        starts |= 1ull << slot;
+                        if (lane == pos) osv = slot;
+                        outacc += ol;
+                        pos += pks & 63u;
+                        pks = 1;
+                    } while (pos < 64u);
+                    if (outacc) {
+                        if (at + outacc > job.out_len) { ok = false; break; }
+                        // the symbols' lanes say where their bytes come from; the batch's lanes find their symbol by counting
                         if ((mark >> lane) & 1ull) {
                             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mark >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mark, 0u));
-                            g_lds[kLens + rank] = (uint8_t)(e >> 11);
+                            const uint32_t src = kd == 1u ? (0x80000000u | v1) : bstart + osv - dv;
+                            *reinterpret_cast<uint2*>(g_lds + kLens + 8u * rank) = make_uint2(src, osv);
                         }
                         __builtin_amdgcn_wave_barrier();
-                        if (lane - used < nl) from = 0x80000000u | (uint32_t)g_lds[kLens + lane - used];
+                        if (lane - used < outacc) {
+                            const uint32_t ord = __builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts, 0u)) +
+                                                 (uint32_t)((starts >> lane) & 1ull) - 1u;
+                            const uint2 sy = *reinterpret_cast<const uint2*>(g_lds + kLens + 8u * ord);
+                            from = sy.x + (lane - sy.y);
+                        }
                         __builtin_amdgcn_wave_barrier();
-                        used += nl;
-                        at += nl;
-                        b.drop((int)pos);
+                        used += outacc;
+                        at += outacc;
                         if (used == 64u) flush();
-                        continue;
                     }
-                    if (li) {
-                        b.drop((int)(li & 15u));
-                        ex = (li >> 7) & 15u;
-                        val = li >> 11;
-                    } else {   // a code longer than the table's 10 bits
-                        const uint32_t r = uni(decode_slow(b.buf, kLitCount, kLitSymbol));
-                        const uint32_t sy = r >> 4;
-                        if (r == ~0u || sy > 285u) { ok = false; break; }
-                        b.drop((int)(r & 15u));
-                        if (sy < 256u) {
+                    if (pos < 64u && pks != 1u) {
+                        // ONE SYMBOL, step by step, from the 64 bits at `pos` (a symbol takes at most 15 + 5 + 15 + 13)
+                        if (pks != 0u) {   // a match for the walk that does not fit what is left of the batch
+                            if (used) {
+                                flush();
+                                goto advance;
+                            }
+                        }
+                        uint64_t bits = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)x_hi, (int)pos) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)x_lo, (int)pos);
+                        uint32_t kind, val, ex;
+                        const uint32_t li = uni(l32(kLitInfo + 4u * ((uint32_t)bits & ((1u << FAST) - 1u))));
+                        if (li) {
+                            bits >>= li & 15u, pos += li & 15u;
+                            kind = (li >> 4) & 7u;
+                            ex = (li >> 7) & 15u;
+                            val = li >> 11;
+                        } else {   // a code longer than the table's 10 bits
+                            const uint32_t rs = uni(decode_slow(bits, kLitCount, kLitSymbol));
+                            const uint32_t sy = rs >> 4;
+                            if (rs == ~0u || sy > 285u) { ok = false; break; }
+                            bits >>= rs & 15u, pos += rs & 15u;
+                            kind = sy < 256u ? 1u : (sy == 256u ? 2u : 3u);
+                            ex = sy > 256u ? uni((uint32_t)c_len_extra[sy - 257u]) : 0u;
+                            val = sy < 256u ? sy : (sy > 256u ? uni((uint32_t)c_len_base[sy - 257u]) : 0u);
+                        }
+                        if (kind == 1u) {
                             if (at >= job.out_len) { ok = false; break; }
-                            if (lane == used) from = 0x80000000u | sy;
+                            if (lane == used) from = 0x80000000u | val;
                             ++at;
                             if (++used == 64u) flush();
-                            continue;
+                        } else if (kind != 3u) {   // end of block (kind 0: a code the stream may not use)
+                            if (kind != 2u) ok = false;
+                            flush();
+                            r += pos;
+                            break;
+                        } else {
+                            const uint32_t len = val + ((uint32_t)bits & ((1u << ex) - 1u));
+                            bits >>= ex, pos += ex;
+                            const uint32_t di = uni(l32(kDistInfo + 4u * ((uint32_t)bits & ((1u << FAST) - 1u))));
+                            uint32_t dist, dex;
+                            if (di) {
+                                bits >>= di & 15u, pos += di & 15u;
+                                dex = (di >> 7) & 15u;
+                                dist = di >> 11;
+                            } else {
+                                const uint32_t rs = uni(decode_slow(bits, kDistCount, kDistSymbol));
+                                const uint32_t ds = rs >> 4;
+                                if (rs == ~0u || ds > 29u) { ok = false; break; }
+                                bits >>= rs & 15u, pos += rs & 15u;
+                                dex = uni((uint32_t)c_dist_extra[ds]);
+                                dist = uni((uint32_t)c_dist_base[ds]);
+                            }
+                            dist += (uint32_t)bits & ((1u << dex) - 1u);
+                            pos += dex;
+                            if (dist > at || at + len > job.out_len) { ok = false; break; }
+                            // the copy: its bytes join the batch (several batches when it is long).  It reads the dist-byte pattern
+                            // in front of it; should that reach into the batch itself, the batch leaves first.
+                            const uint32_t pat = at - dist, pat_end = pat + (dist < len ? dist : len);
+                            if (pat_end > bstart) flush();
+                            at += len;
+                            auto place = [&](auto src_of) {
+                                uint32_t done = 0;
+                                do {
+                                    const uint32_t space = 64u - used, left = len - done;
+                                    const uint32_t take = left < space ? left : space;
+                                    const uint32_t o = done + lane - used;   // this lane's offset inside the match (if it is one of the `take`)
+                                    if (lane - used < take) from = pat + src_of(o);
+                                    used += take;
+                                    done += take;
+                                    if (used == 64u) flush();
+                                } while (done < len);
+                            };
+                            if (dist >= len) place([](uint32_t o) { return o; });
+                            else if (dist == 1u) place([](uint32_t) { return 0u; });   // (a run of N, of one base)
+                            else place([&](uint32_t o) { return o % dist; });          // the pattern repeats inside the match
                         }
-                        kind = sy == 256u ? 2u : 3u;
-                        ex = sy > 256u ? uni((uint32_t)c_len_extra[sy - 257u]) : 0u;
-                        val = sy > 256u ? uni((uint32_t)c_len_base[sy - 257u]) : 0u;
                     }
-                    if (kind != 3u) {   // end of block (kind 0: a code the stream may not use)
-                        if (kind != 2u) ok = false;
-                        flush();
-                        break;
+                advance:
+                    r += pos;
+                    while (r >= 32u) {
+                        s0 = s1, s1 = s2, s2 = s3, s3 = s4;
+                        s4 = b.word();
+                        ++q;
+                        r -= 32u;
                     }
-                    const uint32_t len = val + b.peek((int)ex);
-                    b.drop((int)ex);
-                    b.need();   // a distance code and its extra bits: <= 15 + 13
-                    const uint32_t di = uni(l32(kDistInfo + 4u * b.peek(FAST)));
-                    uint32_t dist;
-                    if (di) {
-                        b.drop((int)(di & 15u));
-                        const uint32_t dex = (di >> 7) & 15u;
-                        dist = (di >> 11) + b.peek((int)dex);
-                        b.drop((int)dex);
-                    } else {
-                        const uint32_t r = uni(decode_slow(b.buf, kDistCount, kDistSymbol));
-                        const uint32_t ds = r >> 4;
-                        if (r == ~0u || ds > 29u) { ok = false; break; }
-                        b.drop((int)(r & 15u));
-                        const uint32_t dex = uni((uint32_t)c_dist_extra[ds]);
-                        dist = uni((uint32_t)c_dist_base[ds]) + b.peek((int)dex);
-                        b.drop((int)dex);
-                    }
-                    if (dist > at || at + len > job.out_len) { ok = false; break; }
-                    // the copy: its bytes join the batch (several batches when it is long).  It reads the dist-byte pattern in
-                    // front of it; should that reach into the batch itself, the batch leaves first.
-                    const uint32_t pat = at - dist, pat_end = pat + (dist < len ? dist : len);
-                    if (pat_end > bstart) flush();
-                    settle(pat_end);
-                    at += len;
-                    auto place = [&](auto src_of) {
-                        uint32_t done = 0;
-                        do {
-                            const uint32_t room = 64u - used, left = len - done;
-                            const uint32_t take = left < room ? left : room;
-                            const uint32_t o = done + lane - used;   // this lane's offset inside the match (if it is one of the `take`)
-                            if (lane - used < take) from = pat + src_of(o);
-                            used += take;
-                            done += take;
-                            if (used == 64u) flush();
-                        } while (done < len);
-                    };
-                    if (dist >= len) place([](uint32_t o) { return o; });
-                    else if (dist == 1u) place([](uint32_t) { return 0u; });   // (a run of N, of one base)
-                    else place([&](uint32_t o) { return o % dist; });          // the pattern repeats inside the match
+                }
+                if (ok) {   // the reader takes over again where the symbols ended (r may have run past s0)
+                    q += r >> 5;
+                    b.start_at(q, r & 31u);
                 }
                 if (!ok) break;
             }
