@@ -131,9 +131,15 @@ struct dd_ctx {
     PlanEntry plans[8];
     unsigned long long plan_clock = 0;
     hipEvent_t stage_free = nullptr;  // signalled when the last upload from `stage` completed
+    // a second set of staging buffers: dd_sketch_device alternates, so that a call can be issued while the uploads of
+    // the call before it are still queued behind work of other streams (the ingestion pipeline issues batch b + 1
+    // while batch b waits for its files to be copied or inflated)
+    HostBuf stage_alt, stage_jobs_alt, stage_rows_alt;
+    hipEvent_t stage_free_alt = nullptr;
     // ingestion pipeline (dd_sketch_files): pinned host buffers for the loader threads, a copy stream, two
     // device buffer sets (FASTA bytes in, register slabs out) and two pinned bounce buffers for the results
     std::vector<FileBuf*> file_pool;
+    hipStream_t copy_stream_b = nullptr;  // device-inflated batches alternate between two: a launch of the inflate kernel is as long as ONE block takes, two in flight hide each other
     hipStream_t copy_stream = nullptr, out_stream = nullptr;  // H2D and D2H on streams of their own: an in-order stream would park batch b+1's upload behind batch b's results
     DevBuf pipe_fasta[2], pipe_regs[2];
     HostBuf pipe_out[2];
@@ -284,7 +290,8 @@ dd_ctx* dd_create(int device, int log2m, int canonical) {
     c->canonical = canonical ? 1 : 0;
     c->bucket_budget = std::min<size_t>((size_t)48 << 30, std::max<size_t>((size_t)16 << 30, prop.totalGlobalMem / 6));
     DeviceGuard g(device);
-    if (hipEventCreateWithFlags(&c->stage_free, hipEventDisableTiming) != hipSuccess) {
+    if (hipEventCreateWithFlags(&c->stage_free, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->stage_free_alt, hipEventDisableTiming) != hipSuccess) {
         fail(DD_ENODEV, "hipEventCreate failed");
         delete c;
         return nullptr;
@@ -303,6 +310,7 @@ void dd_destroy(dd_ctx* c) {
         }
     for (auto e : c->pool) (void)hipEventDestroy(e);
     if (c->stage_free) (void)hipEventDestroy(c->stage_free);
+    if (c->stage_free_alt) (void)hipEventDestroy(c->stage_free_alt);
     for (auto& pe : c->plans) pe.jobtab.release();
     for (DevBuf* b : {&c->tokens, &c->scratch, &c->tables, &c->fasta, &c->regs, &c->ptrs, &c->hist,
                       &c->est, &c->ord, &c->bitmaps, &c->bigmaps, &c->exact, &c->buckets, &c->gram, &c->synth})
@@ -310,6 +318,9 @@ void dd_destroy(dd_ctx* c) {
     c->stage.release();
     c->stage_jobs.release();
     c->stage_rows.release();
+    c->stage_alt.release();
+    c->stage_jobs_alt.release();
+    c->stage_rows_alt.release();
     for (FileBuf* fb : c->file_pool) delete fb;
     for (int i = 0; i < 2; ++i) {
         c->pipe_fasta[i].release();
@@ -333,6 +344,7 @@ void dd_destroy(dd_ctx* c) {
         (void)hipEventDestroy(c->side_stagger);
     }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->copy_stream_b) (void)hipStreamDestroy(c->copy_stream_b);
     if (c->out_stream) (void)hipStreamDestroy(c->out_stream);
     delete c;
 }
@@ -475,7 +487,11 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     const size_t pack_off = align_up(sizeof(dd::SweepGenome) * ngenomes, 256);
     const size_t gtab_bytes = pack_off + align_up(sizeof(dd::PackGenome) * ngenomes, 256);
     if ((rc = c->tables.reserve(gtab_bytes))) return rc;
-    // the staging buffers may still be feeding a previous call's uploads
+    // the staging buffers may still be feeding the uploads of the call before last (they alternate: dd_ctx)
+    std::swap(c->stage, c->stage_alt);
+    std::swap(c->stage_jobs, c->stage_jobs_alt);
+    std::swap(c->stage_rows, c->stage_rows_alt);
+    std::swap(c->stage_free, c->stage_free_alt);
     DD_HIP(hipEventSynchronize(c->stage_free));
     if ((rc = c->stage.reserve(gtab_bytes))) return rc;
     char* tdev = static_cast<char*>(c->tables.p);
@@ -883,15 +899,19 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
     // (a context's FIRST call at log2m >= 17 keeps to 128 MB: the record areas and the pinned register staging are
     // allocated for a batch's rows, and hipMalloc + hipHostMalloc of a 512 MB batch's 5.5 GB + 0.4 GB cost a one-shot
     // `dandd tree -r 20` 0.23 s against 0.06 s; a long-lived context grows them on its second call)
-    // (BGZF files inflated on the device: a launch of the inflate kernel takes as long as ONE block does -- 10 ms, the
-    // serial walk of a deflate stream by one wave -- whether it holds 1 block or the 3840 the chip keeps in flight, so
-    // those calls batch ~320 MB of text: five 50 Mbp files, one round of blocks)
+    // (BGZF files inflated on the device: a launch of the inflate kernel takes as long as ONE block does -- 3 ms, the
+    // serial walk of a deflate stream by one wave -- whether it holds 1 block or the 4 000 the chip keeps in flight, so
+    // those calls batch ~320 MB of text -- five 50 Mbp files, one round of blocks --, in two batches at least (the
+    // second's inflate runs under the first's sweep), and a batch waits up to 3 ms for its files instead of leaving
+    // with the first one loaded: 64 x 5 Mbp went out as 2 + 8 + 8 + 46 files, four launches one behind the other)
     const size_t kBatchBytes = (size_t)(getenv("DD_BATCH_MB") ? std::max(1, atoi(getenv("DD_BATCH_MB")))
                                         : (c->p >= 17 ? (c->ingest_calls == 0 ? 128 : 512) : (any_gz && gpu_inflate ? 320 : 128))) << 20;
     // (at most 256 files per launch: the loaders' window is two batches of host buffers of 2 MiB at least; with 64,
     // a thousand 100 kbp plasmids took 23 launches of ~3 ms each)
     const size_t kMaxBatchFiles = getenv("DD_BATCH_FILES") ? (size_t)std::max(1, atoi(getenv("DD_BATCH_FILES"))) : 256;
-    const int batch_files = (int)std::max<size_t>(1, std::min<size_t>(kMaxBatchFiles, kBatchBytes / avg));
+    int batch_files = (int)std::max<size_t>(1, std::min<size_t>(kMaxBatchFiles, kBatchBytes / avg));
+    const bool full_batches = any_gz && gpu_inflate;
+    if (full_batches && nfiles >= 2) batch_files = std::min(batch_files, (nfiles + 1) / 2);
     // loaders may run two batches ahead of the GPU
     const int window = std::max(nthreads + 2, 2 * batch_files + nthreads);
     // Pinning host memory costs ~0.4 ms per MB: a buffer starts pageable (a one-shot `dandd tree` process never
@@ -901,6 +921,7 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
     const bool promote = ++c->ingest_calls >= 2;
     if (!c->copy_stream) {
         DD_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        DD_HIP(hipStreamCreateWithFlags(&c->copy_stream_b, hipStreamNonBlocking));
         DD_HIP(hipStreamCreateWithFlags(&c->out_stream, hipStreamNonBlocking));
         for (int i = 0; i < 2; ++i) {
             DD_HIP(hipEventCreateWithFlags(&c->pipe_h2d[i], hipEventDisableTiming));
@@ -1060,7 +1081,7 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
         if (arrived && !refused)
             parallel_copy(regs + (size_t)f.first * slab, static_cast<const uint8_t*>(c->pipe_out[set].p), (size_t)f.count * slab, nthreads);
         else
-            (void)hipStreamSynchronize(c->copy_stream);  // nothing may still read the host buffers that go back below
+            (void)hipStreamSynchronize(c->copy_stream), (void)hipStreamSynchronize(c->copy_stream_b);  // nothing may still read the host buffers that go back below
         {
             std::lock_guard<std::mutex> lk(mu);
             for (int i = f.first; i < f.first + f.count; ++i) free_bufs.push_back(slots[i].buf);
@@ -1090,13 +1111,19 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
         {
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return slots[i].done; });
+            if (full_batches)
+                cv.wait_for(lk, std::chrono::milliseconds(3), [&] {
+                    for (int j = i; j < std::min(nfiles, i + batch_files); ++j)
+                        if (!slots[j].done) return false;
+                    return true;
+                });
             // as many as a batch wants and are already loaded (at least one): the GPU is never kept waiting for a
             // full batch; equal batches also let dd_sketch_device reuse its job tables and the buffers below
             while (count < batch_files && i + count < nfiles && slots[i + count].done) ++count;
             // (a directory of small files: batch sizes come from a short list -- powers of two, the full batch, the
             // tail -- so that the job tables of every shape are in the plan cache from the second call on; planning
             // a shape never seen costs ~2 ms of host time with the GPU waiting)
-            if (count < batch_files && i + count < nfiles)
+            if (!full_batches && count < batch_files && i + count < nfiles)
                 while (count & (count - 1)) count &= count - 1;
         }
         t_wait += now() - ta;
@@ -1157,6 +1184,7 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             continue;
         }
         hipError_t e = hipSuccess;
+        hipStream_t cs = (njobs && set) ? c->copy_stream_b : c->copy_stream;
         std::vector<const uint8_t*> ptrs(count);
         dd::InflateJob* jobs_host = njobs ? static_cast<dd::InflateJob*>(c->pipe_jobs_host[set].p) : nullptr;
         size_t nj = 0;
@@ -1167,23 +1195,23 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             if (sj.dev_inflate) {
                 // the COMPRESSED file goes over PCIe (a quarter of the text); its blocks are inflated into ptrs[j] below
                 uint8_t* gz = static_cast<uint8_t*>(c->pipe_gz[set].p) + gz_off[j];
-                e = hipMemcpyAsync(gz, fbj.data(), fbj.size(), hipMemcpyHostToDevice, c->copy_stream);
+                e = hipMemcpyAsync(gz, fbj.data(), fbj.size(), hipMemcpyHostToDevice, cs);
                 for (const BgzfBlock& b : sj.blks)
                     jobs_host[nj++] = dd::InflateJob{gz + b.in_off, b.in_len, b.out_len, const_cast<uint8_t*>(ptrs[j]) + b.out_off};
             } else if (sizes[j]) {
-                e = hipMemcpyAsync(const_cast<uint8_t*>(ptrs[j]), fbj.data(), sizes[j], hipMemcpyHostToDevice, c->copy_stream);
+                e = hipMemcpyAsync(const_cast<uint8_t*>(ptrs[j]), fbj.data(), sizes[j], hipMemcpyHostToDevice, cs);
             }
         }
         if (njobs && e == hipSuccess) {
-            e = hipMemsetAsync(c->pipe_err[set].p, 0, 4, c->copy_stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(c->pipe_jobs[set].p, jobs_host, njobs * sizeof(dd::InflateJob), hipMemcpyHostToDevice, c->copy_stream);
+            e = hipMemsetAsync(c->pipe_err[set].p, 0, 4, cs);
+            if (e == hipSuccess) e = hipMemcpyAsync(c->pipe_jobs[set].p, jobs_host, njobs * sizeof(dd::InflateJob), hipMemcpyHostToDevice, cs);
             if (e == hipSuccess) {
-                dd::launch_inflate_bgzf(static_cast<const dd::InflateJob*>(c->pipe_jobs[set].p), (int)njobs, static_cast<uint32_t*>(c->pipe_err[set].p), c->copy_stream);
+                dd::launch_inflate_bgzf(static_cast<const dd::InflateJob*>(c->pipe_jobs[set].p), (int)njobs, static_cast<uint32_t*>(c->pipe_err[set].p), cs);
                 e = hipGetLastError();
             }
-            if (e == hipSuccess) e = hipMemcpyAsync(c->pipe_err_host[set].p, c->pipe_err[set].p, 4, hipMemcpyDeviceToHost, c->copy_stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(c->pipe_err_host[set].p, c->pipe_err[set].p, 4, hipMemcpyDeviceToHost, cs);
         }
-        if (e == hipSuccess) e = hipEventRecord(c->pipe_h2d[set], c->copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(c->pipe_h2d[set], cs);
         if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->pipe_h2d[set], 0);
         if (e == hipSuccess) {
             rc = dd_sketch_device(c, ptrs.data(), sizes.data(), count, kmin, kmax, static_cast<uint8_t*>(c->pipe_regs[set].p));
@@ -1199,7 +1227,7 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             first_err = std::string("ingestion pipeline: ") + hipGetErrorString(e);
         }
         if (rc != DD_OK) {
-            (void)hipStreamSynchronize(c->copy_stream);  // nothing may still read the host buffers
+            (void)hipStreamSynchronize(c->copy_stream), (void)hipStreamSynchronize(c->copy_stream_b);  // nothing may still read the host buffers
             (void)hipStreamSynchronize(c->stream);
             (void)hipStreamSynchronize(c->out_stream);
             release_unsent(i, count);
@@ -1222,7 +1250,7 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
         if (rc == DD_OK) {
             if ((rc = retire(set)) != DD_OK) first_err = g_err;
         } else if (fly[set].active) {
-            (void)hipStreamSynchronize(c->copy_stream);
+            (void)hipStreamSynchronize(c->copy_stream), (void)hipStreamSynchronize(c->copy_stream_b);
             release_unsent(fly[set].first, fly[set].count);
             fly[set].active = false;
             cv.notify_all();
