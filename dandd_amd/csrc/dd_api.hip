@@ -146,7 +146,8 @@ struct dd_ctx {
     // BGZF files inflated on the device (dd_ginflate.hip): compressed bytes, block table and error count of a batch
     DevBuf pipe_gz[2], pipe_jobs[2], pipe_err[2];
     HostBuf pipe_jobs_host[2], pipe_err_host[2];
-    bool no_gpu_inflate = false;   // a block the device decoder refused: this context inflates on the host from now on
+    bool no_gpu_inflate = false;   // this context inflates on the host (set for the retry of a call, for good after three)
+    int inflate_refusals = 0;      // calls in which the device decoder refused a block
     bool inflate_retry = false;    // ... and the call that met it is run again
     hipEvent_t pipe_h2d[2] = {nullptr, nullptr}, pipe_done[2] = {nullptr, nullptr}, pipe_d2h[2] = {nullptr, nullptr};
     hipStream_t side[8] = {};  // k classes of a small call run side by side
@@ -798,9 +799,13 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
     if (rc != DD_OK && c->inflate_retry) {
         // a BGZF block the device decoder would not take: the whole call again with every .gz inflated on the host, whose
         // decoder either reads the file or says what is wrong with it
+        // (only this call -- one damaged file must not cost a long-lived context its device path --, unless it keeps
+        // happening: three refusals and the context stays on the host)
         c->inflate_retry = false;
+        const bool was = c->no_gpu_inflate;
         c->no_gpu_inflate = true;
         rc = sketch_files_impl(c, paths, nfiles, kmin, kmax, regs, nthreads);
+        c->no_gpu_inflate = was || ++c->inflate_refusals >= 3;
     }
     return rc;
 }

@@ -6,20 +6,21 @@
 // while the kernels behind them run at 20-36 Gbp/s.  A BGZF file (bgzip, htslib) is a sequence of independent gzip
 // members of <= 64 KiB of text each, every one saying its own compressed size: they can be decoded anywhere, in any order.
 //
-// One wave per block.  A deflate stream is a serial thing -- every Huffman code starts where the previous one ended --
-// so the wave walks it in LOCKSTEP: all lanes hold the same bit buffer and look the same table entry up (LDS broadcasts),
-// and what a symbol makes is done by the lanes together: a match of length L is copied by L lanes at once, dynamic-code
-// tables are filled code by code with the replicas of a code spread over the lanes.
-// The block's TEXT lives where it is going -- the FASTA buffer in HBM --, not in LDS: a wave then needs 10 KiB of LDS (its
-// code tables and a ring of compressed input) instead of 76, sixteen waves share a CU instead of two, and the serial
-// chain of one block (table lookup -> table lookup -> copy, ~10^3 cycles per symbol with the round trips to L2) hides
-// behind fifteen others.  (The first form kept a 64 KiB image per wave in LDS: 5 ms per block with nothing to overlap,
-// 20 ms per 1600-block launch, slower than the host's sixteen threads; profiles/r04_bgzf.txt.)  A copy reads what earlier
-// symbols of the same wave stored: stores are awaited (vmcnt) only when the source reaches into the part of the text
-// that may still be in flight, and the bytes are read past the vector L1 (sc1).
+// One wave per block.  A deflate stream is a serial thing -- every Huffman code starts where the previous one ended --,
+// but the wave does not walk it one symbol at a time: LANE i DECODES THE SYMBOL THAT WOULD START AT BIT i of a 64-bit
+// window (literal/length code, extra bits, distance code, extra bits: two table gathers from LDS), a scalar walk follows
+// the chain of symbols that really are there (one v_readlane each), and the lanes of the 64-byte output batch look up the
+// symbol they belong to and note where their byte comes from -- a literal, or an earlier position of the text.  A batch
+// costs ONE load and ONE contiguous store.  Block headers, code tables (built code by code, the replicas of a code spread
+// over the lanes), codes longer than the tables' 10 bits, overlapping and near copies go one symbol at a time.
+// The block's TEXT lives where it is going -- the FASTA buffer in HBM --, not in LDS: a wave needs 9.25 KiB of LDS (its
+// code tables), seventeen waves share a CU, and the serial chain of one block hides behind sixteen others.  What bounds a
+// launch is the CU's scalar issue slot: instructions per symbol (profiles/r04_bgzf.txt: 10 ms per block -> 3.1).
+// A copy reads what earlier batches of the same wave stored: a batch waits for the stores before it (issued a batch ago:
+// free) and reads past the vector L1 (sc1).
 // Anything that is not a valid block -- bad code lengths, a distance before the block's start, a length that does not
-// match the member's ISIZE -- raises the launch's error count and the caller falls back to the host decoder
-// (dd_inflate.h), which words the error.  The member's CRC-32 is NOT checked here (ISIZE and the deflate structure are).
+// match the member's ISIZE, a text whose CRC-32 is not the member's (the wave reads its text back: text_crc) -- raises the
+// launch's error count and the caller runs the call again with the host decoder (dd_inflate.h), which words the error.
 #include "dd_common.h"
 #include "dd_kernels.h"
 
@@ -191,6 +192,69 @@ __device__ __noinline__ uint32_t decode_slow(uint64_t bits, uint32_t cnt_off, ui
         code <<= 1;
     }
     return ~0u;
+}
+
+// ---- CRC-32 of the inflated text (the member's trailer carries it) ----
+// x^(2^n) mod P for n = 0..31 in zlib's reflected notation (bit 31 = x^0), P = 0xedb88320: each entry is the square of
+// the one before (multmodp below); generated by squaring 0x40000000 (= x^1).
+__constant__ uint32_t c_x2n[32] = {0x40000000u, 0x20000000u, 0x08000000u, 0x00800000u, 0x00008000u, 0xedb88320u, 0xb1e6b092u, 0xa06a2517u, 0xed627daeu, 0x88d14467u, 0xd7bbfe6au, 0xec447f11u, 0x8e7ea170u, 0x6427800eu, 0x4d47bae0u, 0x09fe548fu, 0x83852d0fu, 0x30362f1au, 0x7b5a9cc3u, 0x31fec169u, 0x9fec022au, 0x6c8dedc4u, 0x15d6874du, 0x5fde7a4eu, 0xbad90e37u, 0x2e4e5eefu, 0x4eaba214u, 0xa8a472c0u, 0x429a969eu, 0x148d302au, 0xc40ba6d0u, 0xc4e22c3cu};
+
+// a(x) * b(x) mod P.  `a` is wave-uniform (the loop's exit is), b is per lane.
+DD_D uint32_t multmodp(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (uint32_t m = 0x80000000u;; m >>= 1) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1u)) == 0u) break;
+        }
+        b = (b >> 1) ^ ((b & 1u) ? 0xedb88320u : 0u);
+    }
+    return p;
+}
+
+// The CRC-32 of text[0, n), by the whole wave: lane i takes the i-th 1/64 of the text (the FIRST lane's part is the short
+// one, so that every right-hand operand of a combination has a length that depends on the level only), byte-wise with a
+// 256-entry table in LDS -- the Huffman tables' place, the block is decoded --, then six levels of
+//   crc(A || B) = crc(A) * x^(8 |B|) mod P  ^  crc(B)          (zlib's crc32_combine).
+// ~1 % of a block's instructions.  The text is read back past the vector L1; the caller has waited for its stores.
+__device__ __noinline__ uint32_t text_crc(const uint8_t* text, uint32_t n) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t i = lane; i < 256u; i += 64u) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? 0xedb88320u : 0u);
+        l32(kLitInfo + 4u * i) = c;
+    }
+    __builtin_amdgcn_wave_barrier();
+    auto byte_in = [](uint32_t crc, uint32_t v) { return l32(kLitInfo + 4u * ((crc ^ v) & 255u)) ^ (crc >> 8); };
+    uint32_t lo = 0, hi = n, len = 0;
+    if (n >= 8192u) {   // (shorter: a file's last block; every lane does all of it)
+        len = (n + 63u) / 64u;
+        const uint32_t pad = 64u * len - n;   // < 64 <= len
+        lo = lane ? lane * len - pad : 0u;
+        hi = (lane + 1u) * len - pad;
+    }
+    uint32_t crc = ~0u, p = lo;
+    for (; p < hi && ((reinterpret_cast<uintptr_t>(text) + p) & 3u); ++p) crc = byte_in(crc, gload1_fresh(text + p));
+    for (; p + 4u <= hi; p += 4u) {
+        const uint32_t v = gload4_fresh(text + p);
+        crc = byte_in(crc, v);
+        crc = byte_in(crc, v >> 8);
+        crc = byte_in(crc, v >> 16);
+        crc = byte_in(crc, v >> 24);
+    }
+    for (; p < hi; ++p) crc = byte_in(crc, gload1_fresh(text + p));
+    crc = ~crc;
+    if (n >= 8192u) {
+        uint32_t c = 0x80000000u;   // x^(8 len): x^0, times x^(2^(k + 3)) for every bit k of len
+        for (uint32_t k = 0, m = len; m; m >>= 1, ++k)
+            if (m & 1u) c = uni(multmodp(uni(c_x2n[(k + 3u) & 31u]), c));
+        for (int j = 0; j < 6; ++j) {
+            const uint32_t right = (uint32_t)__shfl_down((int)crc, 1u << j);
+            crc = multmodp(c, crc) ^ right;
+            c = uni(multmodp(c, c));
+        }
+    }
+    return uni(crc);
 }
 
 }  // namespace
@@ -493,14 +557,19 @@ __global__ __launch_bounds__(64) void inflate_bgzf_kernel(const InflateJob* __re
             if (bfinal) break;
         }
     }
-    // the member's trailer: CRC-32 (not checked), ISIZE
+    // the member's trailer: CRC-32, ISIZE
     if (ok) {
         const uint32_t used = b.bytes_used(in + hdr);
         if (hdr + used + 8u > n) ok = false;
         else {
-            const uint8_t* t = in + hdr + used + 4u;
-            const uint32_t isize = uni(gload1(t)) | (uni(gload1(t + 1)) << 8) | (uni(gload1(t + 2)) << 16) | (uni(gload1(t + 3)) << 24);
+            const uint8_t* t = in + hdr + used;
+            auto le32 = [&](const uint8_t* q) { return uni(gload1(q)) | (uni(gload1(q + 1)) << 8) | (uni(gload1(q + 2)) << 16) | (uni(gload1(q + 3)) << 24); };
+            const uint32_t crc = le32(t), isize = le32(t + 4);
             if (isize != at || at != job.out_len) ok = false;
+            else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the text's last batch has landed
+                if (text_crc(out, at) != crc) ok = false;
+            }
         }
     }
     if (!ok) {

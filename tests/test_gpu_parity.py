@@ -450,8 +450,63 @@ def test_bgzf_files_are_inflated_on_the_device(engine_factory, orc, tmp_path, mo
             raise AssertionError("a damaged BGZF file was sketched although zlib refuses it")
     except EngineError:
         pass
-    # (the context now inflates on the host; a fresh one takes the device path again)
+    # (only that call went to the host decoder)
     assert np.array_equal(eng.sketch_files([cases[0][1]], 19, 21)[0], got[0])
+
+
+def test_damaged_bgzf_blocks_are_refused_or_read_like_zlib(orc, torch_cuda, tmp_path):
+    """Bit flips and overwritten bytes in the deflate data, in the CRC-32 and in the ISIZE of single BGZF blocks (the
+    container's size fields intact, so the file still goes to the device decoder): the call either raises -- exactly when
+    zlib refuses the file -- or gives the registers of the text zlib reads.  The device checks the deflate structure, the
+    member's length AND its CRC-32 (dd_ginflate.hip: text_crc); what it refuses is run again on the host."""
+    import gzip
+    import zlib
+    from dandd_amd.engine import Engine, EngineError
+    eng = Engine(device=0, log2m=14, canonical=True)     # (a context of its own: three refusals keep a context on the host)
+    raw = orc.synth_fasta(SEED, 3, 300_000, 2).tobytes()
+    rng = np.random.default_rng(11)
+    outcomes = {"refused": 0, "read": 0}
+    try:
+        for level in (1, 6):
+            good = _bgzf(raw, level=level)
+            blocks, off = [], 0
+            while off < len(good):
+                size = int.from_bytes(good[off + 16:off + 18], "little") + 1
+                blocks.append((off, size))
+                off += size
+            for t in range(12):
+                bad = bytearray(good)
+                off, size = blocks[int(rng.integers(len(blocks) - 1))]     # (not the empty EOF block)
+                kind = t % 4
+                if kind == 0:
+                    bad[off + 18 + int(rng.integers(size - 26))] ^= 1 << int(rng.integers(8))
+                elif kind == 1:
+                    for _ in range(3):
+                        bad[off + 18 + int(rng.integers(size - 26))] = int(rng.integers(256))
+                elif kind == 2:
+                    bad[off + size - 8 + int(rng.integers(4))] ^= 1 << int(rng.integers(8))
+                else:
+                    bad[off + size - 4] ^= 1
+                path = tmp_path / f"bad{level}_{t}.fa.gz"
+                path.write_bytes(bytes(bad))
+                try:
+                    want = eng.sketch_buffer(np.frombuffer(gzip.decompress(bytes(bad)), dtype=np.uint8), 19, 21)
+                except (OSError, EOFError, zlib.error):
+                    want = None
+                try:
+                    got = eng.sketch_files([str(path)], 19, 21)[0]
+                except EngineError:
+                    got = None
+                assert (got is None) == (want is None), (level, t, kind)
+                if want is not None:
+                    assert np.array_equal(got, want), (level, t, kind)
+                outcomes["refused" if got is None else "read"] += 1
+                if got is None:      # a fresh context: the next file meets the device decoder again
+                    eng.close()
+                    eng = Engine(device=0, log2m=14, canonical=True)
+    finally:
+        eng.close()
+    assert outcomes["refused"] >= 12, outcomes
 
 
 def test_large_gzip_files_are_inflated_in_parallel(engine_factory, orc, tmp_path, monkeypatch):
