@@ -317,7 +317,9 @@ __global__ __launch_bounds__(64) void inflate_bgzf_kernel(const InflateJob* __re
                 if (btype == 1u) {
                     for (uint32_t i = lane; i < 320u; i += 64u) g_lds[kLens + i] = (uint8_t)(i < 144u ? 8 : i < 256u ? 9 : i < 280u ? 7 : i < 288u ? 8 : 5);
                     __builtin_amdgcn_wave_barrier();
-                    if (!uni(build_table(0, 288, 0, kLitInfo, kLitCount, kLitSymbol)) || !uni(build_table(288, 30, 1, kDistInfo, kDistCount, kDistSymbol))) { ok = false; break; }
+                    // (the fixed distance code has 32 codes of 5 bits -- 30 and 31 may not occur, their table entries stay
+                    // empty; with 30 the code is incomplete and every fixed block was refused: DD_INFLATE_STRICT found it)
+                    if (!uni(build_table(0, 288, 0, kLitInfo, kLitCount, kLitSymbol)) || !uni(build_table(288, 32, 1, kDistInfo, kDistCount, kDistSymbol))) { ok = false; break; }
                 } else {
                     const uint32_t hlit = b.take(5) + 257u, hdist = b.take(5) + 1u, hclen = b.take(4) + 4u;
                     if (hlit > 286u || hdist > 30u) { ok = false; break; }

@@ -235,6 +235,16 @@ inline bool has_plus_line(const uint8_t* p, size_t n) {
         if (q > p && q[-1] == '\n') return true;
     return false;
 }
+// the same question for one piece [off, off + len) of a buffer that is being read in pieces by several threads: a '+'
+// at the piece's first byte is NOT looked at (the byte before it may not be there yet: plus_at_piece_start)
+inline bool piece_has_plus_line(const uint8_t* p, size_t off, size_t len) {
+    if (len && off == 0 && p[0] == '+') return true;
+    const uint8_t* end = p + off + len;
+    for (const uint8_t* q = p + off + 1; q < end && (q = static_cast<const uint8_t*>(memchr(q, '+', (size_t)(end - q)))) != nullptr; ++q)
+        if (q[-1] == '\n') return true;
+    return false;
+}
+inline bool plus_at_piece_start(const uint8_t* p, size_t off) { return off > 0 && p[off] == '+' && p[off - 1] == '\n'; }
 // src[0..n) -> dst (at least n + 2 bytes; may be src itself: the output never runs ahead of the input by more than two
 // bytes, which memmove tolerates); returns the bytes written
 inline size_t fastq_to_fasta(const uint8_t* src, size_t n, uint8_t* dst) {
@@ -297,8 +307,8 @@ inline size_t fastq_to_fasta(const uint8_t* src, size_t n, uint8_t* dst) {
     return o;
 }
 // a file's bytes as K0 wants them; false: out of memory
-inline bool normalize_records(FileBuf& fb) {
-    if (!has_plus_line(fb.p, fb.len)) return true;
+inline bool normalize_records(FileBuf& fb, int known_plus = -1) {   // known_plus: 0 / 1 = the caller has looked already
+    if (known_plus == 0 || (known_plus < 0 && !has_plus_line(fb.p, fb.len))) return true;
     if (!fb.reserve(fb.len + 16)) return false;
     fb.len = fastq_to_fasta(fb.p, fb.len, fb.p);
     return true;

@@ -1,0 +1,83 @@
+"""Randomized check of the device inflate (dd_ginflate.hip): random texts (DNA, repeats, runs, soft-masked, junk bytes, long
+header lines), random zlib level / strategy / memLevel / BGZF block size; the registers of the BGZF file through dd_sketch_files
+must equal those of the plain bytes, with DD_INFLATE_STRICT=1 so that a refused block fails the call instead of going to the
+host decoder (the device checks every block's CRC-32, so a wrong byte anywhere is a refusal).
+    python scripts/fuzz_inflate.py [N] [SEED]"""
+import os, sys, time, tempfile, zlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch  # noqa: F401
+from dandd_amd.engine import Engine
+
+def bgzf(raw, level, strategy, memlevel, block):
+    out = bytearray()
+    parts = [raw[a:a + block] for a in range(0, len(raw), block)] + [b""]
+    while parts:
+        part = parts.pop(0)
+        c = zlib.compressobj(level, zlib.DEFLATED, -15, memlevel, strategy)
+        body = c.compress(part) + c.flush()
+        if len(body) + 26 > 65536:     # (a member must fit BGZF's 16-bit size field: halve the text)
+            parts[:0] = [part[:len(part) // 2], part[len(part) // 2:]]
+            continue
+        out += (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + (len(body) + 25).to_bytes(2, "little") + body +
+                zlib.crc32(part).to_bytes(4, "little") + len(part).to_bytes(4, "little"))
+    return bytes(out)
+
+n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+os.environ["DD_INFLATE_STRICT"] = "1"
+eng = Engine(0, 14, True)
+d = tempfile.mkdtemp()
+alph = [b"ACGT", b"ACGTacgtN", b"AC", b"ACGTACGTACGTRYKMn-* 0", bytes(range(32, 127))]
+t0 = time.time()
+nblocks = 0
+for it in range(n_cfg):
+    paths, raws = [], []
+    for f in range(int(rng.integers(1, 5))):
+        parts = []
+        for r in range(int(rng.integers(1, 4))):
+            parts.append(b">rec %d " % r + bytes(rng.choice(np.frombuffer(alph[4], np.uint8), size=int(rng.choice([0, 10, 300, 70000]) * rng.random()))).replace(b">", b"x") + b"\n")
+            total = int(rng.choice([1, 1000, 70000, 400000, 2000000]) * rng.random()) + 1
+            kind = int(rng.integers(0, 5))
+            if kind == 0:      # i.i.d. bases
+                seq = rng.choice(np.frombuffer(alph[int(rng.integers(0, 4))], np.uint8), size=total).tobytes()
+            elif kind == 1:    # tandem repeats of a short unit: overlapping copies of every distance
+                unit = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(rng.integers(1, 300))).tobytes()
+                seq = (unit * (total // len(unit) + 1))[:total]
+            elif kind == 2:    # long runs (distance 1) between random stretches
+                seq = b"".join((b"N" if rng.integers(0, 2) else b"A") * int(rng.integers(1, 5000)) + rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(rng.integers(1, 3000))).tobytes()
+                               for _ in range(total // 4000 + 1))[:total]
+            elif kind == 3:    # a mutated copy of an earlier stretch: long far matches
+                base = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=min(total, 40000))
+                reps = []
+                for _ in range(total // len(base) + 1):
+                    c = base.copy()
+                    idx = rng.integers(0, len(c), size=len(c) // 200 + 1)
+                    c[idx] = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=len(idx))
+                    reps.append(c.tobytes())
+                seq = b"".join(reps)[:total]
+            else:              # high-entropy bytes (mostly literals, long codes)
+                seq = bytes(rng.integers(33, 127, size=total, dtype=np.uint8)).replace(b">", b"x").replace(b"@", b"x").replace(b"+", b"x")
+            width = int(rng.choice([60, 61, 80, 1000, 10 ** 9]))
+            parts.append(b"\n".join(seq[i:i + width] for i in range(0, len(seq), width)) + b"\n")
+        raw = b"".join(parts)
+        level = int(rng.choice([0, 1, 2, 4, 6, 9]))
+        strategy = int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED]))
+        memlevel = int(rng.choice([1, 4, 8, 9]))
+        block = int(rng.choice([1, 17, 4096, 30000, 65280, 65536]))
+        if block < 4096 and len(raw) > 20000:
+            raw = raw[:20000]
+        p = os.path.join(d, f"f{f}.fa.gz")
+        data = bgzf(raw, level, strategy, memlevel, block)
+        open(p, "wb").write(data)
+        nblocks += len(raw) // block + 2
+        paths.append(p)
+        raws.append((raw, level, strategy, memlevel, block))
+    got = eng.sketch_files(paths, 19, 21)
+    for g, (raw, *cfg) in zip(got, raws):
+        want = eng.sketch_buffer(np.frombuffer(raw, np.uint8), 19, 21)
+        if not np.array_equal(g, want):
+            print(f"MISMATCH cfg {it}: {cfg} bytes={len(raw)}")
+            open(f"gpurun_out/fuzz_inflate_fail_{it}.bin", "wb").write(raw)
+            sys.exit(1)
+print(f"{n_cfg} random configurations, ~{nblocks} BGZF blocks: the device decoder took every block, registers equal, in {time.time() - t0:.1f} s")

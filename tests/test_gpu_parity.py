@@ -396,6 +396,36 @@ def test_sketch_files_gz_and_plain(engine_factory, orc, tmp_path):
     assert eng.sketch_files([], 9, 14).shape == (0, 6, 1 << 12)
 
 
+def test_sketch_files_fastq_read_in_pieces(engine_factory, orc, tmp_path):
+    """Plain files are read in pieces (2 MiB, then 8 MiB) by several loaders, each of which looks through its own piece for
+    the '+' line that makes a file FASTQ (dd_io.h: piece_has_plus_line): FASTQ files whose '+' lines fall inside pieces, one
+    whose ONLY '+' line starts exactly at a piece boundary, its .gz, and a FASTA file whose one '+' sits mid-line (not
+    FASTQ) -- registers == the oracle's on the same bytes (the oracle reads records the way kseq does)."""
+    import gzip
+    eng = engine_factory(12, True)
+    rng = np.random.default_rng(5)
+
+    def seq(n):
+        return rng.choice(np.frombuffer(b"ACGT", np.uint8), size=n).tobytes()
+
+    many = b"".join(b"@r%d\n" % i + (s := seq(int(rng.integers(50, 3000)))) + b"\n+\n" + b"I" * len(s) + b"\n" for i in range(4000))
+    assert len(many) > (10 << 20)
+    head = b"@only\n"
+    body = seq((2 << 20) - len(head) - 1)                       # the '+' of the one record is byte 2 MiB of the file
+    edge = head + body + b"\n+\n" + b"J" * len(body) + b"\n"
+    assert edge[2 << 20] == ord("+") and edge[(2 << 20) - 1] == 10
+    fasta = b">plain\n" + seq(3 << 20) + b"+" + seq(1000) + b"\n"   # a '+' that does not start a line
+    cases = {"many.fq": many, "edge.fastq": edge, "edge.fq.gz": gzip.compress(edge, 1), "plain.fa": fasta}
+    paths = []
+    for name, data in cases.items():
+        (tmp_path / name).write_bytes(data)
+        paths.append(str(tmp_path / name))
+    got = eng.sketch_files(paths, 15, 18, nthreads=4)
+    for g, (name, data) in zip(got, cases.items()):
+        raw = gzip.decompress(data) if name.endswith(".gz") else data
+        assert np.array_equal(g, orc.sketch_sweep(np.frombuffer(raw, np.uint8), 15, 18, 12)), name
+
+
 def _bgzf(raw, level=1, strategy=0, block=65280):
     """bgzip's container: <= 64 KiB gzip members with a 'BC' extra subfield that holds the member's size - 1, + the empty EOF block"""
     import zlib
@@ -427,7 +457,9 @@ def test_bgzf_files_are_inflated_on_the_device(engine_factory, orc, tmp_path, mo
         path = tmp_path / f"{name}.fa.gz"
         path.write_bytes(_bgzf(raw, **kw))
         cases.append((name, str(path), np.frombuffer(raw, dtype=np.uint8)))
+    monkeypatch.setenv("DD_INFLATE_STRICT", "1")                 # a block the device refuses fails the call: no silent host fallback here
     got = eng.sketch_files([p for _, p, _ in cases], 19, 21)
+    monkeypatch.delenv("DD_INFLATE_STRICT")
     assert eng.last_ingest_stats()[2] >= 1
     for (name, _, fa), regs in zip(cases, got):
         assert np.array_equal(regs, eng.sketch_buffer(fa, 19, 21)), name
