@@ -146,6 +146,10 @@ struct dd_ctx {
     // BGZF files inflated on the device (dd_ginflate.hip): compressed bytes, block table and error count of a batch
     DevBuf pipe_gz[2], pipe_jobs[2], pipe_err[2];
     HostBuf pipe_jobs_host[2], pipe_err_host[2];
+    // single-member gzip files inflated on the device: symbols, windows, the piece tables (RawFile[], starts, lens, offs,
+    // chunk0, crcs) and their host copies
+    DevBuf pipe_sym[2], pipe_win[2], pipe_raw[2];
+    HostBuf pipe_raw_host[2], pipe_crc_host[2];
     bool no_gpu_inflate = false;   // this context inflates on the host (set for the retry of a call, for good after three)
     int inflate_refusals = 0;      // calls in which the device decoder refused a block
     bool inflate_retry = false;    // ... and the call that met it is run again
@@ -328,6 +332,11 @@ void dd_destroy(dd_ctx* c) {
         c->pipe_regs[i].release();
         c->pipe_out[i].release();
         c->pipe_gz[i].release();
+        c->pipe_sym[i].release();
+        c->pipe_win[i].release();
+        c->pipe_raw[i].release();
+        c->pipe_raw_host[i].release();
+        c->pipe_crc_host[i].release();
         c->pipe_jobs[i].release();
         c->pipe_err[i].release();
         c->pipe_jobs_host[i].release();
@@ -873,6 +882,60 @@ static bool bgzf_for_device(const char* path, FileBuf& fb, std::vector<BgzfBlock
     return true;
 }
 
+// One single-member gzip file for the device path (dd_ginflate.hip: launch_gunzip_members): the raw bytes into `fb`, where
+// the deflate data starts, the trailer's CRC-32 and ISIZE.  false: not a file that path takes (small, huge, not gzip,
+// FASTQ): the host decoder reads it.  (Whether the file is ONE member only the decoding shows: the device refuses a
+// stream whose final block is not followed by exactly the 8 trailer bytes.)
+struct GzMember {
+    uint32_t first_bit = 0, isize = 0, crc = 0;
+};
+static bool gzip_member_for_device(const char* path, FileBuf& fb, GzMember& gm) {
+    struct stat sb;
+    const size_t min_bytes = (size_t)(getenv("DD_GUNZIP_MIN_KB") ? std::max(1, atoi(getenv("DD_GUNZIP_MIN_KB"))) : 1024) << 10;
+    if (stat(path, &sb) != 0 || !S_ISREG(sb.st_mode) || (size_t)sb.st_size < min_bytes || (size_t)sb.st_size >= ((size_t)500 << 20)) return false;
+    FILE* f = fopen(path, "rb");
+    if (!f) return false;
+    const size_t n = (size_t)sb.st_size;
+    fb.len = 0;
+    const bool ok = fb.reserve(n + 16) && fread(fb.p, 1, n, f) == n;
+    fclose(f);
+    if (!ok) return false;
+    const uint8_t* p = fb.p;
+    if (n < 64 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xE0)) return false;
+    size_t h = 10;
+    if (p[3] & 4) {
+        if (h + 2 > n) return false;
+        h += 2 + ((size_t)p[h] | ((size_t)p[h + 1] << 8));
+    }
+    for (int bit : {8, 16})
+        if (p[3] & bit) {
+            while (h < n && p[h]) ++h;
+            ++h;
+        }
+    if (p[3] & 2) h += 2;
+    if (h + 16 > n) return false;
+    const uint8_t* t = p + n - 8;
+    gm.first_bit = (uint32_t)(8 * h);
+    gm.crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+    gm.isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+    if (gm.isize < n / 2 || (size_t)gm.isize > (size_t)1032 * n || gm.isize >= (1u << 31)) return false;   // (a multi-member file's last ISIZE is usually smaller than the file)
+    // FASTQ needs the host's record pass: look at the first bytes of text
+    uint8_t first[256];
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, 15 + 16) != Z_OK) return false;
+    zs.next_in = fb.p;
+    zs.avail_in = (uInt)std::min<size_t>(n, 1 << 16);
+    zs.next_out = first;
+    zs.avail_out = sizeof first;
+    const int zr = inflate(&zs, Z_SYNC_FLUSH);
+    const size_t made = sizeof first - zs.avail_out;
+    inflateEnd(&zs);
+    if ((zr != Z_OK && zr != Z_STREAM_END) || !made || first[0] == '@' || dd::has_plus_line(first, made)) return false;
+    fb.len = n;
+    return true;
+}
+
 static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, int kmin, int kmax, uint8_t* regs, int nthreads) {
     if (nfiles < 0 || (nfiles && (!paths || !regs))) return fail(DD_EINVAL, "null argument");
     if (kmin < 1 || kmax > 64 || kmin > kmax) return fail(DD_EINVAL, "k range %d..%d outside 1..64", kmin, kmax);
@@ -950,8 +1013,11 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
         bool dev_inflate = false;             // BGZF: the buffer holds the COMPRESSED file, the device inflates its blocks
         size_t out_size = 0;                  // ... into this many bytes of text
         std::vector<BgzfBlock> blks;
+        bool dev_gunzip = false;              // ONE gzip member: the buffer holds the compressed file, the device inflates it in pieces
+        GzMember gm;
     };
     std::vector<Slot> slots(nfiles);
+    const bool gpu_gunzip = gpu_inflate && !getenv("DD_NO_GPU_GUNZIP");
     // Work items in file order.  A plain file is cut into 8 MiB pieces that different loaders pread into the
     // file's pinned buffer -- the first file of a directory is then in memory after one piece-time instead of
     // one file-time, which is what the GPU waits for at the start; a gzip file is one item (zlib is serial).
@@ -1041,6 +1107,7 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             }
             if (it.len == 0) {
                 if (gpu_inflate && bgzf_for_device(paths[it.file], fb, sl.blks, sl.out_size)) sl.dev_inflate = true;
+                else if (gpu_gunzip && gzip_member_for_device(paths[it.file], fb, sl.gm)) sl.dev_gunzip = true, sl.out_size = sl.gm.isize;
                 else ok = read_fasta_file(paths[it.file], fb, err, gz_par);
             } else if (ok && fb.cap >= sl.plain_size) {
                 FILE* f = fopen(paths[it.file], "rb");
@@ -1086,6 +1153,10 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
         int first = 0, count = 0;   // files of the batch
         bool active = false;
         bool inflated = false;      // some of its files were inflated on the device: the error count is looked at
+        struct Member {             // a single-member gzip file inflated on the device: its text's CRC-32 is put together here
+            uint32_t chunk0, nchunks, isize, crc;
+        };
+        std::vector<Member> members;
     };
     InFlight fly[2];
     // hand a finished batch's results to the caller and its host buffers back to the pool
@@ -1094,7 +1165,21 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
         if (!f.active) return DD_OK;
         f.active = false;
         const bool arrived = hipEventSynchronize(c->pipe_d2h[set]) == hipSuccess;
-        const bool refused = arrived && f.inflated && *static_cast<const uint32_t*>(c->pipe_err_host[set].p) != 0;
+        bool refused = arrived && f.inflated && *static_cast<const uint32_t*>(c->pipe_err_host[set].p) != 0;
+        if (arrived && !refused) {
+            const uint32_t* crcs = static_cast<const uint32_t*>(c->pipe_crc_host[set].p);
+            for (const InFlight::Member& m : f.members) {
+                uLong crc = 0;
+                for (uint32_t k = 0; k < m.nchunks; ++k) {
+                    const uint32_t len = std::min<uint32_t>(65536u, m.isize - k * 65536u);
+                    crc = k ? crc32_combine(crc, crcs[m.chunk0 + k], (z_off_t)len) : crcs[m.chunk0];
+                }
+                if ((uint32_t)crc != m.crc) {
+                    refused = true;
+                    *static_cast<uint32_t*>(c->pipe_err_host[set].p) = 1;
+                }
+            }
+        }
         if (arrived && !refused)
             parallel_copy(regs + (size_t)f.first * slab, static_cast<const uint8_t*>(c->pipe_out[set].p), (size_t)f.count * slab, nthreads);
         else
@@ -1108,7 +1193,7 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
         // (a failed batch has still given its buffers back: the loaders must never wait for ever)
         if (refused) {
             c->inflate_retry = true;
-            return fail(DD_EIO, "ingestion pipeline: %u BGZF block(s) refused by the device decoder", *static_cast<const uint32_t*>(c->pipe_err_host[set].p));
+            return fail(DD_EIO, "ingestion pipeline: %u block(s) / piece(s) / file(s) refused by the device decoder", *static_cast<const uint32_t*>(c->pipe_err_host[set].p));
         }
         return arrived ? DD_OK : fail(DD_EHIP, "ingestion pipeline: D2H failed");
     };
@@ -1169,16 +1254,43 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
         size_t tot = 0;
         size_t gz_tot = 0, njobs = 0;
         std::vector<size_t> gz_off(count, 0);
+        // (single-member gzip files: the finder looks at one range of `guess_bits` per piece; 32 KiB of compressed data are ~2
+        // deflate blocks of gzip -6 DNA, so a third of every range is scanned before its first block start turns up)
+        const size_t guess_bits = (size_t)(getenv("DD_GUNZIP_GUESS_KB") ? std::max(4, atoi(getenv("DD_GUNZIP_GUESS_KB"))) : 32) << 13;
+        size_t nmem = 0, npieces = 0, nchunks = 0, sym_tot = 0, win_tot = 0;
         for (int j = 0; j < count; ++j) {
             const Slot& sj = slots[i + j];
-            sizes[j] = sj.dev_inflate ? sj.out_size : c->file_pool[sj.buf]->size();
+            sizes[j] = (sj.dev_inflate || sj.dev_gunzip) ? sj.out_size : c->file_pool[sj.buf]->size();
             offs[j] = tot;
             tot += align_up(sizes[j] + 16, 256);
-            if (sj.dev_inflate) {
+            if (sj.dev_inflate || sj.dev_gunzip) {
                 gz_off[j] = gz_tot;
                 gz_tot += align_up(c->file_pool[sj.buf]->size() + 16, 256);
                 njobs += sj.blks.size();
             }
+            if (sj.dev_gunzip) {
+                const size_t bits = c->file_pool[sj.buf]->size() * 8 - sj.gm.first_bit;
+                const size_t ng = (bits + guess_bits - 1) / guess_bits;
+                ++nmem;
+                npieces += ng;
+                nchunks += (sj.gm.isize + 65535u) / 65536u;
+                sym_tot += align_up((size_t)sj.gm.isize * 2 + 256, 256);
+                win_tot += ng * 32768;
+            }
+        }
+        // the piece tables of the batch's single-member gzip files, one block of device memory: RawFile[nmem],
+        // starts / lens / offs [npieces], chunk0 [nmem + 1], crcs [nchunks]
+        const size_t raw_files = align_up(nmem * sizeof(dd::RawFile), 256), raw_u32 = align_up(npieces * 4, 256), raw_chunk0 = align_up((nmem + 1) * 4, 256);
+        const size_t raw_bytes = raw_files + 3 * raw_u32 + raw_chunk0 + align_up(nchunks * 4, 256);
+        if (nmem && ((rc = c->pipe_gz[set].reserve(gz_tot + 16)) != DD_OK || (rc = c->pipe_sym[set].reserve(sym_tot)) != DD_OK ||
+                     (rc = c->pipe_win[set].reserve(win_tot)) != DD_OK || (rc = c->pipe_raw[set].reserve(raw_bytes)) != DD_OK ||
+                     (rc = c->pipe_raw_host[set].reserve(raw_files + raw_chunk0)) != DD_OK || (rc = c->pipe_crc_host[set].reserve(nchunks * 4 + 256)) != DD_OK ||
+                     (rc = c->pipe_err[set].reserve(256)) != DD_OK || (rc = c->pipe_err_host[set].reserve(256)) != DD_OK)) {
+            first_err = g_err;
+            release_unsent(i, count);
+            cv.notify_all();
+            i += count;
+            continue;
         }
         total_bytes += tot;
         if (njobs && ((rc = c->pipe_gz[set].reserve(gz_tot + 16)) != DD_OK || (rc = c->pipe_jobs[set].reserve(njobs * sizeof(dd::InflateJob))) != DD_OK ||
@@ -1201,10 +1313,14 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             continue;
         }
         hipError_t e = hipSuccess;
-        hipStream_t cs = (njobs && set) ? c->copy_stream_b : c->copy_stream;
+        hipStream_t cs = ((njobs || nmem) && set) ? c->copy_stream_b : c->copy_stream;
         std::vector<const uint8_t*> ptrs(count);
         dd::InflateJob* jobs_host = njobs ? static_cast<dd::InflateJob*>(c->pipe_jobs_host[set].p) : nullptr;
         size_t nj = 0;
+        dd::RawFile* raw_host = nmem ? static_cast<dd::RawFile*>(c->pipe_raw_host[set].p) : nullptr;
+        uint32_t* chunk0_host = nmem ? reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(c->pipe_raw_host[set].p) + raw_files) : nullptr;
+        size_t mi = 0, piece_at = 0, chunk_at = 0, sym_at = 0, win_at = 0;
+        std::vector<InFlight::Member> members;
         for (int j = 0; j < count && e == hipSuccess; ++j) {
             ptrs[j] = static_cast<const uint8_t*>(c->pipe_fasta[set].p) + offs[j];
             const Slot& sj = slots[i + j];
@@ -1215,19 +1331,56 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
                 e = hipMemcpyAsync(gz, fbj.data(), fbj.size(), hipMemcpyHostToDevice, cs);
                 for (const BgzfBlock& b : sj.blks)
                     jobs_host[nj++] = dd::InflateJob{gz + b.in_off, b.in_len, b.out_len, const_cast<uint8_t*>(ptrs[j]) + b.out_off};
+            } else if (sj.dev_gunzip) {
+                uint8_t* gz = static_cast<uint8_t*>(c->pipe_gz[set].p) + gz_off[j];
+                e = hipMemcpyAsync(gz, fbj.data(), fbj.size(), hipMemcpyHostToDevice, cs);
+                dd::RawFile& rf = raw_host[mi];
+                const size_t ng = (fbj.size() * 8 - sj.gm.first_bit + guess_bits - 1) / guess_bits;
+                rf.in = gz;
+                rf.in_len = (uint32_t)fbj.size();
+                rf.first_bit = sj.gm.first_bit;
+                rf.guess_bits = (uint32_t)guess_bits;
+                rf.nguess = (uint32_t)ng;
+                rf.piece0 = (uint32_t)piece_at;
+                rf.isize = sj.gm.isize;
+                rf.sym = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(c->pipe_sym[set].p) + sym_at);
+                rf.windows = static_cast<uint8_t*>(c->pipe_win[set].p) + win_at;
+                rf.text = const_cast<uint8_t*>(ptrs[j]);
+                chunk0_host[mi] = (uint32_t)chunk_at;
+                members.push_back(InFlight::Member{(uint32_t)chunk_at, (sj.gm.isize + 65535u) / 65536u, sj.gm.isize, sj.gm.crc});
+                piece_at += ng;
+                chunk_at += (sj.gm.isize + 65535u) / 65536u;
+                sym_at += align_up((size_t)sj.gm.isize * 2 + 256, 256);
+                win_at += ng * 32768;
+                ++mi;
             } else if (sizes[j]) {
                 e = hipMemcpyAsync(const_cast<uint8_t*>(ptrs[j]), fbj.data(), sizes[j], hipMemcpyHostToDevice, cs);
             }
         }
+        if ((njobs || nmem) && e == hipSuccess) e = hipMemsetAsync(c->pipe_err[set].p, 0, 4, cs);
+        if (nmem && e == hipSuccess) {
+            // block starts -> piece lengths -> offsets -> symbols -> windows -> text -> CRC-32 of every 64 KiB (dd_ginflate.hip)
+            chunk0_host[nmem] = (uint32_t)chunk_at;
+            uint8_t* rb = static_cast<uint8_t*>(c->pipe_raw[set].p);
+            e = hipMemcpyAsync(rb, raw_host, nmem * sizeof(dd::RawFile), hipMemcpyHostToDevice, cs);
+            if (e == hipSuccess) e = hipMemcpyAsync(rb + raw_files + 3 * raw_u32, chunk0_host, (nmem + 1) * 4, hipMemcpyHostToDevice, cs);
+            if (e == hipSuccess) {
+                uint32_t* u = reinterpret_cast<uint32_t*>(rb + raw_files);
+                uint32_t* crcs_dev = reinterpret_cast<uint32_t*>(rb + raw_files + 3 * raw_u32 + raw_chunk0);
+                dd::launch_gunzip_members(reinterpret_cast<const dd::RawFile*>(rb), (int)nmem, (int)npieces, (int)nchunks, u, u + raw_u32 / 4, u + 2 * (raw_u32 / 4),
+                                          reinterpret_cast<const uint32_t*>(rb + raw_files + 3 * raw_u32), crcs_dev, static_cast<uint32_t*>(c->pipe_err[set].p), cs);
+                e = hipGetLastError();
+                if (e == hipSuccess) e = hipMemcpyAsync(c->pipe_crc_host[set].p, crcs_dev, nchunks * 4, hipMemcpyDeviceToHost, cs);
+            }
+        }
         if (njobs && e == hipSuccess) {
-            e = hipMemsetAsync(c->pipe_err[set].p, 0, 4, cs);
-            if (e == hipSuccess) e = hipMemcpyAsync(c->pipe_jobs[set].p, jobs_host, njobs * sizeof(dd::InflateJob), hipMemcpyHostToDevice, cs);
+            e = hipMemcpyAsync(c->pipe_jobs[set].p, jobs_host, njobs * sizeof(dd::InflateJob), hipMemcpyHostToDevice, cs);
             if (e == hipSuccess) {
                 dd::launch_inflate_bgzf(static_cast<const dd::InflateJob*>(c->pipe_jobs[set].p), (int)njobs, static_cast<uint32_t*>(c->pipe_err[set].p), cs);
                 e = hipGetLastError();
             }
-            if (e == hipSuccess) e = hipMemcpyAsync(c->pipe_err_host[set].p, c->pipe_err[set].p, 4, hipMemcpyDeviceToHost, cs);
         }
+        if ((njobs || nmem) && e == hipSuccess) e = hipMemcpyAsync(c->pipe_err_host[set].p, c->pipe_err[set].p, 4, hipMemcpyDeviceToHost, cs);
         if (e == hipSuccess) e = hipEventRecord(c->pipe_h2d[set], cs);
         if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->pipe_h2d[set], 0);
         if (e == hipSuccess) {
@@ -1253,7 +1406,8 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             fly[set].first = i;
             fly[set].count = count;
             fly[set].active = true;
-            fly[set].inflated = njobs != 0;
+            fly[set].inflated = njobs != 0 || nmem != 0;
+            fly[set].members = std::move(members);
             ++nbatches;
         }
         if (trace)

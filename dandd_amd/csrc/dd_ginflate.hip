@@ -259,60 +259,128 @@ __device__ __noinline__ uint32_t text_crc(const uint8_t* text, uint32_t n) {
 
 }  // namespace
 
-// grid = blocks; one wave each.  `errors`: blocks that could not be decoded (the caller falls back to the host).
-__global__ __launch_bounds__(64) void inflate_bgzf_kernel(const InflateJob* __restrict__ jobs, uint32_t* __restrict__ errors) {
-    const InflateJob job = jobs[blockIdx.x];
+// the piece a wave of the raw-deflate modes works on: entry `idx` of the batch's piece table
+struct PieceRef {
+    int file;
+    uint32_t start, end;   // bit positions; end = ~0u: up to the stream's final block
+};
+DD_D bool piece_of(const RawFile* files, int nfiles, const uint32_t* starts, uint32_t idx, PieceRef& r) {
+    int f = 0;
+    while (f + 1 < nfiles && idx >= uni(files[f + 1].piece0)) ++f;
+    const uint32_t j = idx - uni(files[f].piece0), ng = uni(files[f].nguess);
+    r.file = f;
+    r.start = uni(starts[idx]);
+    r.end = ~0u;
+    if (j >= ng || r.start == ~0u) return false;
+    for (uint32_t k = j + 1; k < ng; ++k) {
+        const uint32_t e = uni(starts[idx - j + k]);
+        if (e != ~0u) { r.end = e; break; }
+    }
+    return true;
+}
+
+// MODE 0: grid = BGZF blocks (jobs), one wave each; the text goes out as bytes, the member's ISIZE and CRC-32 are checked.
+// MODE 1 / 2: grid = pieces of single-member gzip files (files / starts): raw deflate data from a block start found by
+// find_starts_kernel up to the next one, decoded WITHOUT its 32 KiB of history -- a copy that reaches in front of the
+// piece yields placeholders 0x8000 | position in that unknown window (pugz's idea; dd_inflate.h does the same on the
+// host).  MODE 1 only counts the piece's text (lens[idx]); MODE 2 writes 16-bit symbols at sym + offs[idx].
+// `errors`: blocks / pieces that could not be decoded (the caller falls back to the host).
+template <int MODE>
+__global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restrict__ jobs, const RawFile* __restrict__ files, int nfiles,
+                                                     const uint32_t* __restrict__ starts, uint32_t* __restrict__ lens, const uint32_t* __restrict__ offs,
+                                                     uint32_t* __restrict__ errors) {
+    constexpr bool RAW = MODE != 0;
+    constexpr uint32_t kLit = RAW ? 0x40000000u : 0x80000000u;   // a batch lane's source: a literal (else an offset in the text; RAW: negative = in front of the piece)
     const uint32_t lane = threadIdx.x & 63u;
     bool ok = true;
-    const uint8_t* in = job.in;
-    const uint32_t n = job.in_len;
-    uint8_t* const out = job.out;
+    const uint8_t* in;
+    uint32_t n, out_len, piece_end = ~0u;
+    uint8_t* out = nullptr;
+    uint16_t* sym = nullptr;
+    PieceRef pr{0, 0, ~0u};
+    if (!RAW) {
+        const InflateJob job = jobs[blockIdx.x];
+        in = job.in, n = job.in_len, out = job.out, out_len = job.out_len;
+    } else {
+        if (!piece_of(files, nfiles, starts, blockIdx.x, pr)) {
+            if (MODE == 1 && lane == 0) lens[blockIdx.x] = 0;
+            return;
+        }
+        const RawFile rf = files[pr.file];
+        in = rf.in, n = rf.in_len, piece_end = pr.end;
+        out_len = MODE == 1 ? rf.isize : uni(lens[blockIdx.x]);
+        if (MODE == 2) sym = rf.sym + uni(offs[blockIdx.x]);
+    }
     uint32_t at = 0;
     // The text goes out 64 bytes at a time: every lane owns one byte of the batch [bstart, bstart + used) and knows where it
     // comes from -- a literal, or an earlier position of the text --, so a batch of ~8 symbols costs ONE load and ONE
     // (contiguous) store, and the serial chain pays a round trip to L2 per batch instead of per symbol.
     uint32_t bstart = 0, used = 0;   // wave-uniform
-    uint32_t from = 0;               // this lane's byte: 0x80000000 | literal, or its source offset in the text
+    uint32_t from = 0;               // this lane's byte: kLit | literal, or its source offset in the text
     auto flush = [&]() {
         if (used) {
-            uint32_t v = from & 0xFFu;
-            // (what the batch copies was stored by earlier batches of this wave: they have landed before it is read --
-            // a batch ago they were issued, the wait is free -- and the bytes are read past the vector L1)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane < used && !(from >> 31)) v = gload1_fresh(out + from);
-            if (lane < used) out[bstart + lane] = (uint8_t)v;
+            if (MODE == 0) {
+                uint32_t v = from & 0xFFu;
+                // (what the batch copies was stored by earlier batches of this wave: they have landed before it is read --
+                // a batch ago they were issued, the wait is free -- and the bytes are read past the vector L1)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane < used && !(from >> 31)) v = gload1_fresh(out + from);
+                if (lane < used) out[bstart + lane] = (uint8_t)v;
+            } else if (MODE == 2) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane < used) {
+                    const int f = (int)from;
+                    uint32_t v;
+                    if (f < 0) v = 0x8000u | (uint32_t)(f + 32768);   // (>= -32768: checked where the copy was met)
+                    else if (from & kLit) v = from & 0xFFu;
+                    else v = __hip_atomic_load((const DD_GLOBAL uint16_t*)(sym + f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    *(DD_GLOBAL uint16_t*)(sym + bstart + lane) = (uint16_t)v;
+                }
+            }
             bstart += used;
             used = 0;
         }
     };
     // gzip member header: 10 fixed bytes, FEXTRA (BGZF's 'BC' field lives there), then -- not in BGZF, but legal -- name, comment, CRC16
     uint32_t hdr = 0;
-    if (n < 28u || uni(gload1(in)) != 0x1fu || uni(gload1(in + 1)) != 0x8bu || uni(gload1(in + 2)) != 8u) ok = false;
-    if (ok) {
-        const uint32_t flg = uni(gload1(in + 3));
-        hdr = 10;
-        if (flg & 4u) hdr += 2u + (uni(gload1(in + 10)) | (uni(gload1(in + 11)) << 8));
-        if (flg & (8u | 16u | 2u | 0xE0u)) ok = false;   // (name / comment / header CRC: bgzip writes none; the host decoder takes such files)
-        if (hdr + 8u > n) ok = false;
+    if (!RAW) {
+        if (n < 28u || uni(gload1(in)) != 0x1fu || uni(gload1(in + 1)) != 0x8bu || uni(gload1(in + 2)) != 8u) ok = false;
+        if (ok) {
+            const uint32_t flg = uni(gload1(in + 3));
+            hdr = 10;
+            if (flg & 4u) hdr += 2u + (uni(gload1(in + 10)) | (uni(gload1(in + 11)) << 8));
+            if (flg & (8u | 16u | 2u | 0xE0u)) ok = false;   // (name / comment / header CRC: bgzip writes none; the host decoder takes such files)
+            if (hdr + 8u > n) ok = false;
+        }
     }
     WBits b;
+    bool final_seen = false;
     if (ok) {
-        b.init(in + hdr, n - hdr);
+        if (!RAW) b.init(in + hdr, n - hdr);
+        else {
+            b.w = reinterpret_cast<const uint32_t*>(in);   // (the file's bytes start on a 256-byte boundary)
+            b.nwords = (n + 3u) / 4u;
+            b.start_at(pr.start >> 5, pr.start & 31u);
+        }
         for (;;) {
             const uint32_t bfinal = b.take(1), btype = b.take(2);
             if (btype == 3u) { ok = false; break; }
             if (btype == 0u) {
                 b.drop(b.cnt & 7);
                 const uint32_t len = b.take(16), nlen = b.take(16);
-                if ((len ^ nlen) != 0xffffu || at + len > job.out_len) { ok = false; break; }
-                // stored bytes: the reader's buffered bits first (whole bytes now), the rest straight from the input
-                const uint32_t used_in = b.bytes_used(in + hdr);   // bytes consumed up to the data's first byte (a byte boundary)
-                if (hdr + used_in + len + 8u > n) { ok = false; break; }
+                if ((len ^ nlen) != 0xffffu || at + len > out_len) { ok = false; break; }
+                // stored bytes: straight from the input (the reader stands on a byte boundary; its word base stays)
+                const uint8_t* const base = reinterpret_cast<const uint8_t*>(b.w);
+                const uint32_t data = b.bit_pos() >> 3;   // byte offset of the data from the reader's base
+                if ((uint32_t)(base - in) + data + len + 8u > n) { ok = false; break; }
                 flush();
-                for (uint32_t i = lane; i < len; i += 64u) out[at + i] = (uint8_t)gload1(in + hdr + used_in + i);
+                if (MODE == 0)
+                    for (uint32_t i = lane; i < len; i += 64u) out[at + i] = (uint8_t)gload1(base + data + i);
+                if (MODE == 2)
+                    for (uint32_t i = lane; i < len; i += 64u) *(DD_GLOBAL uint16_t*)(sym + at + i) = (uint16_t)gload1(base + data + i);
                 bstart = at + len;
                 at += len;
-                b.init(in + hdr + used_in + len, n - hdr - used_in - len);
+                b.start_at((data + len) >> 2, 8u * ((data + len) & 3u));
             } else {
                 if (btype == 1u) {
                     for (uint32_t i = lane; i < 320u; i += 64u) g_lds[kLens + i] = (uint8_t)(i < 144u ? 8 : i < 256u ? 9 : i < 280u ? 7 : i < 288u ? 8 : 5);
@@ -428,7 +496,7 @@ __global__ __launch_bounds__(64) void inflate_bgzf_kernel(const InflateJob* __re
                     // bits 0..5: the symbol's length in bits; 6..14: bytes it makes; 0 = not for the walk
                     uint32_t pk = 0;
                     if (kd == 1u) pk = l1 | (1u << 6);
-                    else if (kd == 3u && e2 != 0u && dv >= v1 + 64u && dv <= at) pk = (t1 + l2 + ex2) | (v1 << 6);
+                    else if (kd == 3u && e2 != 0u && dv >= v1 + 64u && dv <= at + (RAW ? 32768u : 0u)) pk = (t1 + l2 + ex2) | (v1 << 6);
                     unsigned long long mark = 0, starts = 0;
                     uint32_t pos = 0, outacc = 0, pks = 0;
                     const uint32_t room = 64u - used;
@@ -445,11 +513,11 @@ __global__ __launch_bounds__(64) void inflate_bgzf_kernel(const InflateJob* __re
                         pks = 1;
                     } while (pos < 64u);
                     if (outacc) {
-                        if (at + outacc > job.out_len) { ok = false; break; }
+                        if (at + outacc > out_len) { ok = false; break; }
                         // the symbols' lanes say where their bytes come from; the batch's lanes find their symbol by counting
                         if ((mark >> lane) & 1ull) {
                             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mark >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mark, 0u));
-                            const uint32_t src = kd == 1u ? (0x80000000u | v1) : bstart + osv - dv;
+                            const uint32_t src = kd == 1u ? (kLit | v1) : bstart + osv - dv;   // (RAW: may wrap below zero = in front of the piece)
                             *reinterpret_cast<uint2*>(g_lds + kLens + 8u * rank) = make_uint2(src, osv);
                         }
                         __builtin_amdgcn_wave_barrier();
@@ -490,8 +558,8 @@ __global__ __launch_bounds__(64) void inflate_bgzf_kernel(const InflateJob* __re
                             val = sy < 256u ? sy : (sy > 256u ? uni((uint32_t)c_len_base[sy - 257u]) : 0u);
                         }
                         if (kind == 1u) {
-                            if (at >= job.out_len) { ok = false; break; }
-                            if (lane == used) from = 0x80000000u | val;
+                            if (at >= out_len) { ok = false; break; }
+                            if (lane == used) from = kLit | val;
                             ++at;
                             if (++used == 64u) flush();
                         } else if (kind != 3u) {   // end of block (kind 0: a code the stream may not use)
@@ -518,11 +586,11 @@ __global__ __launch_bounds__(64) void inflate_bgzf_kernel(const InflateJob* __re
                             }
                             dist += (uint32_t)bits & ((1u << dex) - 1u);
                             pos += dex;
-                            if (dist > at || at + len > job.out_len) { ok = false; break; }
+                            if (dist > at + (RAW ? 32768u : 0u) || at + len > out_len) { ok = false; break; }
                             // the copy: its bytes join the batch (several batches when it is long).  It reads the dist-byte pattern
                             // in front of it; should that reach into the batch itself, the batch leaves first.
-                            const uint32_t pat = at - dist, pat_end = pat + (dist < len ? dist : len);
-                            if (pat_end > bstart) flush();
+                            const uint32_t pat = at - dist, pat_end = pat + (dist < len ? dist : len);   // (RAW: both may be "negative")
+                            if ((int)pat_end > (int)bstart) flush();
                             at += len;
                             auto place = [&](auto src_of) {
                                 uint32_t done = 0;
@@ -556,8 +624,24 @@ __global__ __launch_bounds__(64) void inflate_bgzf_kernel(const InflateJob* __re
                 }
                 if (!ok) break;
             }
-            if (bfinal) break;
+            if (bfinal) {
+                final_seen = true;
+                break;
+            }
+            if (RAW) {   // the piece ends where the next one starts -- exactly there, or the starts are not block starts
+                const uint32_t P = b.bit_pos();
+                if (P == piece_end) break;
+                if (P > piece_end) { ok = false; break; }
+            }
         }
+    }
+    if (RAW) {
+        if (ok && final_seen != (piece_end == ~0u)) ok = false;
+        if (ok && final_seen && b.bytes_used(in) + 8u != n) ok = false;   // ONE member: CRC-32 and ISIZE right behind the final block
+        if (MODE == 1 && lane == 0) lens[blockIdx.x] = ok ? at : 0u;
+        if (MODE == 2 && ok && at != out_len) ok = false;
+        if (!ok && lane == 0) atomicAdd(errors, 1u);
+        return;
     }
     // the member's trailer: CRC-32, ISIZE
     if (ok) {
@@ -567,7 +651,7 @@ __global__ __launch_bounds__(64) void inflate_bgzf_kernel(const InflateJob* __re
             const uint8_t* t = in + hdr + used;
             auto le32 = [&](const uint8_t* q) { return uni(gload1(q)) | (uni(gload1(q + 1)) << 8) | (uni(gload1(q + 2)) << 16) | (uni(gload1(q + 3)) << 24); };
             const uint32_t crc = le32(t), isize = le32(t + 4);
-            if (isize != at || at != job.out_len) ok = false;
+            if (isize != at || at != out_len) ok = false;
             else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the text's last batch has landed
                 if (text_crc(out, at) != crc) ok = false;
@@ -580,20 +664,311 @@ __global__ __launch_bounds__(64) void inflate_bgzf_kernel(const InflateJob* __re
     }
 }
 
+// ---- single-member gzip files: where do deflate blocks start? ---------------------------------------------------
+// A wave per guess: file f's guess j covers the bit positions [first_bit + j G, first_bit + (j + 1) G) and reports the
+// FIRST position in it that heads a valid dynamic-Huffman block (guess 0 reports first_bit itself).  Lane i tests the
+// position base + i: block type 2, HLIT <= 29, HDIST <= 29, the code-length code complete (or a single code) -- 22 % pass
+// the first, ~1 % of those the second --; survivors queue up in LDS and are put to the full test 64 at a time, a
+// candidate per lane: its code lengths decoded with a bit reader of the lane's own, the literal/length code complete
+// with an end-of-block code, the distance code complete or a single code.  What passes that is a block start or a
+// one-in-10^9 impostor; an impostor makes a piece end somewhere else than the next one starts and the call goes to the
+// host decoder.  Stored and fixed blocks are not looked for (they are decoded as parts of pieces).
+constexpr uint32_t kFindQueue = kLitSymbol;         // u32[128]: candidate bit positions waiting for the full test (behind the tables)
+constexpr uint32_t kFindTable = kLitInfo;           // u8[64][128]: every lane's code-length code (7-bit lookup): the place of both symbol tables
+constexpr uint8_t k_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};   // (c_cl_order, for unrolled loops)
+
+__global__ __launch_bounds__(64) void find_starts_kernel(const RawFile* __restrict__ files, int nfiles, uint32_t* __restrict__ starts) {
+    const uint32_t lane = threadIdx.x & 63u;
+    int f = 0;
+    while (f + 1 < nfiles && blockIdx.x >= uni(files[f + 1].piece0)) ++f;
+    const RawFile rf = files[f];
+    const uint32_t j = blockIdx.x - rf.piece0;
+    if (j >= rf.nguess) return;
+    if (j == 0) {
+        if (lane == 0) starts[blockIdx.x] = rf.first_bit;
+        return;
+    }
+    const uint32_t total_bits = (rf.in_len - 8u) * 8u;               // (the trailer is no place for a block)
+    const uint64_t lo64 = (uint64_t)rf.first_bit + (uint64_t)j * rf.guess_bits;
+    uint32_t found = ~0u;
+    if (lo64 + 64u < total_bits) {
+        const uint32_t lo = (uint32_t)lo64;
+        const uint32_t hi = (uint32_t)(lo64 + rf.guess_bits < total_bits ? lo64 + rf.guess_bits : total_bits);
+        const uint32_t* const W = reinterpret_cast<const uint32_t*>(rf.in);
+        const uint32_t nwords = (rf.in_len + 3u) / 4u;
+        auto word_at = [&](uint32_t i) { return i < nwords ? gload4(W + i) : 0u; };
+        // the full test of up to 64 queued candidates, one per lane; -> the smallest that passes, or ~0u
+        auto full_test = [&](uint32_t nq) -> uint32_t {
+            const uint32_t cand = lane < nq ? l32(kFindQueue + 4u * lane) : 0u;
+            bool live = lane < nq;
+            // the lane's bit reader
+            uint32_t wi = cand >> 5;
+            uint64_t buf = ((uint64_t)word_at(wi + 1u) << 32 | word_at(wi)) >> (cand & 31u);
+            int cnt = 64 - (int)(cand & 31u);
+            wi += 2u;
+            auto need = [&](int k) {
+                if (cnt < k) {
+                    buf |= (uint64_t)word_at(wi) << cnt;
+                    cnt += 32;
+                    ++wi;
+                }
+            };
+            auto take = [&](int k) {
+                need(k);
+                const uint32_t v = (uint32_t)buf & ((1u << k) - 1u);
+                buf >>= k, cnt -= k;
+                return v;
+            };
+            (void)take(3);
+            const uint32_t hlit = take(5) + 257u, hdist = take(5) + 1u, hclen = take(4) + 4u;
+            // its code-length code: lengths, canonical codes, a 128-entry table of its own in LDS
+            uint32_t cl[19];
+#pragma unroll
+            for (int i = 0; i < 19; ++i) cl[i] = 0;
+            uint32_t count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 19; ++i) {
+                const uint32_t v = (uint32_t)i < hclen ? take(3) : 0u;
+#pragma unroll
+                for (int s2 = 0; s2 < 19; ++s2)
+                    if (k_cl_order[i] == s2) cl[s2] = v;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 19; ++s2)
+#pragma unroll
+                for (int l = 1; l < 8; ++l) count[l] += cl[s2] == (uint32_t)l ? 1u : 0u;
+            uint32_t next[8], c = 0;
+#pragma unroll
+            for (int l = 1; l < 8; ++l) {
+                next[l] = c;
+                c = (c + count[l]) << 1;
+            }
+            uint8_t* const tab = g_lds + kFindTable + 128u * lane;
+            for (int i = 0; i < 128; i += 4) *reinterpret_cast<uint32_t*>(tab + i) = 0;
+#pragma unroll
+            for (int s2 = 0; s2 < 19; ++s2) {
+                const uint32_t l = cl[s2];
+                if (live && l) {
+                    uint32_t code = 0;
+#pragma unroll
+                    for (int q = 1; q < 8; ++q)
+                        if (l == (uint32_t)q) code = next[q]++;
+                    const uint32_t rev = __builtin_bitreverse32(code) >> (32u - l);
+                    for (uint32_t e = rev; e < 128u; e += 1u << l) tab[e] = (uint8_t)(l | ((uint32_t)s2 << 3));
+                }
+            }
+            // the literal/length and distance code lengths, run-length coded: Kraft sums in units of 2^-15
+            const uint32_t totalsym = hlit + hdist;
+            uint32_t i = 0, prev = 0, kraft_ll = 0, kraft_d = 0, nz_d = 0, eob = 0;
+            while (__any(live && i < totalsym)) {
+                if (live && i < totalsym) {
+                    need(14);
+                    const uint32_t e = tab[(uint32_t)buf & 127u];
+                    if (!e) live = false;
+                    else {
+                        buf >>= e & 7u, cnt -= (int)(e & 7u);
+                        const uint32_t sy = e >> 3;
+                        uint32_t rep = 1, val = sy;
+                        if (sy == 16u) {
+                            if (!i) live = false;
+                            val = prev;
+                            rep = 3u + ((uint32_t)buf & 3u);
+                            buf >>= 2, cnt -= 2;
+                        } else if (sy == 17u) {
+                            val = 0;
+                            rep = 3u + ((uint32_t)buf & 7u);
+                            buf >>= 3, cnt -= 3;
+                        } else if (sy == 18u) {
+                            val = 0;
+                            rep = 11u + ((uint32_t)buf & 127u);
+                            buf >>= 7, cnt -= 7;
+                        }
+                        if (i + rep > totalsym) live = false;
+                        if (live && val) {
+                            const uint32_t n_ll = i < hlit ? (hlit - i < rep ? hlit - i : rep) : 0u, n_d = rep - n_ll;
+                            kraft_ll += n_ll << (15u - val);
+                            kraft_d += n_d << (15u - val);
+                            nz_d += n_d;
+                            if (i <= 256u && 256u < i + rep) eob = val;
+                        }
+                        i += rep;
+                        prev = val;
+                    }
+                }
+            }
+            const bool pass = live && eob != 0u && kraft_ll == (1u << 15) && (kraft_d == (1u << 15) || nz_d <= 1u) && hlit <= 286u && hdist <= 30u;
+            const unsigned long long m = __ballot(pass);
+            return m ? (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)__builtin_ctzll(m)) : ~0u;
+        };
+        uint32_t nq = 0;
+        for (uint32_t base = lo; base < hi && found == ~0u; base += 64u) {
+            // the 96 bits from position base + lane on
+            const uint32_t pos = base + lane, wq = pos >> 5, sh = pos & 31u;
+            const uint32_t w0 = word_at(wq), w1 = word_at(wq + 1u), w2 = word_at(wq + 2u), w3 = word_at(wq + 3u);
+            const uint32_t x0 = __builtin_amdgcn_alignbit(w1, w0, sh), x1 = __builtin_amdgcn_alignbit(w2, w1, sh), x2 = __builtin_amdgcn_alignbit(w3, w2, sh);
+            const uint32_t hclen = ((x0 >> 13) & 15u) + 4u;
+            bool cand = pos < hi && ((x0 >> 1) & 3u) == 2u && ((x0 >> 3) & 31u) <= 29u && ((x0 >> 8) & 31u) <= 29u;
+            // Kraft sum of the code-length code (3-bit lengths from bit 17 on) in units of 2^-7
+            uint32_t kraft = 0, nz = 0;
+#pragma unroll
+            for (int i = 0; i < 19; ++i) {
+                const int bp = 17 + 3 * i;
+                uint32_t l;
+                if (bp + 3 <= 32) l = (x0 >> bp) & 7u;
+                else if (bp < 32) l = ((x0 >> bp) | (x1 << (32 - bp))) & 7u;
+                else if (bp + 3 <= 64) l = (x1 >> (bp - 32)) & 7u;
+                else if (bp < 64) l = ((x1 >> (bp - 32)) | (x2 << (64 - bp))) & 7u;
+                else l = (x2 >> (bp - 64)) & 7u;
+                const bool in = (uint32_t)i < hclen && l != 0u;
+                kraft += in ? (128u >> l) : 0u;
+                nz += in ? 1u : 0u;
+            }
+            cand = cand && (kraft == 128u || nz == 1u);
+            const unsigned long long m = __ballot(cand);
+            if (m) {
+                if (cand) l32(kFindQueue + 4u * (nq + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)))) = pos;
+                nq += (uint32_t)__builtin_popcountll(m);
+                __builtin_amdgcn_wave_barrier();
+                if (nq >= 64u) {
+                    found = full_test(64u);
+                    __builtin_amdgcn_wave_barrier();
+                    // the rest of the queue moves to the front
+                    const uint32_t restv = lane < nq - 64u ? l32(kFindQueue + 4u * (64u + lane)) : 0u;
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < nq - 64u) l32(kFindQueue + 4u * lane) = restv;
+                    nq -= 64u;
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        if (found == ~0u && nq) found = full_test(nq);
+    }
+    if (lane == 0) starts[blockIdx.x] = found;
+}
+
+// text offsets of the pieces (one wave per file; <= a few thousand pieces): offs[i] = sum of the lens before i; the sum
+// must be the member's ISIZE
+__global__ __launch_bounds__(64) void piece_offsets_kernel(const RawFile* __restrict__ files, const uint32_t* __restrict__ lens, uint32_t* __restrict__ offs,
+                                                           uint32_t* __restrict__ errors) {
+    const RawFile rf = files[blockIdx.x];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t run = 0;
+    for (uint32_t b0 = 0; b0 < rf.nguess; b0 += 64u) {
+        const uint32_t i = b0 + lane, mine = i < rf.nguess ? lens[rf.piece0 + i] : 0u;
+        uint32_t incl = mine;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+            if ((int)lane >= d) incl += up;
+        }
+        if (i < rf.nguess) offs[rf.piece0 + i] = run + incl - mine;
+        run += (uint32_t)__shfl((int)incl, 63);
+    }
+    if (run != rf.isize && lane == 0) atomicAdd(errors, 1u);
+}
+
+// The windows: what the 32 KiB in front of every piece hold.  One workgroup per file walks its pieces in order with the
+// current window in LDS: the window in front of piece i is stored for the translation below, then the piece's last
+// 32 KiB of symbols -- placeholders looked up in the window -- (and, of a shorter piece, the window's tail in front of
+// them) become the next window.  ~3 us per piece: a chain of a few hundred steps per file, the files side by side.
+__global__ __launch_bounds__(1024) void windows_kernel(const RawFile* __restrict__ files, const uint32_t* __restrict__ lens, const uint32_t* __restrict__ offs) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t win[];   // [2][32768]
+    const RawFile rf = files[blockIdx.x];
+    for (uint32_t t = threadIdx.x; t < 32768u / 4u; t += 1024u) reinterpret_cast<uint32_t*>(win)[t] = 0;
+    __syncthreads();
+    uint32_t cur = 0;
+    for (uint32_t i = 0; i < rf.nguess; ++i) {
+        const uint32_t L = lens[rf.piece0 + i];
+        if (!L) continue;
+        const uint16_t* const s = rf.sym + offs[rf.piece0 + i];
+        uint8_t* const before = rf.windows + (size_t)i * 32768u;
+        const uint8_t* const w = win + cur * 32768u;
+        uint8_t* const nw = win + (cur ^ 1u) * 32768u;
+        for (uint32_t t = threadIdx.x; t < 32768u / 4u; t += 1024u) reinterpret_cast<uint32_t*>(before)[t] = reinterpret_cast<const uint32_t*>(w)[t];
+        for (uint32_t t = threadIdx.x; t < 32768u; t += 1024u) {
+            const int p = (int)L - 32768 + (int)t;
+            uint32_t v;
+            if (p >= 0) {
+                const uint32_t sy = s[p];
+                v = (sy & 0x8000u) ? w[sy & 0x7fffu] : sy;
+            } else v = w[t + L];
+            nw[t] = (uint8_t)v;
+        }
+        __syncthreads();
+        cur ^= 1u;
+    }
+}
+
+// symbols -> text: one workgroup per 64 KiB of a file's text; a placeholder is looked up in the window in front of its piece
+__global__ __launch_bounds__(256) void translate_kernel(const RawFile* __restrict__ files, int nfiles, const uint32_t* __restrict__ chunk0,
+                                                        const uint32_t* __restrict__ lens, const uint32_t* __restrict__ offs) {
+    int f = 0;
+    while (f + 1 < nfiles && blockIdx.x >= chunk0[f + 1]) ++f;
+    const RawFile rf = files[f];
+    const uint32_t c = blockIdx.x - chunk0[f], begin = c * 65536u, end = begin + 65536u < rf.isize ? begin + 65536u : rf.isize;
+    if (begin >= rf.isize) return;
+    // the piece that holds `begin`: the last one with offs <= begin and a text of its own (binary search, then a few steps)
+    uint32_t lo = 0, hi = rf.nguess;
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) / 2u;
+        if (offs[rf.piece0 + mid] <= begin) lo = mid;
+        else hi = mid;
+    }
+    uint32_t pi = lo;
+    for (uint32_t p = begin + threadIdx.x; p < end; p += 256u) {
+        while (pi + 1u < rf.nguess && (lens[rf.piece0 + pi] == 0u || p >= offs[rf.piece0 + pi] + lens[rf.piece0 + pi])) ++pi;
+        const uint32_t sy = rf.sym[p];
+        rf.text[p] = (uint8_t)((sy & 0x8000u) ? rf.windows[(size_t)pi * 32768u + (sy & 0x7fffu)] : sy);
+    }
+}
+
+// CRC-32 of every 64 KiB of the texts (one wave each): the host combines them (zlib's crc32_combine) and compares with the trailer's
+__global__ __launch_bounds__(64) void chunk_crc_kernel(const RawFile* __restrict__ files, int nfiles, const uint32_t* __restrict__ chunk0, uint32_t* __restrict__ crcs) {
+    int f = 0;
+    while (f + 1 < nfiles && blockIdx.x >= uni(chunk0[f + 1])) ++f;
+    const RawFile rf = files[f];
+    const uint32_t c = blockIdx.x - uni(chunk0[f]), begin = c * 65536u;
+    if (begin >= rf.isize) return;
+    const uint32_t n = rf.isize - begin < 65536u ? rf.isize - begin : 65536u;
+    const uint32_t crc = text_crc(rf.text + begin, n);
+    if ((threadIdx.x & 63u) == 0u) crcs[blockIdx.x] = crc;
+}
+
 size_t inflate_lds_bytes() { return kInflateLds; }
 
-void launch_inflate_bgzf(const InflateJob* jobs_dev, int njobs, uint32_t* errors_dev, hipStream_t st) {
-    if (njobs <= 0) return;
-    static std::atomic<unsigned long long> done{0};   // one bit per device: the attribute is per device
+static void inflate_attributes() {
+    static std::atomic<unsigned long long> done{0};   // one bit per device: the attributes are per device
     int dev = 0;
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
-    if (!(done.load(std::memory_order_relaxed) & bit)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(inflate_bgzf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLds) != hipSuccess)
-            (void)hipGetLastError();
-        done.fetch_or(bit, std::memory_order_relaxed);
+    if (done.load(std::memory_order_relaxed) & bit) return;
+    for (const void* k : {reinterpret_cast<const void*>(inflate_kernel<0>), reinterpret_cast<const void*>(inflate_kernel<1>), reinterpret_cast<const void*>(inflate_kernel<2>),
+                          reinterpret_cast<const void*>(find_starts_kernel), reinterpret_cast<const void*>(chunk_crc_kernel)})
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLds) != hipSuccess) (void)hipGetLastError();
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(windows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess) (void)hipGetLastError();
+    done.fetch_or(bit, std::memory_order_relaxed);
+}
+
+void launch_inflate_bgzf(const InflateJob* jobs_dev, int njobs, uint32_t* errors_dev, hipStream_t st) {
+    if (njobs <= 0) return;
+    inflate_attributes();
+    hipLaunchKernelGGL(inflate_kernel<0>, dim3((unsigned)njobs), dim3(64), kInflateLds, st, jobs_dev, nullptr, 0, nullptr, nullptr, nullptr, errors_dev);
+}
+
+// Single-member gzip files on the device: block starts -> piece lengths -> offsets -> symbols -> windows -> text -> CRCs.
+// npieces = sum of the files' nguess; nchunks = sum of their 64 KiB text chunks (chunk0_dev: first chunk of each file, nfiles + 1 entries).
+void launch_gunzip_members(const RawFile* files_dev, int nfiles, int npieces, int nchunks, uint32_t* starts_dev, uint32_t* lens_dev, uint32_t* offs_dev,
+                           const uint32_t* chunk0_dev, uint32_t* crcs_dev, uint32_t* errors_dev, hipStream_t st) {
+    if (nfiles <= 0 || npieces <= 0) return;
+    inflate_attributes();
+    hipLaunchKernelGGL(find_starts_kernel, dim3((unsigned)npieces), dim3(64), kInflateLds, st, files_dev, nfiles, starts_dev);
+    hipLaunchKernelGGL(inflate_kernel<1>, dim3((unsigned)npieces), dim3(64), kInflateLds, st, nullptr, files_dev, nfiles, starts_dev, lens_dev, nullptr, errors_dev);
+    hipLaunchKernelGGL(piece_offsets_kernel, dim3((unsigned)nfiles), dim3(64), 0, st, files_dev, lens_dev, offs_dev, errors_dev);
+    hipLaunchKernelGGL(inflate_kernel<2>, dim3((unsigned)npieces), dim3(64), kInflateLds, st, nullptr, files_dev, nfiles, starts_dev, lens_dev, offs_dev, errors_dev);
+    hipLaunchKernelGGL(windows_kernel, dim3((unsigned)nfiles), dim3(1024), 65536, st, files_dev, lens_dev, offs_dev);
+    if (nchunks > 0) {
+        hipLaunchKernelGGL(translate_kernel, dim3((unsigned)nchunks), dim3(256), 0, st, files_dev, nfiles, chunk0_dev, lens_dev, offs_dev);
+        hipLaunchKernelGGL(chunk_crc_kernel, dim3((unsigned)nchunks), dim3(64), kInflateLds, st, files_dev, nfiles, chunk0_dev, crcs_dev);
     }
-    hipLaunchKernelGGL(inflate_bgzf_kernel, dim3((unsigned)njobs), dim3(64), kInflateLds, st, jobs_dev, errors_dev);
 }
 
 }  // namespace dd

@@ -226,7 +226,22 @@ struct InflateJob {
     uint32_t out_len;           // its ISIZE (<= 65536)
     uint8_t* out;               // where its text goes
 };
+// one single-member gzip file of a batch, inflated on the device in pieces (dd_ginflate.hip: launch_gunzip_members)
+struct RawFile {
+    const uint8_t* in;          // the whole file on the device, 256-byte aligned
+    uint32_t in_len;
+    uint32_t first_bit;         // where its deflate data starts (behind the gzip header)
+    uint32_t guess_bits;        // the block-start finder looks at one range of this many bits per piece
+    uint32_t nguess;            // ranges = entries of this file in starts / lens / offs
+    uint32_t piece0;            // its first entry there
+    uint32_t isize;             // bytes of text (the member's ISIZE)
+    uint16_t* sym;              // [isize] symbols: a byte, or 0x8000 | position in the 32 KiB in front of the piece
+    uint8_t* windows;           // [nguess][32768]: those 32 KiB, per piece
+    uint8_t* text;              // [isize] where the text goes
+};
 size_t inflate_lds_bytes();
+void launch_gunzip_members(const RawFile* files_dev, int nfiles, int npieces, int nchunks, uint32_t* starts_dev, uint32_t* lens_dev, uint32_t* offs_dev,
+                           const uint32_t* chunk0_dev, uint32_t* crcs_dev, uint32_t* errors_dev, hipStream_t st);
 // *errors_dev += blocks that did not decode (the caller falls back to the host decoder)
 void launch_inflate_bgzf(const InflateJob* jobs_dev, int njobs, uint32_t* errors_dev, hipStream_t st);
 
