@@ -259,6 +259,81 @@ __device__ __noinline__ uint32_t text_crc(const uint8_t* text, uint32_t n) {
 
 }  // namespace
 
+// The header of a dynamic-Huffman block (the reader stands behind BTYPE): code-length code, the two trees' code lengths,
+// both symbol tables into LDS.  Wave-uniform; false: not a valid header.
+DD_D bool dynamic_tables(WBits& b) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t hlit = b.take(5) + 257u, hdist = b.take(5) + 1u, hclen = b.take(4) + 4u;
+    if (hlit > 286u || hdist > 30u) return false;
+    // the code-length code: 19 lengths of 3 bits, a 7-bit table
+    if (lane < 19u) g_lds[kLens + lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = 0; i < hclen; ++i) {
+        const uint32_t v = b.take(3);
+        if (lane == 0) g_lds[kLens + c_cl_order[i]] = (uint8_t)v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+        int left = 1;
+        uint32_t mine = 0;   // lane l: how many of the 19 have length l, then its next code
+        if (lane < 8u)
+            for (int i = 0; i < 19; ++i) mine += ((uint32_t)g_lds[kLens + i] == lane) ? 1u : 0u;
+        const uint32_t zeros = lane_value(mine, 0);
+        uint32_t c = 0, my_code = 0;
+        for (uint32_t l = 1; l <= 7u; ++l) {
+            const uint32_t cl = lane_value(mine, l);
+            left = (left << 1) - (int)cl;
+            if (lane == l) my_code = c;
+            c = (c + cl) << 1;
+        }
+        if (left != 0 && !(zeros == 18u && left > 0)) return false;   // (one code of one bit is tolerated, as zlib does)
+        for (uint32_t i = lane; i < 128u; i += 64u) l16(kClInfo + 2u * i) = 0;
+        __builtin_amdgcn_wave_barrier();
+        for (int i = 0; i < 19; ++i) {
+            const uint32_t l = uni((uint32_t)g_lds[kLens + i]);
+            if (!l) continue;
+            const uint32_t cd = lane_value(my_code, l);
+            if (lane == l) ++my_code;
+            const uint32_t rev = __builtin_bitreverse32(cd) >> (32u - l);
+            for (uint32_t f = rev + (lane << l); f < 128u; f += 64u << l) l16(kClInfo + 2u * f) = (uint16_t)(l | ((uint32_t)i << 4));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // the literal/length and distance code lengths, run-length coded
+    uint32_t i = 0, prev = 0;
+    while (i < hlit + hdist) {
+        b.need();
+        const uint32_t e = uni(l16(kClInfo + 2u * b.peek(7)));
+        if (!e) return false;
+        b.drop((int)(e & 15u));
+        const uint32_t s = e >> 4;
+        uint32_t rep = 1, val = s;
+        if (s == 16u) {
+            if (!i) return false;
+            val = prev;
+            rep = 3u + b.take(2);
+        } else if (s == 17u) {
+            val = 0;
+            rep = 3u + b.take(3);
+        } else if (s == 18u) {
+            val = 0;
+            rep = 11u + b.take(7);
+        }
+        if (i + rep > hlit + hdist) return false;
+        // (lengths of the two trees go to their own places: literal/length at 0.., distance at 288..)
+        for (uint32_t r = lane; r < rep; r += 64u) {
+            const uint32_t sym = i + r;
+            g_lds[kLens + (sym < hlit ? sym : 288u + (sym - hlit))] = (uint8_t)val;
+        }
+        i += rep;
+        prev = val;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (uni((uint32_t)g_lds[kLens + 256u]) == 0u) return false;   // no end-of-block code
+    if (!uni(build_table(0, (int)hlit, 0, kLitInfo, kLitCount, kLitSymbol)) || !uni(build_table(288, (int)hdist, 1, kDistInfo, kDistCount, kDistSymbol))) return false;
+    return true;
+}
+
 // the piece a wave of the raw-deflate modes works on: entry `idx` of the batch's piece table
 struct PieceRef {
     int file;
@@ -389,75 +464,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
                     // empty; with 30 the code is incomplete and every fixed block was refused: DD_INFLATE_STRICT found it)
                     if (!uni(build_table(0, 288, 0, kLitInfo, kLitCount, kLitSymbol)) || !uni(build_table(288, 32, 1, kDistInfo, kDistCount, kDistSymbol))) { ok = false; break; }
                 } else {
-                    const uint32_t hlit = b.take(5) + 257u, hdist = b.take(5) + 1u, hclen = b.take(4) + 4u;
-                    if (hlit > 286u || hdist > 30u) { ok = false; break; }
-                    // the code-length code: 19 lengths of 3 bits, a 7-bit table
-                    if (lane < 19u) g_lds[kLens + lane] = 0;
-                    __builtin_amdgcn_wave_barrier();
-                    for (uint32_t i = 0; i < hclen; ++i) {
-                        const uint32_t v = b.take(3);
-                        if (lane == 0) g_lds[kLens + c_cl_order[i]] = (uint8_t)v;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    {
-                        int left = 1;
-                        uint32_t mine = 0;   // lane l: how many of the 19 have length l, then its next code
-                        if (lane < 8u)
-                            for (int i = 0; i < 19; ++i) mine += ((uint32_t)g_lds[kLens + i] == lane) ? 1u : 0u;
-                        const uint32_t zeros = lane_value(mine, 0);
-                        uint32_t c = 0, my_code = 0;
-                        for (uint32_t l = 1; l <= 7u; ++l) {
-                            const uint32_t cl = lane_value(mine, l);
-                            left = (left << 1) - (int)cl;
-                            if (lane == l) my_code = c;
-                            c = (c + cl) << 1;
-                        }
-                        if (left != 0 && !(zeros == 18u && left > 0)) { ok = false; break; }   // (one code of one bit is tolerated, as zlib does)
-                        for (uint32_t i = lane; i < 128u; i += 64u) l16(kClInfo + 2u * i) = 0;
-                        __builtin_amdgcn_wave_barrier();
-                        for (int i = 0; i < 19; ++i) {
-                            const uint32_t l = uni((uint32_t)g_lds[kLens + i]);
-                            if (!l) continue;
-                            const uint32_t cd = lane_value(my_code, l);
-                            if (lane == l) ++my_code;
-                            const uint32_t rev = __builtin_bitreverse32(cd) >> (32u - l);
-                            for (uint32_t f = rev + (lane << l); f < 128u; f += 64u << l) l16(kClInfo + 2u * f) = (uint16_t)(l | ((uint32_t)i << 4));
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                    // the literal/length and distance code lengths, run-length coded
-                    uint32_t i = 0, prev = 0;
-                    while (i < hlit + hdist) {
-                        b.need();
-                        const uint32_t e = uni(l16(kClInfo + 2u * b.peek(7)));
-                        if (!e) { ok = false; break; }
-                        b.drop((int)(e & 15u));
-                        const uint32_t s = e >> 4;
-                        uint32_t rep = 1, val = s;
-                        if (s == 16u) {
-                            if (!i) { ok = false; break; }
-                            val = prev;
-                            rep = 3u + b.take(2);
-                        } else if (s == 17u) {
-                            val = 0;
-                            rep = 3u + b.take(3);
-                        } else if (s == 18u) {
-                            val = 0;
-                            rep = 11u + b.take(7);
-                        }
-                        if (i + rep > hlit + hdist) { ok = false; break; }
-                        // (lengths of the two trees go to their own places: literal/length at 0.., distance at 288..)
-                        for (uint32_t r = lane; r < rep; r += 64u) {
-                            const uint32_t sym = i + r;
-                            g_lds[kLens + (sym < hlit ? sym : 288u + (sym - hlit))] = (uint8_t)val;
-                        }
-                        i += rep;
-                        prev = val;
-                    }
-                    if (!ok) break;
-                    __builtin_amdgcn_wave_barrier();
-                    if (uni((uint32_t)g_lds[kLens + 256u]) == 0u) { ok = false; break; }   // no end-of-block code
-                    if (!uni(build_table(0, (int)hlit, 0, kLitInfo, kLitCount, kLitSymbol)) || !uni(build_table(288, (int)hdist, 1, kDistInfo, kDistCount, kDistSymbol))) { ok = false; break; }
+                    if (!dynamic_tables(b)) { ok = false; break; }
                 }
                 // THE BLOCK'S SYMBOLS, a window of 64 bit positions at a time.
                 // A wave issues one instruction in ~4-8 cycles and the waves of a CU share ONE scalar issue slot: a launch
@@ -673,7 +680,8 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
 // with an end-of-block code, the distance code complete or a single code.  What passes that is a block start or a
 // one-in-10^9 impostor; an impostor makes a piece end somewhere else than the next one starts and the call goes to the
 // host decoder.  Stored and fixed blocks are not looked for (they are decoded as parts of pieces).
-constexpr uint32_t kFindQueue = kLitSymbol;         // u32[128]: candidate bit positions waiting for the full test (behind the tables)
+constexpr uint32_t kFindQueue = kInflateLds;        // u32[128]: candidate bit positions waiting for the full test (behind everything a header parse writes)
+constexpr uint32_t kFindLds = kInflateLds + 512u;
 constexpr uint32_t kFindTable = kLitInfo;           // u8[64][128]: every lane's code-length code (7-bit lookup): the place of both symbol tables
 constexpr uint8_t k_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};   // (c_cl_order, for unrolled loops)
 
@@ -797,8 +805,53 @@ __global__ __launch_bounds__(64) void find_starts_kernel(const RawFile* __restri
                 }
             }
             const bool pass = live && eob != 0u && kraft_ll == (1u << 15) && (kraft_d == (1u << 15) || nz_d <= 1u) && hlit <= 286u && hdist <= 30u;
-            const unsigned long long m = __ballot(pass);
-            return m ? (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)__builtin_ctzll(m)) : ~0u;
+            // What passes is a block start or, once in ~10^9 positions, an impostor (8 x 50 Mbp of gzip -6 held one).  The
+            // last word has a trial decoding, wave-uniform, with the decoder's own tables: the header parsed again, then
+            // the first symbols -- every code valid, every literal a byte of text (9 .. 126: FASTA has no others).
+            unsigned long long m = __ballot(pass);
+            while (m) {
+                const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)__builtin_ctzll(m));
+                m &= m - 1ull;
+                WBits v;
+                v.w = W, v.nwords = nwords;
+                v.start_at(c0 >> 5, c0 & 31u);
+                (void)v.take(3);
+                bool good = dynamic_tables(v);
+                for (int k = 0; good && k < 24; ++k) {
+                    v.need();
+                    const uint32_t li = uni(l32(kLitInfo + 4u * v.peek(FAST)));
+                    uint32_t kind, ex;
+                    if (li) {
+                        v.drop((int)(li & 15u));
+                        kind = (li >> 4) & 7u, ex = (li >> 7) & 15u;
+                        if (kind == 1u && ((li >> 11) < 9u || (li >> 11) > 126u)) good = false;
+                    } else {
+                        const uint32_t r = uni(decode_slow(v.buf, kLitCount, kLitSymbol));
+                        const uint32_t sy = r >> 4;
+                        if (r == ~0u || sy > 285u) { good = false; break; }
+                        v.drop((int)(r & 15u));
+                        kind = sy < 256u ? 1u : (sy == 256u ? 2u : 3u);
+                        ex = sy > 256u ? uni((uint32_t)c_len_extra[sy - 257u]) : 0u;
+                        if (kind == 1u && (sy < 9u || sy > 126u)) good = false;
+                    }
+                    if (kind == 2u) break;
+                    if (kind == 3u) {
+                        v.drop((int)ex);
+                        v.need();
+                        const uint32_t di = uni(l32(kDistInfo + 4u * v.peek(FAST)));
+                        if (di) v.drop((int)((di & 15u) + ((di >> 7) & 15u)));
+                        else {
+                            const uint32_t r = uni(decode_slow(v.buf, kDistCount, kDistSymbol));
+                            if (r == ~0u || (r >> 4) > 29u) { good = false; break; }
+                            v.drop((int)(r & 15u));
+                            v.need();
+                            v.drop((int)uni((uint32_t)c_dist_extra[r >> 4]));
+                        }
+                    } else if (kind != 1u) good = false;
+                }
+                if (good) return c0;
+            }
+            return ~0u;
         };
         uint32_t nq = 0;
         for (uint32_t base = lo; base < hi && found == ~0u; base += 64u) {
@@ -943,7 +996,7 @@ static void inflate_attributes() {
     if (done.load(std::memory_order_relaxed) & bit) return;
     for (const void* k : {reinterpret_cast<const void*>(inflate_kernel<0>), reinterpret_cast<const void*>(inflate_kernel<1>), reinterpret_cast<const void*>(inflate_kernel<2>),
                           reinterpret_cast<const void*>(find_starts_kernel), reinterpret_cast<const void*>(chunk_crc_kernel)})
-        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kInflateLds) != hipSuccess) (void)hipGetLastError();
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFindLds) != hipSuccess) (void)hipGetLastError();
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(windows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess) (void)hipGetLastError();
     done.fetch_or(bit, std::memory_order_relaxed);
 }
@@ -960,7 +1013,7 @@ void launch_gunzip_members(const RawFile* files_dev, int nfiles, int npieces, in
                            const uint32_t* chunk0_dev, uint32_t* crcs_dev, uint32_t* errors_dev, hipStream_t st) {
     if (nfiles <= 0 || npieces <= 0) return;
     inflate_attributes();
-    hipLaunchKernelGGL(find_starts_kernel, dim3((unsigned)npieces), dim3(64), kInflateLds, st, files_dev, nfiles, starts_dev);
+    hipLaunchKernelGGL(find_starts_kernel, dim3((unsigned)npieces), dim3(64), kFindLds, st, files_dev, nfiles, starts_dev);
     hipLaunchKernelGGL(inflate_kernel<1>, dim3((unsigned)npieces), dim3(64), kInflateLds, st, nullptr, files_dev, nfiles, starts_dev, lens_dev, nullptr, errors_dev);
     hipLaunchKernelGGL(piece_offsets_kernel, dim3((unsigned)nfiles), dim3(64), 0, st, files_dev, lens_dev, offs_dev, errors_dev);
     hipLaunchKernelGGL(inflate_kernel<2>, dim3((unsigned)npieces), dim3(64), kInflateLds, st, nullptr, files_dev, nfiles, starts_dev, lens_dev, offs_dev, errors_dev);
