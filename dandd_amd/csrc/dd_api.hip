@@ -882,6 +882,28 @@ static bool bgzf_for_device(const char* path, FileBuf& fb, std::vector<BgzfBlock
     return true;
 }
 
+// CRC-32 of a concatenation from the CRCs of its parts (zlib's crc32_combine; this image's zlib 1.2.11 has no
+// crc32_combine_gen, and its crc32_combine squares a 32 x 32 matrix per call: ~3 us x 7 700 chunks held a batch back 20 ms).
+// Reflected polynomial arithmetic as in zlib >= 1.2.12: a(x) b(x) mod P, P = 0xedb88320, bit 31 = x^0.
+static uint32_t crc_multmodp(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (uint32_t m = 0x80000000u;; m >>= 1) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1u)) == 0u) break;
+        }
+        b = (b >> 1) ^ ((b & 1u) ? 0xedb88320u : 0u);
+    }
+    return p;
+}
+static uint32_t crc_x8n(uint32_t nbytes) {   // x^(8 nbytes) mod P
+    uint32_t p = 0x80000000u, sq = 0x40000000u;   // x^0, x^1
+    for (int i = 0; i < 3; ++i) sq = crc_multmodp(sq, sq);   // x^8
+    for (; nbytes; nbytes >>= 1, sq = crc_multmodp(sq, sq))
+        if (nbytes & 1u) p = crc_multmodp(sq, p);
+    return p;
+}
+
 // One single-member gzip file for the device path (dd_ginflate.hip: launch_gunzip_members): the raw bytes into `fb`, where
 // the deflate data starts, the trailer's CRC-32 and ISIZE.  false: not a file that path takes (small, huge, not gzip,
 // FASTQ): the host decoder reads it.  (Whether the file is ONE member only the decoding shows: the device refuses a
@@ -1169,12 +1191,13 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
         if (arrived && !refused) {
             const uint32_t* crcs = static_cast<const uint32_t*>(c->pipe_crc_host[set].p);
             for (const InFlight::Member& m : f.members) {
-                uLong crc = 0;
+                uint32_t crc = 0;
+                const uint32_t full = crc_x8n(65536u);
                 for (uint32_t k = 0; k < m.nchunks; ++k) {
                     const uint32_t len = std::min<uint32_t>(65536u, m.isize - k * 65536u);
-                    crc = k ? crc32_combine(crc, crcs[m.chunk0 + k], (z_off_t)len) : crcs[m.chunk0];
+                    crc = k ? (crc_multmodp(len == 65536u ? full : crc_x8n(len), crc) ^ crcs[m.chunk0 + k]) : crcs[m.chunk0];
                 }
-                if ((uint32_t)crc != m.crc) {
+                if (crc != m.crc) {
                     refused = true;
                     *static_cast<uint32_t*>(c->pipe_err_host[set].p) = 1;
                 }

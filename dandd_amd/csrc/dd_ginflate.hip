@@ -522,13 +522,14 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
                     if (outacc) {
                         if (at + outacc > out_len) { ok = false; break; }
                         // the symbols' lanes say where their bytes come from; the batch's lanes find their symbol by counting
-                        if ((mark >> lane) & 1ull) {
+                        // (the counting pass of the raw mode needs none of it)
+                        if (MODE != 1 && ((mark >> lane) & 1ull)) {
                             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mark >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mark, 0u));
                             const uint32_t src = kd == 1u ? (kLit | v1) : bstart + osv - dv;   // (RAW: may wrap below zero = in front of the piece)
                             *reinterpret_cast<uint2*>(g_lds + kLens + 8u * rank) = make_uint2(src, osv);
                         }
                         __builtin_amdgcn_wave_barrier();
-                        if (lane - used < outacc) {
+                        if (MODE != 1 && lane - used < outacc) {
                             const uint32_t ord = __builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts, 0u)) +
                                                  (uint32_t)((starts >> lane) & 1ull) - 1u;
                             const uint2 sy = *reinterpret_cast<const uint2*>(g_lds + kLens + 8u * ord);
@@ -605,7 +606,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
                                     const uint32_t space = 64u - used, left = len - done;
                                     const uint32_t take = left < space ? left : space;
                                     const uint32_t o = done + lane - used;   // this lane's offset inside the match (if it is one of the `take`)
-                                    if (lane - used < take) from = pat + src_of(o);
+                                    if (MODE != 1 && lane - used < take) from = pat + src_of(o);
                                     used += take;
                                     done += take;
                                     if (used == 64u) flush();
@@ -928,26 +929,46 @@ __global__ __launch_bounds__(1024) void windows_kernel(const RawFile* __restrict
     const RawFile rf = files[blockIdx.x];
     for (uint32_t t = threadIdx.x; t < 32768u / 4u; t += 1024u) reinterpret_cast<uint32_t*>(win)[t] = 0;
     __syncthreads();
-    uint32_t cur = 0;
-    for (uint32_t i = 0; i < rf.nguess; ++i) {
+    // A step's symbols are asked for a step ahead: the chain then waits for LDS and a barrier per piece, not for HBM
+    // (17 us per piece when every step loaded its own: 8.5 ms for the 500 pieces of a 50 Mbp file).  A thread owns the
+    // window positions t, t + 1024, ..: a wave's loads are 128 contiguous bytes (32 consecutive positions per thread made
+    // every wave-load touch 64 cache lines: 20 us per piece).
+    auto next_piece = [&](uint32_t i) {   // first piece with text at or behind i
+        while (i < rf.nguess && lens[rf.piece0 + i] == 0u) ++i;
+        return i;
+    };
+    const uint32_t t0 = threadIdx.x;
+    uint16_t cur_s[32], nxt_s[32];
+    auto fetch = [&](uint32_t i, uint16_t (&dst)[32]) {
+        if (i >= rf.nguess) return;
         const uint32_t L = lens[rf.piece0 + i];
-        if (!L) continue;
         const uint16_t* const s = rf.sym + offs[rf.piece0 + i];
+        const int p0 = (int)L - 32768 + (int)t0;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) dst[q] = (p0 + 1024 * q >= 0) ? s[p0 + 1024 * q] : (uint16_t)0;
+    };
+    uint32_t i = next_piece(0), cur = 0;
+    fetch(i, cur_s);
+    while (i < rf.nguess) {
+        const uint32_t L = lens[rf.piece0 + i], inext = next_piece(i + 1u);
+        fetch(inext, nxt_s);
         uint8_t* const before = rf.windows + (size_t)i * 32768u;
         const uint8_t* const w = win + cur * 32768u;
         uint8_t* const nw = win + (cur ^ 1u) * 32768u;
-        for (uint32_t t = threadIdx.x; t < 32768u / 4u; t += 1024u) reinterpret_cast<uint32_t*>(before)[t] = reinterpret_cast<const uint32_t*>(w)[t];
-        for (uint32_t t = threadIdx.x; t < 32768u; t += 1024u) {
-            const int p = (int)L - 32768 + (int)t;
-            uint32_t v;
-            if (p >= 0) {
-                const uint32_t sy = s[p];
-                v = (sy & 0x8000u) ? w[sy & 0x7fffu] : sy;
-            } else v = w[t + L];
-            nw[t] = (uint8_t)v;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) reinterpret_cast<uint32_t*>(before)[t0 + 1024u * q] = reinterpret_cast<const uint32_t*>(w)[t0 + 1024u * q];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const uint32_t pos = t0 + 1024u * q;
+            const int p = (int)L - 32768 + (int)pos;
+            const uint32_t sy = cur_s[q];
+            nw[pos] = (uint8_t)(p >= 0 ? ((sy & 0x8000u) ? (uint32_t)w[sy & 0x7fffu] : sy) : (uint32_t)w[pos + L]);
         }
         __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 32; ++q) cur_s[q] = nxt_s[q];
         cur ^= 1u;
+        i = inext;
     }
 }
 
