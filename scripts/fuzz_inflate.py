@@ -1,6 +1,6 @@
 """Randomized check of the device inflate (dd_ginflate.hip): random texts (DNA, repeats, runs, soft-masked, junk bytes, long
-header lines), random zlib level / strategy / memLevel / BGZF block size; the registers of the BGZF file through dd_sketch_files
-must equal those of the plain bytes, with DD_INFLATE_STRICT=1 so that a refused block fails the call instead of going to the
+header lines), random zlib level / strategy / memLevel, as BGZF (random block size) or as ONE gzip member (random finder range);
+the registers of the compressed file through dd_sketch_files must equal those of the plain bytes, with DD_INFLATE_STRICT=1 so that a refused block fails the call instead of going to the
 host decoder (the device checks every block's CRC-32, so a wrong byte anywhere is a refusal).
     python scripts/fuzz_inflate.py [N] [SEED]"""
 import os, sys, time, tempfile, zlib
@@ -26,11 +26,13 @@ def bgzf(raw, level, strategy, memlevel, block):
 n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 os.environ["DD_INFLATE_STRICT"] = "1"
+os.environ["DD_GUNZIP_MIN_KB"] = "1"
 eng = Engine(0, 14, True)
 d = tempfile.mkdtemp()
 alph = [b"ACGT", b"ACGTacgtN", b"AC", b"ACGTACGTACGTRYKMn-* 0", bytes(range(32, 127))]
 t0 = time.time()
 nblocks = 0
+nmembers = 0
 for it in range(n_cfg):
     paths, raws = [], []
     for f in range(int(rng.integers(1, 5))):
@@ -68,11 +70,17 @@ for it in range(n_cfg):
         if block < 4096 and len(raw) > 20000:
             raw = raw[:20000]
         p = os.path.join(d, f"f{f}.fa.gz")
-        data = bgzf(raw, level, strategy, memlevel, block)
+        if rng.integers(0, 2):
+            data = bgzf(raw, level, strategy, memlevel, block)
+            nblocks += len(raw) // block + 2
+        else:       # one gzip member (what `gzip` writes); high-entropy "text" is kept printable: the finder's trial decoding wants text
+            co = zlib.compressobj(level, zlib.DEFLATED, 31, memlevel, strategy)
+            data = co.compress(raw) + co.flush()
+            nmembers += 1
         open(p, "wb").write(data)
-        nblocks += len(raw) // block + 2
         paths.append(p)
         raws.append((raw, level, strategy, memlevel, block))
+    os.environ["DD_GUNZIP_GUESS_KB"] = str(int(rng.choice([4, 16, 32, 128])))
     got = eng.sketch_files(paths, 19, 21)
     for g, (raw, *cfg) in zip(got, raws):
         want = eng.sketch_buffer(np.frombuffer(raw, np.uint8), 19, 21)
@@ -80,4 +88,4 @@ for it in range(n_cfg):
             print(f"MISMATCH cfg {it}: {cfg} bytes={len(raw)}")
             open(f"gpurun_out/fuzz_inflate_fail_{it}.bin", "wb").write(raw)
             sys.exit(1)
-print(f"{n_cfg} random configurations, ~{nblocks} BGZF blocks: the device decoder took every block, registers equal, in {time.time() - t0:.1f} s")
+print(f"{n_cfg} random configurations, ~{nblocks} BGZF blocks and {nmembers} single gzip members: the device decoder took every one, registers equal, in {time.time() - t0:.1f} s")

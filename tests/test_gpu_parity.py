@@ -541,6 +541,108 @@ def test_damaged_bgzf_blocks_are_refused_or_read_like_zlib(orc, torch_cuda, tmp_
     assert outcomes["refused"] >= 12, outcomes
 
 
+def test_single_member_gzip_files_are_inflated_on_the_device(engine_factory, orc, tmp_path, monkeypatch):
+    """What `gzip` writes -- ONE member, deflate blocks of any size with 32 KiB of history across them -- through
+    dd_sketch_files on the device (dd_ginflate.hip: launch_gunzip_members): block starts found by trial, every piece decoded
+    without its history into 16-bit symbols, placeholders resolved along the chain of windows, CRC-32 checked.  Levels 1 / 6 / 9
+    on uniform and repeat-rich text, a header with FNAME, files whose blocks are all stored or all fixed-Huffman (no dynamic
+    block start to find: one piece), Huffman-only and RLE strategies, small and large finder ranges: registers == the sketch of
+    the plain bytes, with DD_INFLATE_STRICT=1 (a refused piece fails the test; nothing goes to the host decoder).  A
+    two-member file and a FASTQ file are not for this path: they come out right through the host decoder."""
+    import gzip
+    import io
+    import zlib
+    eng = engine_factory(14, True)
+    uniform, real = orc.synth_fasta(SEED, 0, 3_000_000, 4).tobytes(), orc.synth_realistic(SEED, 1, 2_500_000).tobytes()
+    lowent = (b">x\n" + b"ACGT" * 20 + b"\n") * 30000 + uniform[:200_000]
+
+    def member(raw, level=6, strategy=0, name=None):
+        if name is not None:
+            buf = io.BytesIO()
+            with gzip.GzipFile(filename=name, mode="wb", fileobj=buf, compresslevel=level, mtime=0) as f:
+                f.write(raw)
+            return buf.getvalue()
+        co = zlib.compressobj(level, zlib.DEFLATED, 31, 8, strategy)
+        return co.compress(raw) + co.flush()
+
+    cases = [("l1", uniform, member(uniform, 1)), ("l6", uniform, member(uniform, 6)), ("l9", real, member(real, 9)),
+             ("named", real[:1_500_000], member(real[:1_500_000], 6, name="genome.fa")), ("stored", uniform[:600_000], member(uniform[:600_000], 0)),
+             ("fixed", uniform[:300_000], member(uniform[:300_000], 6, zlib.Z_FIXED)), ("huff", uniform[:500_000], member(uniform[:500_000], 6, zlib.Z_HUFFMAN_ONLY)),
+             ("rle", real[:500_000], member(real[:500_000], 6, zlib.Z_RLE)), ("lowent", lowent, member(lowent, 9))]
+    paths = []
+    for name, raw, data in cases:
+        (tmp_path / f"{name}.fa.gz").write_bytes(data)
+        paths.append(str(tmp_path / f"{name}.fa.gz"))
+    want = [eng.sketch_buffer(np.frombuffer(raw, np.uint8), 19, 21) for _, raw, _ in cases]
+    monkeypatch.setenv("DD_GUNZIP_MIN_KB", "16")
+    monkeypatch.setenv("DD_INFLATE_STRICT", "1")
+    for guess_kb in ("32", "4", "256"):
+        monkeypatch.setenv("DD_GUNZIP_GUESS_KB", guess_kb)
+        got = eng.sketch_files(paths, 19, 21)
+        for (name, _, _), g, w in zip(cases, got, want):
+            assert np.array_equal(g, w), (name, guess_kb)
+    monkeypatch.delenv("DD_GUNZIP_GUESS_KB")
+    monkeypatch.delenv("DD_INFLATE_STRICT")
+    # not for the device: two members (the device refuses a final block that is not followed by the trailer alone; the call
+    # is run again on the host), FASTQ (seen in the first bytes; never sent)
+    two = member(uniform[:800_000], 6) + member(uniform[800_000:1_500_000], 6)
+    fq = b"".join(b"@r%d\n" % i + uniform[100 + 80 * i:180 + 80 * i].replace(b"\n", b"A").replace(b">", b"A") + b"\n+\n" + b"I" * 80 + b"\n" for i in range(4000))
+    (tmp_path / "two.fa.gz").write_bytes(two)
+    (tmp_path / "reads.fq.gz").write_bytes(member(fq, 6))
+    got = eng.sketch_files([str(tmp_path / "two.fa.gz"), str(tmp_path / "reads.fq.gz")], 19, 21)
+    assert np.array_equal(got[0], eng.sketch_buffer(np.frombuffer(uniform[:1_500_000], np.uint8), 19, 21))
+    assert np.array_equal(got[1], eng.sketch_buffer(np.frombuffer(fq, np.uint8), 19, 21))
+
+
+def test_damaged_single_member_gzip_is_refused_or_read_like_zlib(orc, torch_cuda, tmp_path, monkeypatch):
+    """Bit flips and overwritten bytes in the deflate data, the CRC-32 and the ISIZE of a single-member .gz that takes the
+    device path: the call raises exactly when zlib refuses the file, else gives the registers of zlib's text (the device
+    refuses; the host decoder has the last word)."""
+    import gzip
+    import zlib
+    from dandd_amd.engine import Engine, EngineError
+    monkeypatch.setenv("DD_GUNZIP_MIN_KB", "16")
+    raw = orc.synth_fasta(SEED, 5, 600_000, 2).tobytes()
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    good = co.compress(raw) + co.flush()
+    rng = np.random.default_rng(23)
+    eng = Engine(device=0, log2m=14, canonical=True)
+    outcomes = {"refused": 0, "read": 0}
+    try:
+        for t in range(16):
+            bad = bytearray(good)
+            kind = t % 4
+            if kind == 0:
+                bad[10 + int(rng.integers(len(good) - 18))] ^= 1 << int(rng.integers(8))
+            elif kind == 1:
+                for _ in range(3):
+                    bad[10 + int(rng.integers(len(good) - 18))] = int(rng.integers(256))
+            elif kind == 2:
+                bad[len(good) - 8 + int(rng.integers(4))] ^= 1 << int(rng.integers(8))
+            else:
+                bad[len(good) - 4] ^= 1
+            path = tmp_path / f"bad{t}.fa.gz"
+            path.write_bytes(bytes(bad))
+            try:
+                want = eng.sketch_buffer(np.frombuffer(gzip.decompress(bytes(bad)), dtype=np.uint8), 19, 21)
+            except (OSError, EOFError, zlib.error):
+                want = None
+            try:
+                got = eng.sketch_files([str(path)], 19, 21)[0]
+            except EngineError:
+                got = None
+            assert (got is None) == (want is None), (t, kind)
+            if want is not None:
+                assert np.array_equal(got, want), (t, kind)
+            outcomes["refused" if got is None else "read"] += 1
+            if got is None:
+                eng.close()
+                eng = Engine(device=0, log2m=14, canonical=True)
+    finally:
+        eng.close()
+    assert outcomes["refused"] >= 8, outcomes
+
+
 def test_large_gzip_files_are_inflated_in_parallel(engine_factory, orc, tmp_path, monkeypatch):
     """One big .gz through dd_sketch_fasta / dd_sketch_files: a single gzip member cut at deflate block boundaries and
     decoded piecewise without its history (dd_inflate.h), a BGZF file block by block, a realistic (repeat-rich: long,
