@@ -496,7 +496,7 @@ def ingest_probe(eng, ng, nb, nrec, kmin, kmax, torch, gz=False, reps=10):
         _, wait, batches, nbytes = eng.last_ingest_stats()
         return {"value": ng * nb / med / 1e9, "unit": "Gbp/s", "ms": med * 1e3, "best_value": ng * nb / best / 1e9, "best_ms": best * 1e3,
                 "launches": batches, "fasta_MB": nbytes / 1e6,
-                "what": f"dd_sketch_files: {ng} x {nb/1e6:g} Mbp {'BGZF (bgzip -6; blocks inflated on the GPU, dd_ginflate.hip)' if gz == 'bgzf' else 'gzip -1' if gz else 'plain'} FASTA files in {base or 'the temp dir'} (warm page cache) -> "
+                "what": f"dd_sketch_files: {ng} x {nb/1e6:g} Mbp {'BGZF (bgzip -6; blocks inflated on the GPU, dd_ginflate.hip)' if gz == 'bgzf' else 'gzip -1 (one member per file; inflated on the GPU in pieces, dd_ginflate.hip, unless DD_NO_GPU_GUNZIP)' if gz else 'plain'} FASTA files in {base or 'the temp dir'} (warm page cache) -> "
                         f"pinned host buffers -> H2D on a copy stream overlapped with K0/K1 -> registers back to the host; "
                         f"k {kmin}-{kmax}; `value` = MEDIAN of calls {'4-' + str(reps) if reps > 4 else '2-' + str(reps)} on one context, best beside it "
                         f"(PCIe-inclusive: reported beside the headline `value`, never as it)"}
@@ -765,8 +765,17 @@ def main():
             extras["ingest"] = ingest_probe(eng, ng, nb, cfg["nrec"], kmin, kmax, torch)
             # the cfg 3 shape of the same path: many small files coalesced into a few launches
             extras["ingest"]["small_files"] = ingest_probe(eng, 64, 5_000_000, cfg["nrec"], kmin, kmax, torch)
-            # ... and as most genome directories really are: .gz (host inflate: libdeflate or zlib, one thread per file)
+            # ... and as most genome directories really are: .gz, ONE gzip member per file.  Round 4: inflated on the GPU too
+            # (dd_ginflate.hip: block starts found by trial, pieces decoded without their history, placeholders resolved along a
+            # chain of windows); DD_NO_GPU_GUNZIP=1 beside it = the host decoder (libdeflate or zlib, one thread per file)
             extras["ingest"]["gzip_files"] = ingest_probe(eng, ng, nb, cfg["nrec"], kmin, kmax, torch, gz=True)
+            os.environ["DD_NO_GPU_GUNZIP"] = "1"
+            try:
+                extras["ingest"]["gzip_files"]["host_decoder_value"] = ingest_probe(eng, ng, nb, cfg["nrec"], kmin, kmax, torch, gz=True, reps=5)["value"]
+            except Exception as e:
+                extras["ingest"]["gzip_files"]["host_decoder_value"] = f"{type(e).__name__}: {e}"
+            finally:
+                del os.environ["DD_NO_GPU_GUNZIP"]
             # ... and bgzip'd (htslib's blocked gzip): independent <= 64 KiB members, inflated on the GPU (dd_ginflate.hip) -- the
             # compressed bytes cross PCIe, the host only walks the block sizes; DD_NO_GPU_INFLATE=1 beside it = the host decoder
             try:
@@ -783,12 +792,18 @@ def main():
             # decoder (libdeflate, one thread) beside it
             try:
                 big_nb = max(40_000_000, 8 * nb)     # 400 Mbp for the headline workload
-                big = ingest_probe(eng, 1, big_nb, 24, kmin, kmax, torch, gz=True, reps=4)
-                os.environ["DD_NO_PARALLEL_GZIP"] = "1"
+                big = ingest_probe(eng, 1, big_nb, 24, kmin, kmax, torch, gz=True, reps=4)     # (round 4: on the GPU)
+                os.environ["DD_NO_GPU_GUNZIP"] = "1"
                 try:
-                    ser = ingest_probe(eng, 1, big_nb, 24, kmin, kmax, torch, gz=True, reps=3)
+                    par = ingest_probe(eng, 1, big_nb, 24, kmin, kmax, torch, gz=True, reps=4)  # the host's parallel decoder
+                    os.environ["DD_NO_PARALLEL_GZIP"] = "1"
+                    try:
+                        ser = ingest_probe(eng, 1, big_nb, 24, kmin, kmax, torch, gz=True, reps=3)
+                    finally:
+                        del os.environ["DD_NO_PARALLEL_GZIP"]
                 finally:
-                    del os.environ["DD_NO_PARALLEL_GZIP"]
+                    del os.environ["DD_NO_GPU_GUNZIP"]
+                big["host_parallel_decoder_value"] = par["value"]
                 big["serial_decoder_value"] = ser["value"]
                 big["serial_decoder_ms"] = ser["ms"]
                 extras["ingest"]["one_big_gzip_file"] = big

@@ -1280,6 +1280,8 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
         // (single-member gzip files: the finder looks at one range of `guess_bits` per piece; 32 KiB of compressed data are ~2
         // deflate blocks of gzip -6 DNA, so a third of every range is scanned before its first block start turns up)
         const size_t guess_bits = (size_t)(getenv("DD_GUNZIP_GUESS_KB") ? std::max(4, atoi(getenv("DD_GUNZIP_GUESS_KB"))) : 32) << 13;
+        // a range's symbols: 5 x its compressed bytes (DNA inflates 3-4 x) + 32 Ki; a piece that needs more takes the arena
+        const size_t range_syms = 5 * (guess_bits / 8) + 32768;
         size_t nmem = 0, npieces = 0, nchunks = 0, sym_tot = 0, win_tot = 0;
         for (int j = 0; j < count; ++j) {
             const Slot& sj = slots[i + j];
@@ -1297,14 +1299,14 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
                 ++nmem;
                 npieces += ng;
                 nchunks += (sj.gm.isize + 65535u) / 65536u;
-                sym_tot += align_up((size_t)sj.gm.isize * 2 + 256, 256);
+                sym_tot += align_up(ng * range_syms * 2 + 256, 256) + align_up((size_t)sj.gm.isize * 2 + 256, 256);   // the ranges' symbols, the arena
                 win_tot += ng * 32768;
             }
         }
         // the piece tables of the batch's single-member gzip files, one block of device memory: RawFile[nmem],
-        // starts / lens / offs [npieces], chunk0 [nmem + 1], crcs [nchunks]
+        // starts / lens / offs / over / abase [npieces], chunk0 [nmem + 1], crcs [nchunks]
         const size_t raw_files = align_up(nmem * sizeof(dd::RawFile), 256), raw_u32 = align_up(npieces * 4, 256), raw_chunk0 = align_up((nmem + 1) * 4, 256);
-        const size_t raw_bytes = raw_files + 3 * raw_u32 + raw_chunk0 + align_up(nchunks * 4, 256);
+        const size_t raw_bytes = raw_files + 5 * raw_u32 + raw_chunk0 + align_up(nchunks * 4, 256);
         if (nmem && ((rc = c->pipe_gz[set].reserve(gz_tot + 16)) != DD_OK || (rc = c->pipe_sym[set].reserve(sym_tot)) != DD_OK ||
                      (rc = c->pipe_win[set].reserve(win_tot)) != DD_OK || (rc = c->pipe_raw[set].reserve(raw_bytes)) != DD_OK ||
                      (rc = c->pipe_raw_host[set].reserve(raw_files + raw_chunk0)) != DD_OK || (rc = c->pipe_crc_host[set].reserve(nchunks * 4 + 256)) != DD_OK ||
@@ -1367,13 +1369,15 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
                 rf.piece0 = (uint32_t)piece_at;
                 rf.isize = sj.gm.isize;
                 rf.sym = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(c->pipe_sym[set].p) + sym_at);
+                rf.range_syms = (uint32_t)range_syms;
+                rf.arena = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(c->pipe_sym[set].p) + sym_at + align_up(ng * range_syms * 2 + 256, 256));
                 rf.windows = static_cast<uint8_t*>(c->pipe_win[set].p) + win_at;
                 rf.text = const_cast<uint8_t*>(ptrs[j]);
                 chunk0_host[mi] = (uint32_t)chunk_at;
                 members.push_back(InFlight::Member{(uint32_t)chunk_at, (sj.gm.isize + 65535u) / 65536u, sj.gm.isize, sj.gm.crc});
                 piece_at += ng;
                 chunk_at += (sj.gm.isize + 65535u) / 65536u;
-                sym_at += align_up((size_t)sj.gm.isize * 2 + 256, 256);
+                sym_at += align_up(ng * range_syms * 2 + 256, 256) + align_up((size_t)sj.gm.isize * 2 + 256, 256);
                 win_at += ng * 32768;
                 ++mi;
             } else if (sizes[j]) {
@@ -1386,12 +1390,11 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             chunk0_host[nmem] = (uint32_t)chunk_at;
             uint8_t* rb = static_cast<uint8_t*>(c->pipe_raw[set].p);
             e = hipMemcpyAsync(rb, raw_host, nmem * sizeof(dd::RawFile), hipMemcpyHostToDevice, cs);
-            if (e == hipSuccess) e = hipMemcpyAsync(rb + raw_files + 3 * raw_u32, chunk0_host, (nmem + 1) * 4, hipMemcpyHostToDevice, cs);
+            if (e == hipSuccess) e = hipMemcpyAsync(rb + raw_files + 5 * raw_u32, chunk0_host, (nmem + 1) * 4, hipMemcpyHostToDevice, cs);
             if (e == hipSuccess) {
-                uint32_t* u = reinterpret_cast<uint32_t*>(rb + raw_files);
-                uint32_t* crcs_dev = reinterpret_cast<uint32_t*>(rb + raw_files + 3 * raw_u32 + raw_chunk0);
-                dd::launch_gunzip_members(reinterpret_cast<const dd::RawFile*>(rb), (int)nmem, (int)npieces, (int)nchunks, u, u + raw_u32 / 4, u + 2 * (raw_u32 / 4),
-                                          reinterpret_cast<const uint32_t*>(rb + raw_files + 3 * raw_u32), crcs_dev, static_cast<uint32_t*>(c->pipe_err[set].p), cs);
+                uint32_t* crcs_dev = reinterpret_cast<uint32_t*>(rb + raw_files + 5 * raw_u32 + raw_chunk0);
+                dd::launch_gunzip_members(reinterpret_cast<const dd::RawFile*>(rb), (int)nmem, (int)npieces, (int)nchunks, reinterpret_cast<uint32_t*>(rb + raw_files), raw_u32 / 4,
+                                          reinterpret_cast<const uint32_t*>(rb + raw_files + 5 * raw_u32), crcs_dev, static_cast<uint32_t*>(c->pipe_err[set].p), cs);
                 e = hipGetLastError();
                 if (e == hipSuccess) e = hipMemcpyAsync(c->pipe_crc_host[set].p, crcs_dev, nchunks * 4, hipMemcpyDeviceToHost, cs);
             }

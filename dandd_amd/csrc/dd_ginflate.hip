@@ -338,6 +338,7 @@ DD_D bool dynamic_tables(WBits& b) {
 struct PieceRef {
     int file;
     uint32_t start, end;   // bit positions; end = ~0u: up to the stream's final block
+    uint32_t j, ranges;    // the finder range it starts in, and how many ranges it runs over
 };
 DD_D bool piece_of(const RawFile* files, int nfiles, const uint32_t* starts, uint32_t idx, PieceRef& r) {
     int f = 0;
@@ -346,10 +347,16 @@ DD_D bool piece_of(const RawFile* files, int nfiles, const uint32_t* starts, uin
     r.file = f;
     r.start = uni(starts[idx]);
     r.end = ~0u;
+    r.j = j;
+    r.ranges = ng - j;
     if (j >= ng || r.start == ~0u) return false;
     for (uint32_t k = j + 1; k < ng; ++k) {
         const uint32_t e = uni(starts[idx - j + k]);
-        if (e != ~0u) { r.end = e; break; }
+        if (e != ~0u) {
+            r.end = e;
+            r.ranges = k - j;
+            break;
+        }
     }
     return true;
 }
@@ -358,13 +365,19 @@ DD_D bool piece_of(const RawFile* files, int nfiles, const uint32_t* starts, uin
 // MODE 1 / 2: grid = pieces of single-member gzip files (files / starts): raw deflate data from a block start found by
 // find_starts_kernel up to the next one, decoded WITHOUT its 32 KiB of history -- a copy that reaches in front of the
 // piece yields placeholders 0x8000 | position in that unknown window (pugz's idea; dd_inflate.h does the same on the
-// host).  MODE 1 only counts the piece's text (lens[idx]); MODE 2 writes 16-bit symbols at sym + offs[idx].
+// host).  MODE 3, the one pass nearly every piece needs: 16-bit symbols into the piece's own ranges of the file's symbol
+// area (5 x the compressed bytes + 32 Ki symbols per range: DNA inflates 3-4 x), lens[idx] = its text; a piece that
+// does not fit (runs of N, repeats) is marked in over[idx] instead and gets MODE 1 -- only count its text -- and, once
+// the offsets are known, MODE 2 -- write its symbols into the file's arena at abase[idx].  (Counting EVERY piece first
+// and writing dense symbols second cost two full passes: 21 of the 47 ms of ten 50 Mbp files.)
 // `errors`: blocks / pieces that could not be decoded (the caller falls back to the host).
 template <int MODE>
 __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restrict__ jobs, const RawFile* __restrict__ files, int nfiles,
-                                                     const uint32_t* __restrict__ starts, uint32_t* __restrict__ lens, const uint32_t* __restrict__ offs,
-                                                     uint32_t* __restrict__ errors) {
+                                                     const uint32_t* __restrict__ starts, uint32_t* __restrict__ lens, uint32_t* __restrict__ over,
+                                                     const uint32_t* __restrict__ abase, uint32_t* __restrict__ errors) {
     constexpr bool RAW = MODE != 0;
+    constexpr bool WRITES = MODE == 2 || MODE == 3;   // (16-bit symbols)
+    bool too_long = false;                             // MODE 3: the piece does not fit its ranges
     constexpr uint32_t kLit = RAW ? 0x40000000u : 0x80000000u;   // a batch lane's source: a literal (else an offset in the text; RAW: negative = in front of the piece)
     const uint32_t lane = threadIdx.x & 63u;
     bool ok = true;
@@ -378,13 +391,20 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
         in = job.in, n = job.in_len, out = job.out, out_len = job.out_len;
     } else {
         if (!piece_of(files, nfiles, starts, blockIdx.x, pr)) {
-            if (MODE == 1 && lane == 0) lens[blockIdx.x] = 0;
+            if (MODE == 3 && lane == 0) lens[blockIdx.x] = 0, over[blockIdx.x] = 0;
             return;
         }
+        if (MODE != 3 && uni(over[blockIdx.x]) == 0u) return;   // (the piece fitted its ranges)
         const RawFile rf = files[pr.file];
         in = rf.in, n = rf.in_len, piece_end = pr.end;
-        out_len = MODE == 1 ? rf.isize : uni(lens[blockIdx.x]);
-        if (MODE == 2) sym = rf.sym + uni(offs[blockIdx.x]);
+        if (MODE == 3) {
+            const uint64_t cap = (uint64_t)pr.ranges * rf.range_syms;
+            out_len = cap < rf.isize ? (uint32_t)cap : rf.isize;
+            sym = rf.sym + (size_t)pr.j * rf.range_syms;
+        } else {
+            out_len = MODE == 1 ? rf.isize : uni(lens[blockIdx.x]);
+            if (MODE == 2) sym = rf.arena + uni(abase[blockIdx.x]);
+        }
     }
     uint32_t at = 0;
     // The text goes out 64 bytes at a time: every lane owns one byte of the batch [bstart, bstart + used) and knows where it
@@ -401,7 +421,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane < used && !(from >> 31)) v = gload1_fresh(out + from);
                 if (lane < used) out[bstart + lane] = (uint8_t)v;
-            } else if (MODE == 2) {
+            } else if (WRITES) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane < used) {
                     const int f = (int)from;
@@ -443,7 +463,8 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
             if (btype == 0u) {
                 b.drop(b.cnt & 7);
                 const uint32_t len = b.take(16), nlen = b.take(16);
-                if ((len ^ nlen) != 0xffffu || at + len > out_len) { ok = false; break; }
+                if ((len ^ nlen) != 0xffffu) { ok = false; break; }
+                if (at + len > out_len) { ok = false, too_long = true; break; }
                 // stored bytes: straight from the input (the reader stands on a byte boundary; its word base stays)
                 const uint8_t* const base = reinterpret_cast<const uint8_t*>(b.w);
                 const uint32_t data = b.bit_pos() >> 3;   // byte offset of the data from the reader's base
@@ -451,7 +472,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
                 flush();
                 if (MODE == 0)
                     for (uint32_t i = lane; i < len; i += 64u) out[at + i] = (uint8_t)gload1(base + data + i);
-                if (MODE == 2)
+                if (WRITES)
                     for (uint32_t i = lane; i < len; i += 64u) *(DD_GLOBAL uint16_t*)(sym + at + i) = (uint16_t)gload1(base + data + i);
                 bstart = at + len;
                 at += len;
@@ -520,7 +541,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
                         pks = 1;
                     } while (pos < 64u);
                     if (outacc) {
-                        if (at + outacc > out_len) { ok = false; break; }
+                        if (at + outacc > out_len) { ok = false, too_long = true; break; }
                         // the symbols' lanes say where their bytes come from; the batch's lanes find their symbol by counting
                         // (the counting pass of the raw mode needs none of it)
                         if (MODE != 1 && ((mark >> lane) & 1ull)) {
@@ -566,7 +587,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
                             val = sy < 256u ? sy : (sy > 256u ? uni((uint32_t)c_len_base[sy - 257u]) : 0u);
                         }
                         if (kind == 1u) {
-                            if (at >= out_len) { ok = false; break; }
+                            if (at >= out_len) { ok = false, too_long = true; break; }
                             if (lane == used) from = kLit | val;
                             ++at;
                             if (++used == 64u) flush();
@@ -594,7 +615,8 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
                             }
                             dist += (uint32_t)bits & ((1u << dex) - 1u);
                             pos += dex;
-                            if (dist > at + (RAW ? 32768u : 0u) || at + len > out_len) { ok = false; break; }
+                            if (dist > at + (RAW ? 32768u : 0u)) { ok = false; break; }
+                            if (at + len > out_len) { ok = false, too_long = true; break; }
                             // the copy: its bytes join the batch (several batches when it is long).  It reads the dist-byte pattern
                             // in front of it; should that reach into the batch itself, the batch leaves first.
                             const uint32_t pat = at - dist, pat_end = pat + (dist < len ? dist : len);   // (RAW: both may be "negative")
@@ -646,7 +668,12 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
     if (RAW) {
         if (ok && final_seen != (piece_end == ~0u)) ok = false;
         if (ok && final_seen && b.bytes_used(in) + 8u != n) ok = false;   // ONE member: CRC-32 and ISIZE right behind the final block
-        if (MODE == 1 && lane == 0) lens[blockIdx.x] = ok ? at : 0u;
+        if (MODE == 3 && !ok && too_long && out_len < files[pr.file].isize) {   // not an error: the piece is counted, then written to the arena
+            if (lane == 0) lens[blockIdx.x] = 0, over[blockIdx.x] = 1;
+            return;
+        }
+        if (MODE == 3 && lane == 0) over[blockIdx.x] = 0;
+        if ((MODE == 1 || MODE == 3) && lane == 0) lens[blockIdx.x] = ok ? at : 0u;
         if (MODE == 2 && ok && at != out_len) ok = false;
         if (!ok && lane == 0) atomicAdd(errors, 1u);
         return;
@@ -902,29 +929,37 @@ __global__ __launch_bounds__(64) void find_starts_kernel(const RawFile* __restri
 
 // text offsets of the pieces (one wave per file; <= a few thousand pieces): offs[i] = sum of the lens before i; the sum
 // must be the member's ISIZE
-__global__ __launch_bounds__(64) void piece_offsets_kernel(const RawFile* __restrict__ files, const uint32_t* __restrict__ lens, uint32_t* __restrict__ offs,
-                                                           uint32_t* __restrict__ errors) {
+// ... and abase[i] = the same sum over the pieces that go to the arena
+__global__ __launch_bounds__(64) void piece_offsets_kernel(const RawFile* __restrict__ files, const uint32_t* __restrict__ lens, const uint32_t* __restrict__ over,
+                                                           uint32_t* __restrict__ offs, uint32_t* __restrict__ abase, uint32_t* __restrict__ errors) {
     const RawFile rf = files[blockIdx.x];
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t run = 0;
+    uint32_t run = 0, arun = 0;
     for (uint32_t b0 = 0; b0 < rf.nguess; b0 += 64u) {
-        const uint32_t i = b0 + lane, mine = i < rf.nguess ? lens[rf.piece0 + i] : 0u;
-        uint32_t incl = mine;
+        const uint32_t i = b0 + lane, mine = i < rf.nguess ? lens[rf.piece0 + i] : 0u, amine = (i < rf.nguess && over[rf.piece0 + i]) ? mine : 0u;
+        uint32_t incl = mine, aincl = amine;
         for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
-            if ((int)lane >= d) incl += up;
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d), aup = (uint32_t)__shfl_up((int)aincl, d);
+            if ((int)lane >= d) incl += up, aincl += aup;
         }
-        if (i < rf.nguess) offs[rf.piece0 + i] = run + incl - mine;
+        if (i < rf.nguess) offs[rf.piece0 + i] = run + incl - mine, abase[rf.piece0 + i] = arun + aincl - amine;
         run += (uint32_t)__shfl((int)incl, 63);
+        arun += (uint32_t)__shfl((int)aincl, 63);
     }
     if (run != rf.isize && lane == 0) atomicAdd(errors, 1u);
+}
+
+// where a piece's symbols are: its ranges of the symbol area, or the arena
+DD_D const uint16_t* piece_symbols(const RawFile& rf, uint32_t i, const uint32_t* over, const uint32_t* abase) {
+    return over[rf.piece0 + i] ? rf.arena + abase[rf.piece0 + i] : rf.sym + (size_t)i * rf.range_syms;
 }
 
 // The windows: what the 32 KiB in front of every piece hold.  One workgroup per file walks its pieces in order with the
 // current window in LDS: the window in front of piece i is stored for the translation below, then the piece's last
 // 32 KiB of symbols -- placeholders looked up in the window -- (and, of a shorter piece, the window's tail in front of
 // them) become the next window.  ~3 us per piece: a chain of a few hundred steps per file, the files side by side.
-__global__ __launch_bounds__(1024) void windows_kernel(const RawFile* __restrict__ files, const uint32_t* __restrict__ lens, const uint32_t* __restrict__ offs) {
+__global__ __launch_bounds__(1024) void windows_kernel(const RawFile* __restrict__ files, const uint32_t* __restrict__ lens, const uint32_t* __restrict__ over,
+                                                       const uint32_t* __restrict__ abase) {
     extern __shared__ __attribute__((aligned(16))) uint8_t win[];   // [2][32768]
     const RawFile rf = files[blockIdx.x];
     for (uint32_t t = threadIdx.x; t < 32768u / 4u; t += 1024u) reinterpret_cast<uint32_t*>(win)[t] = 0;
@@ -942,7 +977,7 @@ __global__ __launch_bounds__(1024) void windows_kernel(const RawFile* __restrict
     auto fetch = [&](uint32_t i, uint16_t (&dst)[32]) {
         if (i >= rf.nguess) return;
         const uint32_t L = lens[rf.piece0 + i];
-        const uint16_t* const s = rf.sym + offs[rf.piece0 + i];
+        const uint16_t* const s = piece_symbols(rf, i, over, abase);
         const int p0 = (int)L - 32768 + (int)t0;
 #pragma unroll
         for (int q = 0; q < 32; ++q) dst[q] = (p0 + 1024 * q >= 0) ? s[p0 + 1024 * q] : (uint16_t)0;
@@ -974,7 +1009,8 @@ __global__ __launch_bounds__(1024) void windows_kernel(const RawFile* __restrict
 
 // symbols -> text: one workgroup per 64 KiB of a file's text; a placeholder is looked up in the window in front of its piece
 __global__ __launch_bounds__(256) void translate_kernel(const RawFile* __restrict__ files, int nfiles, const uint32_t* __restrict__ chunk0,
-                                                        const uint32_t* __restrict__ lens, const uint32_t* __restrict__ offs) {
+                                                        const uint32_t* __restrict__ lens, const uint32_t* __restrict__ offs, const uint32_t* __restrict__ over,
+                                                        const uint32_t* __restrict__ abase) {
     int f = 0;
     while (f + 1 < nfiles && blockIdx.x >= chunk0[f + 1]) ++f;
     const RawFile rf = files[f];
@@ -990,7 +1026,7 @@ __global__ __launch_bounds__(256) void translate_kernel(const RawFile* __restric
     uint32_t pi = lo;
     for (uint32_t p = begin + threadIdx.x; p < end; p += 256u) {
         while (pi + 1u < rf.nguess && (lens[rf.piece0 + pi] == 0u || p >= offs[rf.piece0 + pi] + lens[rf.piece0 + pi])) ++pi;
-        const uint32_t sy = rf.sym[p];
+        const uint32_t sy = piece_symbols(rf, pi, over, abase)[p - offs[rf.piece0 + pi]];
         rf.text[p] = (uint8_t)((sy & 0x8000u) ? rf.windows[(size_t)pi * 32768u + (sy & 0x7fffu)] : sy);
     }
 }
@@ -1015,7 +1051,7 @@ static void inflate_attributes() {
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
     if (done.load(std::memory_order_relaxed) & bit) return;
-    for (const void* k : {reinterpret_cast<const void*>(inflate_kernel<0>), reinterpret_cast<const void*>(inflate_kernel<1>), reinterpret_cast<const void*>(inflate_kernel<2>),
+    for (const void* k : {reinterpret_cast<const void*>(inflate_kernel<0>), reinterpret_cast<const void*>(inflate_kernel<1>), reinterpret_cast<const void*>(inflate_kernel<2>), reinterpret_cast<const void*>(inflate_kernel<3>),
                           reinterpret_cast<const void*>(find_starts_kernel), reinterpret_cast<const void*>(chunk_crc_kernel)})
         if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFindLds) != hipSuccess) (void)hipGetLastError();
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(windows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess) (void)hipGetLastError();
@@ -1025,23 +1061,26 @@ static void inflate_attributes() {
 void launch_inflate_bgzf(const InflateJob* jobs_dev, int njobs, uint32_t* errors_dev, hipStream_t st) {
     if (njobs <= 0) return;
     inflate_attributes();
-    hipLaunchKernelGGL(inflate_kernel<0>, dim3((unsigned)njobs), dim3(64), kInflateLds, st, jobs_dev, nullptr, 0, nullptr, nullptr, nullptr, errors_dev);
+    hipLaunchKernelGGL(inflate_kernel<0>, dim3((unsigned)njobs), dim3(64), kInflateLds, st, jobs_dev, nullptr, 0, nullptr, nullptr, nullptr, nullptr, errors_dev);
 }
 
 // Single-member gzip files on the device: block starts -> piece lengths -> offsets -> symbols -> windows -> text -> CRCs.
 // npieces = sum of the files' nguess; nchunks = sum of their 64 KiB text chunks (chunk0_dev: first chunk of each file, nfiles + 1 entries).
-void launch_gunzip_members(const RawFile* files_dev, int nfiles, int npieces, int nchunks, uint32_t* starts_dev, uint32_t* lens_dev, uint32_t* offs_dev,
+void launch_gunzip_members(const RawFile* files_dev, int nfiles, int npieces, int nchunks, uint32_t* tables_dev, size_t stride,
                            const uint32_t* chunk0_dev, uint32_t* crcs_dev, uint32_t* errors_dev, hipStream_t st) {
     if (nfiles <= 0 || npieces <= 0) return;
     inflate_attributes();
-    hipLaunchKernelGGL(find_starts_kernel, dim3((unsigned)npieces), dim3(64), kFindLds, st, files_dev, nfiles, starts_dev);
-    hipLaunchKernelGGL(inflate_kernel<1>, dim3((unsigned)npieces), dim3(64), kInflateLds, st, nullptr, files_dev, nfiles, starts_dev, lens_dev, nullptr, errors_dev);
-    hipLaunchKernelGGL(piece_offsets_kernel, dim3((unsigned)nfiles), dim3(64), 0, st, files_dev, lens_dev, offs_dev, errors_dev);
-    hipLaunchKernelGGL(inflate_kernel<2>, dim3((unsigned)npieces), dim3(64), kInflateLds, st, nullptr, files_dev, nfiles, starts_dev, lens_dev, offs_dev, errors_dev);
-    hipLaunchKernelGGL(windows_kernel, dim3((unsigned)nfiles), dim3(1024), 65536, st, files_dev, lens_dev, offs_dev);
+    uint32_t *starts = tables_dev, *lens = tables_dev + stride, *offs = tables_dev + 2 * stride, *over = tables_dev + 3 * stride, *abase = tables_dev + 4 * stride;
+    const dim3 grid((unsigned)npieces), wave(64);
+    hipLaunchKernelGGL(find_starts_kernel, grid, wave, kFindLds, st, files_dev, nfiles, starts);
+    hipLaunchKernelGGL(inflate_kernel<3>, grid, wave, kInflateLds, st, nullptr, files_dev, nfiles, starts, lens, over, nullptr, errors_dev);
+    hipLaunchKernelGGL(inflate_kernel<1>, grid, wave, kInflateLds, st, nullptr, files_dev, nfiles, starts, lens, over, nullptr, errors_dev);   // (the pieces marked in `over` only)
+    hipLaunchKernelGGL(piece_offsets_kernel, dim3((unsigned)nfiles), wave, 0, st, files_dev, lens, over, offs, abase, errors_dev);
+    hipLaunchKernelGGL(inflate_kernel<2>, grid, wave, kInflateLds, st, nullptr, files_dev, nfiles, starts, lens, over, abase, errors_dev);
+    hipLaunchKernelGGL(windows_kernel, dim3((unsigned)nfiles), dim3(1024), 65536, st, files_dev, lens, over, abase);
     if (nchunks > 0) {
-        hipLaunchKernelGGL(translate_kernel, dim3((unsigned)nchunks), dim3(256), 0, st, files_dev, nfiles, chunk0_dev, lens_dev, offs_dev);
-        hipLaunchKernelGGL(chunk_crc_kernel, dim3((unsigned)nchunks), dim3(64), kInflateLds, st, files_dev, nfiles, chunk0_dev, crcs_dev);
+        hipLaunchKernelGGL(translate_kernel, dim3((unsigned)nchunks), dim3(256), 0, st, files_dev, nfiles, chunk0_dev, lens, offs, over, abase);
+        hipLaunchKernelGGL(chunk_crc_kernel, dim3((unsigned)nchunks), wave, kInflateLds, st, files_dev, nfiles, chunk0_dev, crcs_dev);
     }
 }
 

@@ -235,12 +235,16 @@ struct RawFile {
     uint32_t nguess;            // ranges = entries of this file in starts / lens / offs
     uint32_t piece0;            // its first entry there
     uint32_t isize;             // bytes of text (the member's ISIZE)
-    uint16_t* sym;              // [isize] symbols: a byte, or 0x8000 | position in the 32 KiB in front of the piece
+    uint16_t* sym;              // [nguess][range_syms] symbols (a byte, or 0x8000 | position in the 32 KiB in front of the piece):
+                                //   a piece that starts in range j and runs over r ranges owns r x range_syms of them
+    uint32_t range_syms;
+    uint16_t* arena;            // [isize]: the symbols of pieces too long for their ranges (counted first, then written here)
     uint8_t* windows;           // [nguess][32768]: those 32 KiB, per piece
     uint8_t* text;              // [isize] where the text goes
 };
 size_t inflate_lds_bytes();
-void launch_gunzip_members(const RawFile* files_dev, int nfiles, int npieces, int nchunks, uint32_t* starts_dev, uint32_t* lens_dev, uint32_t* offs_dev,
+// tables_dev: five arrays of npieces u32 (starts, lens, offs, over, abase), `stride` words apart
+void launch_gunzip_members(const RawFile* files_dev, int nfiles, int npieces, int nchunks, uint32_t* tables_dev, size_t stride,
                            const uint32_t* chunk0_dev, uint32_t* crcs_dev, uint32_t* errors_dev, hipStream_t st);
 // *errors_dev += blocks that did not decode (the caller falls back to the host decoder)
 void launch_inflate_bgzf(const InflateJob* jobs_dev, int njobs, uint32_t* errors_dev, hipStream_t st);
