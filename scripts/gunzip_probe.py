@@ -10,11 +10,12 @@ ng = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 nb = int(float(sys.argv[2]) * 1e6) if len(sys.argv) > 2 else 5_000_000
 level = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 p = int(sys.argv[4]) if len(sys.argv) > 4 else 14
+realistic = len(sys.argv) > 5 and sys.argv[5] == "realistic"   # GC 35 %, repeats, 2 % N in long runs, short contigs (dd_synth.hip's second generator)
 d = tempfile.mkdtemp(dir="/dev/shm")
 eng = Engine(0, p, True)
 paths, raws = [], []
 for g in range(ng):
-    raw = orc.synth_fasta(0xD4ADD, g, nb, 5).tobytes()
+    raw = (orc.synth_realistic(0xD4ADD, g, nb) if realistic else orc.synth_fasta(0xD4ADD, g, nb, 5)).tobytes()
     co = zlib.compressobj(level, zlib.DEFLATED, 31)
     data = co.compress(raw) + co.flush()
     q = os.path.join(d, f"g{g}.fa.gz")

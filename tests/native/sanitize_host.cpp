@@ -231,6 +231,17 @@ static void fastq_rewrite_cases() {
         // a line end -- where it is an ambiguous byte behind the record's last k-mer either way)
         std::vector<uint8_t> again(m + 2);
         CHECK(dd::fastq_to_fasta(out.data(), m, again.data()) <= m, "FASTQ rewrite: a second pass grew the buffer");
+        // the loaders' form of has_plus_line: every piece looked through on its own (exactly sized copies: ASan sees a read
+        // outside a piece's bytes other than the one byte in front of it), the pieces' first bytes afterwards
+        bool piecewise = false;
+        std::vector<size_t> cuts{0};
+        while (cuts.back() < n) cuts.push_back(std::min(n, cuts.back() + 1 + rng() % 40));
+        std::vector<uint8_t> whole(in.begin(), in.end());
+        for (size_t c = 0; c + 1 < cuts.size(); ++c) {
+            piecewise |= dd::piece_has_plus_line(whole.data(), cuts[c], cuts[c + 1] - cuts[c]);
+            piecewise |= dd::plus_at_piece_start(whole.data(), cuts[c]);
+        }
+        CHECK(piecewise == dd::has_plus_line(whole.data(), n), "FASTQ detection: piece by piece differs from the whole buffer");
     }
 }
 
