@@ -914,7 +914,7 @@ struct GzMember {
 static bool gzip_member_for_device(const char* path, FileBuf& fb, GzMember& gm) {
     struct stat sb;
     const size_t min_bytes = (size_t)(getenv("DD_GUNZIP_MIN_KB") ? std::max(1, atoi(getenv("DD_GUNZIP_MIN_KB"))) : 1024) << 10;
-    if (stat(path, &sb) != 0 || !S_ISREG(sb.st_mode) || (size_t)sb.st_size < min_bytes || (size_t)sb.st_size >= ((size_t)500 << 20)) return false;
+    if (stat(path, &sb) != 0 || !S_ISREG(sb.st_mode) || (size_t)sb.st_size < min_bytes || (size_t)sb.st_size >= ((size_t)3500 << 20)) return false;
     FILE* f = fopen(path, "rb");
     if (!f) return false;
     const size_t n = (size_t)sb.st_size;
@@ -940,7 +940,7 @@ static bool gzip_member_for_device(const char* path, FileBuf& fb, GzMember& gm) 
     gm.first_bit = (uint32_t)(8 * h);
     gm.crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
     gm.isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
-    if (gm.isize < n / 2 || (size_t)gm.isize > (size_t)1032 * n || gm.isize >= (1u << 31)) return false;   // (a multi-member file's last ISIZE is usually smaller than the file)
+    if (gm.isize < n / 2 || (size_t)gm.isize > (size_t)1032 * n) return false;   // (a multi-member file's last ISIZE is usually smaller than the file)
     // FASTQ needs the host's record pass: look at the first bytes of text
     uint8_t first[256];
     z_stream zs;
@@ -1282,7 +1282,7 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
         // (files of 48 MB and more take 64 KiB ranges: half as many links in the chain of windows, which one workgroup per
         // file walks at ~7 us a piece -- 1 x 400 Mbp: 5.4 -> 6.9 Gbp/s, 3 x 300 Mbp: 7.2 -> 8.1)
         auto guess_bits_of = [&](size_t file_bytes) {
-            return (size_t)(getenv("DD_GUNZIP_GUESS_KB") ? std::max(4, atoi(getenv("DD_GUNZIP_GUESS_KB"))) : (file_bytes >= ((size_t)48 << 20) ? 64 : 32)) << 13;
+            return (size_t)(getenv("DD_GUNZIP_GUESS_KB") ? std::max(4, atoi(getenv("DD_GUNZIP_GUESS_KB"))) : (file_bytes >= ((size_t)400 << 20) ? 128 : file_bytes >= ((size_t)48 << 20) ? 64 : 32)) << 13;
         };
         // a range's symbols: 5 x its compressed bytes (DNA inflates 3-4 x) + 32 Ki; a piece that needs more takes the arena
         auto range_syms_of = [&](size_t guess_bits) { return 5 * (guess_bits / 8) + 32768; };
@@ -1309,9 +1309,9 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             }
         }
         // the piece tables of the batch's single-member gzip files, one block of device memory: RawFile[nmem],
-        // starts / lens / offs / over / abase [npieces], chunk0 [nmem + 1], crcs [nchunks]
+        // starts (u64) / lens / offs / over / abase [npieces], chunk0 [nmem + 1], crcs [nchunks]
         const size_t raw_files = align_up(nmem * sizeof(dd::RawFile), 256), raw_u32 = align_up(npieces * 4, 256), raw_chunk0 = align_up((nmem + 1) * 4, 256);
-        const size_t raw_bytes = raw_files + 5 * raw_u32 + raw_chunk0 + align_up(nchunks * 4, 256);
+        const size_t raw_bytes = raw_files + 6 * raw_u32 + raw_chunk0 + align_up(nchunks * 4, 256);   // (starts are 64-bit: two of the six)
         if (nmem && ((rc = c->pipe_gz[set].reserve(gz_tot + 16)) != DD_OK || (rc = c->pipe_sym[set].reserve(sym_tot)) != DD_OK ||
                      (rc = c->pipe_win[set].reserve(win_tot)) != DD_OK || (rc = c->pipe_raw[set].reserve(raw_bytes)) != DD_OK ||
                      (rc = c->pipe_raw_host[set].reserve(raw_files + raw_chunk0)) != DD_OK || (rc = c->pipe_crc_host[set].reserve(nchunks * 4 + 256)) != DD_OK ||
@@ -1396,11 +1396,12 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             chunk0_host[nmem] = (uint32_t)chunk_at;
             uint8_t* rb = static_cast<uint8_t*>(c->pipe_raw[set].p);
             e = hipMemcpyAsync(rb, raw_host, nmem * sizeof(dd::RawFile), hipMemcpyHostToDevice, cs);
-            if (e == hipSuccess) e = hipMemcpyAsync(rb + raw_files + 5 * raw_u32, chunk0_host, (nmem + 1) * 4, hipMemcpyHostToDevice, cs);
+            if (e == hipSuccess) e = hipMemcpyAsync(rb + raw_files + 6 * raw_u32, chunk0_host, (nmem + 1) * 4, hipMemcpyHostToDevice, cs);
             if (e == hipSuccess) {
-                uint32_t* crcs_dev = reinterpret_cast<uint32_t*>(rb + raw_files + 5 * raw_u32 + raw_chunk0);
-                dd::launch_gunzip_members(reinterpret_cast<const dd::RawFile*>(rb), (int)nmem, (int)npieces, (int)nchunks, reinterpret_cast<uint32_t*>(rb + raw_files), raw_u32 / 4,
-                                          reinterpret_cast<const uint32_t*>(rb + raw_files + 5 * raw_u32), crcs_dev, static_cast<uint32_t*>(c->pipe_err[set].p), cs);
+                uint32_t* crcs_dev = reinterpret_cast<uint32_t*>(rb + raw_files + 6 * raw_u32 + raw_chunk0);
+                dd::launch_gunzip_members(reinterpret_cast<const dd::RawFile*>(rb), (int)nmem, (int)npieces, (int)nchunks, reinterpret_cast<uint64_t*>(rb + raw_files),
+                                          reinterpret_cast<uint32_t*>(rb + raw_files + 2 * raw_u32), raw_u32 / 4,
+                                          reinterpret_cast<const uint32_t*>(rb + raw_files + 6 * raw_u32), crcs_dev, static_cast<uint32_t*>(c->pipe_err[set].p), cs);
                 e = hipGetLastError();
                 if (e == hipSuccess) e = hipMemcpyAsync(c->pipe_crc_host[set].p, crcs_dev, nchunks * 4, hipMemcpyDeviceToHost, cs);
             }

@@ -102,7 +102,7 @@ struct WBits {
         nwords = (skip + nbytes + 3u) / 4u;
         start_at(0, 8u * skip);
     }
-    DD_D uint32_t bit_pos() const { return (wi - 1u) * 32u - (uint32_t)cnt; }   // bits of W consumed (`ahead` is read but not in the buffer)
+    DD_D uint64_t bit_pos() const { return (uint64_t)(wi - 1u) * 32u - (uint64_t)cnt; }   // bits of W consumed (`ahead` is read but not in the buffer)
     DD_D void refill() {   // from >= 0 valid bits to >= 32
         buf |= (uint64_t)ahead << cnt;
         cnt += 32;
@@ -337,22 +337,22 @@ DD_D bool dynamic_tables(WBits& b) {
 // the piece a wave of the raw-deflate modes works on: entry `idx` of the batch's piece table
 struct PieceRef {
     int file;
-    uint32_t start, end;   // bit positions; end = ~0u: up to the stream's final block
+    uint64_t start, end;   // bit positions (a 3 Gbp assembly's .gz has 7 x 10^9); end = ~0: up to the stream's final block
     uint32_t j, ranges;    // the finder range it starts in, and how many ranges it runs over
 };
-DD_D bool piece_of(const RawFile* files, int nfiles, const uint32_t* starts, uint32_t idx, PieceRef& r) {
+DD_D bool piece_of(const RawFile* files, int nfiles, const uint64_t* starts, uint32_t idx, PieceRef& r) {
     int f = 0;
     while (f + 1 < nfiles && idx >= uni(files[f + 1].piece0)) ++f;
     const uint32_t j = idx - uni(files[f].piece0), ng = uni(files[f].nguess);
     r.file = f;
-    r.start = uni(starts[idx]);
-    r.end = ~0u;
+    r.start = uni64(starts[idx]);
+    r.end = ~0ull;
     r.j = j;
     r.ranges = ng - j;
-    if (j >= ng || r.start == ~0u) return false;
+    if (j >= ng || r.start == ~0ull) return false;
     for (uint32_t k = j + 1; k < ng; ++k) {
-        const uint32_t e = uni(starts[idx - j + k]);
-        if (e != ~0u) {
+        const uint64_t e = uni64(starts[idx - j + k]);
+        if (e != ~0ull) {
             r.end = e;
             r.ranges = k - j;
             break;
@@ -373,7 +373,7 @@ DD_D bool piece_of(const RawFile* files, int nfiles, const uint32_t* starts, uin
 // `errors`: blocks / pieces that could not be decoded (the caller falls back to the host).
 template <int MODE>
 __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restrict__ jobs, const RawFile* __restrict__ files, int nfiles,
-                                                     const uint32_t* __restrict__ starts, uint32_t* __restrict__ lens, uint32_t* __restrict__ over,
+                                                     const uint64_t* __restrict__ starts, uint32_t* __restrict__ lens, uint32_t* __restrict__ over,
                                                      const uint32_t* __restrict__ abase, uint32_t* __restrict__ errors) {
     constexpr bool RAW = MODE != 0;
     constexpr bool WRITES = MODE == 2 || MODE == 3;   // (16-bit symbols)
@@ -382,10 +382,11 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
     const uint32_t lane = threadIdx.x & 63u;
     bool ok = true;
     const uint8_t* in;
-    uint32_t n, out_len, piece_end = ~0u;
+    uint32_t n, out_len;
+    uint64_t piece_end = ~0ull;
     uint8_t* out = nullptr;
     uint16_t* sym = nullptr;
-    PieceRef pr{0, 0, ~0u};
+    PieceRef pr{0, 0, ~0ull, 0, 0};
     if (!RAW) {
         const InflateJob job = jobs[blockIdx.x];
         in = job.in, n = job.in_len, out = job.out, out_len = job.out_len;
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
         else {
             b.w = reinterpret_cast<const uint32_t*>(in);   // (the file's bytes start on a 256-byte boundary)
             b.nwords = (n + 3u) / 4u;
-            b.start_at(pr.start >> 5, pr.start & 31u);
+            b.start_at((uint32_t)(pr.start >> 5), (uint32_t)pr.start & 31u);
         }
         for (;;) {
             const uint32_t bfinal = b.take(1), btype = b.take(2);
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
                 if (at + len > out_len) { ok = false, too_long = true; break; }
                 // stored bytes: straight from the input (the reader stands on a byte boundary; its word base stays)
                 const uint8_t* const base = reinterpret_cast<const uint8_t*>(b.w);
-                const uint32_t data = b.bit_pos() >> 3;   // byte offset of the data from the reader's base
+                const uint32_t data = (uint32_t)(b.bit_pos() >> 3);   // byte offset of the data from the reader's base
                 if ((uint32_t)(base - in) + data + len + 8u > n) { ok = false; break; }
                 flush();
                 if (MODE == 0)
@@ -501,9 +502,9 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
                 // inside the batch (distance < length + 64) or before the text's start, one that does not fit a batch.
                 uint32_t q, r, s0, s1, s2, s3, s4;   // the window: bit r of word W[q] = s0; s0..s4 = W[q .. q + 4]
                 {
-                    const uint32_t P = b.bit_pos();
-                    q = P >> 5;
-                    r = P & 31u;
+                    const uint64_t P = b.bit_pos();
+                    q = (uint32_t)(P >> 5);
+                    r = (uint32_t)P & 31u;
                     b.seek(q);
                     s0 = b.word(), s1 = b.word(), s2 = b.word(), s3 = b.word(), s4 = b.word();
                 }
@@ -659,14 +660,14 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
                 break;
             }
             if (RAW) {   // the piece ends where the next one starts -- exactly there, or the starts are not block starts
-                const uint32_t P = b.bit_pos();
+                const uint64_t P = b.bit_pos();
                 if (P == piece_end) break;
                 if (P > piece_end) { ok = false; break; }
             }
         }
     }
     if (RAW) {
-        if (ok && final_seen != (piece_end == ~0u)) ok = false;
+        if (ok && final_seen != (piece_end == ~0ull)) ok = false;
         if (ok && final_seen && b.bytes_used(in) + 8u != n) ok = false;   // ONE member: CRC-32 and ISIZE right behind the final block
         if (MODE == 3 && !ok && too_long && out_len < files[pr.file].isize) {   // not an error: the piece is counted, then written to the arena
             if (lane == 0) lens[blockIdx.x] = 0, over[blockIdx.x] = 1;
@@ -713,7 +714,7 @@ constexpr uint32_t kFindLds = kInflateLds + 512u;
 constexpr uint32_t kFindTable = kLitInfo;           // u8[64][128]: every lane's code-length code (7-bit lookup): the place of both symbol tables
 constexpr uint8_t k_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};   // (c_cl_order, for unrolled loops)
 
-__global__ __launch_bounds__(64) void find_starts_kernel(const RawFile* __restrict__ files, int nfiles, uint32_t* __restrict__ starts) {
+__global__ __launch_bounds__(64) void find_starts_kernel(const RawFile* __restrict__ files, int nfiles, uint64_t* __restrict__ starts) {
     const uint32_t lane = threadIdx.x & 63u;
     int f = 0;
     while (f + 1 < nfiles && blockIdx.x >= uni(files[f + 1].piece0)) ++f;
@@ -724,23 +725,22 @@ __global__ __launch_bounds__(64) void find_starts_kernel(const RawFile* __restri
         if (lane == 0) starts[blockIdx.x] = rf.first_bit;
         return;
     }
-    const uint32_t total_bits = (rf.in_len - 8u) * 8u;               // (the trailer is no place for a block)
-    const uint64_t lo64 = (uint64_t)rf.first_bit + (uint64_t)j * rf.guess_bits;
-    uint32_t found = ~0u;
-    if (lo64 + 64u < total_bits) {
-        const uint32_t lo = (uint32_t)lo64;
-        const uint32_t hi = (uint32_t)(lo64 + rf.guess_bits < total_bits ? lo64 + rf.guess_bits : total_bits);
+    const uint64_t total_bits = ((uint64_t)rf.in_len - 8u) * 8u;   // (the trailer is no place for a block)
+    const uint64_t lo = (uint64_t)rf.first_bit + (uint64_t)j * rf.guess_bits;
+    uint64_t found = ~0ull;
+    if (lo + 64u < total_bits) {
+        const uint64_t hi = lo + rf.guess_bits < total_bits ? lo + rf.guess_bits : total_bits;
         const uint32_t* const W = reinterpret_cast<const uint32_t*>(rf.in);
         const uint32_t nwords = (rf.in_len + 3u) / 4u;
         auto word_at = [&](uint32_t i) { return i < nwords ? gload4(W + i) : 0u; };
         // the full test of up to 64 queued candidates, one per lane; -> the smallest that passes, or ~0u
-        auto full_test = [&](uint32_t nq) -> uint32_t {
-            const uint32_t cand = lane < nq ? l32(kFindQueue + 4u * lane) : 0u;
+        auto full_test = [&](uint32_t nq) -> uint64_t {   // (the queue holds positions as offsets from `lo`)
+            const uint64_t cand = lo + (lane < nq ? l32(kFindQueue + 4u * lane) : 0u);
             bool live = lane < nq;
             // the lane's bit reader
-            uint32_t wi = cand >> 5;
-            uint64_t buf = ((uint64_t)word_at(wi + 1u) << 32 | word_at(wi)) >> (cand & 31u);
-            int cnt = 64 - (int)(cand & 31u);
+            uint32_t wi = (uint32_t)(cand >> 5);
+            uint64_t buf = ((uint64_t)word_at(wi + 1u) << 32 | word_at(wi)) >> ((uint32_t)cand & 31u);
+            int cnt = 64 - (int)((uint32_t)cand & 31u);
             wi += 2u;
             auto need = [&](int k) {
                 if (cnt < k) {
@@ -838,11 +838,12 @@ __global__ __launch_bounds__(64) void find_starts_kernel(const RawFile* __restri
             // the first symbols -- every code valid, every literal a byte of text (9 .. 126: FASTA has no others).
             unsigned long long m = __ballot(pass);
             while (m) {
-                const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)__builtin_ctzll(m));
+                const int first = __builtin_ctzll(m);
+                const uint64_t c0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cand >> 32), first) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cand, first);
                 m &= m - 1ull;
                 WBits v;
                 v.w = W, v.nwords = nwords;
-                v.start_at(c0 >> 5, c0 & 31u);
+                v.start_at((uint32_t)(c0 >> 5), (uint32_t)c0 & 31u);
                 (void)v.take(3);
                 bool good = dynamic_tables(v);
                 for (int k = 0; good && k < 24; ++k) {
@@ -879,12 +880,13 @@ __global__ __launch_bounds__(64) void find_starts_kernel(const RawFile* __restri
                 }
                 if (good) return c0;
             }
-            return ~0u;
+            return ~0ull;
         };
         uint32_t nq = 0;
-        for (uint32_t base = lo; base < hi && found == ~0u; base += 64u) {
+        for (uint64_t base = lo; base < hi && found == ~0ull; base += 64u) {
             // the 96 bits from position base + lane on
-            const uint32_t pos = base + lane, wq = pos >> 5, sh = pos & 31u;
+            const uint64_t pos = base + lane;
+            const uint32_t wq = (uint32_t)(pos >> 5), sh = (uint32_t)pos & 31u;
             const uint32_t w0 = word_at(wq), w1 = word_at(wq + 1u), w2 = word_at(wq + 2u), w3 = word_at(wq + 3u);
             const uint32_t x0 = __builtin_amdgcn_alignbit(w1, w0, sh), x1 = __builtin_amdgcn_alignbit(w2, w1, sh), x2 = __builtin_amdgcn_alignbit(w3, w2, sh);
             const uint32_t hclen = ((x0 >> 13) & 15u) + 4u;
@@ -907,7 +909,7 @@ __global__ __launch_bounds__(64) void find_starts_kernel(const RawFile* __restri
             cand = cand && (kraft == 128u || nz == 1u);
             const unsigned long long m = __ballot(cand);
             if (m) {
-                if (cand) l32(kFindQueue + 4u * (nq + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)))) = pos;
+                if (cand) l32(kFindQueue + 4u * (nq + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)))) = (uint32_t)(pos - lo);
                 nq += (uint32_t)__builtin_popcountll(m);
                 __builtin_amdgcn_wave_barrier();
                 if (nq >= 64u) {
@@ -922,7 +924,7 @@ __global__ __launch_bounds__(64) void find_starts_kernel(const RawFile* __restri
                 }
             }
         }
-        if (found == ~0u && nq) found = full_test(nq);
+        if (found == ~0ull && nq) found = full_test(nq);
     }
     if (lane == 0) starts[blockIdx.x] = found;
 }
@@ -1066,11 +1068,11 @@ void launch_inflate_bgzf(const InflateJob* jobs_dev, int njobs, uint32_t* errors
 
 // Single-member gzip files on the device: block starts -> piece lengths -> offsets -> symbols -> windows -> text -> CRCs.
 // npieces = sum of the files' nguess; nchunks = sum of their 64 KiB text chunks (chunk0_dev: first chunk of each file, nfiles + 1 entries).
-void launch_gunzip_members(const RawFile* files_dev, int nfiles, int npieces, int nchunks, uint32_t* tables_dev, size_t stride,
+void launch_gunzip_members(const RawFile* files_dev, int nfiles, int npieces, int nchunks, uint64_t* starts, uint32_t* tables_dev, size_t stride,
                            const uint32_t* chunk0_dev, uint32_t* crcs_dev, uint32_t* errors_dev, hipStream_t st) {
     if (nfiles <= 0 || npieces <= 0) return;
     inflate_attributes();
-    uint32_t *starts = tables_dev, *lens = tables_dev + stride, *offs = tables_dev + 2 * stride, *over = tables_dev + 3 * stride, *abase = tables_dev + 4 * stride;
+    uint32_t *lens = tables_dev, *offs = tables_dev + stride, *over = tables_dev + 2 * stride, *abase = tables_dev + 3 * stride;
     const dim3 grid((unsigned)npieces), wave(64);
     hipLaunchKernelGGL(find_starts_kernel, grid, wave, kFindLds, st, files_dev, nfiles, starts);
     hipLaunchKernelGGL(inflate_kernel<3>, grid, wave, kInflateLds, st, nullptr, files_dev, nfiles, starts, lens, over, nullptr, errors_dev);

@@ -243,8 +243,8 @@ struct RawFile {
     uint8_t* text;              // [isize] where the text goes
 };
 size_t inflate_lds_bytes();
-// tables_dev: five arrays of npieces u32 (starts, lens, offs, over, abase), `stride` words apart
-void launch_gunzip_members(const RawFile* files_dev, int nfiles, int npieces, int nchunks, uint32_t* tables_dev, size_t stride,
+// starts_dev: npieces u64 (bit positions); tables_dev: four arrays of npieces u32 (lens, offs, over, abase), `stride` words apart
+void launch_gunzip_members(const RawFile* files_dev, int nfiles, int npieces, int nchunks, uint64_t* starts_dev, uint32_t* tables_dev, size_t stride,
                            const uint32_t* chunk0_dev, uint32_t* crcs_dev, uint32_t* errors_dev, hipStream_t st);
 // *errors_dev += blocks that did not decode (the caller falls back to the host decoder)
 void launch_inflate_bgzf(const InflateJob* jobs_dev, int njobs, uint32_t* errors_dev, hipStream_t st);

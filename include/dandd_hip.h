@@ -66,7 +66,7 @@ int dd_sketch_fasta(dd_ctx *, const char *path, int kmin, int kmax, uint8_t *reg
  * to the device and batch b-1's registers back while batch b is sketched; consecutive small files
  * share one launch (~128 MB per batch).  regs[nfiles][K][m] on the host.  Replaces the reference's
  * sequential per-genome loop (lib/huffman_dandd.py:402-407), each iteration of which re-inflates the
- * file once per k.  gzip files -- BGZF (bgzip) and ordinary single-member files of 1 MiB .. 500 MB --
+ * file once per k.  gzip files -- BGZF (bgzip) and ordinary single-member files of 1 MiB .. 3.5 GB --
  * are copied compressed and inflated on the device, their CRC-32 and ISIZE checked; a block the device refuses sends the call through the host decoder, which
  * reports what is wrong (DD_NO_GPU_INFLATE=1: host decoder from the start).  FASTQ is accepted (kseq's
  * record rules: oracle/POLICIES.md P10). */
