@@ -911,18 +911,26 @@ static uint32_t crc_x8n(uint32_t nbytes) {   // x^(8 nbytes) mod P
 struct GzMember {
     uint32_t first_bit = 0, isize = 0, crc = 0;
 };
+static bool gzip_member_size_ok(size_t n) {
+    const size_t min_bytes = (size_t)(getenv("DD_GUNZIP_MIN_KB") ? std::max(1, atoi(getenv("DD_GUNZIP_MIN_KB"))) : 1024) << 10;
+    return n >= min_bytes && n < ((size_t)3500 << 20);
+}
+static bool gzip_member_parse(const uint8_t* p, size_t n, GzMember& gm);
 static bool gzip_member_for_device(const char* path, FileBuf& fb, GzMember& gm) {
     struct stat sb;
-    const size_t min_bytes = (size_t)(getenv("DD_GUNZIP_MIN_KB") ? std::max(1, atoi(getenv("DD_GUNZIP_MIN_KB"))) : 1024) << 10;
-    if (stat(path, &sb) != 0 || !S_ISREG(sb.st_mode) || (size_t)sb.st_size < min_bytes || (size_t)sb.st_size >= ((size_t)3500 << 20)) return false;
+    if (stat(path, &sb) != 0 || !S_ISREG(sb.st_mode) || !gzip_member_size_ok((size_t)sb.st_size)) return false;
     FILE* f = fopen(path, "rb");
     if (!f) return false;
     const size_t n = (size_t)sb.st_size;
     fb.len = 0;
     const bool ok = fb.reserve(n + 16) && fread(fb.p, 1, n, f) == n;
     fclose(f);
-    if (!ok) return false;
-    const uint8_t* p = fb.p;
+    if (!ok || !gzip_member_parse(fb.p, n, gm)) return false;
+    fb.len = n;
+    return true;
+}
+// the same for a file whose bytes are in memory already (large files are read in pieces by several loaders)
+static bool gzip_member_parse(const uint8_t* p, size_t n, GzMember& gm) {
     if (n < 64 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xE0)) return false;
     size_t h = 10;
     if (p[3] & 4) {
@@ -946,7 +954,7 @@ static bool gzip_member_for_device(const char* path, FileBuf& fb, GzMember& gm) 
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, 15 + 16) != Z_OK) return false;
-    zs.next_in = fb.p;
+    zs.next_in = const_cast<uint8_t*>(p);
     zs.avail_in = (uInt)std::min<size_t>(n, 1 << 16);
     zs.next_out = first;
     zs.avail_out = sizeof first;
@@ -954,7 +962,6 @@ static bool gzip_member_for_device(const char* path, FileBuf& fb, GzMember& gm) 
     const size_t made = sizeof first - zs.avail_out;
     inflateEnd(&zs);
     if ((zr != Z_OK && zr != Z_STREAM_END) || !made || first[0] == '@' || dd::has_plus_line(first, made)) return false;
-    fb.len = n;
     return true;
 }
 
@@ -1035,11 +1042,13 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
         bool dev_inflate = false;             // BGZF: the buffer holds the COMPRESSED file, the device inflates its blocks
         size_t out_size = 0;                  // ... into this many bytes of text
         std::vector<BgzfBlock> blks;
+        bool gz_raw = false;                  // a large .gz read as it is, in pieces by several loaders (plain_size = its size): meant for the device
         bool dev_gunzip = false;              // ONE gzip member: the buffer holds the compressed file, the device inflates it in pieces
         GzMember gm;
     };
     std::vector<Slot> slots(nfiles);
     const bool gpu_gunzip = gpu_inflate && !getenv("DD_NO_GPU_GUNZIP");
+    const size_t raw_pieces_from = (size_t)(getenv("DD_GUNZIP_PIECES_MB") ? std::max(1, atoi(getenv("DD_GUNZIP_PIECES_MB"))) : 32) << 20;
     // Work items in file order.  A plain file is cut into 8 MiB pieces that different loaders pread into the
     // file's pinned buffer -- the first file of a directory is then in memory after one piece-time instead of
     // one file-time, which is what the GPU waits for at the start; a gzip file is one item (zlib is serial).
@@ -1052,11 +1061,17 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
     const size_t kFirstPiece = (size_t)(getenv("DD_FIRST_PIECE_MB") ? std::max(1, atoi(getenv("DD_FIRST_PIECE_MB"))) : 2) << 20;
     for (int i = 0; i < nfiles; ++i) {
         struct stat sb;
-        unsigned char magic[2] = {0, 0};
+        unsigned char magic[18] = {0};
         bool plain = false;
         if (stat(paths[i], &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
             if (FILE* f = fopen(paths[i], "rb")) {
-                plain = fread(magic, 1, 2, f) == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b);
+                const size_t got = fread(magic, 1, sizeof magic, f);
+                plain = got >= 2 && !(magic[0] == 0x1f && magic[1] == 0x8b);
+                // a large gzip file that is not BGZF (no 'BC' extra field) and may be ONE member: its compressed bytes are read
+                // like a plain file's, by several loaders (one fread of a 700 MB file held the device path back 150 ms)
+                if (!plain && gpu_gunzip && got == sizeof magic && magic[2] == 8 && (size_t)sb.st_size >= raw_pieces_from && gzip_member_size_ok((size_t)sb.st_size) &&
+                    !((magic[3] & 4) && magic[12] == 'B' && magic[13] == 'C'))
+                    plain = slots[i].gz_raw = true;
                 fclose(f);
             }
         }
@@ -1139,7 +1154,7 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             }
             // (every loader looks through the piece it has just read -- the bytes are still in its cache -- instead of one
             // of them through the whole file at the end: that pass held every file back 2-3 ms)
-            const bool plus_here = it.len && ok && dd::piece_has_plus_line(fb.p, it.off, it.len);
+            const bool plus_here = it.len && ok && !sl.gz_raw && dd::piece_has_plus_line(fb.p, it.off, it.len);
             bool last, plus;
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -1151,7 +1166,11 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             if (last) {
                 // a plain file read in pieces is whole now: FASTQ records are resolved before K0 sees the bytes (dd_io.h;
                 // read_fasta_file has done the same for the files that came through zlib)
-                if (it.len && ok) {
+                if (it.len && ok && sl.gz_raw) {
+                    // the compressed file is whole: one member for the device, or (FASTQ, an odd header) the host decoder after all
+                    if (gzip_member_parse(fb.p, sl.plain_size, sl.gm)) sl.dev_gunzip = true, sl.out_size = sl.gm.isize;
+                    else ok = read_fasta_file(paths[it.file], fb, err, gz_par);
+                } else if (it.len && ok) {
                     for (const Item& o : items)
                         if (o.file == it.file && !plus) plus = dd::plus_at_piece_start(fb.p, o.off);
                     if (!dd::normalize_records(fb, plus ? 1 : 0)) ok = false, err = std::string("out of host memory reading ") + paths[it.file];
