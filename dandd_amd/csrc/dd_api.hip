@@ -828,6 +828,7 @@ struct BgzfBlock {
     uint32_t in_len, out_len;
     size_t out_off;
 };
+static bool bgzf_parse(const uint8_t* data, size_t n, std::vector<BgzfBlock>& blks, size_t& out_size);
 static bool bgzf_for_device(const char* path, FileBuf& fb, std::vector<BgzfBlock>& blks, size_t& out_size) {
     using namespace dd::inflate_detail;
     struct stat sb;
@@ -844,17 +845,23 @@ static bool bgzf_for_device(const char* path, FileBuf& fb, std::vector<BgzfBlock
     fb.len = 0;
     bool ok = fb.reserve(n + 16) && fseeko(f, 0, SEEK_SET) == 0 && fread(fb.p, 1, n, f) == n;
     fclose(f);
-    if (!ok) return false;
+    if (!ok || !bgzf_parse(fb.p, n, blks, out_size)) return false;
+    fb.len = n;
+    return true;
+}
+// the same for a file whose bytes are in memory already (large files are read in pieces by several loaders)
+static bool bgzf_parse(const uint8_t* data, size_t n, std::vector<BgzfBlock>& blks, size_t& out_size) {
+    using namespace dd::inflate_detail;
     blks.clear();
     size_t p = 0, total = 0;
     while (p < n) {
-        const size_t bs = bgzf_block_size(fb.p + p, n - p);
+        const size_t bs = bgzf_block_size(data + p, n - p);
         if (!bs) {
             for (size_t q = p; q < n; ++q)
-                if (fb.p[q]) return false;   // (trailing zeros are tolerated, as gzread tolerates them)
+                if (data[q]) return false;   // (trailing zeros are tolerated, as gzread tolerates them)
             break;
         }
-        const uint8_t* t = fb.p + p + bs - 4;
+        const uint8_t* t = data + p + bs - 4;
         const size_t isize = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
         if (isize > 65536) return false;
         if (isize) blks.push_back(BgzfBlock{p, (uint32_t)bs, (uint32_t)isize, total});
@@ -868,7 +875,7 @@ static bool bgzf_for_device(const char* path, FileBuf& fb, std::vector<BgzfBlock
         z_stream zs;
         memset(&zs, 0, sizeof zs);
         if (inflateInit2(&zs, 15 + 16) != Z_OK) return false;
-        zs.next_in = fb.p + blks[0].in_off;
+        zs.next_in = const_cast<uint8_t*>(data) + blks[0].in_off;
         zs.avail_in = blks[0].in_len;
         zs.next_out = first;
         zs.avail_out = sizeof first;
@@ -877,7 +884,6 @@ static bool bgzf_for_device(const char* path, FileBuf& fb, std::vector<BgzfBlock
         inflateEnd(&zs);
         if ((zr != Z_OK && zr != Z_STREAM_END) || !made || first[0] == '@' || dd::has_plus_line(first, made)) return false;
     }
-    fb.len = n;
     out_size = total;
     return true;
 }
@@ -1067,10 +1073,11 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             if (FILE* f = fopen(paths[i], "rb")) {
                 const size_t got = fread(magic, 1, sizeof magic, f);
                 plain = got >= 2 && !(magic[0] == 0x1f && magic[1] == 0x8b);
-                // a large gzip file that is not BGZF (no 'BC' extra field) and may be ONE member: its compressed bytes are read
+                // a large gzip file -- BGZF, or one that may be ONE member --: its compressed bytes are read
                 // like a plain file's, by several loaders (one fread of a 700 MB file held the device path back 150 ms)
-                if (!plain && gpu_gunzip && got == sizeof magic && magic[2] == 8 && (size_t)sb.st_size >= raw_pieces_from && gzip_member_size_ok((size_t)sb.st_size) &&
-                    !((magic[3] & 4) && magic[12] == 'B' && magic[13] == 'C'))
+                const bool bc = (magic[3] & 4) && magic[12] == 'B' && magic[13] == 'C';   // BGZF's extra field
+                if (!plain && got == sizeof magic && magic[2] == 8 && (size_t)sb.st_size >= raw_pieces_from && (size_t)sb.st_size < ((size_t)3 << 30) &&
+                    (bc ? gpu_inflate : (gpu_gunzip && gzip_member_size_ok((size_t)sb.st_size))))
                     plain = slots[i].gz_raw = true;
                 fclose(f);
             }
@@ -1168,7 +1175,8 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
                 // read_fasta_file has done the same for the files that came through zlib)
                 if (it.len && ok && sl.gz_raw) {
                     // the compressed file is whole: one member for the device, or (FASTQ, an odd header) the host decoder after all
-                    if (gzip_member_parse(fb.p, sl.plain_size, sl.gm)) sl.dev_gunzip = true, sl.out_size = sl.gm.isize;
+                    if (bgzf_parse(fb.p, sl.plain_size, sl.blks, sl.out_size)) sl.dev_inflate = true;
+                    else if (gpu_gunzip && gzip_member_parse(fb.p, sl.plain_size, sl.gm)) sl.dev_gunzip = true, sl.out_size = sl.gm.isize;
                     else ok = read_fasta_file(paths[it.file], fb, err, gz_par);
                 } else if (it.len && ok) {
                     for (const Item& o : items)

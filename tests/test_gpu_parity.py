@@ -601,12 +601,14 @@ def test_single_member_gzip_files_are_inflated_on_the_device(engine_factory, orc
     fqbig = b"".join(b"@r%d\n" % i + seq[120 * i:120 * i + 120] + b"\n+\n" + b"I" * 120 + b"\n" for i in range(24000))
     (tmp_path / "bigreads.fq.gz").write_bytes(member(fqbig, 1))
     (tmp_path / "bigtwo.fa.gz").write_bytes(member(uniform[:2_000_000], 1) + member(uniform[2_000_000:], 1))
-    for name in ("big.fa.gz", "bigreads.fq.gz", "bigtwo.fa.gz"):
+    (tmp_path / "bigblocks.fa.gz").write_bytes(_bgzf(big, level=1))       # BGZF takes the same way in
+    for name in ("big.fa.gz", "bigreads.fq.gz", "bigtwo.fa.gz", "bigblocks.fa.gz"):
         assert (tmp_path / name).stat().st_size > (1 << 20), name
-    got = eng.sketch_files([str(tmp_path / "big.fa.gz"), str(tmp_path / "bigreads.fq.gz"), str(tmp_path / "bigtwo.fa.gz")], 19, 21, nthreads=4)
+    got = eng.sketch_files([str(tmp_path / n) for n in ("big.fa.gz", "bigreads.fq.gz", "bigtwo.fa.gz", "bigblocks.fa.gz")], 19, 21, nthreads=4)
     assert np.array_equal(got[0], eng.sketch_buffer(np.frombuffer(big, np.uint8), 19, 21))
     assert np.array_equal(got[1], eng.sketch_buffer(np.frombuffer(fqbig, np.uint8), 19, 21))
     assert np.array_equal(got[2], eng.sketch_buffer(np.frombuffer(uniform, np.uint8), 19, 21))
+    assert np.array_equal(got[3], got[0])
 
 
 def test_damaged_single_member_gzip_is_refused_or_read_like_zlib(orc, torch_cuda, tmp_path, monkeypatch):
