@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--profile", default=None, help="sub-command to run under cProfile (tree|progressive|kij)")
     ap.add_argument("--hillclimb", action="store_true", help="no --ksweep: DandD's default argmax-k search from -k 12")
+    ap.add_argument("--gz", type=int, default=None, help="write the genomes as .fasta.gz (one gzip member, this zlib level): what genome directories really hold")
     args = ap.parse_args()
 
     work = args.dir or tempfile.mkdtemp(prefix="dandd_e2e_")
@@ -46,7 +47,13 @@ def main():
     for g in range(args.ngenomes):
         eng.synth_fasta_device(0xD4ADD, g, nb, 5, buf.data_ptr())
         eng.synchronize()
-        buf[:n].cpu().numpy().tofile(os.path.join(gdir, f"g{g:03d}.fasta"))
+        if args.gz is None:
+            buf[:n].cpu().numpy().tofile(os.path.join(gdir, f"g{g:03d}.fasta"))
+        else:
+            import zlib
+            co = zlib.compressobj(args.gz, zlib.DEFLATED, 31)
+            with open(os.path.join(gdir, f"g{g:03d}.fasta.gz"), "wb") as f:
+                f.write(co.compress(buf[:n].cpu().numpy().tobytes()) + co.flush())
     del eng, buf
     t_gen = time.time() - t0
 
