@@ -21,6 +21,7 @@ for P in 14 16 20; do
   timeout 900 python3 bench.py --config cfg5share --log2m $P --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_cfg5share_p$P.json 2> $OUT/bench_cfg5share_p$P.err
 done
 { python3 scripts/bgzf_probe.py 10 50 14; python3 scripts/bgzf_probe.py 64 5 14; python3 scripts/bgzf_probe.py 3 300 14; } 2>/dev/null | grep -E "bgzf|plain" > $OUT/bgzf_probe.txt
+{ for a in "10 50 6" "10 50 1" "64 5 6" "1 400 6" "3 300 6"; do echo "== $a"; python3 scripts/gunzip_probe.py $a 2>/dev/null | grep -E "files of|median|REFUSED|False"; done; } > $OUT/gunzip_probe.txt
 timeout 600 python3 bench.py --gpus 1 --force-dist --steps 10 --warmup 2 --no-cpu-baseline --no-accuracy --no-secondary --no-ingest > $OUT/bench_rccl_world1.json 2> $OUT/bench_rccl_world1.err
 { python3 scripts/e2e_cli.py 10 50 --registers 14; python3 scripts/e2e_cli.py 10 50 --registers 20; python3 scripts/e2e_cli.py 64 5 --mink 10 --maxk 40; } 2>/dev/null | grep workload > $OUT/e2e_cli.txt
 python3 - <<PY
@@ -35,4 +36,4 @@ for f in sorted(glob.glob("$OUT/bench_*.json")):
         print(os.path.basename(f), "ERR", e)
 PY
 cat $OUT/e2e_cli.txt | cut -c1-330
-cat $OUT/bgzf_probe.txt
+cat $OUT/bgzf_probe.txt $OUT/gunzip_probe.txt
