@@ -1370,7 +1370,7 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             continue;
         }
         hipError_t e = hipSuccess;
-        hipStream_t cs = ((njobs || nmem) && set) ? c->copy_stream_b : c->copy_stream;
+        hipStream_t cs = ((njobs || nmem) && set && !getenv("DD_ONE_COPY_STREAM")) ? c->copy_stream_b : c->copy_stream;
         std::vector<const uint8_t*> ptrs(count);
         dd::InflateJob* jobs_host = njobs ? static_cast<dd::InflateJob*>(c->pipe_jobs_host[set].p) : nullptr;
         size_t nj = 0;

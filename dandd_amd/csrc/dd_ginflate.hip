@@ -961,8 +961,9 @@ DD_D const uint16_t* piece_symbols(const RawFile& rf, uint32_t i, const uint32_t
 // 32 KiB of symbols -- placeholders looked up in the window -- (and, of a shorter piece, the window's tail in front of
 // them) become the next window.  ~3 us per piece: a chain of a few hundred steps per file, the files side by side.
 __global__ __launch_bounds__(1024) void windows_kernel(const RawFile* __restrict__ files, const uint32_t* __restrict__ lens, const uint32_t* __restrict__ over,
-                                                       const uint32_t* __restrict__ abase) {
+                                                       const uint32_t* __restrict__ abase, const uint32_t* __restrict__ errors) {
     extern __shared__ __attribute__((aligned(16))) uint8_t win[];   // [2][32768]
+    if (*errors) return;   // (a refused batch: lengths and offsets may not fit each other; the call goes to the host anyway)
     const RawFile rf = files[blockIdx.x];
     for (uint32_t t = threadIdx.x; t < 32768u / 4u; t += 1024u) reinterpret_cast<uint32_t*>(win)[t] = 0;
     __syncthreads();
@@ -1012,7 +1013,8 @@ __global__ __launch_bounds__(1024) void windows_kernel(const RawFile* __restrict
 // symbols -> text: one workgroup per 64 KiB of a file's text; a placeholder is looked up in the window in front of its piece
 __global__ __launch_bounds__(256) void translate_kernel(const RawFile* __restrict__ files, int nfiles, const uint32_t* __restrict__ chunk0,
                                                         const uint32_t* __restrict__ lens, const uint32_t* __restrict__ offs, const uint32_t* __restrict__ over,
-                                                        const uint32_t* __restrict__ abase) {
+                                                        const uint32_t* __restrict__ abase, const uint32_t* __restrict__ errors) {
+    if (*errors) return;
     int f = 0;
     while (f + 1 < nfiles && blockIdx.x >= chunk0[f + 1]) ++f;
     const RawFile rf = files[f];
@@ -1034,7 +1036,9 @@ __global__ __launch_bounds__(256) void translate_kernel(const RawFile* __restric
 }
 
 // CRC-32 of every 64 KiB of the texts (one wave each): the host combines them (zlib's crc32_combine) and compares with the trailer's
-__global__ __launch_bounds__(64) void chunk_crc_kernel(const RawFile* __restrict__ files, int nfiles, const uint32_t* __restrict__ chunk0, uint32_t* __restrict__ crcs) {
+__global__ __launch_bounds__(64) void chunk_crc_kernel(const RawFile* __restrict__ files, int nfiles, const uint32_t* __restrict__ chunk0, uint32_t* __restrict__ crcs,
+                                                       const uint32_t* __restrict__ errors) {
+    if (*errors) return;
     int f = 0;
     while (f + 1 < nfiles && blockIdx.x >= uni(chunk0[f + 1])) ++f;
     const RawFile rf = files[f];
@@ -1079,10 +1083,10 @@ void launch_gunzip_members(const RawFile* files_dev, int nfiles, int npieces, in
     hipLaunchKernelGGL(inflate_kernel<1>, grid, wave, kInflateLds, st, nullptr, files_dev, nfiles, starts, lens, over, nullptr, errors_dev);   // (the pieces marked in `over` only)
     hipLaunchKernelGGL(piece_offsets_kernel, dim3((unsigned)nfiles), wave, 0, st, files_dev, lens, over, offs, abase, errors_dev);
     hipLaunchKernelGGL(inflate_kernel<2>, grid, wave, kInflateLds, st, nullptr, files_dev, nfiles, starts, lens, over, abase, errors_dev);
-    hipLaunchKernelGGL(windows_kernel, dim3((unsigned)nfiles), dim3(1024), 65536, st, files_dev, lens, over, abase);
+    hipLaunchKernelGGL(windows_kernel, dim3((unsigned)nfiles), dim3(1024), 65536, st, files_dev, lens, over, abase, errors_dev);
     if (nchunks > 0) {
-        hipLaunchKernelGGL(translate_kernel, dim3((unsigned)nchunks), dim3(256), 0, st, files_dev, nfiles, chunk0_dev, lens, offs, over, abase);
-        hipLaunchKernelGGL(chunk_crc_kernel, dim3((unsigned)nchunks), wave, kInflateLds, st, files_dev, nfiles, chunk0_dev, crcs_dev);
+        hipLaunchKernelGGL(translate_kernel, dim3((unsigned)nchunks), dim3(256), 0, st, files_dev, nfiles, chunk0_dev, lens, offs, over, abase, errors_dev);
+        hipLaunchKernelGGL(chunk_crc_kernel, dim3((unsigned)nchunks), wave, kInflateLds, st, files_dev, nfiles, chunk0_dev, crcs_dev, errors_dev);
     }
 }
 
