@@ -864,7 +864,7 @@ static bool bgzf_parse(const uint8_t* data, size_t n, std::vector<BgzfBlock>& bl
         const uint8_t* t = data + p + bs - 4;
         const size_t isize = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
         if (isize > 65536) return false;
-        if (isize) blks.push_back(BgzfBlock{p, (uint32_t)bs, (uint32_t)isize, total});
+        blks.push_back(BgzfBlock{p, (uint32_t)bs, (uint32_t)isize, total});   // (empty members too -- the EOF block --: their CRC-32 and ISIZE are checked like any other's)
         total += isize;
         p += bs;
     }
