@@ -1488,6 +1488,13 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
         }
     }
     for (auto& t : pool) t.join();
+    // (a 3 Gbp assembly's .gz takes 16 GB of symbol area per buffer set: a long-lived context does not keep that for the next
+    // directory of bacterial genomes; every batch has been retired, nothing reads these any more)
+    for (int k2 = 0; k2 < 2; ++k2)
+        if (c->pipe_sym[k2].cap > ((size_t)4 << 30)) {
+            c->pipe_sym[k2].release();
+            c->pipe_win[k2].release();
+        }
     c->ingest_ms[0] = now() - t_begin;
     c->ingest_ms[1] = t_wait;
     c->ingest_ms[2] = nbatches;
