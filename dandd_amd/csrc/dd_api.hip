@@ -1313,7 +1313,7 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
         };
         // a range's symbols: 5 x its compressed bytes (DNA inflates 3-4 x) + 32 Ki; a piece that needs more takes the arena
         auto range_syms_of = [&](size_t guess_bits) { return 5 * (guess_bits / 8) + 32768; };
-        size_t nmem = 0, npieces = 0, nchunks = 0, sym_tot = 0, win_tot = 0;
+        size_t nmem = 0, npieces = 0, nchunks = 0, sym_tot = 0, win_tot = 0, ngroups = 0;
         for (int j = 0; j < count; ++j) {
             const Slot& sj = slots[i + j];
             sizes[j] = (sj.dev_inflate || sj.dev_gunzip) ? sj.out_size : c->file_pool[sj.buf]->size();
@@ -1332,7 +1332,8 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
                 npieces += ng;
                 nchunks += (sj.gm.isize + 65535u) / 65536u;
                 sym_tot += align_up(ng * range_syms * 2 + 256, 256) + align_up((size_t)sj.gm.isize * 2 + 256, 256);   // the ranges' symbols, the arena
-                win_tot += ng * 32768;
+                win_tot += align_up(dd::gunzip_window_bytes(ng), 256);
+                ngroups += (ng + dd::kPieceGroup - 1) / dd::kPieceGroup;
             }
         }
         // the piece tables of the batch's single-member gzip files, one block of device memory: RawFile[nmem],
@@ -1376,7 +1377,7 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
         size_t nj = 0;
         dd::RawFile* raw_host = nmem ? static_cast<dd::RawFile*>(c->pipe_raw_host[set].p) : nullptr;
         uint32_t* chunk0_host = nmem ? reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(c->pipe_raw_host[set].p) + raw_files) : nullptr;
-        size_t mi = 0, piece_at = 0, chunk_at = 0, sym_at = 0, win_at = 0;
+        size_t mi = 0, piece_at = 0, chunk_at = 0, sym_at = 0, win_at = 0, group_at = 0;
         std::vector<InFlight::Member> members;
         for (int j = 0; j < count && e == hipSuccess; ++j) {
             ptrs[j] = static_cast<const uint8_t*>(c->pipe_fasta[set].p) + offs[j];
@@ -1405,13 +1406,16 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
                 rf.range_syms = (uint32_t)range_syms;
                 rf.arena = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(c->pipe_sym[set].p) + sym_at + align_up(ng * range_syms * 2 + 256, 256));
                 rf.windows = static_cast<uint8_t*>(c->pipe_win[set].p) + win_at;
+                rf.group0 = (uint32_t)group_at;
+                rf.ngroups = (uint32_t)((ng + dd::kPieceGroup - 1) / dd::kPieceGroup);
                 rf.text = const_cast<uint8_t*>(ptrs[j]);
                 chunk0_host[mi] = (uint32_t)chunk_at;
                 members.push_back(InFlight::Member{(uint32_t)chunk_at, (sj.gm.isize + 65535u) / 65536u, sj.gm.isize, sj.gm.crc});
                 piece_at += ng;
                 chunk_at += (sj.gm.isize + 65535u) / 65536u;
                 sym_at += align_up(ng * range_syms * 2 + 256, 256) + align_up((size_t)sj.gm.isize * 2 + 256, 256);
-                win_at += ng * 32768;
+                win_at += align_up(dd::gunzip_window_bytes(ng), 256);
+                group_at += (ng + dd::kPieceGroup - 1) / dd::kPieceGroup;
                 ++mi;
             } else if (sizes[j]) {
                 e = hipMemcpyAsync(const_cast<uint8_t*>(ptrs[j]), fbj.data(), sizes[j], hipMemcpyHostToDevice, cs);
@@ -1426,7 +1430,7 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             if (e == hipSuccess) e = hipMemcpyAsync(rb + raw_files + 6 * raw_u32, chunk0_host, (nmem + 1) * 4, hipMemcpyHostToDevice, cs);
             if (e == hipSuccess) {
                 uint32_t* crcs_dev = reinterpret_cast<uint32_t*>(rb + raw_files + 6 * raw_u32 + raw_chunk0);
-                dd::launch_gunzip_members(reinterpret_cast<const dd::RawFile*>(rb), (int)nmem, (int)npieces, (int)nchunks, reinterpret_cast<uint64_t*>(rb + raw_files),
+                dd::launch_gunzip_members(reinterpret_cast<const dd::RawFile*>(rb), (int)nmem, (int)npieces, (int)ngroups, (int)nchunks, reinterpret_cast<uint64_t*>(rb + raw_files),
                                           reinterpret_cast<uint32_t*>(rb + raw_files + 2 * raw_u32), raw_u32 / 4,
                                           reinterpret_cast<const uint32_t*>(rb + raw_files + 6 * raw_u32), crcs_dev, static_cast<uint32_t*>(c->pipe_err[set].p), cs);
                 e = hipGetLastError();

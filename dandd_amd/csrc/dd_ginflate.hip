@@ -956,51 +956,66 @@ DD_D const uint16_t* piece_symbols(const RawFile& rf, uint32_t i, const uint32_t
     return over[rf.piece0 + i] ? rf.arena + abase[rf.piece0 + i] : rf.sym + (size_t)i * rf.range_syms;
 }
 
-// The windows: what the 32 KiB in front of every piece hold.  One workgroup per file walks its pieces in order with the
-// current window in LDS: the window in front of piece i is stored for the translation below, then the piece's last
-// 32 KiB of symbols -- placeholders looked up in the window -- (and, of a shorter piece, the window's tail in front of
-// them) become the next window.  ~3 us per piece: a chain of a few hundred steps per file, the files side by side.
-__global__ __launch_bounds__(1024) void windows_kernel(const RawFile* __restrict__ files, const uint32_t* __restrict__ lens, const uint32_t* __restrict__ over,
-                                                       const uint32_t* __restrict__ abase, const uint32_t* __restrict__ errors) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t win[];   // [2][32768]
+// What stands in the 32 KiB in front of every piece?  Piece i turns the window in front of it into the window behind it:
+// every position of the new window is a byte of the piece or a position of the old window -- a MAP of 32 768 16-bit
+// entries, and maps compose.  Walking a file's pieces one after the other with the window in LDS cost ~7 us a piece on ONE
+// CU (52 of the 241 ms of a 3 Gbp assembly's 7 500 pieces) while the chip waited.  Two levels instead:
+//   piece_maps_kernel     a workgroup per GROUP of 32 ranges, all groups of all files side by side: starting from the
+//                         identity, compose the group's pieces; the map in front of each piece (relative to the group's
+//                         start) is stored, and the group's whole map at the end
+//   group_windows_kernel  a workgroup per file walks its GROUPS (a 32nd of the steps): the window at each group's start
+//   translate_kernel      a placeholder goes through its piece's map and, if that still points in front of the group, through
+//                         the group's window
+// A thread owns the window positions t, t + 1024, ..: a wave's symbol loads are 128 contiguous bytes, and a step's symbols
+// are asked for a step ahead (the chain waits for LDS and a barrier per piece, not for HBM).
+DD_D uint16_t* piece_map(const RawFile& rf, uint32_t i) { return reinterpret_cast<uint16_t*>(rf.windows) + (size_t)i * 32768u; }
+DD_D uint16_t* group_map(const RawFile& rf, uint32_t g) { return reinterpret_cast<uint16_t*>(rf.windows) + ((size_t)rf.nguess + g) * 32768u; }
+DD_D uint8_t* group_window(const RawFile& rf, uint32_t g) { return rf.windows + ((size_t)rf.nguess + rf.ngroups) * 65536u + (size_t)g * 32768u; }
+
+__global__ __launch_bounds__(1024) void piece_maps_kernel(const RawFile* __restrict__ files, int nfiles, const uint32_t* __restrict__ lens,
+                                                          const uint32_t* __restrict__ over, const uint32_t* __restrict__ abase, const uint32_t* __restrict__ errors) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t win[];   // u16 [2][32768]
     if (*errors) return;   // (a refused batch: lengths and offsets may not fit each other; the call goes to the host anyway)
-    const RawFile rf = files[blockIdx.x];
-    for (uint32_t t = threadIdx.x; t < 32768u / 4u; t += 1024u) reinterpret_cast<uint32_t*>(win)[t] = 0;
+    int f = 0;
+    while (f + 1 < nfiles && blockIdx.x >= files[f + 1].group0) ++f;
+    const RawFile rf = files[f];
+    const uint32_t g = blockIdx.x - rf.group0;
+    if (g >= rf.ngroups) return;
+    const uint32_t first = g * kPieceGroup, last = first + kPieceGroup < rf.nguess ? first + kPieceGroup : rf.nguess;
+    uint16_t* maps = reinterpret_cast<uint16_t*>(win);
+    const uint32_t t0 = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) maps[t0 + 1024u * q] = (uint16_t)(0x8000u | (t0 + 1024u * q));   // the identity
     __syncthreads();
-    // A step's symbols are asked for a step ahead: the chain then waits for LDS and a barrier per piece, not for HBM
-    // (17 us per piece when every step loaded its own: 8.5 ms for the 500 pieces of a 50 Mbp file).  A thread owns the
-    // window positions t, t + 1024, ..: a wave's loads are 128 contiguous bytes (32 consecutive positions per thread made
-    // every wave-load touch 64 cache lines: 20 us per piece).
     auto next_piece = [&](uint32_t i) {   // first piece with text at or behind i
-        while (i < rf.nguess && lens[rf.piece0 + i] == 0u) ++i;
+        while (i < last && lens[rf.piece0 + i] == 0u) ++i;
         return i;
     };
-    const uint32_t t0 = threadIdx.x;
     uint16_t cur_s[32], nxt_s[32];
     auto fetch = [&](uint32_t i, uint16_t (&dst)[32]) {
-        if (i >= rf.nguess) return;
+        if (i >= last) return;
         const uint32_t L = lens[rf.piece0 + i];
         const uint16_t* const s = piece_symbols(rf, i, over, abase);
         const int p0 = (int)L - 32768 + (int)t0;
 #pragma unroll
         for (int q = 0; q < 32; ++q) dst[q] = (p0 + 1024 * q >= 0) ? s[p0 + 1024 * q] : (uint16_t)0;
     };
-    uint32_t i = next_piece(0), cur = 0;
+    uint32_t i = next_piece(first), cur = 0;
     fetch(i, cur_s);
-    while (i < rf.nguess) {
+    while (i < last) {
         const uint32_t L = lens[rf.piece0 + i], inext = next_piece(i + 1u);
         fetch(inext, nxt_s);
-        uint8_t* const before = rf.windows + (size_t)i * 32768u;
-        const uint8_t* const w = win + cur * 32768u;
-        uint8_t* const nw = win + (cur ^ 1u) * 32768u;
+        uint16_t* const before = piece_map(rf, i);
+        const uint16_t* const w = maps + cur * 32768u;
+        uint16_t* const nw = maps + (cur ^ 1u) * 32768u;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) reinterpret_cast<uint32_t*>(before)[t0 + 1024u * q] = reinterpret_cast<const uint32_t*>(w)[t0 + 1024u * q];
+        for (int q = 0; q < 16; ++q) reinterpret_cast<uint32_t*>(before)[t0 + 1024u * q] = reinterpret_cast<const uint32_t*>(w)[t0 + 1024u * q];
 #pragma unroll
         for (int q = 0; q < 32; ++q) {
             const uint32_t pos = t0 + 1024u * q;
             const int p = (int)L - 32768 + (int)pos;
             const uint32_t sy = cur_s[q];
-            nw[pos] = (uint8_t)(p >= 0 ? ((sy & 0x8000u) ? (uint32_t)w[sy & 0x7fffu] : sy) : (uint32_t)w[pos + L]);
+            nw[pos] = (uint16_t)(p >= 0 ? ((sy & 0x8000u) ? (uint32_t)w[sy & 0x7fffu] : sy) : (uint32_t)w[pos + L]);
         }
         __syncthreads();
 #pragma unroll
@@ -1008,9 +1023,49 @@ __global__ __launch_bounds__(1024) void windows_kernel(const RawFile* __restrict
         cur ^= 1u;
         i = inext;
     }
+    uint16_t* const gm = group_map(rf, g);
+    const uint16_t* const w = maps + cur * 32768u;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) reinterpret_cast<uint32_t*>(gm)[t0 + 1024u * q] = reinterpret_cast<const uint32_t*>(w)[t0 + 1024u * q];
 }
 
-// symbols -> text: one workgroup per 64 KiB of a file's text; a placeholder is looked up in the window in front of its piece
+__global__ __launch_bounds__(1024) void group_windows_kernel(const RawFile* __restrict__ files, const uint32_t* __restrict__ errors) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t win[];   // u8 [2][32768]
+    if (*errors) return;
+    const RawFile rf = files[blockIdx.x];
+    const uint32_t t0 = threadIdx.x;
+    for (uint32_t t = t0; t < 32768u / 4u; t += 1024u) reinterpret_cast<uint32_t*>(win)[t] = 0;   // nothing stands in front of the stream
+    __syncthreads();
+    uint16_t cur_m[32], nxt_m[32];
+    auto fetch = [&](uint32_t g, uint16_t (&dst)[32]) {
+        if (g >= rf.ngroups) return;
+        const uint16_t* const m = group_map(rf, g);
+#pragma unroll
+        for (int q = 0; q < 32; ++q) dst[q] = m[t0 + 1024u * q];
+    };
+    uint32_t cur = 0;
+    fetch(0, cur_m);
+    for (uint32_t g = 0; g < rf.ngroups; ++g) {
+        fetch(g + 1u, nxt_m);
+        uint8_t* const at_start = group_window(rf, g);
+        const uint8_t* const w = win + cur * 32768u;
+        uint8_t* const nw = win + (cur ^ 1u) * 32768u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) reinterpret_cast<uint32_t*>(at_start)[t0 + 1024u * q] = reinterpret_cast<const uint32_t*>(w)[t0 + 1024u * q];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const uint32_t v = cur_m[q];
+            nw[t0 + 1024u * q] = (uint8_t)((v & 0x8000u) ? (uint32_t)w[v & 0x7fffu] : v);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 32; ++q) cur_m[q] = nxt_m[q];
+        cur ^= 1u;
+    }
+}
+
+// symbols -> text: one workgroup per 64 KiB of a file's text; a placeholder is looked up in the map in front of its piece and, if
+// that points in front of the piece's group, in the window at the group's start
 __global__ __launch_bounds__(256) void translate_kernel(const RawFile* __restrict__ files, int nfiles, const uint32_t* __restrict__ chunk0,
                                                         const uint32_t* __restrict__ lens, const uint32_t* __restrict__ offs, const uint32_t* __restrict__ over,
                                                         const uint32_t* __restrict__ abase, const uint32_t* __restrict__ errors) {
@@ -1030,8 +1085,12 @@ __global__ __launch_bounds__(256) void translate_kernel(const RawFile* __restric
     uint32_t pi = lo;
     for (uint32_t p = begin + threadIdx.x; p < end; p += 256u) {
         while (pi + 1u < rf.nguess && (lens[rf.piece0 + pi] == 0u || p >= offs[rf.piece0 + pi] + lens[rf.piece0 + pi])) ++pi;
-        const uint32_t sy = piece_symbols(rf, pi, over, abase)[p - offs[rf.piece0 + pi]];
-        rf.text[p] = (uint8_t)((sy & 0x8000u) ? rf.windows[(size_t)pi * 32768u + (sy & 0x7fffu)] : sy);
+        uint32_t sy = piece_symbols(rf, pi, over, abase)[p - offs[rf.piece0 + pi]];
+        if (sy & 0x8000u) {
+            sy = piece_map(rf, pi)[sy & 0x7fffu];
+            if (sy & 0x8000u) sy = group_window(rf, pi / kPieceGroup)[sy & 0x7fffu];
+        }
+        rf.text[p] = (uint8_t)sy;
     }
 }
 
@@ -1060,7 +1119,8 @@ static void inflate_attributes() {
     for (const void* k : {reinterpret_cast<const void*>(inflate_kernel<0>), reinterpret_cast<const void*>(inflate_kernel<1>), reinterpret_cast<const void*>(inflate_kernel<2>), reinterpret_cast<const void*>(inflate_kernel<3>),
                           reinterpret_cast<const void*>(find_starts_kernel), reinterpret_cast<const void*>(chunk_crc_kernel)})
         if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFindLds) != hipSuccess) (void)hipGetLastError();
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(windows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess) (void)hipGetLastError();
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(piece_maps_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072) != hipSuccess) (void)hipGetLastError();
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(group_windows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess) (void)hipGetLastError();
     done.fetch_or(bit, std::memory_order_relaxed);
 }
 
@@ -1072,7 +1132,7 @@ void launch_inflate_bgzf(const InflateJob* jobs_dev, int njobs, uint32_t* errors
 
 // Single-member gzip files on the device: block starts -> piece lengths -> offsets -> symbols -> windows -> text -> CRCs.
 // npieces = sum of the files' nguess; nchunks = sum of their 64 KiB text chunks (chunk0_dev: first chunk of each file, nfiles + 1 entries).
-void launch_gunzip_members(const RawFile* files_dev, int nfiles, int npieces, int nchunks, uint64_t* starts, uint32_t* tables_dev, size_t stride,
+void launch_gunzip_members(const RawFile* files_dev, int nfiles, int npieces, int ngroups, int nchunks, uint64_t* starts, uint32_t* tables_dev, size_t stride,
                            const uint32_t* chunk0_dev, uint32_t* crcs_dev, uint32_t* errors_dev, hipStream_t st) {
     if (nfiles <= 0 || npieces <= 0) return;
     inflate_attributes();
@@ -1083,7 +1143,8 @@ void launch_gunzip_members(const RawFile* files_dev, int nfiles, int npieces, in
     hipLaunchKernelGGL(inflate_kernel<1>, grid, wave, kInflateLds, st, nullptr, files_dev, nfiles, starts, lens, over, nullptr, errors_dev);   // (the pieces marked in `over` only)
     hipLaunchKernelGGL(piece_offsets_kernel, dim3((unsigned)nfiles), wave, 0, st, files_dev, lens, over, offs, abase, errors_dev);
     hipLaunchKernelGGL(inflate_kernel<2>, grid, wave, kInflateLds, st, nullptr, files_dev, nfiles, starts, lens, over, abase, errors_dev);
-    hipLaunchKernelGGL(windows_kernel, dim3((unsigned)nfiles), dim3(1024), 65536, st, files_dev, lens, over, abase, errors_dev);
+    hipLaunchKernelGGL(piece_maps_kernel, dim3((unsigned)ngroups), dim3(1024), 131072, st, files_dev, nfiles, lens, over, abase, errors_dev);
+    hipLaunchKernelGGL(group_windows_kernel, dim3((unsigned)nfiles), dim3(1024), 65536, st, files_dev, errors_dev);
     if (nchunks > 0) {
         hipLaunchKernelGGL(translate_kernel, dim3((unsigned)nchunks), dim3(256), 0, st, files_dev, nfiles, chunk0_dev, lens, offs, over, abase, errors_dev);
         hipLaunchKernelGGL(chunk_crc_kernel, dim3((unsigned)nchunks), wave, kInflateLds, st, files_dev, nfiles, chunk0_dev, crcs_dev, errors_dev);

@@ -239,12 +239,20 @@ struct RawFile {
                                 //   a piece that starts in range j and runs over r ranges owns r x range_syms of them
     uint32_t range_syms;
     uint16_t* arena;            // [isize]: the symbols of pieces too long for their ranges (counted first, then written here)
-    uint8_t* windows;           // [nguess][32768]: those 32 KiB, per piece
+    uint8_t* windows;           // what stands in the 32 KiB in front of every piece, in two levels (dd_ginflate.hip: piece_maps_kernel):
+                                //   u16 [nguess][32768] maps relative to the piece's group start, u16 [ngroups][32768] the groups' own maps,
+                                //   u8 [ngroups][32768] the windows at the groups' starts
+    uint32_t group0, ngroups;   // groups of kPieceGroup ranges; group0 = this file's first group in the batch
     uint8_t* text;              // [isize] where the text goes
 };
 size_t inflate_lds_bytes();
 // starts_dev: npieces u64 (bit positions); tables_dev: four arrays of npieces u32 (lens, offs, over, abase), `stride` words apart
-void launch_gunzip_members(const RawFile* files_dev, int nfiles, int npieces, int nchunks, uint64_t* starts_dev, uint32_t* tables_dev, size_t stride,
+constexpr uint32_t kPieceGroup = 32;
+inline size_t gunzip_window_bytes(size_t nguess) {   // the `windows` area of a file with that many ranges
+    const size_t ngroups = (nguess + kPieceGroup - 1) / kPieceGroup;
+    return nguess * 65536 + ngroups * (65536 + 32768);
+}
+void launch_gunzip_members(const RawFile* files_dev, int nfiles, int npieces, int ngroups, int nchunks, uint64_t* starts_dev, uint32_t* tables_dev, size_t stride,
                            const uint32_t* chunk0_dev, uint32_t* crcs_dev, uint32_t* errors_dev, hipStream_t st);
 // *errors_dev += blocks that did not decode (the caller falls back to the host decoder)
 void launch_inflate_bgzf(const InflateJob* jobs_dev, int njobs, uint32_t* errors_dev, hipStream_t st);
