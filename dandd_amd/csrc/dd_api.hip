@@ -1340,6 +1340,13 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
         // starts (u64) / lens / offs / over / abase [npieces], chunk0 [nmem + 1], crcs [nchunks]
         const size_t raw_files = align_up(nmem * sizeof(dd::RawFile), 256), raw_u32 = align_up(npieces * 4, 256), raw_chunk0 = align_up((nmem + 1) * 4, 256);
         const size_t raw_bytes = raw_files + 6 * raw_u32 + raw_chunk0 + align_up(nchunks * 4, 256);   // (starts are 64-bit: two of the six)
+        // (a 3 Gbp assembly's .gz takes 16 GB of symbol area per buffer set: a long-lived context gives that back when a later
+        // batch needs an eighth of it or less -- not at the end of every call: hipFree + hipMalloc of 16 GB per call cost an
+        // occasional 2 s.  The set's previous batch has been retired above: nothing reads the buffer any more.)
+        if (c->pipe_sym[set].cap > ((size_t)4 << 30) && sym_tot <= c->pipe_sym[set].cap / 8) {
+            c->pipe_sym[set].release();
+            c->pipe_win[set].release();
+        }
         if (nmem && ((rc = c->pipe_gz[set].reserve(gz_tot + 16)) != DD_OK || (rc = c->pipe_sym[set].reserve(sym_tot)) != DD_OK ||
                      (rc = c->pipe_win[set].reserve(win_tot)) != DD_OK || (rc = c->pipe_raw[set].reserve(raw_bytes)) != DD_OK ||
                      (rc = c->pipe_raw_host[set].reserve(raw_files + raw_chunk0)) != DD_OK || (rc = c->pipe_crc_host[set].reserve(nchunks * 4 + 256)) != DD_OK ||
@@ -1492,13 +1499,6 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
         }
     }
     for (auto& t : pool) t.join();
-    // (a 3 Gbp assembly's .gz takes 16 GB of symbol area per buffer set: a long-lived context does not keep that for the next
-    // directory of bacterial genomes; every batch has been retired, nothing reads these any more)
-    for (int k2 = 0; k2 < 2; ++k2)
-        if (c->pipe_sym[k2].cap > ((size_t)4 << 30)) {
-            c->pipe_sym[k2].release();
-            c->pipe_win[k2].release();
-        }
     c->ingest_ms[0] = now() - t_begin;
     c->ingest_ms[1] = t_wait;
     c->ingest_ms[2] = nbatches;
