@@ -888,40 +888,16 @@ static bool bgzf_parse(const uint8_t* data, size_t n, std::vector<BgzfBlock>& bl
     return true;
 }
 
-// CRC-32 of a concatenation from the CRCs of its parts (zlib's crc32_combine; this image's zlib 1.2.11 has no
-// crc32_combine_gen, and its crc32_combine squares a 32 x 32 matrix per call: ~3 us x 7 700 chunks held a batch back 20 ms).
-// Reflected polynomial arithmetic as in zlib >= 1.2.12: a(x) b(x) mod P, P = 0xedb88320, bit 31 = x^0.
-static uint32_t crc_multmodp(uint32_t a, uint32_t b) {
-    uint32_t p = 0;
-    for (uint32_t m = 0x80000000u;; m >>= 1) {
-        if (a & m) {
-            p ^= b;
-            if ((a & (m - 1u)) == 0u) break;
-        }
-        b = (b >> 1) ^ ((b & 1u) ? 0xedb88320u : 0u);
-    }
-    return p;
-}
-static uint32_t crc_x8n(uint32_t nbytes) {   // x^(8 nbytes) mod P
-    uint32_t p = 0x80000000u, sq = 0x40000000u;   // x^0, x^1
-    for (int i = 0; i < 3; ++i) sq = crc_multmodp(sq, sq);   // x^8
-    for (; nbytes; nbytes >>= 1, sq = crc_multmodp(sq, sq))
-        if (nbytes & 1u) p = crc_multmodp(sq, p);
-    return p;
-}
-
 // One single-member gzip file for the device path (dd_ginflate.hip: launch_gunzip_members): the raw bytes into `fb`, where
 // the deflate data starts, the trailer's CRC-32 and ISIZE.  false: not a file that path takes (small, huge, not gzip,
 // FASTQ): the host decoder reads it.  (Whether the file is ONE member only the decoding shows: the device refuses a
 // stream whose final block is not followed by exactly the 8 trailer bytes.)
-struct GzMember {
-    uint32_t first_bit = 0, isize = 0, crc = 0;
-};
 static bool gzip_member_size_ok(size_t n) {
     const size_t min_bytes = (size_t)(getenv("DD_GUNZIP_MIN_KB") ? std::max(1, atoi(getenv("DD_GUNZIP_MIN_KB"))) : 1024) << 10;
     return n >= min_bytes && n < ((size_t)3500 << 20);
 }
-static bool gzip_member_parse(const uint8_t* p, size_t n, GzMember& gm);
+using dd::GzMember;
+using dd::gzip_member_parse;
 static bool gzip_member_for_device(const char* path, FileBuf& fb, GzMember& gm) {
     struct stat sb;
     if (stat(path, &sb) != 0 || !S_ISREG(sb.st_mode) || !gzip_member_size_ok((size_t)sb.st_size)) return false;
@@ -935,42 +911,6 @@ static bool gzip_member_for_device(const char* path, FileBuf& fb, GzMember& gm) 
     fb.len = n;
     return true;
 }
-// the same for a file whose bytes are in memory already (large files are read in pieces by several loaders)
-static bool gzip_member_parse(const uint8_t* p, size_t n, GzMember& gm) {
-    if (n < 64 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xE0)) return false;
-    size_t h = 10;
-    if (p[3] & 4) {
-        if (h + 2 > n) return false;
-        h += 2 + ((size_t)p[h] | ((size_t)p[h + 1] << 8));
-    }
-    for (int bit : {8, 16})
-        if (p[3] & bit) {
-            while (h < n && p[h]) ++h;
-            ++h;
-        }
-    if (p[3] & 2) h += 2;
-    if (h + 16 > n) return false;
-    const uint8_t* t = p + n - 8;
-    gm.first_bit = (uint32_t)(8 * h);
-    gm.crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
-    gm.isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
-    if (gm.isize < n / 2 || (size_t)gm.isize > (size_t)1032 * n) return false;   // (a multi-member file's last ISIZE is usually smaller than the file)
-    // FASTQ needs the host's record pass: look at the first bytes of text
-    uint8_t first[256];
-    z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    if (inflateInit2(&zs, 15 + 16) != Z_OK) return false;
-    zs.next_in = const_cast<uint8_t*>(p);
-    zs.avail_in = (uInt)std::min<size_t>(n, 1 << 16);
-    zs.next_out = first;
-    zs.avail_out = sizeof first;
-    const int zr = inflate(&zs, Z_SYNC_FLUSH);
-    const size_t made = sizeof first - zs.avail_out;
-    inflateEnd(&zs);
-    if ((zr != Z_OK && zr != Z_STREAM_END) || !made || first[0] == '@' || dd::has_plus_line(first, made)) return false;
-    return true;
-}
-
 static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, int kmin, int kmax, uint8_t* regs, int nthreads) {
     if (nfiles < 0 || (nfiles && (!paths || !regs))) return fail(DD_EINVAL, "null argument");
     if (kmin < 1 || kmax > 64 || kmin > kmax) return fail(DD_EINVAL, "k range %d..%d outside 1..64", kmin, kmax);
@@ -1219,10 +1159,10 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             const uint32_t* crcs = static_cast<const uint32_t*>(c->pipe_crc_host[set].p);
             for (const InFlight::Member& m : f.members) {
                 uint32_t crc = 0;
-                const uint32_t full = crc_x8n(65536u);
+                const uint32_t full = dd::crc_x8n(65536u);
                 for (uint32_t k = 0; k < m.nchunks; ++k) {
                     const uint32_t len = std::min<uint32_t>(65536u, m.isize - k * 65536u);
-                    crc = k ? (crc_multmodp(len == 65536u ? full : crc_x8n(len), crc) ^ crcs[m.chunk0 + k]) : crcs[m.chunk0];
+                    crc = k ? (dd::crc_multmodp(len == 65536u ? full : dd::crc_x8n(len), crc) ^ crcs[m.chunk0 + k]) : crcs[m.chunk0];
                 }
                 if (crc != m.crc) {
                     refused = true;

@@ -245,6 +245,67 @@ static void fastq_rewrite_cases() {
     }
 }
 
+// ---- dd_io.h: what the device decoder's host side does with untrusted bytes ----------------------------------------------
+// gzip_member_parse on real members with every optional header field, on the same members cut short and with random bytes
+// in their first 64 (exactly sized heap copies: ASan sees any read past the end); the chunk-wise CRC-32 combination against
+// zlib's crc32 of the whole
+static std::string gz_member(const std::string& body, int level, int strategy, const std::string& extra);
+static void device_gunzip_host_side() {
+    std::mt19937 rng(20261005);
+    std::string body;
+    for (int i = 0; i < 40000; ++i) body += "ACGT"[rng() % 4];
+    body = ">seq one\n" + body + "\n";
+    const std::string plain = gz_member(body, 5, Z_DEFAULT_STRATEGY, std::string());   // (level 5: the helper writes no name field)
+    {
+        std::vector<uint8_t> v(plain.begin(), plain.end());
+        dd::GzMember gm;
+        CHECK(dd::gzip_member_parse(v.data(), v.size(), gm) && gm.isize == body.size() && gm.first_bit == 80 && gm.crc == (uint32_t)crc32(0, (const Bytef*)body.data(), (uInt)body.size()),
+              "gzip_member_parse: a plain member");
+    }
+    // FEXTRA + FNAME + FCOMMENT + FHCRC in front of the same deflate data
+    for (int flags = 0; flags < 16; ++flags) {
+        std::string h = plain.substr(0, 10);
+        h[3] = (char)((flags & 1 ? 4 : 0) | (flags & 2 ? 8 : 0) | (flags & 4 ? 16 : 0) | (flags & 8 ? 2 : 0));
+        if (flags & 1) h += std::string("\x05\x00" "AB" "\x01\x00" "x", 7);   // XLEN 5: one subfield 'AB' of one byte
+        if (flags & 2) h += std::string("genome.fa") + '\0';
+        if (flags & 4) h += std::string("a comment") + '\0';
+        if (flags & 8) {   // FHCRC: the low half of the CRC-32 of the header so far (zlib checks it)
+            const uint32_t hc = (uint32_t)crc32(0, (const Bytef*)h.data(), (uInt)h.size());
+            h += (char)(hc & 0xff);
+            h += (char)((hc >> 8) & 0xff);
+        }
+        const std::string file = h + plain.substr(10);
+        std::vector<uint8_t> v(file.begin(), file.end());
+        dd::GzMember gm;
+        CHECK(dd::gzip_member_parse(v.data(), v.size(), gm) && gm.first_bit == 8 * h.size() && gm.isize == body.size(), "gzip_member_parse: optional header fields");
+        for (int it = 0; it < 300; ++it) {     // cut short / damaged: any answer, no read outside the copy
+            const size_t cut = 1 + rng() % std::min<size_t>(v.size(), 200);
+            std::vector<uint8_t> w(v.begin(), v.begin() + (rng() % 3 ? (ptrdiff_t)cut : (ptrdiff_t)v.size()));
+            for (int k = 0; k < 4 && !w.empty(); ++k) w[rng() % std::min<size_t>(w.size(), 64)] = (uint8_t)rng();
+            dd::GzMember g2;
+            (void)dd::gzip_member_parse(w.data(), w.size(), g2);
+        }
+    }
+    {   // FASTQ is not for the device
+        const std::string fq = gz_member("@r1\nACGT\n+\nIIII\n" + body, 5, Z_DEFAULT_STRATEGY, std::string());
+        std::vector<uint8_t> v(fq.begin(), fq.end());
+        dd::GzMember gm;
+        CHECK(!dd::gzip_member_parse(v.data(), v.size(), gm), "gzip_member_parse: FASTQ must go to the host");
+    }
+    for (int it = 0; it < 200; ++it) {      // CRC-32 of 64 KiB chunks combined == CRC-32 of the whole
+        const size_t n = 1 + rng() % 300000;
+        std::vector<uint8_t> d(n);
+        for (auto& c : d) c = (uint8_t)rng();
+        const uint32_t full = dd::crc_x8n(65536u);
+        uint32_t crc = 0;
+        for (size_t a = 0; a < n; a += 65536) {
+            const uint32_t len = (uint32_t)std::min<size_t>(65536, n - a), part = (uint32_t)crc32(0, d.data() + a, len);
+            crc = a ? (dd::crc_multmodp(len == 65536u ? full : dd::crc_x8n(len), crc) ^ part) : part;
+        }
+        CHECK(crc == (uint32_t)crc32(0, d.data(), (uInt)n), "CRC-32 combination differs from zlib's crc32");
+    }
+}
+
 // ---- dd_inflate.h: a gzip member decoded in pieces without their history, BGZF blocks in parallel -------------------
 struct TestBuf {   // the part of FileBuf the decoders use
     uint8_t* p = nullptr;
@@ -260,7 +321,8 @@ struct TestBuf {   // the part of FileBuf the decoders use
     }
 };
 
-static std::string gz_member(const std::string& body, int level, int strategy = Z_DEFAULT_STRATEGY, const std::string& extra = std::string()) {
+static std::string gz_member(const std::string& body, int level, int strategy = Z_DEFAULT_STRATEGY, const std::string& extra = std::string());
+static std::string gz_member(const std::string& body, int level, int strategy, const std::string& extra) {
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, strategy);
@@ -422,6 +484,7 @@ int main(int argc, char** argv) {
     check_gzip_edges(argv[1]);
     check_parallel_inflate();
     fastq_rewrite_cases();
+    device_gunzip_host_side();
     if (failures) fprintf(stderr, "%d failure(s)\n", failures);
     else printf("sanitize_host: ok\n");
     return failures ? 1 : 0;
