@@ -34,6 +34,10 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
+OBJDIR = os.path.join(HERE, "build", "obj")
+COMPILE_FLAGS = [f for f in FLAGS if f != "-shared"]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
@@ -42,21 +46,53 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, extra=(), verbose=False):
+def _stale(obj, src):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(d) > t for d in [src, os.path.abspath(__file__)] + [os.path.join(CSRC, h) for h in HEADERS])
+
+
+def build(force=False, extra=(), verbose=False, jobs=None):
+    """One object per source (compiled side by side, kept under dandd_amd/build/obj so that a change to one kernel file
+    recompiles that file only), linked into the one C-ABI library.  No relocatable device code: no kernel calls across files."""
     if not force and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc()] + FLAGS + list(extra) + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lz", "-ldl", "-lpthread"]
+    os.makedirs(OBJDIR, exist_ok=True)
+    cc = hipcc()
+    todo, objs = [], []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJDIR, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or extra or _stale(obj, src):
+            todo.append([cc] + COMPILE_FLAGS + list(extra) + ["-c", src, "-o", obj])
+    jobs = jobs or max(1, min(len(todo), (os.cpu_count() or 2) - 1, int(os.environ.get("DD_BUILD_JOBS", "6"))))
+    running = []
+    for cmd in todo:
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        running.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
+        while len([1 for _, p in running if p.poll() is None]) >= jobs:
+            running[0][1].wait()
+            running = [r for r in running if r[1].poll() is None] + [r for r in running if r[1].poll() not in (None, 0)]
+            if any(p.poll() not in (None, 0) for _, p in running):
+                break
+    bad = [cmd for cmd, p in running if p.wait() != 0]
+    if bad:
+        raise subprocess.CalledProcessError(1, bad[0])
+    link = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs + ["-lz", "-ldl", "-lpthread"]
     if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd, cwd=CSRC)
+        print(" ".join(link), file=sys.stderr)
+    subprocess.check_call(link, cwd=CSRC)
+    os.replace(LIB + ".tmp", LIB)
     return LIB
 
 
 if __name__ == "__main__":
     extra = []
     if "--save-temps" in sys.argv:
-        os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+        os.makedirs(OBJDIR, exist_ok=True)
         extra += ["-save-temps=obj"]
     build(force="--force" in sys.argv, extra=extra, verbose=True)
     print(LIB)

@@ -153,6 +153,16 @@ struct dd_ctx {
     bool no_gpu_inflate = false;   // this context inflates on the host (set for the retry of a call, for good after three)
     int inflate_refusals = 0;      // calls in which the device decoder refused a block
     bool inflate_retry = false;    // ... and the call that met it is run again
+    // dd_inflate_files: the text of every file of the running dd_sketch_files pass, as K0 is about to read it, goes here
+    struct TextSink {
+        uint8_t* const* out;
+        const size_t* caps;
+        size_t* lens;
+        bool short_buffer;
+    };
+    TextSink* text_sink = nullptr;
+    bool inflate_retry_counts = false;   // ... and counts towards the three strikes (a size mismatch or a lack of device memory does not:
+                                         //     the decoder did its work, the FILE -- damaged trailer, two members, text beyond 4 GiB -- is not for it)
     hipEvent_t pipe_h2d[2] = {nullptr, nullptr}, pipe_done[2] = {nullptr, nullptr}, pipe_d2h[2] = {nullptr, nullptr};
     hipStream_t side[8] = {};  // k classes of a small call run side by side
     hipEvent_t side_done[8] = {}, side_go = nullptr, side_stagger = nullptr;
@@ -804,6 +814,7 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
                     int nthreads) {
     if (check_ctx(c)) return DD_EINVAL;
     c->inflate_retry = false;
+    c->inflate_retry_counts = false;
     int rc = sketch_files_impl(c, paths, nfiles, kmin, kmax, regs, nthreads);
     // (DD_INFLATE_STRICT=1: no second try -- the tests and scripts/fuzz_inflate.py set it so that a decoder bug cannot hide
     // behind the fallback)
@@ -816,7 +827,7 @@ int dd_sketch_files(dd_ctx* c, const char* const* paths, int nfiles, int kmin, i
         const bool was = c->no_gpu_inflate;
         c->no_gpu_inflate = true;
         rc = sketch_files_impl(c, paths, nfiles, kmin, kmax, regs, nthreads);
-        c->no_gpu_inflate = was || ++c->inflate_refusals >= 3;
+        c->no_gpu_inflate = was || (c->inflate_retry_counts && ++c->inflate_refusals >= 3);
     }
     return rc;
 }
@@ -894,7 +905,10 @@ static bool bgzf_parse(const uint8_t* data, size_t n, std::vector<BgzfBlock>& bl
 // stream whose final block is not followed by exactly the 8 trailer bytes.)
 static bool gzip_member_size_ok(size_t n) {
     const size_t min_bytes = (size_t)(getenv("DD_GUNZIP_MIN_KB") ? std::max(1, atoi(getenv("DD_GUNZIP_MIN_KB"))) : 1024) << 10;
-    return n >= min_bytes && n < ((size_t)3500 << 20);
+    // (below 1 GiB: ISIZE is the text's length mod 2^32 and DNA inflates 3.5-4 x, so a larger member's text may lie beyond
+    // 4 GiB, which the device path's 32-bit offsets cannot hold -- a 3 Gbp assembly's .gz is ~0.98 GB; larger files take the
+    // host's parallel decoder.  gzip_member_parse looks at the ratio as well, piece_offsets_kernel sums in 64 bits.)
+    return n >= min_bytes && n < ((size_t)1 << 30);
 }
 using dd::GzMember;
 using dd::gzip_member_parse;
@@ -1183,6 +1197,10 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
         // (a failed batch has still given its buffers back: the loaders must never wait for ever)
         if (refused) {
             c->inflate_retry = true;
+            // (a CRC that does not match, a block the decoder would not take: counted; pieces that decode but do not add up
+            // to the trailer's ISIZE: the file's matter, not the decoder's)
+            const uint32_t ecount = *static_cast<const uint32_t*>(c->pipe_err_host[set].p);
+            if ((ecount & (dd::kSizeMismatch - 1u)) != 0u || ecount < dd::kSizeMismatch) c->inflate_retry_counts = true;
             return fail(DD_EIO, "ingestion pipeline: %u block(s) / piece(s) / file(s) refused by the device decoder", *static_cast<const uint32_t*>(c->pipe_err_host[set].p));
         }
         return arrived ? DD_OK : fail(DD_EHIP, "ingestion pipeline: D2H failed");
@@ -1291,6 +1309,9 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
                      (rc = c->pipe_win[set].reserve(win_tot)) != DD_OK || (rc = c->pipe_raw[set].reserve(raw_bytes)) != DD_OK ||
                      (rc = c->pipe_raw_host[set].reserve(raw_files + raw_chunk0)) != DD_OK || (rc = c->pipe_crc_host[set].reserve(nchunks * 4 + 256)) != DD_OK ||
                      (rc = c->pipe_err[set].reserve(256)) != DD_OK || (rc = c->pipe_err_host[set].reserve(256)) != DD_OK)) {
+            // (10 x the compressed bytes + 2 x the text of symbol area, 64 KiB of windows per piece: a device that cannot
+            // give that can still sketch the file -- the call runs again with the host decoder; not a strike)
+            if (rc == DD_ENOMEM) c->inflate_retry = true;
             first_err = g_err;
             release_unsent(i, count);
             cv.notify_all();
@@ -1392,6 +1413,15 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             }
         }
         if ((njobs || nmem) && e == hipSuccess) e = hipMemcpyAsync(c->pipe_err_host[set].p, c->pipe_err[set].p, 4, hipMemcpyDeviceToHost, cs);
+        if (c->text_sink && e == hipSuccess) {
+            // dd_inflate_files: every file's text as it stands in the buffer K0 reads -- inflated by the kernels above where
+            // the device decoder took the file -- back to the caller, on the stream that made it
+            for (int j = 0; j < count && e == hipSuccess; ++j) {
+                c->text_sink->lens[i + j] = sizes[j];
+                if (sizes[j] > c->text_sink->caps[i + j]) c->text_sink->short_buffer = true;
+                else if (sizes[j]) e = hipMemcpyAsync(c->text_sink->out[i + j], ptrs[j], sizes[j], hipMemcpyDeviceToHost, cs);
+            }
+        }
         if (e == hipSuccess) e = hipEventRecord(c->pipe_h2d[set], cs);
         if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->pipe_h2d[set], 0);
         if (e == hipSuccess) {
@@ -1456,6 +1486,25 @@ int dd_last_ingest_stats(dd_ctx* c, double* wall_ms, double* loader_wait_ms, int
     if (loader_wait_ms) *loader_wait_ms = c->ingest_ms[1];
     if (batches) *batches = (int)c->ingest_ms[2];
     if (bytes) *bytes = (uint64_t)c->ingest_ms[3];
+    return DD_OK;
+}
+
+// The ingestion pipeline's text, for checking the device decoders byte by byte (tests/test_gpu_parity.py, scripts/fuzz_inflate.py):
+// one dd_sketch_files pass (k = 21 only) whose batches also copy every file's text -- as K0 is about to read it -- to the caller.
+int dd_inflate_files(dd_ctx* c, const char* const* paths, int nfiles, uint8_t* const* out, const size_t* caps, size_t* lens, int nthreads) {
+    if (check_ctx(c)) return DD_EINVAL;
+    if (nfiles < 0 || (nfiles && (!paths || !out || !caps || !lens))) return fail(DD_EINVAL, "null argument");
+    for (int i = 0; i < nfiles; ++i) {
+        if (!out[i] && caps[i]) return fail(DD_EINVAL, "null buffer at index %d", i);
+        lens[i] = 0;
+    }
+    std::vector<uint8_t> regs((size_t)nfiles << c->p);
+    dd_ctx::TextSink sink{out, caps, lens, false};
+    c->text_sink = &sink;
+    const int rc = dd_sketch_files(c, paths, nfiles, 21, 21, regs.data(), nthreads);
+    c->text_sink = nullptr;
+    if (rc != DD_OK) return rc;
+    if (sink.short_buffer) return fail(DD_EINVAL, "a buffer is smaller than its file's text (the sizes needed are in lens[])");
     return DD_OK;
 }
 

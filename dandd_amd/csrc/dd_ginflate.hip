@@ -405,6 +405,10 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
             return;
         }
         if (MODE != 3 && uni(over[blockIdx.x]) == 0u) return;   // (the piece fitted its ranges)
+        // (MODE 2 writes into the arena at offsets piece_offsets_kernel made from the counted lengths: a batch that already
+        // holds an error -- lengths that do not add up to the member's ISIZE, an arena total beyond it: a damaged or wrapped
+        // trailer, `cat a.gz b.gz` -- goes to the host decoder anyway and must not be written)
+        if (MODE == 2 && uni(__hip_atomic_load(errors, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u) return;
         const RawFile rf = files[pr.file];
         in = rf.in, n = rf.in_len, piece_end = pr.end;
         if (MODE == 3) {
@@ -413,7 +417,14 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
             sym = rf.sym + (size_t)pr.j * rf.range_syms;
         } else {
             out_len = MODE == 1 ? rf.isize : uni(lens[blockIdx.x]);
-            if (MODE == 2) sym = rf.arena + uni(abase[blockIdx.x]);
+            if (MODE == 2) {
+                const uint32_t ab = uni(abase[blockIdx.x]);
+                if ((uint64_t)ab + out_len > rf.isize) {   // the arena holds ISIZE symbols (piece_offsets_kernel has raised the error already)
+                    if (lane == 0) atomicAdd(errors, 1u);
+                    return;
+                }
+                sym = rf.arena + ab;
+            }
         }
     }
     uint32_t at = 0;
@@ -945,19 +956,24 @@ __global__ __launch_bounds__(64) void piece_offsets_kernel(const RawFile* __rest
                                                            uint32_t* __restrict__ offs, uint32_t* __restrict__ abase, uint32_t* __restrict__ errors) {
     const RawFile rf = files[blockIdx.x];
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t run = 0, arun = 0;
+    // (64-bit sums: a piece's length is bounded by ISIZE, their SUM is not -- a trailer whose ISIZE is smaller than the text
+    // (damage, two members, a text beyond 4 GiB whose ISIZE is the length mod 2^32) must not wrap back into "equal")
+    uint64_t run = 0, arun = 0;
     for (uint32_t b0 = 0; b0 < rf.nguess; b0 += 64u) {
         const uint32_t i = b0 + lane, mine = i < rf.nguess ? lens[rf.piece0 + i] : 0u, amine = (i < rf.nguess && over[rf.piece0 + i]) ? mine : 0u;
-        uint32_t incl = mine, aincl = amine;
+        uint64_t incl = mine, aincl = amine;
         for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = (uint32_t)__shfl_up((int)incl, d), aup = (uint32_t)__shfl_up((int)aincl, d);
+            const uint64_t up = (uint64_t)__shfl_up((long long)incl, d), aup = (uint64_t)__shfl_up((long long)aincl, d);
             if ((int)lane >= d) incl += up, aincl += aup;
         }
-        if (i < rf.nguess) offs[rf.piece0 + i] = run + incl - mine, abase[rf.piece0 + i] = arun + aincl - amine;
-        run += (uint32_t)__shfl((int)incl, 63);
-        arun += (uint32_t)__shfl((int)aincl, 63);
+        // (offsets beyond ISIZE are clamped: nothing reads them once the error below is up, and nothing may index with a wrapped one)
+        const uint64_t o = run + incl - mine, a = arun + aincl - amine;
+        if (i < rf.nguess) offs[rf.piece0 + i] = (uint32_t)(o < rf.isize ? o : rf.isize), abase[rf.piece0 + i] = (uint32_t)(a < rf.isize ? a : rf.isize);
+        run += (uint64_t)__shfl((long long)incl, 63);
+        arun += (uint64_t)__shfl((long long)aincl, 63);
     }
-    if (run != rf.isize && lane == 0) atomicAdd(errors, 1u);
+    // kSizeMismatch: the pieces decoded, but not to the text the trailer announces (the host tells this from a refused block)
+    if ((run != (uint64_t)rf.isize || arun > (uint64_t)rf.isize) && lane == 0) atomicAdd(errors, kSizeMismatch);
 }
 
 // where a piece's symbols are: its ranges of the symbol area, or the arena

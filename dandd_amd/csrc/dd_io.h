@@ -370,6 +370,9 @@ inline bool gzip_member_parse(const uint8_t* p, size_t n, GzMember& gm) {
     gm.crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
     gm.isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
     if (gm.isize < n / 2 || (size_t)gm.isize > (size_t)1032 * n) return false;   // (a multi-member file's last ISIZE is usually smaller than the file)
+    // (ISIZE is the text's length mod 2^32: a large member whose ISIZE says "inflates less than 2 x" is far more likely text
+    // beyond 4 GiB -- FASTA never compresses that badly -- and the device path's offsets are 32-bit)
+    if (n >= ((size_t)256 << 20) && (size_t)gm.isize < 2 * n) return false;
     // FASTQ needs the host's record pass: look at the first bytes of text
     uint8_t first[256];
     z_stream zs;

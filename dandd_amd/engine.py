@@ -18,11 +18,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdandd_hip.so")
 
 KERNEL_PACK, KERNEL_SWEEP, KERNEL_UNION = 0, 1, 2
-ABI_VERSION = 3   # include/dandd_hip.h: DD_ABI_VERSION
+ABI_VERSION = 4   # include/dandd_hip.h: DD_ABI_VERSION
 
 EXPORTS = [
     "dd_abi_version", "dd_last_error", "dd_create", "dd_destroy", "dd_set_stream", "dd_synchronize",
-    "dd_sketch_buffer", "dd_sketch_fasta", "dd_sketch_files", "dd_last_ingest_stats", "dd_sketch_device", "dd_union", "dd_union_device",
+    "dd_sketch_buffer", "dd_sketch_fasta", "dd_sketch_files", "dd_inflate_files", "dd_last_ingest_stats", "dd_sketch_device", "dd_union", "dd_union_device",
     "dd_card", "dd_card_batch", "dd_card_batch_device", "dd_hist_batch_device", "dd_ertl_mle",
     "dd_progressive", "dd_progressive_device", "dd_pairwise", "dd_pairwise_device",
     "dd_exact_count", "dd_exact_count_device",
@@ -86,6 +86,8 @@ def load_library(path=None):
     lib.dd_sketch_fasta.argtypes = [vp, C.c_char_p, i32, i32, vp]
     lib.dd_sketch_files.restype = i32
     lib.dd_sketch_files.argtypes = [vp, C.POINTER(C.c_char_p), i32, i32, i32, vp, i32]
+    lib.dd_inflate_files.restype = i32
+    lib.dd_inflate_files.argtypes = [vp, C.POINTER(C.c_char_p), i32, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), i32]
     lib.dd_last_ingest_stats.restype = i32
     lib.dd_last_ingest_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32), C.POINTER(u64)]
     lib.dd_sketch_device.restype = i32
@@ -241,6 +243,32 @@ class Engine:
         regs = np.empty((n, kmax - kmin + 1, self.m), dtype=np.uint8)
         self._check(self._lib.dd_sketch_files(self._ctx, arr, n, kmin, kmax, regs.ctypes.data, int(nthreads)))
         return regs
+
+    def inflate_files(self, paths, nthreads=0):
+        """The bytes the tokenizer reads for every file of a sketch_files pass (dd_inflate_files): for a .gz FASTA file the
+        text `zcat` prints, inflated on the device where the device decoder takes the file.  -> list of uint8 arrays."""
+        n = len(paths)
+        arr = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+        caps = []
+        for p in paths:       # room: the trailer's ISIZE for a .gz (a multi-member file's is too small: second try below), else the file
+            size = os.path.getsize(p)
+            with open(p, "rb") as f:
+                head = f.read(2)
+                if head == b"\x1f\x8b" and size >= 18:
+                    f.seek(size - 4)
+                    size = max(int.from_bytes(f.read(4), "little"), 4 * size)
+            caps.append(size + 64)
+        for _ in range(2):
+            bufs = [np.empty(c, dtype=np.uint8) for c in caps]
+            outs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+            ccaps = (C.c_size_t * n)(*caps)
+            lens = (C.c_size_t * n)()
+            rc = self._lib.dd_inflate_files(self._ctx, arr, n, outs, ccaps, lens, int(nthreads))
+            if rc == 0 or all(lens[i] <= caps[i] for i in range(n)):
+                break
+            caps = [max(int(lens[i]), caps[i]) + 64 for i in range(n)]
+        self._check(rc)
+        return [bufs[i][:lens[i]] for i in range(n)]
 
     def last_ingest_stats(self):
         """(wall ms, ms waiting for the loader threads, batched launches, FASTA bytes) of the last sketch_files."""

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DD_ABI_VERSION 3
+#define DD_ABI_VERSION 4
 
 #define DD_OK 0
 #define DD_EINVAL (-1)   /* bad argument */
@@ -66,7 +66,7 @@ int dd_sketch_fasta(dd_ctx *, const char *path, int kmin, int kmax, uint8_t *reg
  * to the device and batch b-1's registers back while batch b is sketched; consecutive small files
  * share one launch (~128 MB per batch).  regs[nfiles][K][m] on the host.  Replaces the reference's
  * sequential per-genome loop (lib/huffman_dandd.py:402-407), each iteration of which re-inflates the
- * file once per k.  gzip files -- BGZF (bgzip) and ordinary single-member files of 1 MiB .. 3.5 GB --
+ * file once per k.  gzip files -- BGZF (bgzip) and ordinary single-member files of 1 MiB .. 1 GiB --
  * are copied compressed and inflated on the device, their CRC-32 and ISIZE checked; a block the device refuses sends the call through the host decoder, which
  * reports what is wrong (DD_NO_GPU_INFLATE=1: host decoder from the start).  FASTQ is accepted (kseq's
  * record rules: oracle/POLICIES.md P10). */
@@ -75,6 +75,13 @@ int dd_sketch_files(dd_ctx *, const char *const *paths, int nfiles, int kmin, in
 /* statistics of the last dd_sketch_files call: wall time, time the GPU-driving thread waited for the loader
  * threads, number of batched launches, FASTA bytes sent to the device */
 int dd_last_ingest_stats(dd_ctx *, double *wall_ms, double *loader_wait_ms, int *batches, uint64_t *bytes);
+/* The text dd_sketch_files works on, for verification: the same pipeline (loaders, H2D, the device decoders of BGZF and
+ * single-member .gz files, the host decoder and kseq's FASTQ rewrite where those apply), but every file's bytes AS THE
+ * TOKENIZER IS ABOUT TO READ THEM are copied back into out[i] (caps[i] bytes of room; lens[i] = the text's length, also
+ * when the buffer was too small: DD_EINVAL then).  For a .gz FASTA file that is exactly what `zcat` prints -- the check
+ * that stands in for  zcat <fasta.gz> | cmp - <what dashing's gzread saw>  (lib/species_specifics.py:93: inputs are .gz). */
+int dd_inflate_files(dd_ctx *, const char *const *paths, int nfiles, uint8_t *const *out, const size_t *caps,
+                     size_t *lens, int nthreads);
 /* Batched, HBM-resident form: ngenomes FASTA byte buffers already on the device,
  * regs_dev[ngenomes][K][m] on the device.  Asynchronous on the context's stream. */
 int dd_sketch_device(dd_ctx *, const uint8_t *const *fasta_dev, const size_t *nbytes,

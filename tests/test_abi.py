@@ -32,7 +32,7 @@ def test_header_and_binding_agree(lib):
     assert sorted(engine.EXPORTS) == decl
     for name in decl:
         assert hasattr(lib, name), f"{name} declared in include/dandd_hip.h but not exported"
-    assert lib.dd_abi_version() == 3
+    assert lib.dd_abi_version() == 4
 
 
 def test_exported_symbols_are_plain_c(lib):

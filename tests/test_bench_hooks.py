@@ -101,20 +101,20 @@ def test_bench_two_ranks_on_one_gpu_matches_single_process(torch_cuda):
 @pytest.mark.gpu
 @pytest.mark.parametrize("config,extra", [("cfg3", ["--genomes", "8", "--mbp", "1"]), ("cfg4share", ["--mbp", "2"]),
                                           ("cfg5share", ["--genomes", "2", "--mbp", "3", "--log2m", "18"])])
-def test_bench_config_presets_run(torch_cuda, config, extra):
+def test_bench_config_presets_run(torch_cuda, tmp_path, config, extra):
     """The --config presets (BASELINE cfg 3 / 4 / 5 shapes, shrunk) produce a well-formed line: right k range, the
     extra schedule in the step, strong/weak scaling flag, finite throughput."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--steps", "1", "--warmup", "1",
-                        "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=240, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                        "--no-cpu-baseline", "--detail", str(tmp_path / "detail.json")] + extra, capture_output=True, text=True, timeout=240, cwd=ROOT)
+    j = _line(r)
     want_k = {"cfg3": (2, 32), "cfg4share": (2, 32), "cfg5share": (4, 64)}[config]
     assert (j["config"]["kmin"], j["config"]["kmax"]) == want_k
     assert j["scaling"] == ("strong" if config == "cfg3" else "weak") and j["value"] > 0 and np.isfinite(j["delta_root"])
     assert config in j["config"]["workload"] and j["roofline"]["kernel_ms_per_step"] > 0
     assert "accuracy_vs_exact" not in j and "secondary" not in j      # only the headline config carries those
     # the K2 object names the device form that RAN (dd_last_k2_path), on the roof that form is bound by
-    k2 = j["roofline_k2"]
+    k2 = _detail(j)["roofline_k2"]
+    assert (j["roofline_k2"] or {}).get("path") == (k2 or {}).get("path")
     if config == "cfg3":
         assert k2["path"] == "pairwise_gram" and k2["bound"] == "mfma" and "gram_kernel" in k2["kernel"]
     elif config == "cfg4share":
@@ -124,13 +124,14 @@ def test_bench_config_presets_run(torch_cuda, config, extra):
 
 
 @pytest.mark.gpu
-def test_bench_progressive_line_names_the_bit_plane_scan_at_log2m_20(torch_cuda):
+def test_bench_progressive_line_names_the_bit_plane_scan_at_log2m_20(torch_cuda, tmp_path):
     """From log2m 18 on (n <= 32) dd_progressive_device runs the bit-plane AND-scan: the line must say pscan_kernel and
     price it against the LDS read rate -- round 3's line named progressive_kernel on the HBM roof for a kernel that had not run."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "cfg4share", "--steps", "1", "--warmup", "1", "--mbp", "2",
-                        "--log2m", "20", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    k2 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["roofline_k2"]
+                        "--log2m", "20", "--no-cpu-baseline", "--detail", str(tmp_path / "detail.json")], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    j = _line(r)
+    assert j["roofline_k2"]["path"] == "progressive_pscan" and j["roofline_k2"]["bound"] == "lds" and 0 < j["roofline_k2"]["frac"] < 1
+    k2 = _detail(j)["roofline_k2"]
     assert k2["path"] == "progressive_pscan" and k2["bound"] == "lds" and "pscan_kernel" in k2["kernel"]
     assert k2["unit"] == "GB/s" and k2["peak"] == pytest.approx(128 * 256 * 2.4) and 0 < k2["frac"] < 1 and k2["lds_bytes_read"] > 0
 
@@ -174,7 +175,16 @@ def test_bench_cfg4_two_ranks_gathers_leaves_and_splits_orderings(torch_cuda):
 
 def _line(r):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) <= 6000, (len(lines), len(lines[0]))     # ONE line a bounded reader can take
+    return json.loads(lines[0])
+
+
+def _detail(j):
+    """the sidecar the line names: the full object"""
+    path = j["detail"] if os.path.isabs(j["detail"]) else os.path.join(ROOT, j["detail"])
+    with open(path) as f:
+        return json.load(f)
 
 
 @pytest.mark.gpu
@@ -237,38 +247,78 @@ def test_bench_without_enough_gpus_fails_loudly():
 
 
 @pytest.mark.gpu
-def test_bench_headline_line_has_every_object(torch_cuda):
-    """The driver's command shape on a shrunk workload (3 x 2 Mbp): the ONE line bench.py prints carries the contract's
-    keys and every object the headline run adds -- roofline (with the VALU bound's source when the workload is the
-    profiled one: here it is not, so traffic is null), cpu_baseline with its stages, accuracy_vs_exact, the secondary
-    steps (log2m 16 / 20, small genomes, realistic genomes), ingest (plain, small files, gzip, one big gzip parallel
-    and serial) -- and nothing in it is an error entry."""
+def test_bench_headline_line_has_every_object(torch_cuda, tmp_path):
+    """The driver's command shape on a shrunk workload (3 x 2 Mbp): bench.py prints ONE line of at most 6000 bytes -- round 4's
+    21.9 KB line could not be read by the driver -- that carries the contract's keys, `roofline` (frac, traffic key, the VALU
+    bound's three numbers), `cpu_baseline` (value, cores, kind, sample, stages), the accuracy verdict, one {value, ms, frac,
+    frac_of_mix} entry per secondary step (log2m 16 / 20, small genomes, realistic genomes, the cfg 5 share) and per ingest
+    probe, no prose; the FULL object (every roofline with its per-kernel issue model, every `what` / `why`) is in the sidecar
+    the line names."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--genomes", "3", "--mbp", "2",
-                        "--cpu-sample-mbp", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--cpu-sample-mbp", "2", "--share-mbp", "3", "--detail", str(tmp_path / "bench_detail.json")],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
     j = _line(r)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-                "config", "roofline", "cpu_baseline", "accuracy_vs_exact", "secondary", "ingest", "gpus_active", "collectives"):
+                "config", "roofline", "cpu_baseline", "accuracy_vs_exact", "secondary", "ingest", "gpus_active", "collectives", "detail"):
         assert key in j, key
     assert j["metric"].startswith("Gbp/s") and j["unit"] == "Gbp/s" and j["dtype"] == "u64" and j["vs_baseline"] is None
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "weak" and j["higher_is_better"] is True
+    assert set(j["config"]) == {"workload", "genomes_per_gpu", "bases_per_genome", "kmin", "kmax", "log2m", "parallelism"}
     rf = j["roofline"]
-    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1 and rf["traffic"] is None and rf["valu_bound"] is None
-    # every secondary K1 line carries its own roofline; the small-genome one is a fixed workload with committed counters
-    for name in ("log2m16", "log2m20", "log2m20_64x5Mbp"):
-        r2 = j["secondary"][name]["roofline"]
-        assert r2["bound"] == "hbm" and 0 < r2["frac"] < 1 and r2["kernel_ms_per_step"] > 0, name
-    small = j["secondary"]["log2m20_64x5Mbp"]["roofline"]
-    assert small["traffic"] > 50e9 and "r04_k1_counters_64x5_p20.json" in small["traffic_from"]
-    assert 0 < small["valu_bound"]["frac_of_mix"] < 1.2 and small["valu_bound"]["issue_model"]["by_kernel"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1 and "traffic" in rf and rf["traffic"] is None and rf["valu_bound"] is None
+    assert rf["kernel_ms_per_step"] > 0 and rf["launches_per_step"] > 0 and rf["algorithmic_bytes_per_step"] > 0
     cb = j["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["value"] > 0 and set(cb["stages_s"]) == {"stage1_leaf_sketches", "leaf_cards", "stage2_progressive_unions_and_cards",
-                                                                              "stage3_nway_union_and_card"}
-    assert cb["stage1_only_value"] >= cb["value"] >= cb["with_stage2_value"] > 0
-    assert j["accuracy_vs_exact"]["sketches"] == 4 and abs(j["accuracy_vs_exact"]["card_rel_err_mean_signed"]) < 0.02
-    assert set(j["secondary"]) == {"log2m16", "log2m20", "log2m20_64x5Mbp", "realistic_log2m14", "realistic_log2m20"}
-    assert all("error" not in v and v["value"] > 0 for v in j["secondary"].values())
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "Gbp/s" and len(cb["sample"]) < 260
+    assert set(cb["stages_s"]) == {"stage1_leaf_sketches", "leaf_cards", "stage2_progressive_unions_and_cards", "stage3_nway_union_and_card"}
+    assert j["accuracy_vs_exact"]["sketches"] == 4 and "delta_within_1pct" in j["accuracy_vs_exact"]
+    names = {"log2m16", "log2m20", "log2m20_64x5Mbp", "realistic_log2m14", "realistic_log2m20", "cfg5share_log2m16", "cfg5share_log2m20"}
+    assert set(j["secondary"]) == names
+    for name, v in j["secondary"].items():
+        assert "error" not in v and v["value"] > 0 and v["ms_per_step"] > 0, (name, v)
+        assert not [x for x in v.values() if isinstance(x, (str, dict, list))], (name, v)      # numbers only on the line
+    for name in ("log2m16", "log2m20", "log2m20_64x5Mbp", "cfg5share_log2m16", "cfg5share_log2m20"):
+        assert 0 < j["secondary"][name]["frac"] < 1, name
+    small = j["secondary"]["log2m20_64x5Mbp"]           # a fixed workload with committed counters
+    assert small["traffic"] > 30e9 and 0 < small["frac_of_mix"] < 1.2
+    for name in ("cfg5share_log2m16", "cfg5share_log2m20"):    # the north-star share (shrunk here): its accuracy clause on the line
+        assert "delta_rel_err" in j["secondary"][name] and "delta_within_1pct" in j["secondary"][name], name
     ing = j["ingest"]
     assert ing["value"] > 0 and ing["best_value"] >= ing["value"]
-    for sub in ("small_files", "gzip_files", "one_big_gzip_file"):
+    for sub in ("small_files", "gzip_files", "bgzf_files", "one_big_gzip_file"):
         assert "error" not in ing[sub] and ing[sub]["value"] > 0, sub
     assert ing["one_big_gzip_file"]["serial_decoder_value"] > 0
+    # the sidecar: the full object
+    d = _detail(j)
+    assert d["value"] == pytest.approx(j["value"], rel=1e-4) and d["cpu_baseline"]["stage1_only_value"] >= d["cpu_baseline"]["value"] >= d["cpu_baseline"]["with_stage2_value"] > 0
+    assert abs(d["accuracy_vs_exact"]["card_rel_err_mean_signed"]) < 0.02
+    for name in ("log2m16", "log2m20", "log2m20_64x5Mbp"):
+        r2 = d["secondary"][name]["roofline"]
+        assert r2["bound"] == "hbm" and 0 < r2["frac"] < 1 and r2["kernel_ms_per_step"] > 0, name
+    sm = d["secondary"]["log2m20_64x5Mbp"]["roofline"]
+    assert "k1_counters_64x5_p20.json" in sm["traffic_from"] and sm["valu_bound"]["issue_model"]["by_kernel"]
+    assert "what" in d["ingest"] and "why" in d["secondary"]["log2m16"]
+
+
+def test_compact_line_is_bounded_and_keeps_the_contract():
+    """compact_line on round 4's committed full object (21.9 KB as one line: the driver's `parsed` was null): <= 6000 bytes,
+    valid JSON, the contract's keys intact, nothing but numbers in the secondary entries; and it sheds optional blocks rather
+    than ever exceeding the limit."""
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(os.path.join(ROOT, "profiles", "r04_v4_bench_default.json")) as f:
+        full = json.load(f)
+    assert len(json.dumps(full)) > 20000
+    text = bench.compact_line(full, "bench_detail.json")
+    j = json.loads(text)
+    assert len(text) <= bench.LINE_LIMIT == 6000 and "\n" not in text
+    assert j["value"] == pytest.approx(full["value"], rel=1e-4) and j["ms_per_step"] == pytest.approx(full["ms_per_step"], rel=1e-4)
+    assert j["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-4) and j["roofline"]["traffic"] == pytest.approx(full["roofline"]["traffic"], rel=1e-4)
+    assert j["roofline"]["valu_bound"]["frac_of_mix"] == pytest.approx(0.9686, abs=1e-3)
+    assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] == 15 and j["cpu_baseline"]["kind"] == "port"
+    assert j["secondary"]["log2m20_64x5Mbp"]["traffic"] == pytest.approx(87.3e9, rel=1e-2)
+    assert j["ingest"]["bgzf_files"]["host_decoder_value"] > 0
+    fat = dict(full, gpus_active=["x" * 64] * 8, ingest={f"k{i}": 1.0 for i in range(2000)})
+    fat["ingest"]["value"] = 1.0
+    fat["secondary"] = {f"s{i}": {"value": 1.0, "ms_per_step": 1.0} for i in range(400)}
+    t2 = bench.compact_line(fat, "bench_detail.json")
+    assert len(t2) <= 6000 and json.loads(t2)["value"] == j["value"]
