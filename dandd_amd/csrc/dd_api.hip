@@ -951,6 +951,10 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
         }
     }
     const bool gpu_inflate = !c->no_gpu_inflate && !getenv("DD_NO_GPU_INFLATE");
+    // (DD_INFLATE_STRICT=2, tests: a context whose device decoder has been switched off by three refusals says so instead of
+    // quietly decoding on the host)
+    if (any_gz && c->no_gpu_inflate && getenv("DD_INFLATE_STRICT") && atoi(getenv("DD_INFLATE_STRICT")) >= 2)
+        return fail(DD_EIO, "the device decoder is switched off on this context (three refused calls)");
     const size_t avg = std::max<size_t>(1, disk_bytes / (size_t)nfiles);
     // (log2m >= 17: the scatter/sort/replay path runs epoch by epoch over all rows of a launch and wants many rows)
     // (Batches that grow -- 64, 128, 256 MB -- were measured against fixed 128 MB ones once the job tables of several

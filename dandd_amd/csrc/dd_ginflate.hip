@@ -696,7 +696,8 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
         if (MODE == 3 && lane == 0) over[blockIdx.x] = 0;
         if ((MODE == 1 || MODE == 3) && lane == 0) lens[blockIdx.x] = ok ? at : 0u;
         if (MODE == 2 && ok && at != out_len) ok = false;
-        if (!ok && lane == 0) atomicAdd(errors, 1u);
+        // (a piece that alone is longer than the member's ISIZE: the trailer's matter -- kSizeMismatch --, not the decoder's)
+        if (!ok && lane == 0) atomicAdd(errors, (too_long && out_len >= files[pr.file].isize) ? kSizeMismatch : 1u);
         return;
     }
     // the member's trailer: CRC-32, ISIZE

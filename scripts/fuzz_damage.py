@@ -29,6 +29,13 @@ for raw in raws:
         goods.append(("bgzf", bgzf(raw, level)))
         co = zlib.compressobj(level, zlib.DEFLATED, 31)
         goods.append(("member", co.compress(raw) + co.flush()))
+# ... and text that inflates 50-1000 x (runs of N, one repeated line): its pieces do not fit their ranges and take the ARENA, which is
+# sized by the trailer's ISIZE -- with damage kind 6 (an ISIZE lowered to anywhere in [n / 2, the real length)) the pieces' lengths add
+# up to more than the arena holds (advisor, round 4: inflate_kernel<2> wrote past it; the other texts inflate ~4 x and never get there)
+lowent = (b">x\n" + b"ACGT" * 20 + b"\n") * 60000 + raws[0][:200_000] + b"N" * 3_000_000 + b"\n" + raws[1][:150_000]
+for level in (6, 9):
+    co = zlib.compressobj(level, zlib.DEFLATED, 31)
+    goods.append(("compressible member", co.compress(lowent) + co.flush()))
 d = tempfile.mkdtemp()
 eng, refusals = Engine(0, 14, True), 0
 counts = {"refused": 0, "read": 0}
@@ -38,7 +45,11 @@ for it in range(n_cfg):
     bad = bytearray(good)
     how = int(rng.integers(6))
     lo = 18 if kind == "bgzf" else 10
-    if how == 0:
+    if kind == "compressible member" and rng.integers(3):
+        how = 6
+        real = int.from_bytes(bad[-4:], "little")
+        bad[-4:] = int(rng.integers(len(bad) // 2, real)).to_bytes(4, "little")
+    elif how == 0:
         bad[lo + int(rng.integers(len(bad) - lo))] ^= 1 << int(rng.integers(8))
     elif how == 1:
         for _ in range(int(rng.integers(1, 6))):

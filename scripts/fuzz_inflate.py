@@ -82,10 +82,11 @@ for it in range(n_cfg):
         raws.append((raw, level, strategy, memlevel, block))
     os.environ["DD_GUNZIP_GUESS_KB"] = str(int(rng.choice([4, 16, 32, 128])))
     got = eng.sketch_files(paths, 19, 21)
-    for g, (raw, *cfg) in zip(got, raws):
+    texts = eng.inflate_files(paths)          # (dd_inflate_files: the inflated BYTES as K0 reads them, against the text that was compressed)
+    for g, text, (raw, *cfg) in zip(got, texts, raws):
         want = eng.sketch_buffer(np.frombuffer(raw, np.uint8), 19, 21)
-        if not np.array_equal(g, want):
+        if not np.array_equal(g, want) or text.tobytes() != raw:
             print(f"MISMATCH cfg {it}: {cfg} bytes={len(raw)}")
             open(f"gpurun_out/fuzz_inflate_fail_{it}.bin", "wb").write(raw)
             sys.exit(1)
-print(f"{n_cfg} random configurations, ~{nblocks} BGZF blocks and {nmembers} single gzip members: the device decoder took every one, registers equal, in {time.time() - t0:.1f} s")
+print(f"{n_cfg} random configurations, ~{nblocks} BGZF blocks and {nmembers} single gzip members: the device decoder took every one, inflated bytes and registers equal, in {time.time() - t0:.1f} s")

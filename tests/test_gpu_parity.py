@@ -459,8 +459,14 @@ def test_bgzf_files_are_inflated_on_the_device(engine_factory, orc, tmp_path, mo
         cases.append((name, str(path), np.frombuffer(raw, dtype=np.uint8)))
     monkeypatch.setenv("DD_INFLATE_STRICT", "1")                 # a block the device refuses fails the call: no silent host fallback here
     got = eng.sketch_files([p for _, p, _ in cases], 19, 21)
+    # ... and the inflated BYTES (dd_inflate_files: the text as K0 is about to read it, copied back from the device) are zlib's:
+    # one wrong byte moves a register with p ~ m / n only, the registers alone would miss most of them
+    import gzip
+    texts = eng.inflate_files([p for _, p, _ in cases])
     monkeypatch.delenv("DD_INFLATE_STRICT")
     assert eng.last_ingest_stats()[2] >= 1
+    for (name, path, fa), text in zip(cases, texts):
+        assert text.tobytes() == gzip.decompress(open(path, "rb").read()) == fa.tobytes(), name
     for (name, _, fa), regs in zip(cases, got):
         assert np.array_equal(regs, eng.sketch_buffer(fa, 19, 21)), name
     monkeypatch.setenv("DD_NO_GPU_INFLATE", "1")                 # the host decoder on the same files: same registers
@@ -581,6 +587,9 @@ def test_single_member_gzip_files_are_inflated_on_the_device(engine_factory, orc
         got = eng.sketch_files(paths, 19, 21)
         for (name, _, _), g, w in zip(cases, got, want):
             assert np.array_equal(g, w), (name, guess_kb)
+        # the inflated bytes themselves, against zlib's (dd_inflate_files)
+        for (name, raw, data), text in zip(cases, eng.inflate_files(paths)):
+            assert text.tobytes() == gzip.decompress(data) == raw, (name, guess_kb)
     monkeypatch.delenv("DD_GUNZIP_GUESS_KB")
     monkeypatch.delenv("DD_INFLATE_STRICT")
     # not for the device: two members (the device refuses a final block that is not followed by the trailer alone; the call
@@ -658,6 +667,51 @@ def test_damaged_single_member_gzip_is_refused_or_read_like_zlib(orc, torch_cuda
     finally:
         eng.close()
     assert outcomes["refused"] >= 8, outcomes
+
+
+def test_gunzip_isize_smaller_than_the_text_cannot_write_past_the_arena(orc, torch_cuda, tmp_path, monkeypatch):
+    """A single-member .gz of highly compressible text (runs of one line: its pieces inflate far more than their ranges hold and
+    go through the arena, which is sized by the trailer's ISIZE) whose ISIZE is SMALLER than the text -- damage, `cat a.gz b.gz`,
+    a text beyond 4 GiB.  The pieces' lengths then add up to more than the arena: piece_offsets_kernel must raise the error (64-bit
+    sums) and inflate_kernel<2> must not write.  The call goes to the host decoder, which refuses the file like zlib does; the
+    process survives, a neighbour in the same batch is not corrupted, and the context still decodes good files on the device."""
+    import gzip
+    import zlib
+    from dandd_amd.engine import Engine, EngineError
+    monkeypatch.setenv("DD_GUNZIP_MIN_KB", "16")
+    uniform = orc.synth_fasta(SEED, 6, 900_000, 2).tobytes()
+    text = (b">x\n" + b"ACGT" * 20 + b"\n") * 120000 + uniform[:300_000] + b"N" * 4_000_000 + b"\n" + uniform[300_000:500_000]
+    co = zlib.compressobj(9, zlib.DEFLATED, 31)
+    good = co.compress(text) + co.flush()
+    assert len(good) > (16 << 10) and len(text) > 40 * len(good)
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    other = co.compress(uniform) + co.flush()
+    (tmp_path / "other.fa.gz").write_bytes(other)
+    (tmp_path / "good.fa.gz").write_bytes(good)
+    eng = Engine(device=0, log2m=14, canonical=True)
+    try:
+        monkeypatch.setenv("DD_INFLATE_STRICT", "1")
+        want = eng.sketch_buffer(np.frombuffer(text, np.uint8), 19, 21)
+        want_other = eng.sketch_buffer(np.frombuffer(uniform, np.uint8), 19, 21)
+        got = eng.sketch_files([str(tmp_path / "good.fa.gz"), str(tmp_path / "other.fa.gz")], 19, 21)
+        assert np.array_equal(got[0], want) and np.array_equal(got[1], want_other)
+        assert eng.inflate_files([str(tmp_path / "good.fa.gz")])[0].tobytes() == text
+        monkeypatch.delenv("DD_INFLATE_STRICT")
+        for t, isize in enumerate((len(text) // 2, len(text) // 5, len(text) - 70_000, len(text) - 1, len(good) // 2 + 1, len(good) * 3)):
+            bad = good[:-4] + int(isize).to_bytes(4, "little")
+            path = tmp_path / f"short{t}.fa.gz"
+            path.write_bytes(bad)
+            with pytest.raises((OSError, EOFError, zlib.error)):
+                gzip.decompress(bad)
+            with pytest.raises(EngineError):
+                eng.sketch_files([str(path), str(tmp_path / "other.fa.gz")], 19, 21)
+            # a size mismatch is the file's fault, not a strike against the device decoder: the context keeps its device path
+            monkeypatch.setenv("DD_INFLATE_STRICT", "2")          # (2: fails if the context has given up its device decoder)
+            again = eng.sketch_files([str(tmp_path / "good.fa.gz"), str(tmp_path / "other.fa.gz")], 19, 21)
+            monkeypatch.delenv("DD_INFLATE_STRICT")
+            assert np.array_equal(again[0], want) and np.array_equal(again[1], want_other), t
+    finally:
+        eng.close()
 
 
 def test_large_gzip_files_are_inflated_in_parallel(engine_factory, orc, tmp_path, monkeypatch):
