@@ -572,6 +572,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         if (sc.plan.mode == dd::kBucketMode) bplan = &sc.plan;
     const dd::BucketRow* rows_dev = nullptr;
     const int nrows = ngenomes * K;
+    std::vector<int> group_base(classes.size(), 0);   // row groups: the number of a class's first group, counted through the call
     if (bplan) {
         const size_t flt_bytes = align_up((m >> bplan->logg) * bplan->fbits / 8, 16), area_bytes = (size_t)bplan->cap_chunks * 4096;  // 1024 records per chunk
         const size_t fill_bytes = align_up((size_t)bplan->cap_chunks * 4, 256) + align_up((size_t)bplan->cap_chunks * 32, 256);  // fill + seg
@@ -582,6 +583,14 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
                 hashed_per_genome += sc.klast - sc.kfirst + 1;
             }
         const size_t nhashed = (size_t)ngenomes * hashed_per_genome;
+        // row groups (DD_ROW_GROUP_MB, single-epoch calls): group after group on two alternating streams, the record areas
+        // of a stream's successive groups are the same ring of `group_rows` slots -- written, read back at once, written again
+        int group_rows = 0;
+        for (const dd::SweepClass& sc : classes)
+            if (sc.plan.mode == dd::kBucketMode && sc.group_rows) group_rows = std::max(group_rows, sc.group_rows);
+        if (getenv("DD_SIDE_ALWAYS") && !getenv("DD_NO_SIDE_STREAMS")) group_rows = 0;   // (class pipelines on side streams: every row its own area)
+        // (both halves of the ring whatever the number of rows: a call of two small classes puts the second's only group in the second half)
+        const size_t nareas = group_rows ? (size_t)2 * group_rows : nhashed;
         const size_t tab_bytes = align_up(sizeof(dd::BucketRow) * nrows, 256);
         // one cursor per row, each in a 256-byte slot of its own: every 64-record block of a row is reserved by one
         // atomic add on it, and neighbouring rows are written from other XCDs
@@ -589,12 +598,32 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         const size_t cur_stride = stride_env ? (size_t)std::max(4, atoi(stride_env)) / 4 * 4 : (size_t)256;
         const size_t cur_bytes = align_up((size_t)nrows * cur_stride, 256);
         const size_t flt_tot = align_up(nhashed * flt_bytes, 256);
-        if ((rc = c->buckets.reserve(tab_bytes + cur_bytes + flt_tot + nhashed * (fill_bytes + area_bytes)))) return rc;
+        if ((rc = c->buckets.reserve(tab_bytes + cur_bytes + flt_tot + nareas * (fill_bytes + area_bytes)))) return rc;
         if ((rc = c->stage_rows.reserve(tab_bytes))) return rc;
         char* bb = static_cast<char*>(c->buckets.p);
         char* fills = bb + tab_bytes + cur_bytes + flt_tot;
-        char* areas = fills + nhashed * fill_bytes;
+        char* areas = fills + nareas * fill_bytes;
         std::vector<dd::BucketRow> rtab(nrows);
+        // (row groups: the slot of a row = the ring half of its group's stream + its place in the group; groups are counted
+        // through the classes in launch order)
+        {
+            int gc = 0;
+            for (size_t i = 0; i < classes.size(); ++i) {
+                group_base[i] = gc;
+                if (classes[i].plan.mode == dd::kBucketMode && classes[i].group_rows) gc += (int)classes[i].group_begin.size() - 1;
+            }
+        }
+        auto area_slot = [&](int g, int kk, size_t dense) -> size_t {
+            if (!group_rows) return dense;
+            for (size_t i = 0; i < classes.size(); ++i) {
+                const dd::SweepClass& sc = classes[i];
+                if (sc.plan.mode != dd::kBucketMode || kk < sc.kfirst - kmin || kk > sc.klast - kmin) continue;
+                const int nks = sc.klast - sc.kfirst + 1, local = g * nks + (kk - (sc.kfirst - kmin));
+                const int grp = group_base[i] + local / sc.group_rows;
+                return (size_t)(grp & 1) * group_rows + (size_t)(local % sc.group_rows);
+            }
+            return dense;
+        };
         size_t h = 0;
         for (int g = 0; g < ngenomes; ++g)
             for (int kk = 0; kk < K; ++kk) {
@@ -603,9 +632,10 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
                 r.cursor = reinterpret_cast<uint32_t*>(bb + tab_bytes + ((size_t)g * K + kk) * cur_stride);
                 const bool hashed = kk >= first_hashed && kk < first_hashed + hashed_per_genome;
                 r.filter = hashed ? reinterpret_cast<uint8_t*>(bb + tab_bytes + cur_bytes + h * flt_bytes) : nullptr;
-                r.fill = hashed ? reinterpret_cast<uint32_t*>(fills + h * fill_bytes) : nullptr;
-                r.seg = hashed ? reinterpret_cast<uint16_t*>(fills + h * fill_bytes + align_up((size_t)bplan->cap_chunks * 4, 256)) : nullptr;
-                r.area = hashed ? reinterpret_cast<uint32_t*>(areas + h * area_bytes) : nullptr;
+                const size_t slot = hashed ? area_slot(g, kk, h) : 0;
+                r.fill = hashed ? reinterpret_cast<uint32_t*>(fills + slot * fill_bytes) : nullptr;
+                r.seg = hashed ? reinterpret_cast<uint16_t*>(fills + slot * fill_bytes + align_up((size_t)bplan->cap_chunks * 4, 256)) : nullptr;
+                r.area = hashed ? reinterpret_cast<uint32_t*>(areas + slot * area_bytes) : nullptr;
                 h += hashed ? 1 : 0;
             }
         // cursors and filters start at zero: nothing handed out, every register's lower bound is 0
@@ -675,8 +705,12 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         // first-epoch chunks leave the scatter sorted by index tile: 2 = one 16 384-record chunk per workgroup and 16
         // updates (round 4), 1 = every wave its own 1024-record chunks (DD_FIRST_WG=0), 0 = sorted by a pass of their own
         // (DD_FIRST_WG: 3 = binned tiles of tokens, the default; 2 = 16 384-record sorted chunks; 0 = per-wave chunks)
+        // (round 5: 4 = the bins PACKED to 3 bytes per record through an LDS ring -- needs 64 KiB index tiles: 16 bits of index.
+        // Exact, measured 30 % SLOWER on 64 x 5 Mbp at log2m 20 -- a barrier and a flush every four updates cost the scatter more
+        // than a quarter less traffic gives back, and the replay is not bound by its reads: profiles/r05_bucket_path.txt -- A/B knob)
         const int first_wg = getenv("DD_FIRST_WG") ? atoi(getenv("DD_FIRST_WG")) : 3;
-        const int presorted = bplan->nb_log2 >= 1 && !getenv("DD_NO_PRESORT") ? (first_wg == 0 ? 1 : (first_wg == 2 ? 2 : 3)) : 0;
+        const int presorted = bplan->nb_log2 >= 1 && !getenv("DD_NO_PRESORT")
+                                  ? (first_wg == 0 ? 1 : (first_wg == 2 ? 2 : (first_wg == 4 && p - bplan->nb_log2 == 16 ? 4 : 3))) : 0;
         const dd::ScatterParams sp{rows_dev, K, bplan->logg, bplan->cap_chunks, unit, bplan->nb_log2, presorted};
         if (side_b && (rc = ensure_side_streams(c, (int)classes.size()))) return rc;
         // Every k class is a pipeline of its own -- scatter(e), sort(e), replay(e), scatter(e+1) ... over its own rows
@@ -714,6 +748,28 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
                                      (int)sc.jobs.size(), sc.kclass, sc.plan, ks);
                 }
                 blocks += (int)sc.jobs.size();
+            }
+            if (sc.plan.mode == dd::kBucketMode && sc.group_rows && !side_b) {
+                // row groups: group after group, scatter -> replay at once, on two streams in turn (group i + 1's scatter --
+                // VALU issue -- runs beside group i's replay -- record reads); what a group writes it reads back ~100 us later
+                if ((rc = ensure_side_streams(c, 2))) return rc;
+                if (!phase) phase.reset(new Span(c, DD_KERNEL_SWEEP));
+                DD_HIP(hipEventRecord(c->side_go, st));
+                const int nks = sc.klast - sc.kfirst + 1, ngroups = (int)sc.group_begin.size() - 1;
+                for (int s2 = 0; s2 < 2; ++s2) DD_HIP(hipStreamWaitEvent(c->side[s2], c->side_go, 0));
+                for (int gi = 0; gi < ngroups; ++gi) {
+                    hipStream_t gs = c->side[(group_base[i] + gi) & 1];
+                    const size_t j0 = sc.group_begin[gi], j1 = sc.group_begin[gi + 1];
+                    dd::launch_scatter(reinterpret_cast<const dd::SweepGenome*>(tdev), reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]) + j0,
+                                       (int)(j1 - j0), sc.kclass, sc.plan, sp, gs, true);
+                    dd::launch_replay(rows_dev, ngenomes, K, sc.kfirst - kmin, nks, *bplan, gs, presorted, gi * sc.group_rows, sc.group_rows);
+                    blocks += (int)(j1 - j0);
+                }
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    DD_HIP(hipEventRecord(c->side_done[s2], c->side[s2]));
+                    DD_HIP(hipStreamWaitEvent(st, c->side_done[s2], 0));
+                }
+                continue;
             }
             for (int e = 0; sc.plan.mode == dd::kBucketMode && e < bplan->nepochs; ++e) {
                 const size_t j0 = sc.epoch_begin[e], j1 = sc.epoch_begin[e + 1];

@@ -262,6 +262,7 @@ inline size_t fastq_to_fasta(const uint8_t* src, size_t n, uint8_t* dst) {
         if (i < n) ++i;
         // (in place: everything read so far is at least as long as what goes out, except for a header cut short by the
         // end of the buffer -- hence the two bytes of slack)
+        const size_t o_rec = o;   // (a truncated FASTQ record is taken back: below)
         dst[o++] = '>';
         if (header_closed || i < n) dst[o++] = '\n';
         size_t seq_len = 0;
@@ -292,17 +293,23 @@ inline size_t fastq_to_fasta(const uint8_t* src, size_t n, uint8_t* dst) {
             have_header = true;
             continue;
         }
+        // kseq_read's -2: the input ends inside the '+' line, or the quality text is not exactly as long as the sequence --
+        // `while (kseq_read(ks) >= 0)` then drops this record and everything behind it; one quality line is read even for
+        // an empty sequence (kseq tests the length after the read).  oracle/POLICIES.md P10, oracle/dd_oracle.c: orc_records.
         while (i < n && src[i] != '\n') ++i;  // the rest of the '+' line
-        if (i < n) ++i;
+        if (i >= n) return o_rec;
+        ++i;
         size_t qual_len = 0;
-        while (i < n && qual_len < seq_len) {
+        do {
+            if (i >= n) break;
             size_t e = i;
             while (e < n && src[e] != '\n') ++e;
             size_t len = e - i;
             if (len && src[e - 1] == '\r' && qual_len + len > 1) --len;
             qual_len += len;
             i = e < n ? e + 1 : e;
-        }
+        } while (qual_len < seq_len);
+        if (qual_len != seq_len) return o_rec;
     }
     return o;
 }

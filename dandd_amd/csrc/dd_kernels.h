@@ -155,7 +155,7 @@ void launch_scatter(const SweepGenome* genomes_dev, const SweepJob* jobs_dev, in
 // sort + replay + cursor reset of rows k0 .. k0+nks-1 (indices into a genome's K rows) of every genome
 // (presorted: the form of the chunks the scatter left, ScatterParams::presorted; 0 = unsorted: the sort pass runs first)
 void launch_replay(const BucketRow* rows_dev, int ngenomes, int K, int k0, int nks, const SweepPlan& plan, hipStream_t st,
-                   int presorted = 0);
+                   int presorted = 0, int row0 = 0, int nrows = -1 /* a row group of the class (dd_plan.h); -1: every row */);
 int sweep_max_lds_bytes();
 // small-k class: jobs carry ks <= kBitmapMaxK; records k-mer presence in genome.bitmap
 // (kfirst..klast: the ks of the class; the LDS image covers exactly their bitmaps)

@@ -21,6 +21,11 @@ struct SweepClass {
     // bucket mode (plan.mode == kBucketMode): the jobs of epoch e are jobs[epoch_begin[e] .. epoch_begin[e+1]);
     // one scatter launch per (class, epoch), one replay launch per epoch over the rows of all classes
     std::vector<size_t> epoch_begin;
+    // row groups (knobs.row_group_mb; single-epoch calls only): the class's rows -- numbered genome * nks + (k - kfirst) --
+    // in groups of group_rows; the scatter jobs of group i are jobs[group_begin[i] .. group_begin[i+1]), and the group's
+    // replay follows them at once, while its records are still in the 256 MiB memory-side cache.  Empty = one launch per epoch.
+    std::vector<size_t> group_begin;
+    int group_rows = 0;
 };
 
 // development knobs, read from the environment by from_env() (README.md lists them)
@@ -43,6 +48,7 @@ struct PlanKnobs {
     int bucket_probe = -1;          // second-level filter against the row itself: 1 / 0; -1 = default
     size_t bucket_budget = (size_t)16 << 30;  // HBM for the record areas of one call
     size_t bucket_slots = 8192;     // scatter jobs per (class, epoch) aimed at
+    size_t row_group_mb = 0;        // > 0: scatter -> replay per group of rows whose record areas sum to <= this (DD_ROW_GROUP_MB)
     static PlanKnobs from_env();
     bool operator==(const PlanKnobs& o) const {
         return lds_budget == o.lds_budget && lds_budget_forced == o.lds_budget_forced && jobs_per_cu == o.jobs_per_cu &&
@@ -50,7 +56,7 @@ struct PlanKnobs {
                filter == o.filter && xcd_affinity == o.xcd_affinity && taper == o.taper && buckets == o.buckets &&
                bucket_e0_tiles == o.bucket_e0_tiles && bucket_emax_tiles == o.bucket_emax_tiles &&
                bucket_cap_chunks == o.bucket_cap_chunks && bucket_logg == o.bucket_logg && bucket_fbits == o.bucket_fbits && bucket_probe == o.bucket_probe &&
-               bucket_budget == o.bucket_budget && bucket_slots == o.bucket_slots;
+               bucket_budget == o.bucket_budget && bucket_slots == o.bucket_slots && row_group_mb == o.row_group_mb;
     }
 };
 

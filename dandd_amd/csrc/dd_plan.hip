@@ -34,6 +34,7 @@ PlanKnobs PlanKnobs::from_env() {
     if (const char* e = getenv("DD_BUCKET_FBITS")) k.bucket_fbits = atoi(e) == 4 ? 4 : 8;
     if (const char* e = getenv("DD_BUCKET_PROBE")) k.bucket_probe = atoi(e) ? 1 : 0;
     if (const char* e = getenv("DD_BUCKET_SLOTS")) k.bucket_slots = (size_t)std::max(64, atoi(e));
+    if (const char* e = getenv("DD_ROW_GROUP_MB")) k.row_group_mb = (size_t)std::max(0, atoi(e));
     if (const char* e = getenv("DD_BUCKET_GB")) k.bucket_budget = (size_t)std::max(1, atoi(e)) << 30;
     return k;
 }
@@ -194,6 +195,13 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
             // one k per job; row r of the class goes to XCD r % 8 in every epoch (its filter and the token
             // tiles its ks share stay in that XCD's L2); job 8*i + x is the i-th job of XCD x
             const size_t nepochs = epoch_edge.size() - 1;
+            // (row groups: single-epoch calls with the binned first epoch only -- many small genomes, the regime whose
+            // record traffic is the bound; a row's area is what cap_chunks below comes to: ~(1 + 1/8) x 4 B per token)
+            int group_rows_e0 = 0;
+            if (knobs.row_group_mb && nepochs == 1 && !getenv("DD_BUCKET_NO_FIRST")) {
+                const size_t row_bytes = std::max<size_t>(1, (max_tiles * kTileTokens * 9 / 8) * 4);
+                group_rows_e0 = (int)std::max<size_t>(8, (knobs.row_group_mb << 20) / row_bytes / 8 * 8);
+            }
             size_t max_jobs_row_epoch = 1;
             const SweepJob idle = make_job(0, ka, 1, kmin, 0, 0);
             for (size_t e = 0; e < nepochs; ++e) {
@@ -209,7 +217,9 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
                 // once the epoch is long enough to allow it
                 const size_t slots = knobs.bucket_slots;  // (2048 .. 16384 measured: 8192 is best at log2m 18 and 20)
                 const int nk_e = (e == 0 && !getenv("DD_BUCKET_NO_FIRST")) ? 1 : bucket_nk;
-                const size_t tpj = std::max<size_t>(std::min<size_t>(2, t_hi - t_lo), (tile_rows / nk_e + slots - 1) / slots);
+                size_t tpj = std::max<size_t>(std::min<size_t>(2, t_hi - t_lo), (tile_rows / nk_e + slots - 1) / slots);
+                // (row groups: a group is one round of workgroups; one tile per job fills the chip best -- DD_ROW_GROUP_TPJ for A/B)
+                if (group_rows_e0 && e == 0) tpj = getenv("DD_ROW_GROUP_TPJ") ? (size_t)std::max(1, atoi(getenv("DD_ROW_GROUP_TPJ"))) : 1;
                 std::vector<std::vector<SweepJob>> per_xcd(8);
                 int row = 0;
                 for (int g = 0; g < ngenomes; ++g) {
@@ -222,7 +232,31 @@ std::vector<SweepClass> plan_sweep(int log2m, int canonical, const size_t* nbyte
                         max_jobs_row_epoch = std::max(max_jobs_row_epoch, nj);
                     }
                 }
-                if (!knobs.xcd_affinity) {
+                if (group_rows_e0 && e == 0) {
+                    // row groups: the same order, cut at every group_rows-th row; each group's XCD lists are padded to
+                    // one length of their own, so that a group is a contiguous range of the table
+                    sc.group_rows = group_rows_e0;
+                    std::vector<std::vector<SweepJob>> gx(8);
+                    int grow = 0;
+                    auto flush = [&]() {
+                        size_t longest = 0;
+                        for (auto& v : gx) longest = std::max(longest, v.size());
+                        sc.group_begin.push_back(sc.jobs.size());
+                        for (size_t i = 0; i < longest; ++i)
+                            for (int x = 0; x < 8; ++x) sc.jobs.push_back(i < gx[x].size() ? gx[x][i] : idle);
+                        for (auto& v : gx) v.clear();
+                    };
+                    for (int g = 0; g < ngenomes; ++g) {
+                        const size_t nt = std::min(tiles_of(nbytes[g]), t_hi);
+                        for (int q = 0; q < nks; ++q, ++grow) {
+                            if (grow && grow % group_rows_e0 == 0) flush();
+                            for (size_t t0 = t_lo; t0 < nt; t0 += tpj)
+                                gx[knobs.xcd_affinity ? grow % 8 : 0].push_back(make_job(g, ka + q, 1, kmin, t0, std::min(nt, t0 + tpj)));
+                        }
+                    }
+                    flush();
+                    sc.group_begin.push_back(sc.jobs.size());
+                } else if (!knobs.xcd_affinity) {
                     sc.jobs.insert(sc.jobs.end(), per_xcd[0].begin(), per_xcd[0].end());
                 } else {
                     size_t longest = 0;

@@ -1023,8 +1023,12 @@ __global__ __launch_bounds__(1024) void bigmap_finish_kernel(const SweepGenome* 
 // The rows a sort / replay / reset launch covers: rows k0 .. k0+nks-1 of every genome (one k class), numbered
 // densely; table index = genome * K + k0 + local % nks.
 struct RowSet {
-    int K, k0, nks, nrows;  // nrows = genomes * nks
-    DD_D int index(uint32_t local) const { return (int)(local / (uint32_t)nks) * K + k0 + (int)(local % (uint32_t)nks); }
+    int K, k0, nks, nrows;  // nrows = genomes * nks, or the rows of one row group
+    int row0;               // ... which starts at this row of the class
+    DD_D int index(uint32_t local) const {
+        local += (uint32_t)row0;
+        return (int)(local / (uint32_t)nks) * K + k0 + (int)(local % (uint32_t)nks);
+    }
 };
 constexpr uint32_t kChunkRecords = 1024;         // 4 KiB; one global atomic hands out one chunk of the row's stream
 
@@ -1685,6 +1689,167 @@ __global__ __launch_bounds__(1024) void scatter_first_bin_kernel(
     }
 }
 
+// ---- first epoch, PACKED binned tiles (round 5; DD_FIRST_WG=4: exact, but measured slower than the 4-byte bins -- kept for A/B) ----
+// The binned form above is bound by what it writes: 4 bytes per record at ~2.4-2.7 TB/s, whatever the instruction count
+// (timing-only builds of round 4: hash only 2.09 ms, perfectly coalesced 4-byte stores 3.33, bins 3.76 for the class-0 launch of
+// 64 x 5 Mbp at log2m 20 -- the launch takes what 9 GB of writes take), and the replay by reading them back at 5.2 TB/s.  A
+// record inside its bin (index tile x copy) is 16 bits of index and 6 of rho: 3 bytes in two streams, u16 index + u8 rho.
+// Two sub-dword stores per record from the hash loop would double the L2 write requests (already ~19 per wave-update), so
+// the records are STAGED IN LDS and leave in whole lines: the workgroup's counters hand out ring slots (the one returning
+// LDS atomic per record that the binned form has too), a record is one ds_write, and every kPackPeriod updates, behind one
+// workgroup barrier, wave b packs bin b's records of the period -- eight per lane: one 16-byte store of indices, one 8-byte
+// store of rhos, contiguous across the lanes -- while the others already fill the ring's other half.  A period's records
+// per bin are padded with null records (rho 0) to a multiple of eight, so every store is whole and aligned and the replay
+// needs no tail handling.  MEASURED (profiles/r05_bucket_path.txt): 64 x 5 Mbp at log2m 20 31.0 ms against 23.8 with the 4-byte
+// bins -- the scatter launches 4.8 / 11.7 / 6.9 ms against 3.6 / 8.1 / 4.3 (16 barriers and flushes per tile of tokens), the
+// replay 2.47 against 2.58 ms per launch: 25 % fewer bytes buy it 4 %, it is bound by its LDS compare-and-swaps and their
+// ~26 VALU instructions per record, not by HBM (plain fills run at 6.8 TB/s on this chip: scripts/hbm_probe.py).
+// A bin that overflows its ring half (mean 256 of 384: +8 sigma; a low-complexity stretch can) or
+// its region of the stream sends the record to its register by compare-and-swap, exactly.
+constexpr uint32_t kPackPeriod = 4;                       // updates per thread between flushes: 4096 records per workgroup
+constexpr uint32_t kPackRing = 384;                       // ring slots per (half, bin)
+constexpr uint32_t kPackBinBytes = kBinCap * 3u;          // a bin's region of the stream: u16 [kBinCap] indices, u8 [kBinCap] rhos
+constexpr uint32_t kPackChunkUnits = 16u * kPackBinBytes / 4u;   // 53 760: stream space of one tile of tokens, in 4-byte units (52.5 x 1024)
+constexpr uint32_t kPackCtr = 0u;                         // LDS: counters [2][16] at 0, the job's position at 128, the ring behind
+constexpr uint32_t kPackRingAt = 256u;
+constexpr uint32_t kPackLdsBytes = kPackRingAt + 2u * 16u * kPackRing * 4u;   // 49 408
+static_assert(kBinCap % 8u == 0 && kPackBinBytes % 16u == 0 && (kBinCap * 2u) % 16u == 0, "packed bins: aligned 16-byte pieces");
+
+template <int KC, bool CANON>
+__global__ __launch_bounds__(1024) void scatter_first_pack_kernel(
+    const SweepGenome* __restrict__ genomes, const SweepJob* __restrict__ jobs, int p, ScatterParams sp) {
+    const SweepJob job = jobs[blockIdx.x];
+    if (job.tile_begin >= job.tile_end) return;  // filler of the XCD-affine order
+    lds_starts_at_zero();
+    const SweepGenome g = genomes[job.genome];
+    const int k = job.kfirst;
+    const unsigned long long ntok = uniform64(gload8u(g.ntok));
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+
+    struct TileIn {
+        uint4 hc, sc;
+        uint2 hb, sb;
+        bool live;
+    };
+    auto fetch = [&](unsigned tile, TileIn& t) {
+        const unsigned long long seg = (unsigned long long)tile * blockDim.x + threadIdx.x;
+        t.live = tile < job.tile_end && seg * kSegTokens < ntok;
+        t.hc = make_uint4(0, 0, 0, 0);
+        t.hb = make_uint2(~0u, ~0u);
+        t.sc = make_uint4(0, 0, 0, 0);
+        t.sb = make_uint2(~0u, ~0u);
+        if (!t.live) return;
+        if (seg > 0) {
+            t.hc = gload16(g.codes + (seg - 1) * 4);
+            t.hb = gload8(g.bad + (seg - 1) * 2);
+        }
+        t.sc = gload16(g.codes + seg * 4);
+        t.sb = gload8(g.bad + seg * 2);
+    };
+    TileIn next;
+    fetch(job.tile_begin, next);
+
+    const BucketRow row = sp.rows[(size_t)job.genome * sp.K + job.krow];
+    uint8_t* const area = reinterpret_cast<uint8_t*>(uniform_ptr(row.area));
+    uint16_t* const counts = uniform_ptr(row.seg);  // [chunk][16]: records (nulls included) in each bin
+    uint8_t* const regs = uniform_ptr(row.regs);
+    const uint32_t cap_records = sp.cap_chunks * kChunkRecords;
+    const int cshift = 4 - sp.nb_log2, tile_sh = 32 - sp.nb_log2;
+    if (threadIdx.x < 32u) lds32(kPackCtr + 4u * threadIdx.x) = 0;
+    if (threadIdx.x == 0) lds32(kBinPosSlot) = gadd32(row.cursor, (job.tile_end - job.tile_begin) * kPackChunkUnits);
+    __syncthreads();
+    const uint32_t pos0 = __builtin_amdgcn_readfirstlane(lds32(kBinPosSlot));
+    const uint32_t copy = lane & ((1u << cshift) - 1u);
+    auto to_register = [&](uint32_t rec) {   // the exact way out: straight to the row
+        uint8_t* a = regs + (rec & 0xFFFFFFu);
+        (void)cas_raise<RegsGlobal>(a, RegsGlobal::load32(a), rec >> 24);
+    };
+
+    for (unsigned tile = job.tile_begin; tile < job.tile_end; ++tile) {
+        const TileIn in = next;
+        fetch(tile + 1, next);
+        const uint32_t t = tile - job.tile_begin;
+        const uint32_t cpos = pos0 + t * kPackChunkUnits;
+        const bool room = cpos + kPackChunkUnits <= cap_records;  // else: the stream is full, records go to the registers (exact, slow, rare)
+        const bool any_live = __any(in.live);
+        const uint4 hc = in.hc, sc = in.sc;
+        const uint2 hb = in.hb, sb = in.sb;
+        const uint32_t cw[4] = {sc.x, sc.y, sc.z, sc.w};
+        Windows<KC == 1 ? 5 : (KC == 3 ? 6 : (KC == 2 ? 7 : KC))> win;
+        win.prime(hc);
+        const bool clean = __all((hb.x | hb.y | sb.x | sb.y) == 0u);
+        int run = hb.y ? __builtin_clz(hb.y) : 32 + (hb.x ? __builtin_clz(hb.x) : 32);
+        uint8_t* const mybin = area + (size_t)cpos * 4u + (size_t)wave * kPackBinBytes;   // wave b owns bin b of the chunk
+        uint32_t placed = 0;     // records (nulls included) of this wave's bin stored so far: a multiple of 8
+        uint32_t par = 0;
+        auto update = [&](bool valid, uint32_t ctr, uint32_t ring) {
+            const Probe q = probe(win.template hash<CANON>(k), p);
+            if (!valid) return;
+            const uint32_t rec = (q.hi >> (32 - p)) | (rho_of(q, p) << 24);
+            const uint32_t bin = ((q.hi >> tile_sh) << cshift) | copy;
+            uint32_t slot = kPackRing;
+            if (room) slot = atomicAdd(&lds32(ctr + (bin << 2)), 1u);
+            if (__builtin_expect(slot < kPackRing, 1)) lds32(ring + ((bin * kPackRing + slot) << 2)) = rec;
+            else to_register(rec);
+        };
+        // wave b: bin b's records of the period that has just ended leave for the stream
+        auto flush = [&](uint32_t ctr, uint32_t ring) {
+            uint32_t c = __builtin_amdgcn_readfirstlane(lds32(ctr + 4u * wave));
+            if (c == 0u) return;
+            if (lane == 0u) lds32(ctr + 4u * wave) = 0;
+            c = c < kPackRing ? c : kPackRing;                  // (what came later went to the registers)
+            const uint32_t cp = (c + 7u) & ~7u, i0 = 8u * lane;
+            if (i0 < cp) {
+                const uint32_t src = ring + ((wave * kPackRing + i0) << 2);
+                uint32_t r[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] = i0 + (uint32_t)j < c ? lds32(src + 4u * (uint32_t)j) : 0u;   // (two ds_read_b128; past c: null records)
+                if (__builtin_expect(placed + i0 + 8u <= kBinCap, 1)) {
+                    const uint4 idx = make_uint4((r[0] & 0xFFFFu) | (r[1] << 16), (r[2] & 0xFFFFu) | (r[3] << 16), (r[4] & 0xFFFFu) | (r[5] << 16), (r[6] & 0xFFFFu) | (r[7] << 16));
+                    const uint2 rho = make_uint2((r[0] >> 24) | ((r[1] >> 24) << 8) | ((r[2] >> 24) << 16) | (r[3] & 0xFF000000u),
+                                                 (r[4] >> 24) | ((r[5] >> 24) << 8) | ((r[6] >> 24) << 16) | (r[7] & 0xFF000000u));
+                    gstore16(mybin + 2u * (placed + i0), idx);
+                    gstore8(mybin + 2u * kBinCap + placed + i0, rho);
+                } else {   // the bin's region of the stream is full
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (r[j] >> 24) to_register(r[j]);
+                }
+            }
+            placed = placed + cp < kBinCap ? placed + cp : kBinCap;
+        };
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t bw = ((w & 2) ? sb.y : sb.x) >> ((w & 1) * 16);
+#pragma unroll 1
+            for (uint32_t q4 = 0; q4 < 16u / kPackPeriod; ++q4) {
+                const uint32_t ctr = kPackCtr + par * 64u, ring = kPackRingAt + par * (16u * kPackRing * 4u);
+                if (any_live) {
+                    if (clean) {
+#pragma unroll 1
+                        for (uint32_t j = 0; j < kPackPeriod; ++j) {
+                            win.push((cw[w] >> (2u * (q4 * kPackPeriod + j))) & 3u);
+                            update(true, ctr, ring);
+                        }
+                    } else {
+#pragma unroll 1
+                        for (uint32_t j = 0; j < kPackPeriod; ++j) {
+                            const uint32_t i = q4 * kPackPeriod + j;
+                            run = ((bw >> i) & 1u) ? 0 : run + 1;
+                            win.push((cw[w] >> (2u * i)) & 3u);
+                            update(run >= k, ctr, ring);
+                        }
+                    }
+                }
+                __syncthreads();   // the period's records are in the ring; the other half and its counters are free again
+                flush(ctr, ring);
+                par ^= 1u;
+            }
+        }
+        if (room && lane == 0u) ((DD_GLOBAL uint16_t*)counts)[(size_t)(cpos / kPackChunkUnits) * 16u + wave] = (uint16_t)placed;
+    }
+}
+
 // Between scatter and replay when a row has more than one index tile (log2m >= 17): every chunk of every
 // stream is sorted by index tile in place (one wave per chunk: LDS counting sort), null records dropped,
 // and the start of each tile's segment is noted in seg[chunk][tile].  A replay workgroup then reads only
@@ -1812,7 +1977,59 @@ __global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restric
                 if ((retry >> i) & 1u) (void)cas_raise<RegsLds>(e[i] & (tile - 1u), wd[i], e[i] >> 24);
         }
     };
-    if (FORM == 3) {
+    if (FORM == 4) {
+        // the first epoch's PACKED bins (scatter_first_pack_kernel): chunk C = 16 bins of kPackBinBytes, each u16 [kBinCap]
+        // indices in the tile + u8 [kBinCap] rhos, counts (multiples of 8, null records included) in seg[C][16]; units and
+        // pieces as in FORM 3: 512 records = 1 KiB of indices + 512 B of rhos per piece, 8 records per lane
+        const int cshift = 4 - nb_log2;
+        const uint32_t nunits = (nrec / kPackChunkUnits) << cshift;
+        const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        struct Piece {
+            uint4 idx;
+            uint2 rho;
+            bool any;   // wave-uniform
+        };
+        auto header = [&](uint32_t u) -> uint32_t {  // records in unit u's bin
+            return u < nunits ? (uint32_t)seg[(size_t)(u >> cshift) * 16u + ((b << cshift) | (u & ((1u << cshift) - 1u)))] : 0u;
+        };
+        auto issue = [&](uint32_t u, uint32_t cnt, Piece& P) {
+            const uint32_t off = ((wave - u) & 15u) * 512u;
+            cnt = __builtin_amdgcn_readfirstlane(cnt);
+            P.idx = make_uint4(0, 0, 0, 0);
+            P.rho = make_uint2(0, 0);
+            P.any = off < cnt;
+            if (!P.any) return;
+            const uint8_t* base = reinterpret_cast<const uint8_t*>(row.area) + (size_t)(u >> cshift) * (kPackChunkUnits * 4u) +
+                                  (size_t)((b << cshift) | (u & ((1u << cshift) - 1u))) * kPackBinBytes;
+            const uint32_t i = off + 8u * lane;
+            if (i < cnt) {   // (counts are multiples of 8: a lane's eight records are all there)
+                P.idx = gload16(base + 2u * i);
+                P.rho = gload8(base + 2u * kBinCap + i);
+            }
+        };
+        uint32_t c1 = header(1), c2 = header(2);
+        Piece cur, nxt;
+        issue(0, header(0), cur);
+        for (uint32_t u = 0; u < nunits; ++u) {
+            issue(u + 1u, c1, nxt);
+            c1 = c2;
+            c2 = header(u + 3u);
+            if (cur.any) {
+                const uint32_t ix[4] = {cur.idx.x, cur.idx.y, cur.idx.z, cur.idx.w};
+                uint32_t ea[U], eb[U];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    ea[2 * j] = (ix[j] & 0xFFFFu) | (((cur.rho.x >> (16 * j)) & 0xFFu) << 24);
+                    ea[2 * j + 1] = (ix[j] >> 16) | (((cur.rho.x >> (16 * j + 8)) & 0xFFu) << 24);
+                    eb[2 * j] = (ix[2 + j] & 0xFFFFu) | (((cur.rho.y >> (16 * j)) & 0xFFu) << 24);
+                    eb[2 * j + 1] = (ix[2 + j] >> 16) | (((cur.rho.y >> (16 * j + 8)) & 0xFFu) << 24);
+                }
+                apply_u(ea);
+                apply_u(eb);
+            }
+            cur = nxt;
+        }
+    } else if (FORM == 3) {
         const int cshift = 4 - nb_log2;
         const uint32_t nunits = (nrec / kBinChunkRecords) << cshift;
         const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2092,7 +2309,10 @@ void launch_scatter(const SweepGenome* genomes, const SweepJob* jobs, int njobs,
         // tiles get their chunks sorted on the way out: 4 KiB + 256 B of LDS per wave)
 #define DD_FIRST(KC, CN)                                                                                                           \
     do {                                                                                                                           \
-        if (sp.presorted == 3) {                                                                                                   \
+        if (sp.presorted == 4) {                                                                                                   \
+            auto kern = scatter_first_pack_kernel<KC, CN>;                                                                         \
+            hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3(1024), std::max((size_t)kPackLdsBytes, first_lds_floor), st, genomes, jobs, plan.log2m, sp); \
+        } else if (sp.presorted == 3) {                                                                                            \
             auto kern = scatter_first_bin_kernel<KC, CN>;                                                                          \
             hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3(1024), std::max((size_t)kBinLdsBytes, first_lds_floor), st, genomes, jobs, plan.log2m, sp); \
         } else if (sp.presorted == 2) {                                                                                            \
@@ -2167,8 +2387,8 @@ void launch_scatter(const SweepGenome* genomes, const SweepJob* jobs, int njobs,
 #undef DD_SCATTER_NN
 }
 
-void launch_replay(const BucketRow* rows, int ngenomes, int K, int k0, int nks, const SweepPlan& plan, hipStream_t st, int presorted) {
-    const RowSet rs{K, k0, nks, ngenomes * nks};
+void launch_replay(const BucketRow* rows, int ngenomes, int K, int k0, int nks, const SweepPlan& plan, hipStream_t st, int presorted, int row0, int nrows) {
+    const RowSet rs{K, k0, nks, nrows >= 0 ? std::min(nrows, ngenomes * nks - row0) : ngenomes * nks, row0};
     if (rs.nrows <= 0) return;
     const size_t tile = (size_t)1 << (plan.log2m - plan.nb_log2);
     const unsigned blocks = (unsigned)((rs.nrows + 7) / 8) * 8u << plan.nb_log2;
@@ -2177,14 +2397,15 @@ void launch_replay(const BucketRow* rows, int ngenomes, int K, int k0, int nks, 
         hipLaunchKernelGGL(sort_chunks_kernel, dim3((unsigned)rs.nrows * wgs_per_row), dim3(256), 0, st, rows, rs, plan.log2m,
                            plan.nb_log2, plan.cap_chunks, wgs_per_row);
     }
-    static std::atomic<unsigned long long> attr_done[3] = {{0}, {0}, {0}};
+    static std::atomic<unsigned long long> attr_done[4] = {{0}, {0}, {0}, {0}};
 #define DD_REPLAY(FORM, SLOT)                                                                                                   \
     do {                                                                                                                        \
         allow_full_lds(reinterpret_cast<const void*>(replay_kernel<FORM>), attr_done[SLOT]);                                    \
         hipLaunchKernelGGL(replay_kernel<FORM>, dim3(blocks), dim3(1024), tile, st, rows, rs, plan.log2m, plan.logg, plan.nb_log2, \
                            plan.cap_chunks, plan.fbits);                                                                        \
     } while (0)
-    if (presorted == 3) DD_REPLAY(3, 2);       // the first epoch's binned tiles
+    if (presorted == 4) DD_REPLAY(4, 3);       // the first epoch's packed bins (3 bytes per record)
+    else if (presorted == 3) DD_REPLAY(3, 2);  // ... its binned tiles (4 bytes per record)
     else if (presorted == 2) DD_REPLAY(2, 1);  // ... or its workgroup chunks
     else DD_REPLAY(0, 0);
 #undef DD_REPLAY

@@ -79,8 +79,10 @@ void orc_idx_rho(uint64_t h, int p, uint32_t *idx, uint8_t *rho) {
  *     skipped; the line terminator is dropped, and so is ONE '\r' in front of it;
  *   - a line starting with '>' or '@' starts the next record;
  *   - a line starting with '+' makes the record a FASTQ record: the rest of that line is skipped, then whole lines are
- *     read as quality until they hold at least as many characters as the sequence; the reader then looks for the next
- *     '>' or '@' ANYWHERE in what follows (kseq's last_char = 0).
+ *     read as quality until they hold at least as many characters as the sequence (one line at least); the reader then
+ *     looks for the next '>' or '@' ANYWHERE in what follows (kseq's last_char = 0);
+ *   - a FASTQ record whose '+' line is cut off by the end of the input, or whose quality text is not exactly as long as
+ *     its sequence, is an error (kseq_read returns -2): that record and everything behind it are not read.
  * Output: the sequence bytes of every record verbatim (a '\r' inside a line, digits, anything), each record CLOSED by
  * one '\n' -- a byte that cannot occur in sequence text -- so that the encoder sees one BREAK per record.  `out` needs
  * n + 1 bytes at most (NULL: count only).  Returns the number of bytes written. */
@@ -97,6 +99,7 @@ size_t orc_records(const uint8_t *fa, size_t n, uint8_t *out) {
         while (i < n && fa[i] != '\n') ++i; /* name and comment */
         if (i < n) ++i;
         size_t seq_len = 0;
+        const size_t o_rec = o; /* where this record's text starts: a truncated FASTQ record is taken back */
         int c = -1; /* the character that ended the sequence part; -1: end of input */
         while (i < n) {
             c = fa[i];
@@ -125,18 +128,25 @@ size_t orc_records(const uint8_t *fa, size_t n, uint8_t *out) {
             have_header = 1;
             continue;
         }
-        /* c == '+': FASTQ.  Skip the rest of the '+' line, then quality lines until they cover the sequence. */
+        /* c == '+': FASTQ.  Skip the rest of the '+' line, then quality lines until they cover the sequence.
+         * kseq_read returns -2 -- and the reader's `while (kseq_read(ks) >= 0)` loop drops THIS record and everything
+         * behind it -- when the input ends inside the '+' line ("no quality string") or when the quality text is not
+         * exactly as long as the sequence; its loop tests the length AFTER reading a line, so one quality line is read
+         * even for an empty sequence. */
         while (i < n && fa[i] != '\n') ++i;
-        if (i < n) ++i;
+        if (i >= n) return o_rec;
+        ++i;
         size_t qual_len = 0;
-        while (i < n && qual_len < seq_len) {
+        do {
+            if (i >= n) break; /* ks_getuntil2 at the end of the input: nothing read */
             size_t e = i;
             while (e < n && fa[e] != '\n') ++e;
             size_t len = e - i;
             if (len && fa[e - 1] == '\r' && qual_len + len > 1) --len;
             qual_len += len;
             i = e < n ? e + 1 : e;
-        }
+        } while (qual_len < seq_len);
+        if (qual_len != seq_len) return o_rec;
     }
     return o;
 }

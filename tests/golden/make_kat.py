@@ -17,7 +17,13 @@ for text in ["", ">h\n", ">h", "ACGT", "ACGTNNACGT\n>late\nGGCC\n", "junk junk >
              ">a\r\nACGTAC\r\nGTACGG\r\n", ">a\nAC\rGT\nAA\r\r\nC\n", ">a\nACGT>ACGT\n@b also a header\nTTTT\n",
              "@r1\nACGTACGT\n+\nIIIIIIII\n@r2\nGGCCA\n+r2\nII@>I\n", "@r1\nACGT\nACGT\n+\nIIII\nII@I\n@r2\nTT\n+\n>I\n",
              "@r1\nACGT\n+\nII\n", ">x\nACGT\n+\nACGT\nGGGG>y\nCC\n", "@q\nAC\n+\n@@\n@q2\nGG\n+\n>>\n>f\nTTA\n",
-             "\n\n>x\n\nACG\n\nT\n", ">only\n\n\n", "@", "+\nACGT\n>z\nAC\n"]:
+             "\n\n>x\n\nACG\n\nT\n", ">only\n\n\n", "@", "+\nACGT\n>z\nAC\n",
+             # kseq_read's -2 (round 5): a FASTQ record cut off inside its '+' line, or whose quality text is not exactly as long
+             # as its sequence, ends the reading -- that record and everything behind it are dropped; one quality line is read
+             # even for an empty sequence
+             "@r1\nACGT\n+", "@r1\nACGT\n+\n", "@r1\nACGT\n+\nIIIII\n@r2\nAA\n+\nII\n",
+             "@ok\nAC\n+\nII\n@bad\nACGT\n+\nII\n@after\nGG\n+\nII\n", "@e\n+\n\n@r2\nAA\n+\nII\n", "@e\n+\n@r2\nAA\n+\nII\n",
+             "@e\n+", "@e\n+\n", ">fa\nACGT\n@fq\nGG\n+\nI\n>fa2\nTT\n", "@r\nAC\nGT\n+\nII\nI\n@r2\nCC\n+\nII\n"]:
     kat["records"].append([text, [r.decode("latin-1") for r in pyref.records(text.encode("latin-1"))]])
 for x in [0, 1, 2, 0xDEADBEEF, 2**32, 2**63, 2**64 - 1] + [rnd.getrandbits(64) for _ in range(40)]:
     kat["wang64"].append([hex(x), hex(pyref.wang64(x))])

@@ -35,7 +35,9 @@ def records(fa: bytes):
     """The sequence strings of a FASTA / FASTQ buffer, read the way klib's kseq.h reads it (character by character, as
     kseq_read does with ks_getc / ks_getuntil): what is in front of the first '>' or '@' is skipped; name and comment run to
     the end of the line; sequence lines follow until a line starts with '>', '@' or '+'; a '+' line opens quality lines,
-    read until they are as long as the sequence, after which the reader again looks for '>' or '@' anywhere."""
+    read (one at least) until they are as long as the sequence, after which the reader again looks for '>' or '@' anywhere;
+    a FASTQ record cut off inside its '+' line, or with a quality text of another length than its sequence, ends the reading
+    (kseq_read's -2 under `while (kseq_read(ks) >= 0)`): that record and what follows are dropped."""
     out, i, n = [], 0, len(fa)
     last_char = 0
     while True:
@@ -67,23 +69,35 @@ def records(fa: bytes):
             if len(seq) > 1 and seq[-1] == 13:          # KS_SEP_LINE: one trailing '\r' goes
                 seq.pop()
             c = -1
-        out.append(bytes(seq))
         if c in (62, 64):
+            out.append(bytes(seq))
             last_char = c
             continue
         if c != 43:
+            out.append(bytes(seq))
             return out
-        while i < n and fa[i] != 10:                    # rest of the '+' line
+        while True:                                     # rest of the '+' line: ks_getc until '\n'
+            if i >= n:
+                return out                              # -1 inside the '+' line: kseq_read returns -2, the record is dropped
+            ch = fa[i]
             i += 1
-        i += 1
+            if ch == 10:
+                break
         qual = bytearray()
-        while i < n and len(qual) < len(seq):
+        while True:                                     # do { ks_getuntil2(line, append) } while (qual.l < seq.l)
+            if i >= n:
+                break                                   # nothing left to read: the call returns -1
             while i < n and fa[i] != 10:
                 qual.append(fa[i])
                 i += 1
             i += 1
             if len(qual) > 1 and qual[-1] == 13:
                 qual.pop()
+            if len(qual) >= len(seq):
+                break
+        if len(qual) != len(seq):
+            return out                                  # -2: this record and everything behind it are not read
+        out.append(bytes(seq))
 
 
 def tokenize(fa: bytes):

@@ -115,6 +115,11 @@ BUCKET_KNOBS = {
     "bins_tight": {"DD_BUCKET_CAP": "150", "DD_BUCKET_E0": "3"},       # binned first epoch (70 chunks of stream per tile of tokens) against a 150-chunk stream: two tiles fit, the third overflows
     "wg_chunks_tight": {"DD_FIRST_WG": "2", "DD_BUCKET_CAP": "40", "DD_BUCKET_E0": "3"},
     "bins_big_tiles": {"DD_BUCKET_TILE_LOG2": "17", "DD_BUCKET_E0": "3"},
+    "packed_bins": {"DD_FIRST_WG": "4", "DD_BUCKET_E0": "3"},               # round 5: the first epoch's bins packed to 3 bytes per record through an LDS ring (A/B knob: measured slower)
+    "packed_bins_one_epoch": {"DD_FIRST_WG": "4"},
+    "packed_bins_tight": {"DD_FIRST_WG": "4", "DD_BUCKET_CAP": "110", "DD_BUCKET_E0": "3"},     # packed bins take 52.5 chunks of stream per tile of tokens: two fit, the third goes to the registers
+    "row_groups": {"DD_ROW_GROUP_MB": "1"},                              # round 5: scatter -> replay per group of 8 rows, record areas a ring
+    "row_groups_two_tiles_per_job": {"DD_ROW_GROUP_MB": "1", "DD_ROW_GROUP_TPJ": "2"},
 }
 
 
@@ -150,6 +155,54 @@ def test_bucket_mode_batched_unequal_genomes(engine_factory, torch_cuda, orc, mo
     got = regs.cpu().numpy()
     for g, f in enumerate(fas):
         assert np.array_equal(got[g], orc.sketch_sweep(f, 15, 18, 19)), g
+
+
+@pytest.mark.parametrize("p", [17, 18, 20])
+def test_packed_bins_on_low_complexity_text(engine_factory, orc, monkeypatch, p):
+    """(DD_FIRST_WG=4, an A/B knob since it measured slower.)  The first epoch's packed bins stage a period's records in an LDS ring of 384 slots per bin (mean 256 for uniformly
+    spread hashes).  Homopolymer and short-period stretches put EVERY record of a period into one bin: the ring and the
+    bin's region of the stream overflow and the records go to their registers by compare-and-swap -- exactly."""
+    monkeypatch.setenv("DD_FIRST_WG", "4")
+    eng = engine_factory(p, True)
+    rng = np.random.default_rng(p)
+    mixed = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=150_000))
+    fa = np.frombuffer(b">hp\n" + b"A" * 400_000 + b"\n>di\n" + b"AC" * 150_000 + b"\n>mix\n" + mixed + b"T" * 70_000 + mixed[:50_000] + b"\n", dtype=np.uint8)
+    _sweep_check(eng, orc, fa, 15, 18, True)
+    _sweep_check(eng, orc, fa, 31, 34, True)
+    eng_nc = engine_factory(p, False)
+    _sweep_check(eng_nc, orc, fa, 20, 21, False)
+
+
+@pytest.mark.parametrize("p", [18, 20])
+def test_row_groups_over_unequal_genomes(engine_factory, torch_cuda, orc, monkeypatch, p):
+    """DD_ROW_GROUP_MB (round 5): a single-epoch call's rows go scatter -> replay in groups of 8, on two streams in turn, and the
+    record areas of a stream's successive groups are the same ring of slots.  7 genomes of unequal length (one empty, one of a
+    single tile) x k 12..40 = 4 k classes, 203 rows, 27 groups: every row == the oracle, twice (the ring is reused by the second call)."""
+    torch = torch_cuda
+    monkeypatch.setenv("DD_ROW_GROUP_MB", "1")
+    eng = engine_factory(p, True)
+    sizes = [(0, 500_000, 3), (1, 66_000, 1), (2, 0, 1), (3, 140_000, 2), (4, 300_000, 5), (5, 420_000, 1), (6, 90_000, 2)]
+    fas = [orc.synth_fasta(SEED, g, nb, nr) for g, nb, nr in sizes]
+    bufs = [torch.from_numpy(f.copy()).cuda() if f.size else torch.empty(16, dtype=torch.uint8, device="cuda") for f in fas]
+    regs = torch.empty((len(fas), 29, eng.m), dtype=torch.uint8, device="cuda")
+    want = {}
+    for rep in range(2):
+        regs.zero_()
+        eng.sketch_device([b.data_ptr() for b in bufs], [f.size for f in fas], 12, 40, regs.data_ptr())
+        eng.synchronize()
+        got = regs.cpu().numpy()
+        for g, f in enumerate(fas):
+            for k in (12, 16, 17, 29, 32, 33, 40):
+                if (g, k) not in want:
+                    want[g, k] = orc.sketch(f, k, p, True)
+                assert np.array_equal(got[g, k - 12], want[g, k]), (rep, g, k)
+    # ... and the rows in between against a run without the knob
+    monkeypatch.delenv("DD_ROW_GROUP_MB")
+    eng2 = engine_factory(p, True)
+    regs2 = torch.empty_like(regs)
+    eng2.sketch_device([b.data_ptr() for b in bufs], [f.size for f in fas], 12, 40, regs2.data_ptr())
+    eng2.synchronize()
+    assert torch.equal(regs, regs2)
 
 
 @pytest.mark.parametrize("p", [14, 17, 19, 20])
