@@ -1638,7 +1638,7 @@ __global__ __launch_bounds__(1024) void scatter_first_bin_kernel(
             const uint4 hc = in.hc, sc = in.sc;
             const uint2 hb = in.hb, sb = in.sb;
             const uint32_t cw[4] = {sc.x, sc.y, sc.z, sc.w};
-            uint32_t* const bins = area + cpos + copy * kBinCap;  // this lane's copy of bin 0 of the chunk
+            uint8_t* const chunk = reinterpret_cast<uint8_t*>(area + cpos);   // (wave-uniform: the store below is base + 32-bit offset)
                     Windows<KC == 1 ? 5 : (KC == 3 ? 6 : (KC == 2 ? 7 : KC))> win;
             win.prime(hc);
             // (deferring a record's store until the next update's atomic is out, so that the slot's LDS round trip overlaps a
@@ -1651,7 +1651,11 @@ __global__ __launch_bounds__(1024) void scatter_first_bin_kernel(
                 uint32_t slot = kBinCap;
                 if (room) slot = atomicAdd(&lds32(ctr + ((bin0 | copy) << 2)), 1u);
                 if (__builtin_expect(slot < kBinCap, 1)) {
-                    gstore4(bins + bin0 * kBinCap + slot, rec);
+                    // (round 5: the slot's address as the chunk's uniform base + a 32-bit byte offset -- one v_mad_u32_u24 and a shift
+                    // in front of a store with an SGPR base instead of a multiply and two 64-bit adds; A/B on one box: 23.3-23.6 against
+                    // 23.4-23.8 ms for 64 x 5 Mbp at log2m 20, 25.0-25.2 against 24.9-25.0 for 10 x 50 Mbp -- within the noise: the kernel is
+                    // not waiting for its VALU, profiles/r05_bucket_path.txt)
+                    gstore4(chunk + (__umul24(bin0 | copy, kBinCap) + slot) * 4u, rec);
                 } else {
                     uint8_t* a = regs + (rec & 0xFFFFFFu);
                     (void)cas_raise<RegsGlobal>(a, RegsGlobal::load32(a), rec >> 24);
