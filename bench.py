@@ -684,6 +684,9 @@ def main():
     ap.add_argument("--share-mbp", type=float, default=None, help="size of the genomes of secondary.cfg5share_* (default 3000: the real share)")
     ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
                     help="sidecar with the FULL result object (the stdout line is its compact form and names this file)")
+    ap.add_argument("--abi-comm", action="store_true",
+                    help="data-path collectives through the C ABI (dd_allreduce_max_u8 / dd_allgather_u8: RCCL called by "
+                         "libdandd_hip.so) instead of torch.distributed, which then only carries the communicator's id")
     ap.add_argument("--force-dist", action="store_true",
                     help="run through the launcher and a process group even at --gpus 1 (world size 1): the RCCL "
                          "all-reduce / all-gather of the N>1 path execute in librccl on a one-GPU box")
@@ -742,6 +745,8 @@ def main():
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     wl = Workload(torch, eng, ids, nb, cfg["nrec"], kmin, kmax)
     ng, nbytes = wl.ng, wl.nbytes
+    if args.abi_comm and use_group:
+        ddist.use_abi_comm(eng)
 
     # progressive / pairwise schedules run over the JOB's leaves: with several ranks the leaf slabs are all-gathered
     # first and the orderings split over the ranks (cfg 4 is a 4-GPU config)
@@ -1012,7 +1017,8 @@ def main():
             "unit": "Gbp/s",
             "n_gpus": world,
             "gpus_active": gpus_active,
-            "collectives": dict(ddist.STATS, backend=(dist.get_backend() if use_group else None),
+            "collectives": dict(ddist.STATS, backend=(("rccl via the C ABI (dd_comm_*), id over " + dist.get_backend()) if (use_group and args.abi_comm)
+                                                      else dist.get_backend() if use_group else None),
                                 launcher=("bench.py self-spawn" if os.environ.get("DD_BENCH_SPAWNED") else
                                           "torch.distributed.run" if launched else None)),
             "steps": steps,
@@ -1051,6 +1057,7 @@ def main():
         print(compact_line(out, write_detail(out, os.path.abspath(args.detail))), flush=True)
     if use_group:
         dist.barrier()
+        ddist.drop_abi_comm()
         dist.destroy_process_group()
     eng.close()
 

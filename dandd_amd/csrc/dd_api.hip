@@ -13,6 +13,7 @@
 #include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -174,6 +175,10 @@ struct dd_ctx {
     uint64_t st_tokens = 0, st_updates = 0;
     int st_blocks = 0;
     int k2_path = 0;  // DD_K2_*: what the last progressive / pairwise call ran
+    // multi-GPU (dd_comm_*): this context's rank in an RCCL communicator, one context = one process = one GPU
+    void* comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    unsigned long long comm_calls[2] = {0, 0};   // all-reduces, all-gathers issued
 };
 
 namespace {
@@ -318,6 +323,7 @@ void dd_destroy(dd_ctx* c) {
     if (!c) return;
     DeviceGuard g(c->device);
     (void)hipStreamSynchronize(c->stream);
+    (void)dd_comm_destroy(c);
     for (auto& v : c->spans)
         for (auto& s : v) {
             (void)hipEventDestroy(s.a);
@@ -2062,3 +2068,138 @@ int dd_synth_realistic_device(dd_ctx* c, uint64_t seed, int genome_index, uint64
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------- multi-GPU: RCCL over xGMI behind the C ABI
+// (genome x k) jobs shard over the GPUs of a node with no data-path exchange; what crosses xGMI is the root --
+// every rank's [K][m] slab of byte-max-merged registers through ncclAllReduce(ncclUint8, ncclMax) -- and, for the schedules that
+// need every leaf (progressive, kij), one ncclAllGather of the ranks' leaf slabs.  The reference's only parallelism is
+// `parallel -j 95%` over k on one host (/root/reference/lib/huffman_dandd.py:217).  librccl is opened at the first dd_comm_*
+// call (the copy already mapped into the process if there is one -- PyTorch-ROCm brings its own), never linked: a single-GPU
+// user of this library needs no RCCL.
+#include <rccl/rccl.h>
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+};
+RcclApi* rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {getenv("DD_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (int pass = 0; pass < 2 && !api.lib; ++pass)      // pass 0: a copy that is already mapped (RTLD_NOLOAD)
+            for (const char* n : names)
+                if (n && !api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+        if (!api.lib) {
+            api.why = std::string("librccl.so not found (") + (dlerror() ? dlerror() : "?") + "); set DD_RCCL_LIB";
+            return;
+        }
+        auto sym = [&](const char* n) {
+            void* f = dlsym(api.lib, n);
+            if (!f && api.why.empty()) api.why = std::string("librccl: no symbol ") + n;
+            return f;
+        };
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+        api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+        api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+    });
+    return &api;
+}
+int rccl_ready(RcclApi*& api) {
+    api = rccl();
+    if (!api->why.empty()) return fail(DD_ENODEV, "RCCL: %s", api->why.c_str());
+    return DD_OK;
+}
+#define DD_RCCL(api, expr)                                                                                     \
+    do {                                                                                                       \
+        const ncclResult_t r_ = (expr);                                                                        \
+        if (r_ != ncclSuccess) return fail(DD_EHIP, "RCCL: %s failed: %s", #expr, (api)->GetErrorString(r_)); \
+    } while (0)
+}  // namespace
+
+static_assert(DD_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "dandd_hip.h: DD_COMM_ID_BYTES is ncclUniqueId's size");
+
+int dd_comm_unique_id(uint8_t* id) {
+    if (!id) return fail(DD_EINVAL, "null argument");
+    RcclApi* api;
+    int rc;
+    if ((rc = rccl_ready(api))) return rc;
+    ncclUniqueId u;
+    DD_RCCL(api, api->GetUniqueId(&u));
+    memcpy(id, u.internal, DD_COMM_ID_BYTES);
+    return DD_OK;
+}
+
+int dd_comm_init(dd_ctx* c, int rank, int world, const uint8_t* id) {
+    if (check_ctx(c)) return DD_EINVAL;
+    if (!id || world < 1 || rank < 0 || rank >= world) return fail(DD_EINVAL, "rank %d of %d", rank, world);
+    if (c->comm) return fail(DD_EINVAL, "this context already belongs to a communicator (dd_comm_destroy first)");
+    RcclApi* api;
+    int rc;
+    if ((rc = rccl_ready(api))) return rc;
+    DeviceGuard guard(c->device);   // ncclCommInitRank binds the communicator to the CURRENT device: the context's
+    ncclUniqueId u;
+    memcpy(u.internal, id, DD_COMM_ID_BYTES);
+    ncclComm_t comm = nullptr;
+    DD_RCCL(api, api->CommInitRank(&comm, world, u, rank));
+    c->comm = comm;
+    c->comm_rank = rank;
+    c->comm_world = world;
+    c->comm_calls[0] = c->comm_calls[1] = 0;
+    return DD_OK;
+}
+
+int dd_comm_destroy(dd_ctx* c) {
+    if (!c) return DD_EINVAL;
+    if (!c->comm) return DD_OK;
+    RcclApi* api = rccl();
+    DeviceGuard guard(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    const ncclResult_t r = api->CommDestroy ? api->CommDestroy(static_cast<ncclComm_t>(c->comm)) : ncclSuccess;
+    c->comm = nullptr;
+    c->comm_rank = 0;
+    c->comm_world = 1;
+    return r == ncclSuccess ? DD_OK : fail(DD_EHIP, "RCCL: ncclCommDestroy failed");
+}
+
+int dd_comm_info(dd_ctx* c, int* rank, int* world, unsigned long long* allreduces, unsigned long long* allgathers) {
+    if (check_ctx(c)) return DD_EINVAL;
+    if (rank) *rank = c->comm_rank;
+    if (world) *world = c->comm ? c->comm_world : 0;   // 0: no communicator
+    if (allreduces) *allreduces = c->comm_calls[0];
+    if (allgathers) *allgathers = c->comm_calls[1];
+    return DD_OK;
+}
+
+int dd_allreduce_max_u8(dd_ctx* c, uint8_t* regs_dev, size_t n) {
+    if (check_ctx(c)) return DD_EINVAL;
+    if (!c->comm) return fail(DD_EINVAL, "no communicator on this context (dd_comm_init)");
+    if (n && !regs_dev) return fail(DD_EINVAL, "null argument");
+    if (!n) return DD_OK;
+    RcclApi* api = rccl();
+    DeviceGuard guard(c->device);
+    DD_RCCL(api, api->AllReduce(regs_dev, regs_dev, n, ncclUint8, ncclMax, static_cast<ncclComm_t>(c->comm), c->stream));
+    ++c->comm_calls[0];
+    return DD_OK;
+}
+
+int dd_allgather_u8(dd_ctx* c, const uint8_t* send_dev, size_t n, uint8_t* recv_dev) {
+    if (check_ctx(c)) return DD_EINVAL;
+    if (!c->comm) return fail(DD_EINVAL, "no communicator on this context (dd_comm_init)");
+    if (n && (!send_dev || !recv_dev)) return fail(DD_EINVAL, "null argument");
+    if (!n) return DD_OK;
+    RcclApi* api = rccl();
+    DeviceGuard guard(c->device);
+    DD_RCCL(api, api->AllGather(send_dev, recv_dev, n, ncclUint8, static_cast<ncclComm_t>(c->comm), c->stream));
+    ++c->comm_calls[1];
+    return DD_OK;
+}

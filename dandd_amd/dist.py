@@ -17,6 +17,34 @@ import numpy as np
 STATS = {"all_reduce_max_u8": 0, "all_gather": 0, "all_reduce_scalar": 0}
 
 
+# The data-path collectives can go through the C ABI instead of torch.distributed (dd_allreduce_max_u8 / dd_allgather_u8:
+# RCCL called by libdandd_hip.so itself, what a non-Python host binding of include/dandd_hip.h gets).  torch.distributed is
+# then only the courier of the communicator's 128-byte id.
+_ABI = None
+
+
+def use_abi_comm(engine):
+    """Open an RCCL communicator on `engine`'s context over the ranks of the live process group (rank 0 makes the id, a
+    broadcast carries it) and route allreduce_max_u8 / allgather_leaves through it from now on.  Collective."""
+    global _ABI
+    import torch.distributed as dist
+    from .engine import comm_unique_id
+    rank, world = (dist.get_rank(), dist.get_world_size()) if group_live() else (0, 1)
+    box = [comm_unique_id() if rank == 0 else None]
+    if group_live():
+        dist.broadcast_object_list(box, src=0)
+    engine.comm_init(rank, world, box[0])
+    _ABI = engine
+    return engine
+
+
+def drop_abi_comm():
+    global _ABI
+    if _ABI is not None:
+        _ABI.comm_destroy()
+    _ABI = None
+
+
 def group_live():
     """A process group exists.  World size 1 counts: the collectives then still go through the backend (RCCL on a
     GPU box), which is how a one-GPU machine exercises the N>1 path's calls."""
@@ -49,7 +77,11 @@ def shard_by_weight(weights, world):
 def allreduce_max_u8(t):
     """In-place MAX all-reduce of a uint8 tensor (the HLL union across ranks)."""
     import torch.distributed as dist
-    if group_live():
+    if _ABI is not None:     # RCCL behind the C ABI, on the engine's stream (the caller has set it to torch's current stream)
+        assert t.is_contiguous() and t.dtype.itemsize == 1
+        _ABI.allreduce_max_u8(t.data_ptr(), t.numel())
+        STATS["all_reduce_max_u8"] += 1
+    elif group_live():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         STATS["all_reduce_max_u8"] += 1
     return t
@@ -144,18 +176,26 @@ def allgather_leaves(leaves, mine, n_total):
         full[torch.tensor(list(mine), device=leaves.device, dtype=torch.long)] = leaves
         return full
     world = dist.get_world_size()
-    counts = [torch.zeros(1, dtype=torch.int64, device=leaves.device) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([len(mine)], dtype=torch.int64, device=leaves.device))
+
+    def gather(t):     # every rank's `t` -> list of world tensors (torch.distributed, or dd_allgather_u8 on the tensor's bytes)
+        if _ABI is None:
+            out = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(out, t)
+            return out
+        t = t.contiguous()
+        recv = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        _ABI.allgather_u8(t.data_ptr(), t.numel() * t.element_size(), recv.data_ptr())
+        return [recv[r] for r in range(world)]
+
+    counts = gather(torch.tensor([len(mine)], dtype=torch.int64, device=leaves.device))
     # (shards differ by at most one genome in count when sizes are equal; padded generously: allgather_geometry)
     most = allgather_geometry(n_total, world, K, m, max(int(c.item()) for c in counts))["rows"]
     ids = torch.full((most,), -1, dtype=torch.int64, device=leaves.device)
     ids[:len(mine)] = torch.tensor(list(mine), dtype=torch.int64, device=leaves.device)
     padded = torch.zeros((most, K, m), dtype=torch.uint8, device=leaves.device)
     padded[:len(mine)] = leaves
-    all_ids = [torch.empty_like(ids) for _ in range(world)]
-    all_slabs = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(all_ids, ids)
-    dist.all_gather(all_slabs, padded)
+    all_ids = gather(ids)
+    all_slabs = gather(padded)
     STATS["all_gather"] += 3
     for r in range(world):
         n = int(counts[r].item())

@@ -28,7 +28,9 @@ EXPORTS = [
     "dd_exact_count", "dd_exact_count_device",
     "dd_timing_enable", "dd_timing_read", "dd_timing_reset", "dd_last_sketch_stats", "dd_last_k2_path",
     "dd_synth_size", "dd_synth_fasta_device", "dd_synth_realistic_size", "dd_synth_realistic_device", "dd_plan_sweep",
+    "dd_comm_unique_id", "dd_comm_init", "dd_comm_destroy", "dd_comm_info", "dd_allreduce_max_u8", "dd_allgather_u8",
 ]
+COMM_ID_BYTES = 128   # include/dandd_hip.h: DD_COMM_ID_BYTES
 
 
 class EngineError(RuntimeError):
@@ -86,6 +88,18 @@ def load_library(path=None):
     lib.dd_sketch_fasta.argtypes = [vp, C.c_char_p, i32, i32, vp]
     lib.dd_sketch_files.restype = i32
     lib.dd_sketch_files.argtypes = [vp, C.POINTER(C.c_char_p), i32, i32, i32, vp, i32]
+    lib.dd_comm_unique_id.restype = i32
+    lib.dd_comm_unique_id.argtypes = [vp]
+    lib.dd_comm_init.restype = i32
+    lib.dd_comm_init.argtypes = [vp, i32, i32, vp]
+    lib.dd_comm_destroy.restype = i32
+    lib.dd_comm_destroy.argtypes = [vp]
+    lib.dd_comm_info.restype = i32
+    lib.dd_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    lib.dd_allreduce_max_u8.restype = i32
+    lib.dd_allreduce_max_u8.argtypes = [vp, vp, C.c_size_t]
+    lib.dd_allgather_u8.restype = i32
+    lib.dd_allgather_u8.argtypes = [vp, vp, C.c_size_t, vp]
     lib.dd_inflate_files.restype = i32
     lib.dd_inflate_files.argtypes = [vp, C.POINTER(C.c_char_p), i32, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), i32]
     lib.dd_last_ingest_stats.restype = i32
@@ -182,6 +196,16 @@ def _u8(a):
     return np.ascontiguousarray(a, dtype=np.uint8)
 
 
+def comm_unique_id():
+    """The 128-byte id rank 0 makes for an RCCL communicator (dd_comm_unique_id); every rank passes it to Engine.comm_init."""
+    lib = load_library()
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    rc = lib.dd_comm_unique_id(buf)
+    if rc != 0:
+        raise EngineError(f"libdandd_hip error {rc}: {lib.dd_last_error().decode()}")
+    return bytes(buf)
+
+
 class Engine:
     """One context = one GPU, one HLL size (log2m), canonical or not."""
 
@@ -243,6 +267,30 @@ class Engine:
         regs = np.empty((n, kmax - kmin + 1, self.m), dtype=np.uint8)
         self._check(self._lib.dd_sketch_files(self._ctx, arr, n, kmin, kmax, regs.ctypes.data, int(nthreads)))
         return regs
+
+    # -- multi-GPU: RCCL behind the C ABI (one context = one process = one GPU) --------------
+    def comm_init(self, rank, world, unique_id):
+        """Join the communicator `unique_id` names (collective: every rank calls it, each on the GPU it owns)."""
+        assert len(unique_id) == COMM_ID_BYTES
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self._check(self._lib.dd_comm_init(self._ctx, int(rank), int(world), buf))
+
+    def comm_destroy(self):
+        self._check(self._lib.dd_comm_destroy(self._ctx))
+
+    def comm_info(self):
+        """(rank, world, all-reduces issued, all-gathers issued); world 0 = no communicator."""
+        r, w, a, g = C.c_int(), C.c_int(), C.c_ulonglong(), C.c_ulonglong()
+        self._check(self._lib.dd_comm_info(self._ctx, C.byref(r), C.byref(w), C.byref(a), C.byref(g)))
+        return r.value, w.value, a.value, g.value
+
+    def allreduce_max_u8(self, regs_ptr, n):
+        """In-place byte-max all-reduce of n register bytes at device address regs_ptr (ncclUint8 / ncclMax), on the context's stream."""
+        self._check(self._lib.dd_allreduce_max_u8(self._ctx, C.c_void_p(int(regs_ptr)), int(n)))
+
+    def allgather_u8(self, send_ptr, n, recv_ptr):
+        """n bytes from every rank -> recv[world][n] on every rank (device addresses), on the context's stream."""
+        self._check(self._lib.dd_allgather_u8(self._ctx, C.c_void_p(int(send_ptr)), int(n), C.c_void_p(int(recv_ptr))))
 
     def inflate_files(self, paths, nthreads=0):
         """The bytes the tokenizer reads for every file of a sketch_files pass (dd_inflate_files): for a .gz FASTA file the

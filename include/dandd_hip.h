@@ -191,6 +191,28 @@ typedef struct {
 long dd_plan_sweep(int log2m, const size_t *nbytes, int ngenomes, int kmin, int kmax, dd_plan_job *out,
                    long cap);
 
+/* ---- multi-GPU: one context = one process = one GPU; RCCL over xGMI -----------------------------------------
+ * The reference's only parallelism is GNU parallel over k on one host (lib/huffman_dandd.py:217).  Here (genome x k)
+ * sketch jobs are split over the GPUs of a node by the CALLER (every rank sketches its own genomes: no exchange), and
+ * what crosses xGMI is
+ *   dd_allreduce_max_u8   the root union: every rank's [K][m] slab of byte-max-merged registers, in place
+ *                         (ncclAllReduce, ncclUint8, ncclMax) -- stands in for the N-way  dashing union -z -o <root> <all leaves>
+ *                         (lib/sketch_classes.py:368-373) over leaves that live on different GPUs;
+ *   dd_allgather_u8       every rank's leaf slabs, for the schedules that need all leaves on every rank
+ *                         (dd_progressive*, dd_pairwise*): recv_dev[world][n].
+ * Both run on the context's stream (dd_set_stream) and return once enqueued.  Rank 0 makes the 128-byte id with
+ * dd_comm_unique_id and hands it to the other ranks by any means (a file, MPI, a socket); every rank then calls
+ * dd_comm_init -- collectively -- on a context of the GPU it owns.  librccl.so is opened on first use (DD_RCCL_LIB names
+ * another copy); a process that never calls these needs no RCCL. */
+#define DD_COMM_ID_BYTES 128
+int dd_comm_unique_id(uint8_t *id /* [DD_COMM_ID_BYTES] */);
+int dd_comm_init(dd_ctx *, int rank, int world, const uint8_t *id);
+int dd_comm_destroy(dd_ctx *);
+/* world = 0: the context belongs to no communicator; the counters are the collectives issued since dd_comm_init */
+int dd_comm_info(dd_ctx *, int *rank, int *world, unsigned long long *allreduces, unsigned long long *allgathers);
+int dd_allreduce_max_u8(dd_ctx *, uint8_t *regs_dev, size_t n);
+int dd_allgather_u8(dd_ctx *, const uint8_t *send_dev, size_t n, uint8_t *recv_dev /* [world][n] */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,13 @@ int main(void) {
     }
     if (!strlen(dd_last_error())) return 18;
     if (dd_last_k2_path(NULL) >= 0) return 19; /* ABI 3: a query on no context is an error code, not a path */
+    { /* ABI 4: the multi-GPU entries exist and refuse a null context with an error code */
+        int world = -1;
+        if (dd_comm_info(NULL, NULL, &world, NULL, NULL) >= 0 || dd_allreduce_max_u8(NULL, NULL, 0) >= 0 || dd_allgather_u8(NULL, NULL, 0, NULL) >= 0 ||
+            dd_comm_init(NULL, 0, 1, NULL) >= 0 || dd_comm_unique_id(NULL) >= 0)
+            return 20;
+        if (DD_COMM_ID_BYTES != 128) return 21;
+    }
     printf("abi_consumer: ok (%ld jobs)\n", n);
     return 0;
 }
