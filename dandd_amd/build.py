@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdandd_hip.so")
-SOURCES = ["dd_api.hip", "dd_plan.hip", "dd_pack.hip", "dd_sweep.hip", "dd_union.hip", "dd_gram.hip", "dd_pscan.hip", "dd_synth.hip", "dd_exact.hip", "dd_ginflate.hip"]
+SOURCES = ["dd_api.hip", "dd_plan.hip", "dd_pack.hip", "dd_sweep.hip", "dd_union.hip", "dd_gram.hip", "dd_pscan.hip", "dd_synth.hip", "dd_exact.hip", "dd_ginflate.hip", "dd_fastq.hip"]
 HEADERS = ["dd_common.h", "dd_io.h", "dd_inflate.h", "dd_kernels.h", "dd_plan.h", os.path.join("..", "..", "include", "dandd_hip.h")]
 FLAGS = [
     "-O3",

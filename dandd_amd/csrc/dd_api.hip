@@ -151,6 +151,9 @@ struct dd_ctx {
     // chunk0, crcs) and their host copies
     DevBuf pipe_sym[2], pipe_win[2], pipe_raw[2];
     HostBuf pipe_raw_host[2], pipe_crc_host[2];
+    // kseq's record rules over device-inflated texts (dd_fastq.hip): the batch's TextJob table, newline counts and positions
+    DevBuf pipe_txt[2];
+    HostBuf pipe_txt_host[2];
     bool no_gpu_inflate = false;   // this context inflates on the host (set for the retry of a call, for good after three)
     int inflate_refusals = 0;      // calls in which the device decoder refused a block
     bool inflate_retry = false;    // ... and the call that met it is run again
@@ -353,6 +356,8 @@ void dd_destroy(dd_ctx* c) {
         c->pipe_raw[i].release();
         c->pipe_raw_host[i].release();
         c->pipe_crc_host[i].release();
+        c->pipe_txt[i].release();
+        c->pipe_txt_host[i].release();
         c->pipe_jobs[i].release();
         c->pipe_err[i].release();
         c->pipe_jobs_host[i].release();
@@ -901,8 +906,8 @@ struct BgzfBlock {
     uint32_t in_len, out_len;
     size_t out_off;
 };
-static bool bgzf_parse(const uint8_t* data, size_t n, std::vector<BgzfBlock>& blks, size_t& out_size);
-static bool bgzf_for_device(const char* path, FileBuf& fb, std::vector<BgzfBlock>& blks, size_t& out_size) {
+static bool bgzf_parse(const uint8_t* data, size_t n, std::vector<BgzfBlock>& blks, size_t& out_size, bool& fastq);
+static bool bgzf_for_device(const char* path, FileBuf& fb, std::vector<BgzfBlock>& blks, size_t& out_size, bool& fastq) {
     using namespace dd::inflate_detail;
     struct stat sb;
     if (stat(path, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 28 || (size_t)sb.st_size > ((size_t)3 << 30)) return false;
@@ -918,12 +923,12 @@ static bool bgzf_for_device(const char* path, FileBuf& fb, std::vector<BgzfBlock
     fb.len = 0;
     bool ok = fb.reserve(n + 16) && fseeko(f, 0, SEEK_SET) == 0 && fread(fb.p, 1, n, f) == n;
     fclose(f);
-    if (!ok || !bgzf_parse(fb.p, n, blks, out_size)) return false;
+    if (!ok || !bgzf_parse(fb.p, n, blks, out_size, fastq)) return false;
     fb.len = n;
     return true;
 }
 // the same for a file whose bytes are in memory already (large files are read in pieces by several loaders)
-static bool bgzf_parse(const uint8_t* data, size_t n, std::vector<BgzfBlock>& blks, size_t& out_size) {
+static bool bgzf_parse(const uint8_t* data, size_t n, std::vector<BgzfBlock>& blks, size_t& out_size, bool& fastq) {
     using namespace dd::inflate_detail;
     blks.clear();
     size_t p = 0, total = 0;
@@ -942,7 +947,7 @@ static bool bgzf_parse(const uint8_t* data, size_t n, std::vector<BgzfBlock>& bl
         p += bs;
     }
     if (blks.empty()) return false;
-    // FASTQ (reads, not assemblies) starts with '@' and needs the host's record pass (dd_io.h): look at the first block's text
+    // FASTQ (reads, not assemblies) starts with '@': look at the first block's text
     {
         uint8_t first[256];
         z_stream zs;
@@ -955,7 +960,10 @@ static bool bgzf_parse(const uint8_t* data, size_t n, std::vector<BgzfBlock>& bl
         const int zr = inflate(&zs, Z_SYNC_FLUSH);
         const size_t made = sizeof first - zs.avail_out;
         inflateEnd(&zs);
-        if ((zr != Z_OK && zr != Z_STREAM_END) || !made || first[0] == '@' || dd::has_plus_line(first, made)) return false;
+        if ((zr != Z_OK && zr != Z_STREAM_END) || !made) return false;
+        // (round 5: a text that starts with '@' stays on the device as four-line FASTQ, checked record by record there: dd_fastq.hip)
+        fastq = first[0] == '@';
+        if (fastq ? getenv("DD_NO_GPU_FASTQ") != nullptr : dd::has_plus_line(first, made)) return false;
     }
     out_size = total;
     return true;
@@ -973,8 +981,8 @@ static bool gzip_member_size_ok(size_t n) {
     return n >= min_bytes && n < ((size_t)1 << 30);
 }
 using dd::GzMember;
-using dd::gzip_member_parse;
-static bool gzip_member_for_device(const char* path, FileBuf& fb, GzMember& gm) {
+using dd::gzip_members_parse;
+static bool gzip_member_for_device(const char* path, FileBuf& fb, std::vector<GzMember>& gms) {
     struct stat sb;
     if (stat(path, &sb) != 0 || !S_ISREG(sb.st_mode) || !gzip_member_size_ok((size_t)sb.st_size)) return false;
     FILE* f = fopen(path, "rb");
@@ -983,7 +991,7 @@ static bool gzip_member_for_device(const char* path, FileBuf& fb, GzMember& gm) 
     fb.len = 0;
     const bool ok = fb.reserve(n + 16) && fread(fb.p, 1, n, f) == n;
     fclose(f);
-    if (!ok || !gzip_member_parse(fb.p, n, gm)) return false;
+    if (!ok || !gzip_members_parse(fb.p, n, gms)) return false;
     fb.len = n;
     return true;
 }
@@ -1069,8 +1077,9 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
         size_t out_size = 0;                  // ... into this many bytes of text
         std::vector<BgzfBlock> blks;
         bool gz_raw = false;                  // a large .gz read as it is, in pieces by several loaders (plain_size = its size): meant for the device
-        bool dev_gunzip = false;              // ONE gzip member: the buffer holds the compressed file, the device inflates it in pieces
-        GzMember gm;
+        bool dev_gunzip = false;              // gzip members (usually ONE): the buffer holds the compressed file, the device inflates it in pieces
+        std::vector<GzMember> gms;
+        bool fastq = false;                   // a device-inflated text that starts with '@': four-line FASTQ, checked and resolved on the device
     };
     std::vector<Slot> slots(nfiles);
     const bool gpu_gunzip = gpu_inflate && !getenv("DD_NO_GPU_GUNZIP");
@@ -1170,14 +1179,18 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
                 cv.notify_all();
             }
             if (it.len == 0) {
-                if (gpu_inflate && bgzf_for_device(paths[it.file], fb, sl.blks, sl.out_size)) sl.dev_inflate = true;
-                else if (gpu_gunzip && gzip_member_for_device(paths[it.file], fb, sl.gm)) sl.dev_gunzip = true, sl.out_size = sl.gm.isize;
+                if (gpu_inflate && bgzf_for_device(paths[it.file], fb, sl.blks, sl.out_size, sl.fastq)) sl.dev_inflate = true;
+                else if (gpu_gunzip && gzip_member_for_device(paths[it.file], fb, sl.gms)) sl.dev_gunzip = true;
                 else ok = read_fasta_file(paths[it.file], fb, err, gz_par);
             } else if (ok && fb.cap >= sl.plain_size) {
                 FILE* f = fopen(paths[it.file], "rb");
                 ok = f && fseeko(f, (off_t)it.off, SEEK_SET) == 0 && fread(fb.p + it.off, 1, it.len, f) == it.len;
                 if (!ok) err = std::string("read error on ") + paths[it.file];
                 if (f) fclose(f);
+            }
+            if (sl.dev_gunzip && !sl.out_size) {   // (the members' texts stand one behind the other in the file's text buffer)
+                for (const GzMember& gm : sl.gms) sl.out_size += gm.isize;
+                sl.fastq = sl.gms[0].fastq;
             }
             // (every loader looks through the piece it has just read -- the bytes are still in its cache -- instead of one
             // of them through the whole file at the end: that pass held every file back 2-3 ms)
@@ -1195,9 +1208,14 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
                 // read_fasta_file has done the same for the files that came through zlib)
                 if (it.len && ok && sl.gz_raw) {
                     // the compressed file is whole: one member for the device, or (FASTQ, an odd header) the host decoder after all
-                    if (bgzf_parse(fb.p, sl.plain_size, sl.blks, sl.out_size)) sl.dev_inflate = true;
-                    else if (gpu_gunzip && gzip_member_parse(fb.p, sl.plain_size, sl.gm)) sl.dev_gunzip = true, sl.out_size = sl.gm.isize;
+                    if (bgzf_parse(fb.p, sl.plain_size, sl.blks, sl.out_size, sl.fastq)) sl.dev_inflate = true;
+                    else if (gpu_gunzip && gzip_members_parse(fb.p, sl.plain_size, sl.gms)) sl.dev_gunzip = true;
                     else ok = read_fasta_file(paths[it.file], fb, err, gz_par);
+                    if (sl.dev_gunzip) {
+                        sl.out_size = 0;
+                        for (const GzMember& gm : sl.gms) sl.out_size += gm.isize;
+                        sl.fastq = sl.gms[0].fastq;
+                    }
                 } else if (it.len && ok) {
                     for (const Item& o : items)
                         if (o.file == it.file && !plus) plus = dd::plus_at_piece_start(fb.p, o.off);
@@ -1348,17 +1366,18 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
                 gz_tot += align_up(c->file_pool[sj.buf]->size() + 16, 256);
                 njobs += sj.blks.size();
             }
-            if (sj.dev_gunzip) {
-                const size_t guess_bits = guess_bits_of(c->file_pool[sj.buf]->size()), range_syms = range_syms_of(guess_bits);
-                const size_t bits = c->file_pool[sj.buf]->size() * 8 - sj.gm.first_bit;
-                const size_t ng = (bits + guess_bits - 1) / guess_bits;
-                ++nmem;
-                npieces += ng;
-                nchunks += (sj.gm.isize + 65535u) / 65536u;
-                sym_tot += align_up(ng * range_syms * 2 + 256, 256) + align_up((size_t)sj.gm.isize * 2 + 256, 256);   // the ranges' symbols, the arena
-                win_tot += align_up(dd::gunzip_window_bytes(ng), 256);
-                ngroups += (ng + dd::kPieceGroup - 1) / dd::kPieceGroup;
-            }
+            if (sj.dev_gunzip)
+                for (const GzMember& gm : sj.gms) {   // every member a "file" of the decoder's tables
+                    const size_t guess_bits = guess_bits_of(gm.end - gm.first_bit / 8), range_syms = range_syms_of(guess_bits);
+                    const size_t bits = gm.end * 8 - gm.first_bit;
+                    const size_t ng = (bits + guess_bits - 1) / guess_bits;
+                    ++nmem;
+                    npieces += ng;
+                    nchunks += (gm.isize + 65535u) / 65536u;
+                    sym_tot += align_up(ng * range_syms * 2 + 256, 256) + align_up((size_t)gm.isize * 2 + 256, 256);   // the ranges' symbols, the arena
+                    win_tot += align_up(dd::gunzip_window_bytes(ng), 256);
+                    ngroups += (ng + dd::kPieceGroup - 1) / dd::kPieceGroup;
+                }
         }
         // the piece tables of the batch's single-member gzip files, one block of device memory: RawFile[nmem],
         // starts (u64) / lens / offs / over / abase [npieces], chunk0 [nmem + 1], crcs [nchunks]
@@ -1426,31 +1445,35 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             } else if (sj.dev_gunzip) {
                 uint8_t* gz = static_cast<uint8_t*>(c->pipe_gz[set].p) + gz_off[j];
                 e = hipMemcpyAsync(gz, fbj.data(), fbj.size(), hipMemcpyHostToDevice, cs);
-                dd::RawFile& rf = raw_host[mi];
-                const size_t guess_bits = guess_bits_of(fbj.size()), range_syms = range_syms_of(guess_bits);
-                const size_t ng = (fbj.size() * 8 - sj.gm.first_bit + guess_bits - 1) / guess_bits;
-                rf.in = gz;
-                rf.in_len = (uint32_t)fbj.size();
-                rf.first_bit = sj.gm.first_bit;
-                rf.guess_bits = (uint32_t)guess_bits;
-                rf.nguess = (uint32_t)ng;
-                rf.piece0 = (uint32_t)piece_at;
-                rf.isize = sj.gm.isize;
-                rf.sym = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(c->pipe_sym[set].p) + sym_at);
-                rf.range_syms = (uint32_t)range_syms;
-                rf.arena = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(c->pipe_sym[set].p) + sym_at + align_up(ng * range_syms * 2 + 256, 256));
-                rf.windows = static_cast<uint8_t*>(c->pipe_win[set].p) + win_at;
-                rf.group0 = (uint32_t)group_at;
-                rf.ngroups = (uint32_t)((ng + dd::kPieceGroup - 1) / dd::kPieceGroup);
-                rf.text = const_cast<uint8_t*>(ptrs[j]);
-                chunk0_host[mi] = (uint32_t)chunk_at;
-                members.push_back(InFlight::Member{(uint32_t)chunk_at, (sj.gm.isize + 65535u) / 65536u, sj.gm.isize, sj.gm.crc});
-                piece_at += ng;
-                chunk_at += (sj.gm.isize + 65535u) / 65536u;
-                sym_at += align_up(ng * range_syms * 2 + 256, 256) + align_up((size_t)sj.gm.isize * 2 + 256, 256);
-                win_at += align_up(dd::gunzip_window_bytes(ng), 256);
-                group_at += (ng + dd::kPieceGroup - 1) / dd::kPieceGroup;
-                ++mi;
+                size_t text_at = 0;   // the members' texts one behind the other
+                for (const GzMember& gm : sj.gms) {
+                    dd::RawFile& rf = raw_host[mi];
+                    const size_t guess_bits = guess_bits_of(gm.end - gm.first_bit / 8), range_syms = range_syms_of(guess_bits);
+                    const size_t ng = (gm.end * 8 - gm.first_bit + guess_bits - 1) / guess_bits;
+                    rf.in = gz;                       // (positions are the FILE's: its bytes start on a 256-byte boundary, a member's need not)
+                    rf.in_len = (uint32_t)gm.end;     // ... and the member ends here: CRC-32 and ISIZE right behind its final block
+                    rf.first_bit = gm.first_bit;
+                    rf.guess_bits = (uint32_t)guess_bits;
+                    rf.nguess = (uint32_t)ng;
+                    rf.piece0 = (uint32_t)piece_at;
+                    rf.isize = gm.isize;
+                    rf.sym = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(c->pipe_sym[set].p) + sym_at);
+                    rf.range_syms = (uint32_t)range_syms;
+                    rf.arena = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(c->pipe_sym[set].p) + sym_at + align_up(ng * range_syms * 2 + 256, 256));
+                    rf.windows = static_cast<uint8_t*>(c->pipe_win[set].p) + win_at;
+                    rf.group0 = (uint32_t)group_at;
+                    rf.ngroups = (uint32_t)((ng + dd::kPieceGroup - 1) / dd::kPieceGroup);
+                    rf.text = const_cast<uint8_t*>(ptrs[j]) + text_at;
+                    chunk0_host[mi] = (uint32_t)chunk_at;
+                    members.push_back(InFlight::Member{(uint32_t)chunk_at, (gm.isize + 65535u) / 65536u, gm.isize, gm.crc});
+                    piece_at += ng;
+                    chunk_at += (gm.isize + 65535u) / 65536u;
+                    sym_at += align_up(ng * range_syms * 2 + 256, 256) + align_up((size_t)gm.isize * 2 + 256, 256);
+                    win_at += align_up(dd::gunzip_window_bytes(ng), 256);
+                    group_at += (ng + dd::kPieceGroup - 1) / dd::kPieceGroup;
+                    text_at += gm.isize;
+                    ++mi;
+                }
             } else if (sizes[j]) {
                 e = hipMemcpyAsync(const_cast<uint8_t*>(ptrs[j]), fbj.data(), sizes[j], hipMemcpyHostToDevice, cs);
             }
@@ -1476,6 +1499,56 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             if (e == hipSuccess) {
                 dd::launch_inflate_bgzf(static_cast<const dd::InflateJob*>(c->pipe_jobs[set].p), (int)njobs, static_cast<uint32_t*>(c->pipe_err[set].p), cs);
                 e = hipGetLastError();
+            }
+        }
+        if ((njobs || nmem) && e == hipSuccess) {
+            // kseq's record rules over the texts the device has just inflated (dd_fastq.hip): no line of a FASTA-classed text may
+            // start with '+'; a FASTQ-classed text must be four-line FASTQ, and its '+' and quality lines become header lines
+            std::vector<dd::TextJob> tj;
+            size_t blocks = 0, words = 0;
+            bool any_fastq = false;
+            for (int j = 0; j < count; ++j) {
+                const Slot& sj = slots[i + j];
+                if (!(sj.dev_inflate || sj.dev_gunzip) || !sizes[j]) continue;
+                dd::TextJob t{};
+                t.text = const_cast<uint8_t*>(ptrs[j]);
+                t.n = (uint32_t)sizes[j];
+                t.fastq = sj.fastq ? 1u : 0u;
+                t.block0 = (uint32_t)blocks;
+                const size_t nb4k = (sizes[j] + 4095) / 4096;
+                blocks += nb4k;
+                if (sj.fastq) {
+                    any_fastq = true;
+                    t.nl_cap = (uint32_t)(sizes[j] / 8 + 16);
+                    // (offsets in words from the table's end; turned into pointers below)
+                    t.blk_count = reinterpret_cast<uint32_t*>(words);
+                    t.nl = reinterpret_cast<uint32_t*>(words + nb4k);
+                    t.nl_total = reinterpret_cast<uint32_t*>(words + nb4k + t.nl_cap);
+                    words += nb4k + t.nl_cap + 4;
+                }
+                tj.push_back(t);
+            }
+            if (!tj.empty()) {
+                const size_t tab = align_up(tj.size() * sizeof(dd::TextJob), 256);
+                if ((rc = c->pipe_txt[set].reserve(tab + words * 4 + 256)) != DD_OK || (rc = c->pipe_txt_host[set].reserve(tab)) != DD_OK) {
+                    first_err = g_err;
+                    e = hipErrorOutOfMemory;
+                } else {
+                    uint32_t* base = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(c->pipe_txt[set].p) + tab);
+                    for (dd::TextJob& t : tj)
+                        if (t.fastq) {
+                            t.blk_count = base + reinterpret_cast<size_t>(t.blk_count);
+                            t.nl = base + reinterpret_cast<size_t>(t.nl);
+                            t.nl_total = base + reinterpret_cast<size_t>(t.nl_total);
+                        }
+                    memcpy(c->pipe_txt_host[set].p, tj.data(), tj.size() * sizeof(dd::TextJob));
+                    e = hipMemcpyAsync(c->pipe_txt[set].p, c->pipe_txt_host[set].p, tj.size() * sizeof(dd::TextJob), hipMemcpyHostToDevice, cs);
+                    if (e == hipSuccess) {
+                        dd::launch_text_rules(static_cast<const dd::TextJob*>(c->pipe_txt[set].p), (int)tj.size(), (uint32_t)blocks, any_fastq,
+                                              static_cast<uint32_t*>(c->pipe_err[set].p), cs);
+                        e = hipGetLastError();
+                    }
+                }
             }
         }
         if ((njobs || nmem) && e == hipSuccess) e = hipMemcpyAsync(c->pipe_err_host[set].p, c->pipe_err[set].p, 4, hipMemcpyDeviceToHost, cs);

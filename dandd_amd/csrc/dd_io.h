@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <string>
+#include <vector>
 
 #include "dd_inflate.h"
 
@@ -352,17 +353,26 @@ inline uint32_t crc_x8n(uint32_t nbytes) {   // x^(8 nbytes) mod P
     return p;
 }
 
-// ONE gzip member for the device decoder (dd_ginflate.hip): where its deflate data starts, the trailer's CRC-32 and ISIZE.
-// false: not a file that path takes (not gzip, a header it does not know, an ISIZE that cannot be one member's, FASTQ in
-// the first bytes of text): the host decoder reads it.  Whether the file is ONE member only the decoding shows.
+// The gzip members of a file for the device decoder (dd_ginflate.hip): where each one's deflate data starts, where it ends,
+// its trailer's CRC-32 and ISIZE.  `gzip` and the sequence archives write ONE member; `cat a.fa.gz b.fa.gz` (and pigz -i,
+// and a gzip run that appended) several: a member says nothing about its length, so the next one is looked for by its header
+// -- 1f 8b 08, a flag byte without reserved bits, an XFL and an OS byte of the values RFC 1952 knows, optional fields that
+// fit -- and the eight bytes in front of it are taken for the trailer of the one before.  A header look-alike inside
+// compressed data (~5 per 10^12 bytes) makes a member that does not end at its final block: the device refuses it and the
+// host reads the file.  false: not a file that path takes (not gzip, a header it does not know, an ISIZE that cannot be that
+// member's, small or very many members, a '+' line in the first bytes of a text that does not start with '@'): the host
+// decoder reads it.  Whether every member really ends where the next header stands only the decoding shows.
 struct GzMember {
-    uint32_t first_bit = 0, isize = 0, crc = 0;
+    uint64_t first_bit = 0;   // of the FILE: the member's deflate data starts there
+    size_t end = 0;           // byte offset in the file behind the member's trailer
+    uint32_t isize = 0, crc = 0;
+    bool fastq = false;       // (first member) the text starts with '@': four-line FASTQ is expected and checked on the device (dd_fastq.hip)
 };
-inline bool gzip_member_parse(const uint8_t* p, size_t n, GzMember& gm) {
-    if (n < 64 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xE0)) return false;
+inline size_t gzip_header_bytes(const uint8_t* p, size_t n) {   // 0: not a member header this path knows
+    if (n < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xE0)) return 0;
     size_t h = 10;
     if (p[3] & 4) {
-        if (h + 2 > n) return false;
+        if (h + 2 > n) return 0;
         h += 2 + ((size_t)p[h] | ((size_t)p[h + 1] << 8));
     }
     for (int bit : {8, 16})
@@ -371,16 +381,45 @@ inline bool gzip_member_parse(const uint8_t* p, size_t n, GzMember& gm) {
             ++h;
         }
     if (p[3] & 2) h += 2;
-    if (h + 16 > n) return false;
-    const uint8_t* t = p + n - 8;
-    gm.first_bit = (uint32_t)(8 * h);
-    gm.crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
-    gm.isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
-    if (gm.isize < n / 2 || (size_t)gm.isize > (size_t)1032 * n) return false;   // (a multi-member file's last ISIZE is usually smaller than the file)
-    // (ISIZE is the text's length mod 2^32: a large member whose ISIZE says "inflates less than 2 x" is far more likely text
-    // beyond 4 GiB -- FASTA never compresses that badly -- and the device path's offsets are 32-bit)
-    if (n >= ((size_t)256 << 20) && (size_t)gm.isize < 2 * n) return false;
-    // FASTQ needs the host's record pass: look at the first bytes of text
+    return h + 8 <= n ? h : 0;
+}
+inline bool gzip_members_parse(const uint8_t* p, size_t n, std::vector<GzMember>& ms) {
+    ms.clear();
+    if (n < 64) return false;
+    uint64_t text_total = 0;
+    for (size_t start = 0; start < n;) {
+        const size_t h = gzip_header_bytes(p + start, n - start);
+        if (!h) return false;
+        size_t next = n;   // where the next member's header stands
+        for (size_t q = start + h + 10; q + 18 <= n; ++q) {
+            const uint8_t* r = static_cast<const uint8_t*>(memchr(p + q, 0x1f, n - 17 - q));
+            if (!r) break;
+            q = (size_t)(r - p);
+            if (r[1] == 0x8b && r[2] == 8 && !(r[3] & 0xE0) && (r[8] == 0 || r[8] == 2 || r[8] == 4) && (r[9] <= 13 || r[9] == 255) &&
+                gzip_header_bytes(r, n - q)) {
+                next = q;
+                break;
+            }
+        }
+        GzMember gm;
+        const uint8_t* t = p + next - 8;
+        const size_t len = next - start;
+        gm.first_bit = 8ull * (start + h);
+        gm.end = next;
+        gm.crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        gm.isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+        if (gm.isize < len / 2 || (size_t)gm.isize > (size_t)1032 * len) return false;   // (not this member's length: a header look-alike, or damage)
+        // (ISIZE is the text's length mod 2^32: a large member whose ISIZE says "inflates less than 2 x" is far more likely text
+        // beyond 4 GiB -- FASTA never compresses that badly -- and the device path's offsets are 32-bit)
+        if (len >= ((size_t)256 << 20) && (size_t)gm.isize < 2 * len) return false;
+        text_total += gm.isize;
+        ms.push_back(gm);
+        start = next;
+        // (a file of many small members -- a blocked format this path does not know -- is not worth a piece table per member)
+        if (ms.size() > 64 || (next < n && len < ((size_t)64 << 10))) return false;
+    }
+    if (ms.empty() || text_total >= ((uint64_t)1 << 32) - 65536) return false;
+    // FASTQ: look at the first bytes of text
     uint8_t first[256];
     z_stream zs;
     memset(&zs, 0, sizeof zs);
@@ -392,7 +431,19 @@ inline bool gzip_member_parse(const uint8_t* p, size_t n, GzMember& gm) {
     const int zr = inflate(&zs, Z_SYNC_FLUSH);
     const size_t made = sizeof first - zs.avail_out;
     inflateEnd(&zs);
-    if ((zr != Z_OK && zr != Z_STREAM_END) || !made || first[0] == '@' || has_plus_line(first, made)) return false;
+    if ((zr != Z_OK && zr != Z_STREAM_END) || !made) return false;
+    // a text that starts with '@' is taken for four-line FASTQ -- the device checks every record and resolves it in place
+    // (dd_fastq.hip; anything else comes back to the host's kseq state machine) --, unless DD_NO_GPU_FASTQ sends it to the host
+    // from the start; a '+' line among the first bytes of a text that does not start with '@' is for the host as well
+    ms[0].fastq = first[0] == '@';
+    if (ms[0].fastq ? getenv("DD_NO_GPU_FASTQ") != nullptr : has_plus_line(first, made)) return false;
+    return true;
+}
+// ONE member (the tests' and the sanitizer harness's entry)
+inline bool gzip_member_parse(const uint8_t* p, size_t n, GzMember& gm) {
+    std::vector<GzMember> ms;
+    if (!gzip_members_parse(p, n, ms) || ms.size() != 1) return false;
+    gm = ms[0];
     return true;
 }
 

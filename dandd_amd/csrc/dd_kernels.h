@@ -229,8 +229,8 @@ struct InflateJob {
 // one single-member gzip file of a batch, inflated on the device in pieces (dd_ginflate.hip: launch_gunzip_members)
 struct RawFile {
     const uint8_t* in;          // the whole file on the device, 256-byte aligned
-    uint32_t in_len;
-    uint32_t first_bit;         // where its deflate data starts (behind the gzip header)
+    uint32_t in_len;            // ... up to the end of THIS member (a file of several members: one RawFile each, same `in`)
+    uint64_t first_bit;         // where its deflate data starts (behind the member's gzip header), counted from `in`
     uint32_t guess_bits;        // the block-start finder looks at one range of this many bits per piece
     uint32_t nguess;            // ranges = entries of this file in starts / lens / offs
     uint32_t piece0;            // its first entry there
@@ -245,6 +245,19 @@ struct RawFile {
     uint32_t group0, ngroups;   // groups of kPieceGroup ranges; group0 = this file's first group in the batch
     uint8_t* text;              // [isize] where the text goes
 };
+// one device-inflated text of a batch and what kseq's record rules ask of it (dd_fastq.hip)
+struct TextJob {
+    uint8_t* text;
+    uint32_t n;
+    uint32_t fastq;             // classed by its first bytes: 1 = four-line FASTQ expected, 0 = FASTA (no line may start with '+')
+    uint32_t block0;            // its first 4 KiB block among the batch's
+    uint32_t* blk_count;        // [blocks]: newlines per block, then their exclusive scan (FASTQ only)
+    uint32_t* nl;               // [nl_cap]: the positions of its newlines
+    uint32_t nl_cap;
+    uint32_t* nl_total;
+};
+constexpr uint32_t kNotFourLine = 0x1000000u;   // added to *errors_dev per text that is not what its first bytes said (not a decoder refusal)
+void launch_text_rules(const TextJob* jobs_dev, int njobs, uint32_t nblocks, bool any_fastq, uint32_t* errors_dev, hipStream_t st);
 size_t inflate_lds_bytes();
 // starts_dev: npieces u64 (bit positions); tables_dev: four arrays of npieces u32 (lens, offs, over, abase), `stride` words apart
 constexpr uint32_t kPieceGroup = 32;

@@ -286,11 +286,18 @@ static void device_gunzip_host_side() {
             (void)dd::gzip_member_parse(w.data(), w.size(), g2);
         }
     }
-    {   // FASTQ is not for the device
+    {   // a text that starts with '@' is classed as FASTQ (checked and resolved on the device, dd_fastq.hip); a '+' line among the
+        // first bytes of a text that does not start with '@' goes to the host
         const std::string fq = gz_member("@r1\nACGT\n+\nIIII\n" + body, 5, Z_DEFAULT_STRATEGY, std::string());
         std::vector<uint8_t> v(fq.begin(), fq.end());
         dd::GzMember gm;
-        CHECK(!dd::gzip_member_parse(v.data(), v.size(), gm), "gzip_member_parse: FASTQ must go to the host");
+        CHECK(dd::gzip_member_parse(v.data(), v.size(), gm) && gm.fastq, "gzip_member_parse: a text that starts with '@' is FASTQ for the device");
+        const std::string odd = gz_member(">x\nACGT\n+\nIIII\n" + body, 5, Z_DEFAULT_STRATEGY, std::string());
+        std::vector<uint8_t> w(odd.begin(), odd.end());
+        CHECK(!dd::gzip_member_parse(w.data(), w.size(), gm), "gzip_member_parse: a '+' line behind a '>' header must go to the host");
+        const std::string fa = gz_member(">x\nACGT\n" + body, 5, Z_DEFAULT_STRATEGY, std::string());
+        std::vector<uint8_t> u(fa.begin(), fa.end());
+        CHECK(dd::gzip_member_parse(u.data(), u.size(), gm) && !gm.fastq, "gzip_member_parse: FASTA");
     }
     for (int it = 0; it < 200; ++it) {      // CRC-32 of 64 KiB chunks combined == CRC-32 of the whole
         const size_t n = 1 + rng() % 300000;

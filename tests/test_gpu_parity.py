@@ -605,9 +605,9 @@ def test_single_member_gzip_files_are_inflated_on_the_device(engine_factory, orc
     dd_sketch_files on the device (dd_ginflate.hip: launch_gunzip_members): block starts found by trial, every piece decoded
     without its history into 16-bit symbols, placeholders resolved along the chain of windows, CRC-32 checked.  Levels 1 / 6 / 9
     on uniform and repeat-rich text, a header with FNAME, files whose blocks are all stored or all fixed-Huffman (no dynamic
-    block start to find: one piece), Huffman-only and RLE strategies, small and large finder ranges: registers == the sketch of
-    the plain bytes, with DD_INFLATE_STRICT=1 (a refused piece fails the test; nothing goes to the host decoder).  A
-    two-member file and a FASTQ file are not for this path: they come out right through the host decoder."""
+    block start to find: one piece), Huffman-only and RLE strategies, files of two and three members, small and large finder
+    ranges: registers == the sketch of the plain bytes and the inflated bytes == zlib's, with DD_INFLATE_STRICT=1 (a refused
+    piece fails the test; nothing goes to the host decoder).  A file of many small members is not for this path (the host reads it)."""
     import gzip
     import io
     import zlib
@@ -627,7 +627,11 @@ def test_single_member_gzip_files_are_inflated_on_the_device(engine_factory, orc
     cases = [("l1", uniform, member(uniform, 1)), ("l6", uniform, member(uniform, 6)), ("l9", real, member(real, 9)),
              ("named", real[:1_500_000], member(real[:1_500_000], 6, name="genome.fa")), ("stored", uniform[:600_000], member(uniform[:600_000], 0)),
              ("fixed", uniform[:300_000], member(uniform[:300_000], 6, zlib.Z_FIXED)), ("huff", uniform[:500_000], member(uniform[:500_000], 6, zlib.Z_HUFFMAN_ONLY)),
-             ("rle", real[:500_000], member(real[:500_000], 6, zlib.Z_RLE)), ("lowent", lowent, member(lowent, 9))]
+             ("rle", real[:500_000], member(real[:500_000], 6, zlib.Z_RLE)), ("lowent", lowent, member(lowent, 9)),
+             # round 5: SEVERAL members (`cat a.fa.gz b.fa.gz`; each found by its header, decoded as a stream of its own, the texts one
+             # behind the other) -- two of different levels, three with a named header in the middle and a stored-only one at the end
+             ("two_members", uniform[:1_500_000], member(uniform[:800_000], 6) + member(uniform[800_000:1_500_000], 1)),
+             ("three_members", real[:2_400_000], member(real[:900_000], 9) + member(real[900_000:1_700_000], 6, name="part2.fa") + member(real[1_700_000:2_400_000], 0))]
     paths = []
     for name, raw, data in cases:
         (tmp_path / f"{name}.fa.gz").write_bytes(data)
@@ -645,9 +649,9 @@ def test_single_member_gzip_files_are_inflated_on_the_device(engine_factory, orc
             assert text.tobytes() == gzip.decompress(data) == raw, (name, guess_kb)
     monkeypatch.delenv("DD_GUNZIP_GUESS_KB")
     monkeypatch.delenv("DD_INFLATE_STRICT")
-    # not for the device: two members (the device refuses a final block that is not followed by the trailer alone; the call
-    # is run again on the host), FASTQ (seen in the first bytes; never sent)
-    two = member(uniform[:800_000], 6) + member(uniform[800_000:1_500_000], 6)
+    # two members (round 4: refused by the device, run again on the host) and four-line FASTQ (round 4: seen in the first bytes and
+    # never sent; round 5: resolved on the device, test_gz_fastq_is_resolved_on_the_device): right either way
+    two = b"".join(member(uniform[i:i + 30_000], 6) for i in range(0, 1_500_000, 30_000))      # 50 members of ~8 KB: the host's
     fq = b"".join(b"@r%d\n" % i + uniform[100 + 80 * i:180 + 80 * i].replace(b"\n", b"A").replace(b">", b"A") + b"\n+\n" + b"I" * 80 + b"\n" for i in range(4000))
     (tmp_path / "two.fa.gz").write_bytes(two)
     (tmp_path / "reads.fq.gz").write_bytes(member(fq, 6))
@@ -720,6 +724,76 @@ def test_damaged_single_member_gzip_is_refused_or_read_like_zlib(orc, torch_cuda
     finally:
         eng.close()
     assert outcomes["refused"] >= 8, outcomes
+
+
+def test_gz_fastq_is_resolved_on_the_device(orc, torch_cuda, tmp_path, monkeypatch):
+    """.gz FASTQ (single member and BGZF) stays on the device: inflated there, every record checked against the four-line form
+    (header '@', one sequence line, '+' line, one quality line of the sequence's length) and its '+' and quality lines turned
+    into header lines for K0 (dd_fastq.hip) -- registers == the oracle's kseq reading of the plain bytes, with DD_INFLATE_STRICT=1
+    (nothing may go to the host).  Quality text full of A, C, G, T, '@', '>' and '+', CRLF line ends, a last line without a
+    newline, an empty read.  What is NOT four-line FASTQ -- multi-line records, a truncated last record, FASTA behind '@' headers,
+    a FASTA file with a '+' line far behind its first 256 bytes -- is refused by the device (strict: the call fails) and comes out
+    right through the host's kseq state machine, without costing the context its device path."""
+    import zlib
+    from dandd_amd.engine import Engine, EngineError
+    monkeypatch.setenv("DD_GUNZIP_MIN_KB", "16")
+    rng = np.random.default_rng(5)
+    seq = orc.synth_fasta(SEED, 9, 1_500_000, 1).tobytes().split(b"\n", 1)[1].replace(b"\n", b"")
+
+    def reads(n, length, eol=b"\n", last_newline=True, start=0):
+        out = []
+        for i in range(n):
+            L = length if isinstance(length, int) else int(rng.integers(*length))
+            s = seq[(start + i * 97) % (len(seq) - 400):][:L]
+            q = bytes(rng.choice(np.frombuffer(b"ACGT@>+I#5FFFF", np.uint8), size=len(s)))
+            out.append(b"@read%d extra\n".replace(b"\n", eol) % i + s + eol + b"+" + (b"read%d" % i if i % 3 == 0 else b"") + eol + q + eol)
+        text = b"".join(out)
+        return text if last_newline else text[:-len(eol)]
+
+    def member(raw, level=6):
+        co = zlib.compressobj(level, zlib.DEFLATED, 31)
+        return co.compress(raw) + co.flush()
+
+    good = {"fixed150": reads(9000, 150), "ragged": reads(7000, (1, 400)), "crlf": reads(5000, 100, eol=b"\r\n"),
+            "no_last_newline": reads(4000, 120, last_newline=False), "with_empty_read": reads(2000, 90) + b"@empty\n\n+\n\n" + reads(2000, 90, start=5000)}
+    eng = Engine(device=0, log2m=14, canonical=True)
+    try:
+        paths, texts = [], []
+        for name, text in good.items():
+            for kind in ("gz", "bgzf"):
+                path = tmp_path / f"{name}.{kind}.fq.gz"
+                path.write_bytes(member(text) if kind == "gz" else _bgzf(text, level=6))
+                paths.append(str(path))
+                texts.append(text)
+        monkeypatch.setenv("DD_INFLATE_STRICT", "2")
+        got = eng.sketch_files(paths, 19, 21)
+        for path, text, g in zip(paths, texts, got):
+            assert np.array_equal(g, orc.sketch_sweep(np.frombuffer(text, np.uint8), 19, 21, 14)), path
+        # not four-line FASTQ: the device says so (strict: the call fails) ...
+        multi = b"".join(b"@m%d\n" % i + seq[i * 200:i * 200 + 70] + b"\n" + seq[i * 200 + 70:i * 200 + 130] + b"\n+\n" + b"I" * 70 + b"\n" + b"5" * 60 + b"\n" for i in range(6000))
+        truncated = reads(5000, 120)[:-40]
+        at_fasta = b"".join(b"@contig%d\n" % i + seq[i * 3000:i * 3000 + 3000] + b"\n" for i in range(200))
+        late_plus = b">x\n" + b"\n".join(seq[i:i + 80] for i in range(0, 400_000, 80)) + b"\n+\n" + seq[:300] + b"\n>y\n" + seq[500_000:700_000] + b"\n"
+        bad = {"multi_line": multi, "truncated": truncated, "at_fasta": at_fasta, "late_plus_line": late_plus}
+        for name, text in bad.items():
+            for kind in ("gz", "bgzf"):
+                path = tmp_path / f"{name}.{kind}.gz"
+                path.write_bytes(member(text) if kind == "gz" else _bgzf(text, level=6))
+                monkeypatch.setenv("DD_INFLATE_STRICT", "1")
+                with pytest.raises(EngineError):
+                    eng.sketch_files([str(path)], 19, 21)
+                # ... and the host's kseq state machine reads it (the oracle's reading of the same bytes); not a strike
+                monkeypatch.delenv("DD_INFLATE_STRICT")
+                g = eng.sketch_files([str(path)], 19, 21)[0]
+                assert np.array_equal(g, orc.sketch_sweep(np.frombuffer(text, np.uint8), 19, 21, 14)), (name, kind)
+        monkeypatch.setenv("DD_INFLATE_STRICT", "2")          # eight refusals later the context still decodes on the device
+        assert np.array_equal(eng.sketch_files(paths[:2], 19, 21), got[:2])
+        # DD_NO_GPU_FASTQ=1: round 4's way (host decoder for FASTQ), same registers
+        monkeypatch.delenv("DD_INFLATE_STRICT")
+        monkeypatch.setenv("DD_NO_GPU_FASTQ", "1")
+        assert np.array_equal(eng.sketch_files(paths[:4], 19, 21), got[:4])
+    finally:
+        eng.close()
 
 
 def test_gunzip_isize_smaller_than_the_text_cannot_write_past_the_arena(orc, torch_cuda, tmp_path, monkeypatch):
