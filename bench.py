@@ -603,7 +603,26 @@ def ingest_probe(eng, ng, nb, nrec, kmin, kmax, torch, gz=False, reps=10):
             eng.synth_fasta_device(SEED, g, nb, nrec, buf.data_ptr())
             eng.synchronize()
             p = os.path.join(d, f"g{g:03d}.fasta" + (".gz" if gz else ""))
-            if gz == "bgzf":
+            if gz == "fastq":     # the genome cut into 150-base reads, four-line FASTQ, gzip -6 (one member): resolved on the device (dd_fastq.hip)
+                raw = buf[:n].cpu().numpy()
+                seq = raw[np.isin(raw, np.frombuffer(b"ACGTacgtN", np.uint8))]
+                nreads = seq.size // 150
+                rec = np.empty((nreads, 3 + 150 + 3 + 150 + 1), dtype=np.uint8)
+                rec[:, :3] = np.frombuffer(b"@r\n", np.uint8)
+                rec[:, 3:153] = seq[:nreads * 150].reshape(nreads, 150)
+                rec[:, 153:156] = np.frombuffer(b"\n+\n", np.uint8)
+                rec[:, 156:306] = np.frombuffer(b"FFFFF:FFFF,FFFFFFFF:F", np.uint8)[np.arange(150) % 21]
+                rec[:, 306] = 10
+                co = zlib.compressobj(6, zlib.DEFLATED, 31)
+                with open(p, "wb") as f:
+                    f.write(co.compress(rec.tobytes()) + co.flush())
+            elif gz == "members":   # `cat a.fa.gz b.fa.gz`: two gzip -6 members per file, each decoded as a stream of its own on the device
+                raw = buf[:n].cpu().numpy().tobytes()
+                with open(p, "wb") as f:
+                    for part in (raw[:n // 2], raw[n // 2:]):
+                        co = zlib.compressobj(6, zlib.DEFLATED, 31)
+                        f.write(co.compress(part) + co.flush())
+            elif gz == "bgzf":
                 with open(p, "wb") as f:
                     f.write(bgzf_bytes(buf[:n].cpu().numpy().tobytes()))
             elif gz:  # one gzip member, level 1 (what `gzip -1` writes)
@@ -625,6 +644,8 @@ def ingest_probe(eng, ng, nb, nrec, kmin, kmax, torch, gz=False, reps=10):
                 "launches": batches, "fasta_MB": nbytes / 1e6,
                 "what": f"dd_sketch_files: {ng} x {nb/1e6:g} Mbp {'BGZF (bgzip -6; blocks inflated on the GPU, dd_ginflate.hip)' if gz == 'bgzf' else 'gzip -1 (one member per file; inflated on the GPU in pieces, dd_ginflate.hip, unless DD_NO_GPU_GUNZIP)' if gz else 'plain'} FASTA files in {base or 'the temp dir'} (warm page cache) -> "
                         f"pinned host buffers -> H2D on a copy stream overlapped with K0/K1 -> registers back to the host; "
+                        + ("[four-line FASTQ, 150-base reads, gzip -6: inflated AND resolved on the device, dd_fastq.hip] " if gz == "fastq" else
+                           "[two gzip -6 members per file] " if gz == "members" else "") +
                         f"k {kmin}-{kmax}; `value` = MEDIAN of calls {'4-' + str(reps) if reps > 4 else '2-' + str(reps)} on one context, best beside it "
                         f"(PCIe-inclusive: reported beside the headline `value`, never as it)"}
     finally:
@@ -905,6 +926,17 @@ def main():
                     del os.environ["DD_NO_GPU_INFLATE"]
             except Exception as e:
                 extras["ingest"]["bgzf_files"] = {"error": f"{type(e).__name__}: {e}"}
+            # ... and (round 5) what round 4 still sent to the host decoder: .gz FASTQ, and files of several gzip members
+            for key, mode, off in (("gzip_fastq_files", "fastq", "DD_NO_GPU_FASTQ"), ("multi_member_gzip_files", "members", "DD_NO_GPU_GUNZIP")):
+                try:
+                    extras["ingest"][key] = ingest_probe(eng, ng, nb, cfg["nrec"], kmin, kmax, torch, gz=mode, reps=7)
+                    os.environ[off] = "1"
+                    try:
+                        extras["ingest"][key]["host_decoder_value"] = ingest_probe(eng, ng, nb, cfg["nrec"], kmin, kmax, torch, gz=mode, reps=4)["value"]
+                    finally:
+                        del os.environ[off]
+                except Exception as e:
+                    extras["ingest"][key] = {"error": f"{type(e).__name__}: {e}"}
             # ... and ONE large .gz (a whole assembly as NCBI ships it: a single gzip member): its deflate stream is cut at
             # block boundaries and the pieces are decoded in parallel without their history (dd_inflate.h); the serial
             # decoder (libdeflate, one thread) beside it

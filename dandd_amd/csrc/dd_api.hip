@@ -1079,6 +1079,7 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
         bool gz_raw = false;                  // a large .gz read as it is, in pieces by several loaders (plain_size = its size): meant for the device
         bool dev_gunzip = false;              // gzip members (usually ONE): the buffer holds the compressed file, the device inflates it in pieces
         std::vector<GzMember> gms;
+        std::vector<size_t> magic;            // a .gz read in pieces: where 1f 8b 08 stands (member headers?), found piece by piece by the loaders
         bool fastq = false;                   // a device-inflated text that starts with '@': four-line FASTQ, checked and resolved on the device
     };
     std::vector<Slot> slots(nfiles);
@@ -1195,11 +1196,14 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             // (every loader looks through the piece it has just read -- the bytes are still in its cache -- instead of one
             // of them through the whole file at the end: that pass held every file back 2-3 ms)
             const bool plus_here = it.len && ok && !sl.gz_raw && dd::piece_has_plus_line(fb.p, it.off, it.len);
+            std::vector<size_t> magic_here;   // (a .gz read in pieces: every loader scans what it has just read for member headers)
+            if (it.len && ok && sl.gz_raw && it.len > 2) dd::gzip_magic_scan(fb.p, it.off, it.off + it.len - 2, magic_here);
             bool last, plus;
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (!ok && sl.ok) sl.ok = false, sl.err = err;
                 sl.plus |= plus_here;
+                sl.magic.insert(sl.magic.end(), magic_here.begin(), magic_here.end());
                 plus = sl.plus;
                 last = --sl.pieces_left == 0;
             }
@@ -1209,8 +1213,17 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
                 if (it.len && ok && sl.gz_raw) {
                     // the compressed file is whole: one member for the device, or (FASTQ, an odd header) the host decoder after all
                     if (bgzf_parse(fb.p, sl.plain_size, sl.blks, sl.out_size, sl.fastq)) sl.dev_inflate = true;
-                    else if (gpu_gunzip && gzip_members_parse(fb.p, sl.plain_size, sl.gms)) sl.dev_gunzip = true;
-                    else ok = read_fasta_file(paths[it.file], fb, err, gz_par);
+                    else if (gpu_gunzip) {
+                        // (the positions that straddle two pieces, then all of them in order)
+                        for (const Item& o : items)
+                            if (o.file == it.file && o.off >= 2)
+                                for (size_t q = o.off - 2; q < o.off && q + 2 < sl.plain_size; ++q)
+                                    if (fb.p[q] == 0x1f && fb.p[q + 1] == 0x8b && fb.p[q + 2] == 0x08) sl.magic.push_back(q);
+                        std::sort(sl.magic.begin(), sl.magic.end());
+                        sl.magic.erase(std::unique(sl.magic.begin(), sl.magic.end()), sl.magic.end());
+                        if (gzip_members_parse(fb.p, sl.plain_size, sl.gms, &sl.magic)) sl.dev_gunzip = true;
+                    }
+                    if (!sl.dev_inflate && !sl.dev_gunzip) ok = read_fasta_file(paths[it.file], fb, err, gz_par);
                     if (sl.dev_gunzip) {
                         sl.out_size = 0;
                         for (const GzMember& gm : sl.gms) sl.out_size += gm.isize;
@@ -1306,7 +1319,7 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return slots[i].done; });
             if (full_batches)
-                cv.wait_for(lk, std::chrono::milliseconds(3), [&] {
+                cv.wait_for(lk, std::chrono::milliseconds(getenv("DD_BATCH_WAIT_MS") ? std::max(0, atoi(getenv("DD_BATCH_WAIT_MS"))) : 3), [&] {
                     for (int j = i; j < std::min(nfiles, i + batch_files); ++j)
                         if (!slots[j].done) return false;
                     return true;
@@ -1314,6 +1327,17 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             // as many as a batch wants and are already loaded (at least one): the GPU is never kept waiting for a
             // full batch; equal batches also let dd_sketch_device reuse its job tables and the buffers below
             while (count < batch_files && i + count < nfiles && slots[i + count].done) ++count;
+            // (device-inflated batches: no small batch at the end -- a launch of the inflate kernel over two files' pieces takes as
+            // long as one over five, with a quarter of the chip: ten gzip -1 files went out as 4 + 4 + 2 and the last two cost
+            // 22 of the call's 60 ms.  What would be left is fewer than half a batch: it joins this one, waited for.)
+            if (full_batches && i + count < nfiles && nfiles - (i + count) < (batch_files + 1) / 2 && !getenv("DD_TAIL_BATCH")) {
+                cv.wait(lk, [&] {
+                    for (int j = i + count; j < nfiles; ++j)
+                        if (!slots[j].done) return false;
+                    return true;
+                });
+                count = nfiles - i;
+            }
             // (a directory of small files: batch sizes come from a short list -- powers of two, the full batch, the
             // tail -- so that the job tables of every shape are in the plan cache from the second call on; planning
             // a shape never seen costs ~2 ms of host time with the GPU waiting)
@@ -1351,7 +1375,9 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
         // (files of 48 MB and more take 64 KiB ranges: half as many links in the chain of windows, which one workgroup per
         // file walks at ~7 us a piece -- 1 x 400 Mbp: 5.4 -> 6.9 Gbp/s, 3 x 300 Mbp: 7.2 -> 8.1)
         auto guess_bits_of = [&](size_t file_bytes) {
-            return (size_t)(getenv("DD_GUNZIP_GUESS_KB") ? std::max(4, atoi(getenv("DD_GUNZIP_GUESS_KB"))) : (file_bytes >= ((size_t)400 << 20) ? 128 : file_bytes >= ((size_t)48 << 20) ? 64 : 32)) << 13;
+            // (round 5, with the windows composed in two levels: 16 KiB for files below 48 MB -- ten 50 Mbp gzip -1 files 7.2 -> 7.9-8.3
+            // Gbp/s with 16 / 8 KiB, gzip -6 11.1 -> 11.5 / 11.3, 64 x 5 Mbp 9.1 -> 9.2 / 9.6; profiles/r05_gunzip.txt)
+            return (size_t)(getenv("DD_GUNZIP_GUESS_KB") ? std::max(4, atoi(getenv("DD_GUNZIP_GUESS_KB"))) : (file_bytes >= ((size_t)400 << 20) ? 128 : file_bytes >= ((size_t)48 << 20) ? 64 : 16)) << 13;
         };
         // a range's symbols: 5 x its compressed bytes (DNA inflates 3-4 x) + 32 Ki; a piece that needs more takes the arena
         auto range_syms_of = [&](size_t guess_bits) { return 5 * (guess_bits / 8) + 32768; };

@@ -11,6 +11,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include <algorithm>
 #include <string>
@@ -383,19 +386,43 @@ inline size_t gzip_header_bytes(const uint8_t* p, size_t n) {   // 0: not a memb
     if (p[3] & 2) h += 2;
     return h + 8 <= n ? h : 0;
 }
-inline bool gzip_members_parse(const uint8_t* p, size_t n, std::vector<GzMember>& ms) {
+// the positions q in [lo, hi) with p[q .. q + 2] == 1f 8b 08 (hi + 2 <= the buffer's length), appended in order.  16 positions
+// per step (SSE2: three compares, ~8 GB/s; memchr on one byte stops every 256 bytes, glibc's memmem runs at ~1.5 GB/s -- a
+// 116 MB member was held back 60 ms), because every .gz pays this scan for the rare file that has a second member.
+inline void gzip_magic_scan(const uint8_t* p, size_t lo, size_t hi, std::vector<size_t>& out) {
+    size_t q = lo;
+#if defined(__SSE2__)
+    const __m128i a = _mm_set1_epi8(0x1f), b = _mm_set1_epi8((char)0x8b), c = _mm_set1_epi8(0x08);
+    for (; q + 16 <= hi; q += 16) {
+        const __m128i x = _mm_loadu_si128(reinterpret_cast<const __m128i*>(p + q)), y = _mm_loadu_si128(reinterpret_cast<const __m128i*>(p + q + 1)),
+                      z = _mm_loadu_si128(reinterpret_cast<const __m128i*>(p + q + 2));
+        unsigned m = (unsigned)_mm_movemask_epi8(_mm_and_si128(_mm_and_si128(_mm_cmpeq_epi8(x, a), _mm_cmpeq_epi8(y, b)), _mm_cmpeq_epi8(z, c)));
+        for (; m; m &= m - 1) out.push_back(q + (size_t)__builtin_ctz(m));
+    }
+#endif
+    for (; q < hi; ++q)
+        if (p[q] == 0x1f && p[q + 1] == 0x8b && p[q + 2] == 0x08) out.push_back(q);
+}
+// `magic`: the sorted positions of 1f 8b 08 in the file when the caller has scanned it already (in pieces, by several threads)
+inline bool gzip_members_parse(const uint8_t* p, size_t n, std::vector<GzMember>& ms, const std::vector<size_t>* magic = nullptr) {
     ms.clear();
     if (n < 64) return false;
+    std::vector<size_t> scanned;
+    if (!magic) {
+        gzip_magic_scan(p, 0, n - 17, scanned);
+        magic = &scanned;
+    }
+    size_t mi = 0;
     uint64_t text_total = 0;
     for (size_t start = 0; start < n;) {
         const size_t h = gzip_header_bytes(p + start, n - start);
         if (!h) return false;
         size_t next = n;   // where the next member's header stands
-        for (size_t q = start + h + 10; q + 18 <= n; ++q) {
-            const uint8_t* r = static_cast<const uint8_t*>(memchr(p + q, 0x1f, n - 17 - q));
-            if (!r) break;
-            q = (size_t)(r - p);
-            if (r[1] == 0x8b && r[2] == 8 && !(r[3] & 0xE0) && (r[8] == 0 || r[8] == 2 || r[8] == 4) && (r[9] <= 13 || r[9] == 255) &&
+        for (; mi < magic->size(); ++mi) {
+            const size_t q = (*magic)[mi];
+            if (q < start + h + 10 || q + 18 > n) continue;
+            const uint8_t* r = p + q;
+            if (!(r[3] & 0xE0) && (r[8] == 0 || r[8] == 2 || r[8] == 4) && (r[9] <= 13 || r[9] == 255) &&
                 gzip_header_bytes(r, n - q)) {
                 next = q;
                 break;

@@ -284,7 +284,7 @@ def test_bench_headline_line_has_every_object(torch_cuda, tmp_path):
         assert "delta_rel_err" in j["secondary"][name] and "delta_within_1pct" in j["secondary"][name], name
     ing = j["ingest"]
     assert ing["value"] > 0 and ing["best_value"] >= ing["value"]
-    for sub in ("small_files", "gzip_files", "bgzf_files", "one_big_gzip_file"):
+    for sub in ("small_files", "gzip_files", "bgzf_files", "one_big_gzip_file", "gzip_fastq_files", "multi_member_gzip_files"):
         assert "error" not in ing[sub] and ing[sub]["value"] > 0, sub
     assert ing["one_big_gzip_file"]["serial_decoder_value"] > 0
     # the sidecar: the full object
