@@ -588,7 +588,7 @@ def bgzf_bytes(raw, level=6):
     return bytes(out)
 
 
-def ingest_probe(eng, ng, nb, nrec, kmin, kmax, torch, gz=False, reps=10):
+def ingest_probe(eng, ng, nb, nrec, kmin, kmax, torch, gz=False, reps=10, variants=()):
     """dd_sketch_files over FASTA files (tmpfs when there is one: a warm page cache), third call.
     gz: False plain, True one gzip member per file (gzip -1), "bgzf" bgzip's blocked container (level 6)."""
     import zlib
@@ -632,15 +632,33 @@ def ingest_probe(eng, ng, nb, nrec, kmin, kmax, torch, gz=False, reps=10):
             else:
                 buf[:n].cpu().numpy().tofile(p)
             paths.append(p)
-        times = []
-        for _ in range(reps):  # the context's host buffers are pinned as they are reused: steady from the 4th call on
-            t0 = time.perf_counter()
-            eng.sketch_files(paths, kmin, kmax, 0)
-            times.append(time.perf_counter() - t0)
-        steady = sorted(times[3:] if len(times) > 4 else times[1:])
-        med, best = steady[len(steady) // 2], steady[0]
+        def timed(n):
+            times = []
+            for _ in range(n):  # the context's host buffers are pinned as they are reused: steady from the 4th call on
+                t0 = time.perf_counter()
+                eng.sketch_files(paths, kmin, kmax, 0)
+                times.append(time.perf_counter() - t0)
+            steady = sorted(times[3:] if len(times) > 4 else times[1:])
+            return steady[len(steady) // 2], steady[0]
+
+        med, best = timed(reps)
         _, wait, batches, nbytes = eng.last_ingest_stats()
-        return {"value": ng * nb / med / 1e9, "unit": "Gbp/s", "ms": med * 1e3, "best_value": ng * nb / best / 1e9, "best_ms": best * 1e3,
+        # the same files through other decoders (environment switches of dd_sketch_files), e.g. the host's beside the device's
+        other = {}
+        for key, env, n in variants:
+            saved = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                other[key] = ng * nb / timed(n)[0] / 1e9
+            except Exception as e:
+                other[key] = f"{type(e).__name__}: {e}"
+            finally:
+                for k, v in saved.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+        return {**other, "value": ng * nb / med / 1e9, "unit": "Gbp/s", "ms": med * 1e3, "best_value": ng * nb / best / 1e9, "best_ms": best * 1e3,
                 "launches": batches, "fasta_MB": nbytes / 1e6,
                 "what": f"dd_sketch_files: {ng} x {nb/1e6:g} Mbp {'BGZF (bgzip -6; blocks inflated on the GPU, dd_ginflate.hip)' if gz == 'bgzf' else 'gzip -1 (one member per file; inflated on the GPU in pieces, dd_ginflate.hip, unless DD_NO_GPU_GUNZIP)' if gz else 'plain'} FASTA files in {base or 'the temp dir'} (warm page cache) -> "
                         f"pinned host buffers -> H2D on a copy stream overlapped with K0/K1 -> registers back to the host; "
@@ -907,56 +925,27 @@ def main():
             # ... and as most genome directories really are: .gz, ONE gzip member per file.  Round 4: inflated on the GPU too
             # (dd_ginflate.hip: block starts found by trial, pieces decoded without their history, placeholders resolved along a
             # chain of windows); DD_NO_GPU_GUNZIP=1 beside it = the host decoder (libdeflate or zlib, one thread per file)
-            extras["ingest"]["gzip_files"] = ingest_probe(eng, ng, nb, cfg["nrec"], kmin, kmax, torch, gz=True)
-            os.environ["DD_NO_GPU_GUNZIP"] = "1"
-            try:
-                extras["ingest"]["gzip_files"]["host_decoder_value"] = ingest_probe(eng, ng, nb, cfg["nrec"], kmin, kmax, torch, gz=True, reps=5)["value"]
-            except Exception as e:
-                extras["ingest"]["gzip_files"]["host_decoder_value"] = f"{type(e).__name__}: {e}"
-            finally:
-                del os.environ["DD_NO_GPU_GUNZIP"]
+            host = lambda key, sw, n=5: (key, {sw: "1"}, n)
+            extras["ingest"]["gzip_files"] = ingest_probe(eng, ng, nb, cfg["nrec"], kmin, kmax, torch, gz=True, variants=[host("host_decoder_value", "DD_NO_GPU_GUNZIP")])
             # ... and bgzip'd (htslib's blocked gzip): independent <= 64 KiB members, inflated on the GPU (dd_ginflate.hip) -- the
             # compressed bytes cross PCIe, the host only walks the block sizes; DD_NO_GPU_INFLATE=1 beside it = the host decoder
-            try:
-                extras["ingest"]["bgzf_files"] = ingest_probe(eng, ng, nb, cfg["nrec"], kmin, kmax, torch, gz="bgzf")
-                os.environ["DD_NO_GPU_INFLATE"] = "1"
+            # ... and (round 5) what round 4 still sent to the host decoder: four-line FASTQ in .gz (inflated AND resolved on the
+            # device, dd_fastq.hip), and files of several gzip members (`cat a.fa.gz b.fa.gz`); four files each (zlib -6 in Python is slow)
+            for key, mode, sw, n_files in (("bgzf_files", "bgzf", "DD_NO_GPU_INFLATE", ng), ("gzip_fastq_files", "fastq", "DD_NO_GPU_FASTQ", min(ng, 4)),
+                                           ("multi_member_gzip_files", "members", "DD_NO_GPU_GUNZIP", min(ng, 4))):
                 try:
-                    extras["ingest"]["bgzf_files"]["host_decoder_value"] = ingest_probe(eng, ng, nb, cfg["nrec"], kmin, kmax, torch, gz="bgzf", reps=5)["value"]
-                finally:
-                    del os.environ["DD_NO_GPU_INFLATE"]
-            except Exception as e:
-                extras["ingest"]["bgzf_files"] = {"error": f"{type(e).__name__}: {e}"}
-            # ... and (round 5) what round 4 still sent to the host decoder: .gz FASTQ, and files of several gzip members
-            for key, mode, off in (("gzip_fastq_files", "fastq", "DD_NO_GPU_FASTQ"), ("multi_member_gzip_files", "members", "DD_NO_GPU_GUNZIP")):
-                try:
-                    extras["ingest"][key] = ingest_probe(eng, ng, nb, cfg["nrec"], kmin, kmax, torch, gz=mode, reps=7)
-                    os.environ[off] = "1"
-                    try:
-                        extras["ingest"][key]["host_decoder_value"] = ingest_probe(eng, ng, nb, cfg["nrec"], kmin, kmax, torch, gz=mode, reps=4)["value"]
-                    finally:
-                        del os.environ[off]
+                    extras["ingest"][key] = ingest_probe(eng, n_files, nb, cfg["nrec"], kmin, kmax, torch, gz=mode, reps=8 if key != "bgzf_files" else 10,
+                                                         variants=[host("host_decoder_value", sw, 4)])
                 except Exception as e:
                     extras["ingest"][key] = {"error": f"{type(e).__name__}: {e}"}
             # ... and ONE large .gz (a whole assembly as NCBI ships it: a single gzip member): its deflate stream is cut at
-            # block boundaries and the pieces are decoded in parallel without their history (dd_inflate.h); the serial
-            # decoder (libdeflate, one thread) beside it
+            # block boundaries and the pieces are decoded in parallel without their history -- on the GPU (dd_ginflate.hip), by
+            # the host's loader threads (dd_inflate.h), or serially by one thread (libdeflate)
             try:
                 big_nb = max(40_000_000, 8 * nb)     # 400 Mbp for the headline workload
-                big = ingest_probe(eng, 1, big_nb, 24, kmin, kmax, torch, gz=True, reps=4)     # (round 4: on the GPU)
-                os.environ["DD_NO_GPU_GUNZIP"] = "1"
-                try:
-                    par = ingest_probe(eng, 1, big_nb, 24, kmin, kmax, torch, gz=True, reps=4)  # the host's parallel decoder
-                    os.environ["DD_NO_PARALLEL_GZIP"] = "1"
-                    try:
-                        ser = ingest_probe(eng, 1, big_nb, 24, kmin, kmax, torch, gz=True, reps=3)
-                    finally:
-                        del os.environ["DD_NO_PARALLEL_GZIP"]
-                finally:
-                    del os.environ["DD_NO_GPU_GUNZIP"]
-                big["host_parallel_decoder_value"] = par["value"]
-                big["serial_decoder_value"] = ser["value"]
-                big["serial_decoder_ms"] = ser["ms"]
-                extras["ingest"]["one_big_gzip_file"] = big
+                extras["ingest"]["one_big_gzip_file"] = ingest_probe(
+                    eng, 1, big_nb, 24, kmin, kmax, torch, gz=True, reps=4,
+                    variants=[("host_parallel_decoder_value", {"DD_NO_GPU_GUNZIP": "1"}, 4), ("serial_decoder_value", {"DD_NO_GPU_GUNZIP": "1", "DD_NO_PARALLEL_GZIP": "1"}, 3)])
             except Exception as e:
                 extras["ingest"]["one_big_gzip_file"] = {"error": f"{type(e).__name__}: {e}"}
 

@@ -107,6 +107,89 @@ def kij_command(args):
             pickle.dump(tree.prepare_AFproject(kij_rows, j_rows), f)
 
 
+def serve_command(args):
+    """A resident `dandd`: commands arrive over a unix socket (dandd_amd.host.client), run one at a time in THIS process --
+    whose backends (deltatree._backends: GPU context, kernel modules, pinned buffers, job-table cache) outlive them -- with the
+    client's working directory and DANDD_* / DD_* environment, and their stdout / stderr / exit status go back.  The code that
+    runs is main() below, the one-shot CLI's: same files, byte for byte."""
+    import contextlib
+    import io
+    import socket
+    import time
+    from .client import ENV_PREFIXES, recv_msg, send_msg
+    path = args.socket
+    try:
+        os.unlink(path)
+    except FileNotFoundError:
+        pass
+    srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    srv.bind(path)
+    os.chmod(path, 0o600)      # the socket runs commands as this user: nobody else may connect
+    srv.listen(8)
+    if args.warm:              # bring a backend up before the first command arrives: "<registers>[,nc]"
+        for spec in args.warm:
+            regs, _, flag = spec.partition(",")
+            deltatree.backend_for({"registers": int(regs), "canonicalize": flag != "nc", "tool": "dashing"})
+    print(f"dandd serve: listening on {path}", flush=True)
+    served, home = 0, os.getcwd()
+    try:
+        while True:
+            srv.settimeout(args.idle_exit if args.idle_exit > 0 else None)
+            try:
+                conn, _ = srv.accept()
+            except socket.timeout:
+                break
+            with conn:
+                conn.settimeout(None)
+                req = recv_msg(conn)
+                if req is None:
+                    continue
+                if req.get("op") == "ping":
+                    send_msg(conn, {"rc": 0, "served": served, "pid": os.getpid()})
+                    continue
+                if req.get("op") == "shutdown":
+                    send_msg(conn, {"rc": 0, "served": served})
+                    break
+                out, err = io.StringIO(), io.StringIO()
+                saved = {k: v for k, v in os.environ.items() if k.startswith(ENV_PREFIXES)}
+                t0 = time.perf_counter()
+                rc = 1
+                try:
+                    for k in saved:
+                        del os.environ[k]
+                    os.environ.update({k: str(v) for k, v in (req.get("env") or {}).items() if k.startswith(ENV_PREFIXES)})
+                    os.chdir(req.get("cwd") or home)
+                    deltatree.new_command()
+                    with contextlib.redirect_stdout(out), contextlib.redirect_stderr(err):
+                        try:
+                            argv = list(req.get("argv") or [])
+                            if argv[:1] == ["serve"]:
+                                raise SystemExit("dandd serve: a server does not start servers")
+                            rc = main(argv) or 0
+                        except SystemExit as e:
+                            rc = e.code if isinstance(e.code, int) else (0 if e.code is None else 1)
+                            if isinstance(e.code, str):
+                                print(e.code, file=sys.stderr)
+                        except BaseException:
+                            import traceback
+                            traceback.print_exc()
+                            rc = 1
+                finally:
+                    for k in [k for k in os.environ if k.startswith(ENV_PREFIXES)]:
+                        del os.environ[k]
+                    os.environ.update(saved)
+                    os.chdir(home)
+                served += 1
+                send_msg(conn, {"rc": rc, "stdout": out.getvalue(), "stderr": err.getvalue(), "seconds": time.perf_counter() - t0})
+    finally:
+        srv.close()
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+    return 0
+
+
 def build_parser():
     common = argparse.ArgumentParser(add_help=False)
     common.add_argument("--version", action="version", version="%(prog)s 1.0.0 (dandd_amd / MI355X)")
@@ -160,6 +243,13 @@ def build_parser():
     k.add_argument("--afproject", dest="afproject", default=False, action="store_true")
     k.add_argument("--jaccard", dest="jaccard", default=False, action="store_true")
     k.set_defaults(func=kij_command)
+
+    # (not in the reference: its every command is a fresh process that shells out to fresh `dashing` processes)
+    sv = subs.add_parser("serve", description="keep the GPU context alive and run the commands dandd_amd.host.client forwards")
+    sv.add_argument("--socket", required=True, help="path of the unix socket to listen on (clients: DANDD_SERVER=<path>)")
+    sv.add_argument("--idle-exit", type=float, default=0.0, help="leave after this many seconds without a command (0: never)")
+    sv.add_argument("--warm", action="append", default=[], metavar="REGISTERS[,nc]", help="create this backend before listening, e.g. --warm 20")
+    sv.set_defaults(func=serve_command)
     return parser
 
 

@@ -16,6 +16,7 @@ Differences that are deliberate:
 """
 import csv
 import os
+import weakref
 import pickle
 import sys
 from itertools import permutations
@@ -29,6 +30,12 @@ from .store import Catalog, SketchPath, ensure_dir, forget_sketch, sketch_exists
 # ---------------------------------------------------------------------------------------------
 _backend_factory = None
 _backends = {}
+_SWEPT = weakref.WeakKeyDictionary()   # DeltaTreeNode -> the ks its subtree has been brought up to date for, in this command
+
+
+def new_command():
+    """Forget what an earlier command of this process learned about the sketch directory (dandd serve calls it per command)."""
+    _SWEPT.clear()
 _leaf_batch = None  # set while a tree solves its leaves: sketches missing ks for all of them at once
 
 
@@ -327,10 +334,12 @@ class DeltaTreeNode:
             self.ksketches[0] = sketch_class(self.experiment)(0, template, self.speciesinfo, self.experiment)
         # ks this node (and therefore its whole subtree) was already brought up to date for, in this
         # process: leaves are shared by hundreds of spiders and would otherwise be re-checked every time
-        memo = self.__dict__.get("_swept")
-        if memo is None or memo[0] != os.getpid():
-            memo = self._swept = (os.getpid(), set())
-        swept = memo[1]
+        # (kept BESIDE the node, not in it: a memo inside the object went into the tree pickle -- with this process's pid in
+        # it, so no two runs wrote the same bytes -- and a resident `dandd serve`, whose pid never changes, would have believed a
+        # pickle's memo about sketch files of another day; new_command() forgets everything between commands)
+        swept = _SWEPT.get(self)
+        if swept is None:
+            swept = _SWEPT[self] = set()
         ks = [k for k in range(max(1, mink), maxk + 1) if k not in swept]
         if not ks:
             return
