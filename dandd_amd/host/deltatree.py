@@ -36,6 +36,12 @@ _SWEPT = weakref.WeakKeyDictionary()   # DeltaTreeNode -> the ks its subtree has
 def new_command():
     """Forget what an earlier command of this process learned about the sketch directory (dandd serve calls it per command)."""
     _SWEPT.clear()
+    from . import store
+    store.new_command()
+    for be in _backends.values():          # (registers of sketch files kept in memory: trusted only while size and mtime stand, but a
+        forget = getattr(be, "new_command", None)   # command boundary is a good place to stop trusting altogether)
+        if forget:
+            forget()
 _leaf_batch = None  # set while a tree solves its leaves: sketches missing ks for all of them at once
 
 

@@ -172,6 +172,13 @@ _made_dirs = set()
 _seen_sketches = set()
 
 
+def new_command():
+    """What this process remembers about the file system is true for ONE command: a resident `dandd serve` forgets it
+    between commands (directories and sketch files may have been removed meanwhile)."""
+    _made_dirs.clear()
+    _seen_sketches.clear()
+
+
 def ensure_dir(path):
     """os.makedirs(path, exist_ok=True), once per path and process: the tree code asks for the same
     ngen*/k* directories for every node and every k (a million times in a 32-genome `progressive`)."""

@@ -81,35 +81,29 @@ def main():
     server = None
     if args.server:
         sock = os.path.join(work, "dandd.sock")
-        server = subprocess.Popen(cli + ["serve", "--socket", sock], env=env, cwd=work, stdout=subprocess.PIPE, text=True)
+        server = subprocess.Popen(cli + ["serve", "--socket", sock, "--idle-exit", "300"], env=env, cwd=work, stdout=subprocess.PIPE,
+                                  stderr=open(os.path.join(work, "server.err"), "w"), text=True)
         assert "listening" in server.stdout.readline()
         env = dict(env, DANDD_SERVER=sock, DANDD_SERVER_REQUIRED="1")
         cli = [sys.executable, "-m", "dandd_amd.host.client"]
-        # first pass = cold server (context bring-up inside it); outputs and sketches wiped; second pass below = warm
-        cold = {}
-        run("tree", cli + ["tree", "-d", gdir, "-o", out, "-s", "e2e", "-r", str(args.registers)] + sweep)
-        cold["tree"] = timings["tree"]
-        d0 = os.path.join(out, sorted(f for f in os.listdir(out) if f.endswith(".pickle") and "dtree" in f)[0])
-        run("progressive", cli + ["progressive", "-d", d0, "-o", out, "-n", str(args.norderings)] + sweep)
-        run("kij", cli + ["kij", "-d", d0, "-o", out] + (["--jaccard"] + sweep if sweep else []))
-        cold.update(progressive=timings["progressive"], kij=timings["kij"])
-        shutil.rmtree(out)
-        os.makedirs(out)
-        timings.clear()
-        timings["cold_server_first_pass"] = cold
-    run("tree", cli + ["tree", "-d", gdir, "-o", out, "-s", "e2e", "-r", str(args.registers)] + sweep)
-    pick = [f for f in os.listdir(out) if f.endswith(".pickle") and "dtree" in f]
-    if not pick:
-        pick = [f for f in os.listdir(out) if f.endswith(".pickle")]
-    dtree = os.path.join(out, sorted(pick)[0])
-    run("tree_again_cached", cli + ["tree", "-d", gdir, "-o", out, "-s", "e2e", "-r", str(args.registers)] + sweep)
-    run("progressive", cli + ["progressive", "-d", dtree, "-o", out, "-n", str(args.norderings)] + sweep)
-    run("kij", cli + ["kij", "-d", dtree, "-o", out] + (["--jaccard"] + sweep if sweep else []))
-
-    if server is not None:
-        from dandd_amd.host.client import request
-        request(env["DANDD_SERVER"], {"op": "shutdown"})
-        server.wait(timeout=60)
+    try:
+        if server is not None:
+            # first pass = cold server (context bring-up inside it); outputs and sketches wiped; second pass below = warm
+            measure(args, run, cli, gdir, out, sweep, timings)
+            cold = dict(timings)
+            shutil.rmtree(out)
+            os.makedirs(out)
+            timings.clear()
+            timings["cold_server_first_pass"] = cold
+        measure(args, run, cli, gdir, out, sweep, timings)
+    finally:
+        if server is not None:
+            from dandd_amd.host.client import request
+            request(env["DANDD_SERVER"], {"op": "shutdown"}, timeout=10)
+            try:
+                server.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                server.kill()
     gbp = args.ngenomes * nb / 1e9
     print(json.dumps({
         "mode": "resident server (dandd serve + dandd_amd.host.client), warm" if args.server else "one-shot processes",
@@ -120,6 +114,18 @@ def main():
         "outputs": sorted(os.listdir(out))[:12]}))
     if not args.keep and not args.dir:
         shutil.rmtree(work, ignore_errors=True)
+
+
+def measure(args, run, cli, gdir, out, sweep, timings):
+    run("tree", cli + ["tree", "-d", gdir, "-o", out, "-s", "e2e", "-r", str(args.registers)] + sweep)
+    pick = [f for f in os.listdir(out) if f.endswith(".pickle") and "dtree" in f]
+    if not pick:
+        pick = [f for f in os.listdir(out) if f.endswith(".pickle")]
+    dtree = os.path.join(out, sorted(pick)[0])
+    run("tree_again_cached", cli + ["tree", "-d", gdir, "-o", out, "-s", "e2e", "-r", str(args.registers)] + sweep)
+    run("progressive", cli + ["progressive", "-d", dtree, "-o", out, "-n", str(args.norderings)] + sweep)
+    run("kij", cli + ["kij", "-d", dtree, "-o", out] + (["--jaccard"] + sweep if sweep else []))
+
 
 
 if __name__ == "__main__":

@@ -52,7 +52,7 @@ tcc, _, _ = load("TCC_HIT_sum")
 K1 = ("sweep_kernel", "bitmap_kernel", "bitmap_finish_kernel", "scatter_kernel", "scatter_first", "sort_chunks_kernel", "replay_kernel", "bigmap_kernel",
       "bigmap_finish_kernel", "bucket_", "cursor", "filter")
 out = {"workload": {"genomes": NG, "mbp": NB / 1e6, "kmin": KMIN, "kmax": KMAX, "log2m": P},
-       "made_by": "scripts/profile_r04.sh (profile_r03.sh in round 3) + scripts/make_counters_json.py (rocprofv3 --pmc, one counter set per pass)",
+       "made_by": "scripts/profile_k1_counters.sh (profile_r04.sh / profile_r03.sh in rounds 4 / 3) + scripts/make_counters_json.py (rocprofv3 --pmc, one counter set per pass)",
        "note": f"per STEP (one dd_sketch_device call over {NG} x {NB / 1e6:g} Mbp); fetch_bytes = 2 x FETCH_SIZE (gfx950 wide-read correction), "
                "fetch_raw_bytes as counted; synth/pack/union kernels listed but not summed into k1",
        "kernels": {}}

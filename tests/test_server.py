@@ -71,11 +71,23 @@ def _run_both(tmp_path, backend_env, regs, timeout=600):
                     r = subprocess.run([sys.executable, "-m", "dandd_amd.host.client"] + argv, env=cenv, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
                     times.append(time.perf_counter() - t0)
                     assert r.returncode == 0, (argv, r.stdout[-2000:], r.stderr[-3000:])
+                # the sketch directory vanishes between two commands (what the server remembers about the file system is true for
+                # one command only): the same tree again, from nothing, same rows
+                deltas = os.path.join(out, "t_5_dashing_deltas.csv")
+                before = open(deltas, "rb").read()
+                shutil.rmtree(os.path.join(out, "sketchdb"))
+                os.remove(deltas)
+                r = subprocess.run([sys.executable, "-m", "dandd_amd.host.client"] + _commands(out, data, regs)[0], env=cenv, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+                assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+                assert open(deltas, "rb").read() == before
+                for argv in _commands(out, data, regs)[1:]:      # (and the files the comparison below looks at, rewritten over the new sketches)
+                    r = subprocess.run([sys.executable, "-m", "dandd_amd.host.client"] + argv, env=cenv, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+                    assert r.returncode == 0, (argv, r.stdout[-2000:], r.stderr[-3000:])
                 # a command that fails in the server comes back as a status and a message, and the server lives on
                 r = subprocess.run([sys.executable, "-m", "dandd_amd.host.client", "tree", "-o", out], env=cenv, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
                 assert r.returncode == 1 and "ERROR: You must provide" in r.stdout
                 from dandd_amd.host.client import request
-                assert request(sock, {"op": "ping"})["served"] == 4
+                assert request(sock, {"op": "ping"})["served"] == 7
                 assert request(sock, {"op": "shutdown"})["rc"] == 0
                 srv.wait(timeout=60)
             finally:
