@@ -267,7 +267,7 @@ def cpu_baseline(nbases, nrec, kmin, kmax, log2m, ngenomes=4):
 
 
 def load_counters(genomes, mbp, kmin, kmax, p):
-    """The committed rocprofv3 passes over this very workload -- profiles/r04_k1_counters_*.json (scripts/profile_r04.sh:
+    """The committed rocprofv3 passes over this very workload -- profiles/r0[45]_k1_counters_*.json, the newest round first (scripts/profile_k1_counters.sh:
     FETCH_SIZE, WRITE_SIZE, SQ and TCC in separate --pmc passes, round-4 kernels) -- or None when no file matches."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[45]_k1_counters_*.json")), reverse=True):   # the newest round's first
@@ -284,13 +284,17 @@ def load_counters(genomes, mbp, kmin, kmax, p):
 
 
 def isa_table():
-    """profiles/r04_isa_classes.json: instruction classes of K1's hot loops, counted by scripts/isa_classes.py in the ISA of
+    """profiles/r0N_isa_classes.json: instruction classes of K1's hot loops, counted by scripts/isa_classes.py in the ISA of
     the shipped build and priced with the measured issue costs (profiles/r01_ubench_issue_costs.txt)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r04_isa_classes.json")) as f:
-            return json.load(f)
-    except (OSError, ValueError):
-        return None
+    for rnd in ("r05", "r04"):      # the newest round's table first
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{rnd}_isa_classes.json")) as f:
+                t = json.load(f)
+            t["_file"] = f"profiles/{rnd}_isa_classes.json"
+            return t
+        except (OSError, ValueError):
+            pass
+    return None
 
 
 def issue_model(counters, kernel_s_per_step):
@@ -324,7 +328,7 @@ def issue_model(counters, kernel_s_per_step):
     frac = busy_ns * 1e-9 / (1024.0 * kernel_s_per_step)
     return {"frac_of_mix": frac, "simd_busy_ms_per_step": busy_ns * 1e-6 / 1024.0, "kernel_ms_per_step": kernel_s_per_step * 1e3,
             "cheap_ns": costs["cheap_ns"], "dear_ns": costs["dear_ns"], "by_kernel": rows,
-            "from": "profiles/r04_isa_classes.json (scripts/isa_classes.py over the shipped build's ISA) x " + counters.get("_file", "the counter file") +
+            "from": isa.get("_file", "profiles/r0N_isa_classes.json") + " (scripts/isa_classes.py over the shipped build's ISA) x " + counters.get("_file", "the counter file") +
                     " (SQ_INSTS_VALU per kernel and step); kernels that overlap on side streams (log2m >= 17) share the step's SIMD time"}
 
 

@@ -137,8 +137,8 @@ def test_bench_progressive_line_names_the_bit_plane_scan_at_log2m_20(torch_cuda,
 
 
 def test_committed_counter_files_feed_the_issue_model():
-    """bench.py's valu_bound is computed from COMMITTED evidence only: profiles/r04_k1_counters_*.json (PMC passes) and
-    profiles/r04_isa_classes.json (instruction classes of the hot loops in the shipped ISA x measured issue costs).
+    """bench.py's valu_bound is computed from COMMITTED evidence only: profiles/r0[45]_k1_counters_*.json (PMC passes; the newest round first) and
+    profiles/r0[45]_isa_classes.json (instruction classes of the hot loops in the shipped ISA x measured issue costs).
     On the CPU: the files load for the headline workload, for DandD's default registers, for the small-genome
     regime and for the cfg 5 share; the log2m 14 kernels come out at 90-105 % of issue for their own instruction mix."""
     sys.path.insert(0, ROOT)
