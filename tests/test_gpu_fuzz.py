@@ -17,6 +17,7 @@ FUZZ = [
     ("fuzz_buckets.py", 1000, 506, "log2m 16-20 scatter / sort / replay path with random schedule knobs == oracle"),
     ("fuzz_inflate.py", 100, 507, "device-inflated BGZF blocks and single gzip members: bytes == the compressed text, registers == plain sketch (strict)"),
     ("fuzz_damage.py", 300, 508, "damaged .gz files: the call raises exactly when zlib's gzread fails, else the registers of gzread's text"),
+    ("fuzz_fastq.py", 250, 510, "FASTQ-like texts in .gz / BGZF / two members, clean and broken: whichever of the device's rules or the host's kseq state machine takes a text, registers == the oracle's kseq reading"),
     ("fuzz_k2.py", 50, 509, "Gram all-pairs == streaming kernel, bit-plane progressive scan == streaming kernel"),
 ]
 
