@@ -299,6 +299,78 @@ static void device_gunzip_host_side() {
         std::vector<uint8_t> u(fa.begin(), fa.end());
         CHECK(dd::gzip_member_parse(u.data(), u.size(), gm) && !gm.fastq, "gzip_member_parse: FASTA");
     }
+    {   // round 5: files of SEVERAL members.  gzip_magic_scan == a byte-wise search on buffers with the pattern at every alignment and
+        // across the 16-byte steps; gzip_members_parse finds the members of `cat a.gz b.gz c.gz` (texts of >= 64 KiB each), with
+        // the scan done by the caller in pieces too; damaged and cut-short copies: any answer, no read outside the copy
+        for (int it = 0; it < 300; ++it) {
+            const size_t n = 3 + rng() % 400;
+            std::vector<uint8_t> v(n);
+            for (auto& c : v) c = (uint8_t)(rng() % 5 == 0 ? 0x1f : rng());
+            for (int k = 0; k < 6; ++k) {
+                const size_t q = rng() % (n - 2);
+                v[q] = 0x1f, v[q + 1] = 0x8b, v[q + 2] = 0x08;
+            }
+            std::vector<size_t> want, got;
+            for (size_t q = 0; q + 2 < n; ++q)
+                if (v[q] == 0x1f && v[q + 1] == 0x8b && v[q + 2] == 0x08) want.push_back(q);
+            const size_t lo = rng() % (n - 2), hi = lo + rng() % (n - 2 - lo + 1);
+            dd::gzip_magic_scan(v.data(), lo, hi, got);
+            std::vector<size_t> sub;
+            for (size_t q : want)
+                if (q >= lo && q < hi) sub.push_back(q);
+            CHECK(got == sub, "gzip_magic_scan: differs from the byte-wise search");
+        }
+        std::string bodies[3];
+        for (int b = 0; b < 3; ++b) {
+            for (int i = 0; i < 300000 + 60000 * b; ++i) bodies[b] += "ACGT"[rng() % 4];   // (>= 64 KiB compressed each: smaller members are the host's)
+            bodies[b] = ">seq " + std::to_string(b) + "\n" + bodies[b] + "\n";
+        }
+        const std::string m0 = gz_member(bodies[0], 6, Z_DEFAULT_STRATEGY, std::string()), m1 = gz_member(bodies[1], 1, Z_DEFAULT_STRATEGY, std::string()),
+                          m2 = gz_member(bodies[2], 9, Z_DEFAULT_STRATEGY, std::string());
+        const std::string file = m0 + m1 + m2;
+        std::vector<uint8_t> v(file.begin(), file.end());
+        std::vector<dd::GzMember> ms;
+        CHECK(dd::gzip_members_parse(v.data(), v.size(), ms) && ms.size() == 3, "gzip_members_parse: three members");
+        if (ms.size() == 3) {
+            CHECK(ms[0].end == m0.size() && ms[1].end == m0.size() + m1.size() && ms[2].end == file.size(), "gzip_members_parse: member ends");
+            CHECK(ms[1].first_bit == 8 * (m0.size() + 10) && ms[2].first_bit == 8 * (m0.size() + m1.size() + 10), "gzip_members_parse: first bits are the file's");
+            for (int b = 0; b < 3; ++b)
+                CHECK(ms[b].isize == bodies[b].size() && ms[b].crc == (uint32_t)crc32(0, (const Bytef*)bodies[b].data(), (uInt)bodies[b].size()), "gzip_members_parse: trailers");
+        }
+        // the caller's own scan, in pieces with the straddling positions checked separately (what the loader threads do)
+        std::vector<size_t> magic;
+        const size_t piece = 70001;
+        for (size_t off = 0; off < v.size(); off += piece) {
+            const size_t len = std::min(piece, v.size() - off);
+            if (len > 2) dd::gzip_magic_scan(v.data(), off, off + len - 2, magic);
+            if (off >= 2)
+                for (size_t q = off - 2; q < off && q + 2 < v.size(); ++q)
+                    if (v[q] == 0x1f && v[q + 1] == 0x8b && v[q + 2] == 0x08) magic.push_back(q);
+        }
+        std::sort(magic.begin(), magic.end());
+        magic.erase(std::unique(magic.begin(), magic.end()), magic.end());
+        std::vector<dd::GzMember> ms2;
+        CHECK(dd::gzip_members_parse(v.data(), v.size(), ms2, &magic) && ms2.size() == 3 && ms2[1].end == ms[1].end, "gzip_members_parse: with the caller's scan");
+        dd::GzMember one;
+        CHECK(!dd::gzip_member_parse(v.data(), v.size(), one), "gzip_member_parse: three members are not ONE");
+        for (int it = 0; it < 300; ++it) {
+            std::vector<uint8_t> w(v.begin(), v.begin() + (ptrdiff_t)(rng() % 3 ? 1 + rng() % v.size() : v.size()));
+            for (int k = 0; k < 6; ++k) w[rng() % w.size()] = (uint8_t)rng();
+            if (rng() % 2) {   // a header look-alike somewhere
+                const size_t q = rng() % w.size();
+                const uint8_t fake[10] = {0x1f, 0x8b, 0x08, 0, 0, 0, 0, 0, 0, 3};
+                for (size_t k = 0; k < 10 && q + k < w.size(); ++k) w[q + k] = fake[k];
+            }
+            std::vector<dd::GzMember> m3;
+            (void)dd::gzip_members_parse(w.data(), w.size(), m3);
+            for (const dd::GzMember& g : m3) CHECK(g.end <= w.size() && g.first_bit / 8 < g.end, "gzip_members_parse: a member outside the buffer");
+        }
+        // many small members: not for the device
+        std::string small;
+        for (int b = 0; b < 5; ++b) small += gz_member(bodies[0].substr(0, 20000), 6, Z_DEFAULT_STRATEGY, std::string());
+        std::vector<uint8_t> sv(small.begin(), small.end());
+        CHECK(!dd::gzip_members_parse(sv.data(), sv.size(), ms), "gzip_members_parse: small members must go to the host");
+    }
     for (int it = 0; it < 200; ++it) {      // CRC-32 of 64 KiB chunks combined == CRC-32 of the whole
         const size_t n = 1 + rng() % 300000;
         std::vector<uint8_t> d(n);
