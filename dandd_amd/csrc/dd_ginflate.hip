@@ -40,17 +40,21 @@ namespace {
 
 extern __shared__ __attribute__((aligned(16))) uint8_t g_lds[];
 
-constexpr uint32_t kLitInfo = 0;                  // u32[1024]: literal / length code table (10-bit lookup)
-constexpr uint32_t kDistInfo = kLitInfo + 4096u;  // u32[1024]: distance code table
-constexpr uint32_t kLitCount = kDistInfo + 4096u; // u16[16] + u16[288]: codes longer than 10 bits, puff-style
+// (round 5, measured and put back: 9-bit tables -- 2 KiB each, 5.25 KiB per wave instead of 9.25, 24-28 waves per CU instead of
+// 17 -- gave ten gzip -1 files 8.0 -> 8.3 Gbp/s and took one 400 Mbp gzip -6 file from 10.3 to 9.4 (codes of 10 bits go through
+// decode_slow); BGZF and gzip -6 directories unchanged: profiles/r05_gunzip.txt)
+constexpr int FAST = 10;
+constexpr uint32_t kTableBytes = 4u << FAST;
+constexpr uint32_t kLitInfo = 0;                  // u32[1 << FAST]: literal / length code table (FAST-bit lookup)
+constexpr uint32_t kDistInfo = kLitInfo + kTableBytes;  // u32[1 << FAST]: distance code table
+constexpr uint32_t kLitCount = kDistInfo + kTableBytes; // u16[16] + u16[288]: codes longer than FAST bits, puff-style
 constexpr uint32_t kLitSymbol = kLitCount + 32u;
 constexpr uint32_t kDistCount = kLitSymbol + 576u;
 constexpr uint32_t kDistSymbol = kDistCount + 32u;
 constexpr uint32_t kLens = kDistSymbol + 64u;     // u8[320]: code lengths while a table is built
 constexpr uint32_t kClInfo = kLens + 320u;        // u16[128]: code-length code table (7-bit lookup)
 constexpr uint32_t kInflateLds = (kClInfo + 256u + 15u) & ~15u;   // 9.25 KiB: seventeen one-wave workgroups per CU
-
-constexpr int FAST = 10;
+static_assert(kTableBytes >= 1024u, "text_crc keeps its 256-entry table in the literal table's place");
 
 __constant__ uint16_t c_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __constant__ uint8_t c_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -370,6 +374,73 @@ DD_D bool piece_of(const RawFile* files, int nfiles, const uint64_t* starts, uin
     return true;
 }
 
+// ---- the walk over a window's symbols, all lanes at once (round 5) ------------------------------------------------------
+// The scalar walk below follows the chain of symbols one v_readlane and ~20 scalar instructions at a time.  That is the right
+// shape for gzip -6 text -- three or four matches per 64-bit window -- and the wrong one for gzip -1 and for anything else
+// that is mostly LITERALS: DNA's four letters get 2-bit codes, a window holds up to 32 symbols, and the walk, not the decoding,
+// is what a launch spends its instructions on (ten gzip -1 files: 32 ms of inflate kernel against 18 for gzip -6 of the same text).
+// The chain is a linked list -- lane i's successor is lane i + len_i -- and "which lanes does the list from lane 0 visit" is
+// pointer jumping: every lane keeps the set R of lanes its first 2^k steps visit and the lane J it stands on then; six rounds of
+// R |= R[J], J = J[J] (three ds_bpermute each) and lane 0 holds the whole chain, however many symbols it has.  A wave-wide prefix
+// sum of the symbols' output lengths (DPP) places them in the batch; the first one that does not fit ends the batch.
+// ~70 instructions per window whatever it holds, against ~22 per symbol.  MEASURED (profiles/r05_gunzip.txt): no difference --
+// ten gzip -1 files 7.98 / 7.90 / 7.87 Gbp/s with the scalar walk / this one behind windows of five symbols or more / this one
+// always, BGZF 16.6-17.1 all three: gzip -1 DNA is not literal runs but SHORT MATCHES (2.3 bits per base: ~3 symbols per window,
+// where the two walks cost the same), and swapping 66 scalar instructions for 70 vector ones changes nothing because the kernel
+// is bound by neither unit's issue rate but by its waves' serial chains.  Kept behind DD_INFLATE_PWALK (default 0) for texts
+// that ARE literal runs; bit-exact in all three modes (strict tests, scripts/fuzz_inflate.py).
+template <int CTRL, int ROW_MASK>
+DD_D uint32_t dpp_add(uint32_t x) {
+    return x + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, false);
+}
+DD_D uint32_t wave_inclusive_sum(uint32_t x) {
+    x = dpp_add<0x111, 0xf>(x);   // row_shr:1
+    x = dpp_add<0x112, 0xf>(x);   // row_shr:2
+    x = dpp_add<0x114, 0xf>(x);   // row_shr:4
+    x = dpp_add<0x118, 0xf>(x);   // row_shr:8   -> inclusive sums inside every row of 16
+    x = dpp_add<0x142, 0xa>(x);   // row_bcast:15 into rows 1 and 3
+    x = dpp_add<0x143, 0xc>(x);   // row_bcast:31 into rows 2 and 3
+    return x;
+}
+DD_D uint32_t bperm(uint32_t lane_index, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lane_index << 2), (int)v); }
+// pk: what lane i's symbol is (0: not for the walk; else bits 0..5 its length in bits, 6..14 the bytes it makes).  Out: the
+// lanes whose symbols join the batch, each one's slot (osv), the bytes they make, where the walk stands and what it found there
+// (pks: 1 = the window is used up, 0 = a symbol the lanes could not finish, else the pk of a symbol the batch has no room for).
+DD_D void parallel_walk(uint32_t pk, uint32_t lane, uint32_t used, unsigned long long& mark, uint32_t& pos, uint32_t& outacc, uint32_t& pks, uint32_t& osv) {
+    const uint32_t room = 64u - used;
+    const bool valid = pk != 0u;
+    const uint32_t nxt = lane + (pk & 63u);
+    uint32_t J = (valid && nxt < 64u) ? nxt : lane;    // (a lane the walk stops at points at itself)
+    uint32_t rlo = lane < 32u ? 1u << lane : 0u, rhi = lane < 32u ? 0u : 1u << (lane - 32u);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const uint32_t jn = bperm(J, J), a = bperm(J, rlo), b = bperm(J, rhi);
+        rlo |= a, rhi |= b;
+        J = jn;
+    }
+    const unsigned long long chain = ((unsigned long long)uni(rhi) << 32) | uni(rlo);   // (lane 0's: the walk starts at the window's first bit)
+    const unsigned long long vm = __ballot(valid);
+    const uint32_t t = 63u - (uint32_t)__builtin_clzll(chain);   // where the chain ends: a symbol that leaves the window, or one the lanes could not finish
+    const bool t_valid = (vm >> t) & 1ull;
+    const unsigned long long all = chain & vm;
+    const uint32_t ol = ((all >> lane) & 1ull) ? pk >> 6 : 0u;
+    const uint32_t incl = wave_inclusive_sum(ol), before = incl - ol;
+    const unsigned long long bad = __ballot(ol != 0u && incl > room);
+    if (bad) {
+        const uint32_t fb = (uint32_t)__builtin_ctzll(bad);
+        mark = all & ((1ull << fb) - 1ull);
+        pos = fb;
+        pks = lane_value(pk, fb);
+        outacc = lane_value(before, fb);
+    } else {
+        mark = all;
+        pos = t_valid ? t + (lane_value(pk, t) & 63u) : t;
+        pks = t_valid ? 1u : 0u;
+        outacc = lane_value(incl, 63u);
+    }
+    if ((mark >> lane) & 1ull) osv = used + before;
+}
+
 // MODE 0: grid = BGZF blocks (jobs), one wave each; the text goes out as bytes, the member's ISIZE and CRC-32 are checked.
 // MODE 1 / 2: grid = pieces of single-member gzip files (files / starts): raw deflate data from a block start found by
 // find_starts_kernel up to the next one, decoded WITHOUT its 32 KiB of history -- a copy that reaches in front of the
@@ -383,7 +454,7 @@ DD_D bool piece_of(const RawFile* files, int nfiles, const uint64_t* starts, uin
 template <int MODE>
 __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restrict__ jobs, const RawFile* __restrict__ files, int nfiles,
                                                      const uint64_t* __restrict__ starts, uint32_t* __restrict__ lens, uint32_t* __restrict__ over,
-                                                     const uint32_t* __restrict__ abase, uint32_t* __restrict__ errors) {
+                                                     const uint32_t* __restrict__ abase, uint32_t* __restrict__ errors, int pwalk) {
     constexpr bool RAW = MODE != 0;
     constexpr bool WRITES = MODE == 2 || MODE == 3;   // (16-bit symbols)
     bool too_long = false;                             // MODE 3: the piece does not fit its ranges
@@ -529,6 +600,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
                     s0 = b.word(), s1 = b.word(), s2 = b.word(), s3 = b.word(), s4 = b.word();
                 }
                 uint32_t osv = 0;   // a symbol's lane: the batch slot of its first byte
+                bool many_symbols = false;   // the window before held five symbols or more: the walk goes to all lanes at once
                 for (;;) {
                     // lane i: the 64 bits from bit r + i on
                     const uint32_t t = lane + r, kq = t >> 5, sh = t & 31u;
@@ -549,18 +621,29 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
                     unsigned long long mark = 0, starts = 0;
                     uint32_t pos = 0, outacc = 0, pks = 0;
                     const uint32_t room = 64u - used;
-                    do {
-                        pks = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)pos);
-                        const uint32_t ol = pks >> 6;
-                        if (!pks || outacc + ol > room) break;
-                        const uint32_t slot = used + outacc;
-                        mark |= 1ull << pos;
-                        starts |= 1ull << slot;
-                        if (lane == pos) osv = slot;
-                        outacc += ol;
-                        pos += pks & 63u;
-                        pks = 1;
-                    } while (pos < 64u);
+                    if (pwalk == 2 || (pwalk == 1 && many_symbols)) {
+                        parallel_walk(pk, lane, used, mark, pos, outacc, pks, osv);
+                        // which slots of the batch start a symbol: the symbols' lanes say so in LDS, the slots' lanes read it back
+                        g_lds[kLens + 512u + lane] = 0;
+                        __builtin_amdgcn_wave_barrier();
+                        if ((mark >> lane) & 1ull) g_lds[kLens + 512u + osv] = 1;
+                        __builtin_amdgcn_wave_barrier();
+                        starts = __ballot(g_lds[kLens + 512u + lane] != 0);
+                    } else {
+                        do {
+                            pks = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)pos);
+                            const uint32_t ol = pks >> 6;
+                            if (!pks || outacc + ol > room) break;
+                            const uint32_t slot = used + outacc;
+                            mark |= 1ull << pos;
+                            starts |= 1ull << slot;
+                            if (lane == pos) osv = slot;
+                            outacc += ol;
+                            pos += pks & 63u;
+                            pks = 1;
+                        } while (pos < 64u);
+                    }
+                    many_symbols = __builtin_popcountll(mark) >= 5;
                     if (outacc) {
                         if (at + outacc > out_len) { ok = false, too_long = true; break; }
                         // the symbols' lanes say where their bytes come from; the batch's lanes find their symbol by counting
@@ -730,9 +813,10 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
 // with an end-of-block code, the distance code complete or a single code.  What passes that is a block start or a
 // one-in-10^9 impostor; an impostor makes a piece end somewhere else than the next one starts and the call goes to the
 // host decoder.  Stored and fixed blocks are not looked for (they are decoded as parts of pieces).
-constexpr uint32_t kFindQueue = kInflateLds;        // u32[128]: candidate bit positions waiting for the full test (behind everything a header parse writes)
-constexpr uint32_t kFindLds = kInflateLds + 512u;
-constexpr uint32_t kFindTable = kLitInfo;           // u8[64][128]: every lane's code-length code (7-bit lookup): the place of both symbol tables
+constexpr uint32_t kFindTable = kLitInfo;           // u8[64][128]: every lane's code-length code (7-bit lookup): 8 KiB from the symbol tables' place on
+constexpr uint32_t kFindQueue = kInflateLds > 8192u ? kInflateLds : 8192u;   // u32[128]: candidate bit positions waiting for the full test (behind the lanes' tables
+                                                                              // and behind everything a header parse writes)
+constexpr uint32_t kFindLds = kFindQueue + 512u;
 constexpr uint8_t k_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};   // (c_cl_order, for unrolled loops)
 
 __global__ __launch_bounds__(64) void find_starts_kernel(const RawFile* __restrict__ files, int nfiles, uint64_t* __restrict__ starts) {
@@ -1150,10 +1234,17 @@ static void inflate_attributes() {
     done.fetch_or(bit, std::memory_order_relaxed);
 }
 
+// DD_INFLATE_PWALK: 0 = the scalar walk only (default: round 4's), 1 = the lanes' walk for windows behind a window of five symbols
+// or more, 2 = always (tests)
+static int pwalk_mode() {
+    const char* e = getenv("DD_INFLATE_PWALK");
+    return e ? std::max(0, std::min(2, atoi(e))) : 0;
+}
+
 void launch_inflate_bgzf(const InflateJob* jobs_dev, int njobs, uint32_t* errors_dev, hipStream_t st) {
     if (njobs <= 0) return;
     inflate_attributes();
-    hipLaunchKernelGGL(inflate_kernel<0>, dim3((unsigned)njobs), dim3(64), kInflateLds, st, jobs_dev, nullptr, 0, nullptr, nullptr, nullptr, nullptr, errors_dev);
+    hipLaunchKernelGGL(inflate_kernel<0>, dim3((unsigned)njobs), dim3(64), kInflateLds, st, jobs_dev, nullptr, 0, nullptr, nullptr, nullptr, nullptr, errors_dev, pwalk_mode());
 }
 
 // Single-member gzip files on the device: block starts -> piece lengths -> offsets -> symbols -> windows -> text -> CRCs.
@@ -1164,11 +1255,12 @@ void launch_gunzip_members(const RawFile* files_dev, int nfiles, int npieces, in
     inflate_attributes();
     uint32_t *lens = tables_dev, *offs = tables_dev + stride, *over = tables_dev + 2 * stride, *abase = tables_dev + 3 * stride;
     const dim3 grid((unsigned)npieces), wave(64);
+    const int pw = pwalk_mode();
     hipLaunchKernelGGL(find_starts_kernel, grid, wave, kFindLds, st, files_dev, nfiles, starts);
-    hipLaunchKernelGGL(inflate_kernel<3>, grid, wave, kInflateLds, st, nullptr, files_dev, nfiles, starts, lens, over, nullptr, errors_dev);
-    hipLaunchKernelGGL(inflate_kernel<1>, grid, wave, kInflateLds, st, nullptr, files_dev, nfiles, starts, lens, over, nullptr, errors_dev);   // (the pieces marked in `over` only)
+    hipLaunchKernelGGL(inflate_kernel<3>, grid, wave, kInflateLds, st, nullptr, files_dev, nfiles, starts, lens, over, nullptr, errors_dev, pw);
+    hipLaunchKernelGGL(inflate_kernel<1>, grid, wave, kInflateLds, st, nullptr, files_dev, nfiles, starts, lens, over, nullptr, errors_dev, pw);   // (the pieces marked in `over` only)
     hipLaunchKernelGGL(piece_offsets_kernel, dim3((unsigned)nfiles), wave, 0, st, files_dev, lens, over, offs, abase, errors_dev);
-    hipLaunchKernelGGL(inflate_kernel<2>, grid, wave, kInflateLds, st, nullptr, files_dev, nfiles, starts, lens, over, abase, errors_dev);
+    hipLaunchKernelGGL(inflate_kernel<2>, grid, wave, kInflateLds, st, nullptr, files_dev, nfiles, starts, lens, over, abase, errors_dev, pw);
     hipLaunchKernelGGL(piece_maps_kernel, dim3((unsigned)ngroups), dim3(1024), 131072, st, files_dev, nfiles, lens, over, abase, errors_dev);
     hipLaunchKernelGGL(group_windows_kernel, dim3((unsigned)nfiles), dim3(1024), 65536, st, files_dev, errors_dev);
     if (nchunks > 0) {

@@ -512,6 +512,12 @@ def test_bgzf_files_are_inflated_on_the_device(engine_factory, orc, tmp_path, mo
         cases.append((name, str(path), np.frombuffer(raw, dtype=np.uint8)))
     monkeypatch.setenv("DD_INFLATE_STRICT", "1")                 # a block the device refuses fails the call: no silent host fallback here
     got = eng.sketch_files([p for _, p, _ in cases], 19, 21)
+    for mode in ("1", "2"):                                      # the walk over a window's symbols by all lanes at once (round 5 knob): same registers, same bytes
+        monkeypatch.setenv("DD_INFLATE_PWALK", mode)
+        assert np.array_equal(eng.sketch_files([p for _, p, _ in cases], 19, 21), got), mode
+        for (name, path, fa), text in zip(cases, eng.inflate_files([p for _, p, _ in cases])):
+            assert text.tobytes() == fa.tobytes(), (name, mode)
+    monkeypatch.delenv("DD_INFLATE_PWALK")
     # ... and the inflated BYTES (dd_inflate_files: the text as K0 is about to read it, copied back from the device) are zlib's:
     # one wrong byte moves a register with p ~ m / n only, the registers alone would miss most of them
     import gzip
