@@ -1044,7 +1044,16 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
     const size_t kMaxBatchFiles = getenv("DD_BATCH_FILES") ? (size_t)std::max(1, atoi(getenv("DD_BATCH_FILES"))) : 256;
     int batch_files = (int)std::max<size_t>(1, std::min<size_t>(kMaxBatchFiles, kBatchBytes / avg));
     const bool full_batches = any_gz && gpu_inflate;
-    if (full_batches && nfiles >= 2) batch_files = std::min(batch_files, (nfiles + 1) / 2);
+    if (full_batches && nfiles >= 2) {
+        // two batches at least (the second's inflate runs under the first's sweep), and EQUAL ones; and rather two batches a
+        // quarter larger than three: there are two sets of buffers, so a third batch is issued only when the first has retired
+        // -- ten gzip -1 files went out as 4 + 4 at t = 4 ms and 2 at t = 40 ms, whose find + inflate + sweep then ran alone
+        // for the call's last 22 of 62 ms (DD_TRACE_FILES; profiles/r05_gunzip.txt)
+        int nb = (nfiles + batch_files - 1) / batch_files;
+        if (nb == 3 && nfiles * 2 <= batch_files * 5 && !getenv("DD_TAIL_BATCH")) nb = 2;
+        nb = std::max(nb, 2);
+        batch_files = (nfiles + nb - 1) / nb;
+    }
     // loaders may run two batches ahead of the GPU
     const int window = std::max(nthreads + 2, 2 * batch_files + nthreads);
     // Pinning host memory costs ~0.4 ms per MB: a buffer starts pageable (a one-shot `dandd tree` process never
@@ -1505,6 +1514,9 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             }
         }
         if ((njobs || nmem) && e == hipSuccess) e = hipMemsetAsync(c->pipe_err[set].p, 0, 4, cs);
+        // (round 5, measured and dropped: the second batch's decoders BEHIND the first's -- an event between the two copy streams --
+        // instead of side by side: ten gzip -1 files 55.0 -> 60.4 ms, gzip -6 43.2 -> 47.5, 64 x 5 Mbp 33.9 -> 38.8: a lone
+        // inflate launch cannot fill the chip, its time is its longest piece's, and two launches hide each other's tails)
         if (nmem && e == hipSuccess) {
             // block starts -> piece lengths -> offsets -> symbols -> windows -> text -> CRC-32 of every 64 KiB (dd_ginflate.hip)
             chunk0_host[nmem] = (uint32_t)chunk_at;
