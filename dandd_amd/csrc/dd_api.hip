@@ -1384,9 +1384,10 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
         // (files of 48 MB and more take 64 KiB ranges: half as many links in the chain of windows, which one workgroup per
         // file walks at ~7 us a piece -- 1 x 400 Mbp: 5.4 -> 6.9 Gbp/s, 3 x 300 Mbp: 7.2 -> 8.1)
         auto guess_bits_of = [&](size_t file_bytes) {
-            // (round 5, with the windows composed in two levels: 16 KiB for files below 48 MB -- ten 50 Mbp gzip -1 files 7.2 -> 7.9-8.3
+            // (round 5, with the windows composed in two levels: 16 KiB up to 400 MB of compressed file (was 32, and 64 from 48 MB: one
+            // 400 Mbp member 7.5-7.7 -> 8.3 Gbp/s at gzip -1, 9.7-10.1 -> 10.3 at gzip -6) -- ten 50 Mbp gzip -1 files 7.2 -> 7.9-8.3
             // Gbp/s with 16 / 8 KiB, gzip -6 11.1 -> 11.5 / 11.3, 64 x 5 Mbp 9.1 -> 9.2 / 9.6; profiles/r05_gunzip.txt)
-            return (size_t)(getenv("DD_GUNZIP_GUESS_KB") ? std::max(4, atoi(getenv("DD_GUNZIP_GUESS_KB"))) : (file_bytes >= ((size_t)400 << 20) ? 128 : file_bytes >= ((size_t)48 << 20) ? 64 : 16)) << 13;
+            return (size_t)(getenv("DD_GUNZIP_GUESS_KB") ? std::max(4, atoi(getenv("DD_GUNZIP_GUESS_KB"))) : (file_bytes >= ((size_t)400 << 20) ? 128 : 16)) << 13;
         };
         // a range's symbols: 5 x its compressed bytes (DNA inflates 3-4 x) + 32 Ki; a piece that needs more takes the arena
         auto range_syms_of = [&](size_t guess_bits) { return 5 * (guess_bits / 8) + 32768; };
