@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void text_scan_kernel(const TextJob* __restric
         }
     }
     if (!t.fastq) {
-        if (__any(plus) && (threadIdx.x & 63u) == 0u) atomicAdd(errors, kNotFourLine);
+        if (__any(plus) && (threadIdx.x & 63u) == 0u) atomicOr(errors, kNotFourLine);
         return;
     }
     __shared__ uint32_t part[4];
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void text_newlines_kernel(const TextJob* __res
     for (uint32_t w = 0; w < wave; ++w) at += wsum[w];
     for (uint32_t m = nl; m; m &= m - 1u, ++at) {
         if (at < t.nl_cap) t.nl[at] = off + (uint32_t)__builtin_ctz(m);
-        else if (at == t.nl_cap) atomicAdd(errors, kNotFourLine);   // (more lines than a FASTQ text of this size has: lines of < 8 bytes on average)
+        else if (at == t.nl_cap) atomicOr(errors, kNotFourLine);   // (more lines than a FASTQ text of this size has: lines of < 8 bytes on average)
     }
 }
 
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void fastq_records_kernel(const TextJob* __res
     if (count > t.nl_cap) return;                                  // (reported by text_newlines_kernel)
     const uint32_t nlines = count + ((t.n && t.text[t.n - 1] != 0x0Au) ? 1u : 0u);
     const uint32_t r = local * 256u + threadIdx.x;
-    if (r == 0u && (nlines == 0u || (nlines & 3u) != 0u)) atomicAdd(errors, kNotFourLine);
+    if (r == 0u && (nlines == 0u || (nlines & 3u) != 0u)) atomicOr(errors, kNotFourLine);
     if (4u * r + 3u >= nlines) return;
     auto start = [&](uint32_t i) { return i ? t.nl[i - 1] + 1u : 0u; };
     auto end = [&](uint32_t i) { return i < count ? t.nl[i] : t.n; };
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void fastq_records_kernel(const TextJob* __res
     }
     ok = ok && len(s, se) == len(q, qe);
     if (!ok) {
-        atomicAdd(errors, kNotFourLine);
+        atomicOr(errors, kNotFourLine);
         return;
     }
     t.text[p] = '>';
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void fastq_records_kernel(const TextJob* __res
 }  // namespace
 
 // texts of one batch: FASTA-classed ones are scanned for a '+' line, FASTQ-classed ones get their '+' and quality lines turned into
-// header lines; *errors_dev += kNotFourLine for every text that is not what it was classed as (the caller goes to the host)
+// header lines; *errors_dev |= kNotFourLine when a text is not what it was classed as (the caller goes to the host)
 void launch_text_rules(const TextJob* jobs_dev, int njobs, uint32_t nblocks, bool any_fastq, uint32_t* errors_dev, hipStream_t st) {
     if (njobs <= 0 || !nblocks) return;
     hipLaunchKernelGGL(text_scan_kernel, dim3(nblocks), dim3(256), 0, st, jobs_dev, njobs, errors_dev);

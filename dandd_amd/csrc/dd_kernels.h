@@ -256,7 +256,10 @@ struct TextJob {
     uint32_t nl_cap;
     uint32_t* nl_total;
 };
-constexpr uint32_t kNotFourLine = 0x1000000u;   // added to *errors_dev per text that is not what its first bytes said (not a decoder refusal)
+// OR-ed into *errors_dev when a text is not what its first bytes said (not a decoder refusal).  OR-ed, not added: one thread per
+// offending RECORD raises it, and 2304 records x 2^24 is 9 x 2^32 = 0 -- a text with exactly that many odd records once came out
+// "accepted" (scripts/fuzz_fastq.py, seed 510 draw 206)
+constexpr uint32_t kNotFourLine = 0x1000000u;
 void launch_text_rules(const TextJob* jobs_dev, int njobs, uint32_t nblocks, bool any_fastq, uint32_t* errors_dev, hipStream_t st);
 size_t inflate_lds_bytes();
 // starts_dev: npieces u64 (bit positions); tables_dev: four arrays of npieces u32 (lens, offs, over, abase), `stride` words apart
