@@ -780,7 +780,10 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
         if ((MODE == 1 || MODE == 3) && lane == 0) lens[blockIdx.x] = ok ? at : 0u;
         if (MODE == 2 && ok && at != out_len) ok = false;
         // (a piece that alone is longer than the member's ISIZE: the trailer's matter -- kSizeMismatch --, not the decoder's)
-        if (!ok && lane == 0) atomicAdd(errors, (too_long && out_len >= files[pr.file].isize) ? kSizeMismatch : 1u);
+        if (!ok && lane == 0) {   // (class bits are OR-ed, counts added: 65 536 pieces x 2^16 would add up to zero)
+            if (too_long && out_len >= files[pr.file].isize) atomicOr(errors, kSizeMismatch);
+            else atomicAdd(errors, 1u);
+        }
         return;
     }
     // the member's trailer: CRC-32, ISIZE
@@ -1058,7 +1061,7 @@ __global__ __launch_bounds__(64) void piece_offsets_kernel(const RawFile* __rest
         arun += (uint64_t)__shfl((long long)aincl, 63);
     }
     // kSizeMismatch: the pieces decoded, but not to the text the trailer announces (the host tells this from a refused block)
-    if ((run != (uint64_t)rf.isize || arun > (uint64_t)rf.isize) && lane == 0) atomicAdd(errors, kSizeMismatch);
+    if ((run != (uint64_t)rf.isize || arun > (uint64_t)rf.isize) && lane == 0) atomicOr(errors, kSizeMismatch);
 }
 
 // where a piece's symbols are: its ranges of the symbol area, or the arena

@@ -264,7 +264,7 @@ void launch_text_rules(const TextJob* jobs_dev, int njobs, uint32_t nblocks, boo
 size_t inflate_lds_bytes();
 // starts_dev: npieces u64 (bit positions); tables_dev: four arrays of npieces u32 (lens, offs, over, abase), `stride` words apart
 constexpr uint32_t kPieceGroup = 32;
-constexpr uint32_t kSizeMismatch = 0x10000u;   // added to *errors_dev per file whose pieces do not add up to its ISIZE (other refusals add 1)
+constexpr uint32_t kSizeMismatch = 0x10000u;   // OR-ed into *errors_dev when a file's pieces do not add up to its ISIZE (decoder refusals ADD 1 each)
 inline size_t gunzip_window_bytes(size_t nguess) {   // the `windows` area of a file with that many ranges
     const size_t ngroups = (nguess + kPieceGroup - 1) / kPieceGroup;
     return nguess * 65536 + ngroups * (65536 + 32768);
