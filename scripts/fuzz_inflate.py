@@ -70,9 +70,17 @@ for it in range(n_cfg):
         if block < 4096 and len(raw) > 20000:
             raw = raw[:20000]
         p = os.path.join(d, f"f{f}.fa.gz")
-        if rng.integers(0, 2):
+        kind = int(rng.integers(0, 5))
+        if kind <= 1:
             data = bgzf(raw, level, strategy, memlevel, block)
             nblocks += len(raw) // block + 2
+        elif kind == 2 and len(raw) > 600000:      # (round 5) two or three members, `cat a.gz b.gz`: cut anywhere, levels of their own
+            cuts = sorted(int(x) for x in rng.integers(1, len(raw), size=int(rng.integers(1, 3))))
+            data = b""
+            for a, b2 in zip([0] + cuts, cuts + [len(raw)]):
+                co = zlib.compressobj(int(rng.choice([1, 6, 9])), zlib.DEFLATED, 31, memlevel, strategy)
+                data += co.compress(raw[a:b2]) + co.flush()
+            nmembers += len(cuts) + 1
         else:       # one gzip member (what `gzip` writes); high-entropy "text" is kept printable: the finder's trial decoding wants text
             co = zlib.compressobj(level, zlib.DEFLATED, 31, memlevel, strategy)
             data = co.compress(raw) + co.flush()
