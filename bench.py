@@ -184,12 +184,18 @@ def cpu_baseline(nbases, nrec, kmin, kmax, log2m, ngenomes=4):
             note = f"`{exe}` found but unusable ({type(e).__name__}: {e}); "
     else:
         note = ""
-    path = None
+    path = cli = None
     try:  # native-arch build for a fair timing; fall back to the portable build
         path = orc.build(arch="native", out=os.path.join("/tmp", f"liboracle_native_{os.getpid()}.so"))
         lib = orc.lib(path)
     except Exception:
         lib = orc.lib()
+    # round 5: every job a PROCESS (oracle/orc_cli.c behind Dashing's command lines), as `parallel` starts `dashing` processes --
+    # fork / exec, the FASTA re-read and re-parsed, the register file written, per job; threads of one process only if gcc is missing
+    try:
+        cli = orc.build_cli(arch="native", out=os.path.join("/tmp", f"orc_cli_{os.getpid()}"))
+    except Exception:
+        cli = None
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     work = tempfile.mkdtemp(prefix="dd_cpu_", dir=base)
     m = 1 << log2m
@@ -222,6 +228,21 @@ def cpu_baseline(nbases, nrec, kmin, kmax, log2m, ngenomes=4):
             r = np.fromfile(reg_of(name, k), dtype=np.uint8)
             return lib.orc_card(r.ctypes.data, log2m)
 
+        if cli:
+            def sketch_job(gk):          # `dashing sketch -k<K> -S <p> --prefix <dir> <fasta>`; the thread only waits for its child process
+                g, k = gk
+                subprocess.run([cli, "sketch", f"-k{k}", "-S", str(log2m), "--prefix", work, fastas[g]], check=True)
+                os.replace(os.path.join(work, f"g{g}.fasta.w.{k}.spacing.{log2m}.hll"), reg_of(f"g{g}", k))
+
+            def union_job(args):         # `dashing union -o <out> <in...>`
+                out, ins, k = args
+                subprocess.run([cli, "union", "-o", reg_of(out, k)] + [reg_of(name, k) for name in ins], check=True)
+
+            def card_job(args):          # `dashing card --presketched <path>`, its TSV parsed as lib/sketch_classes.py:318-321 parses it
+                name, k = args
+                r = subprocess.run([cli, "card", "--presketched", reg_of(name, k)], check=True, capture_output=True, text=True)
+                return float(r.stdout.splitlines()[1].split("\t")[-1])
+
         def timed(fn, items):
             t0 = time.perf_counter()
             with ThreadPoolExecutor(max_workers=jobs) as ex:
@@ -243,8 +264,9 @@ def cpu_baseline(nbases, nrec, kmin, kmax, log2m, ngenomes=4):
         t3 += timed(card_job, [("root", k) for k in ks])
     finally:
         shutil.rmtree(work, ignore_errors=True)
-        if path and os.path.exists(path):
-            os.remove(path)
+        for tmp in (path, cli):
+            if tmp and os.path.exists(tmp):
+                os.remove(tmp)
     total = per * ngenomes
     step_s = t1 + tc + t3
     return {
@@ -255,14 +277,16 @@ def cpu_baseline(nbases, nrec, kmin, kmax, log2m, ngenomes=4):
         "stages_s": {"stage1_leaf_sketches": t1, "leaf_cards": tc, "stage2_progressive_unions_and_cards": t2, "stage3_nway_union_and_card": t3},
         "stage1_only_value": total / t1 / 1e9,
         "with_stage2_value": total / (step_s + t2) / 1e9,
-        "sample_short": f"{ngenomes} x {per/1e6:g} Mbp FASTA files in tmpfs, k {kmin}-{kmax}, log2m {log2m}: oracle job per (genome,k) re-reading its file "
-                        f"+ cards + root union, {jobs} threads in flight, {step_s:.1f} s",
+        "sample_short": f"{ngenomes} x {per/1e6:g} Mbp FASTA files in tmpfs, k {kmin}-{kmax}, log2m {log2m}: oracle {'PROCESS' if cli else 'thread'} per (genome,k) re-reading its file "
+                        f"+ cards + root union, {jobs} in flight, {step_s:.1f} s",
         "sample": note + f"{ngenomes} synthetic genomes x {per/1e6:g} Mbp as FASTA files in {base or 'the temp dir'}, k {kmin}-{kmax}, log2m={log2m}: "
                          f"one single-threaded oracle job per (genome, k) that re-reads and re-parses its file and writes its registers, "
                          f"then `card` jobs per sketch, the N-way root union per k and its `card` (stage 1 + cards + stage 3 = the work of "
                          f"one GPU step = `value`, {step_s:.1f} s wall); stage 2 = seed-42 progressive 2-way unions + cards, reported beside; "
                          f"{jobs} jobs in flight on {ncpu} usable host CPUs ({os.cpu_count()} logical, cgroup quota applied); "
-                         f"jobs are threads calling the C oracle, not processes: no fork/exec cost is charged; no `dashing` on PATH",
+                         + ("every job is a PROCESS (oracle/orc_cli.c: fork / exec, file read and register file per job, as `parallel` runs `dashing`)"
+                            if cli else "jobs are threads calling the C oracle, not processes (gcc missing): no fork/exec cost is charged") + "; no `dashing` on PATH",
+        "process_per_job": bool(cli),
     }
 
 

@@ -25,6 +25,16 @@ def build(arch=None, out=None):
     return out or os.path.join(_HERE, "liboracle.so")
 
 
+def build_cli(arch=None, out=None):
+    """Compile orc_cli (oracle/orc_cli.c: the oracle behind `dashing sketch | union | card` command lines) -> its path."""
+    out = out or os.path.join(_HERE, "orc_cli")
+    cmd = ["make", "-s", "-C", _HERE, "-B", "cli", f"CLI={out}"]
+    if arch:
+        cmd.append(f"ARCH={arch}")
+    subprocess.check_call(cmd)
+    return out
+
+
 def _bind(lib):
     u8p, szp = C.POINTER(C.c_uint8), C.POINTER(C.c_size_t)
     lib.orc_wang64.restype = C.c_uint64
