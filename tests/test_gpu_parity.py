@@ -1035,12 +1035,16 @@ def _random_slab(rng, n, K, p, kind):
     return slab
 
 
-@pytest.mark.parametrize("p,n,K", [(12, 2, 3), (12, 33, 4), (14, 64, 5), (14, 70, 3), (16, 31, 3), (18, 130, 2), (20, 5, 3), (20, 64, 2)])
+@pytest.mark.parametrize("p,n,K", [(12, 2, 3), (12, 33, 4), (14, 64, 5), (14, 70, 3), (16, 31, 3), (18, 130, 2), (20, 5, 3), (20, 64, 2),
+                                   (14, 128, 3), (14, 129, 2), (13, 257, 2), (14, 100, 70)])
 def test_pairwise_gram_equals_streaming_kernel(engine_factory, torch_cuda, orc, monkeypatch, p, n, K):
     """dd_pairwise_device through the int8 Gram matrices on the matrix cores (dd_gram.hip) == the streaming byte-max
     kernel (DD_PAIRWISE_STREAM=1, dd_union.hip) for every (i, j, k), as doubles -- n not a multiple of 32 or 64, more
-    than one 64-row super-block (n = 70, 130: the off-diagonal kernel), several register ranges per row (log2m 18,
-    20), degenerate threshold ranges -- and == the oracle's estimator on the byte-max for sampled pairs."""
+    than one 64-row super-block (n = 70 ... 257: 128-row diagonal units in eight-wave workgroups, round 5, with an odd 64-row
+    block left over at 129 and 257, and the off-diagonal kernel without the pairs those units hold; DD_GRAM_DIAG2=0, round 4's
+    64-row diagonal units, must give the same), more than 64 k columns (the compact workgroup ids count columns in chunks of
+    64), several register ranges per row (log2m 18, 20), degenerate threshold ranges -- and == the oracle's estimator on the
+    byte-max for sampled pairs."""
     torch = torch_cuda
     eng = engine_factory(p, True)
     rng = np.random.default_rng(1000 * p + n)
@@ -1053,6 +1057,10 @@ def test_pairwise_gram_equals_streaming_kernel(engine_factory, torch_cuda, orc, 
     bad = np.argwhere(gram != stream)
     assert bad.size == 0, f"{len(bad)} of {gram.size} entries differ, first (i, j, k) = {bad[0]}: gram {gram[tuple(bad[0])]} stream {stream[tuple(bad[0])]}"
     assert np.array_equal(gram, gram.transpose(1, 0, 2))
+    if n > 64:
+        monkeypatch.setenv("DD_GRAM_DIAG2", "0")
+        assert np.array_equal(eng.pairwise_device(dev.data_ptr(), n, K), gram)
+        monkeypatch.delenv("DD_GRAM_DIAG2")
     for _ in range(6):
         i, j, k = int(rng.integers(n)), int(rng.integers(n)), int(rng.integers(K))
         want = orc.card(np.maximum(slab[i, k], slab[j, k]), p)
