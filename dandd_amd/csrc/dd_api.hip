@@ -407,6 +407,15 @@ int dd_synchronize(dd_ctx* c) {
 // The side streams the k classes of a call run on: `n` of them (at most 8), made when first asked for -- a stream
 // costs 2 ms to create (4 with a priority) and as much again to destroy, which a one-shot process pays in full.
 // DD_SIDE_PRIO (experiments): one digit per stream, 0 = the device's highest queue priority, 1 = normal, 2 = lowest.
+// first epoch of the log2m >= 17 path with its rho = 1 updates as bits (ScatterParams::presorted 5): the binned form must be the
+// one that runs and a row's bits must fit LDS beside its counters
+static bool first_ones_form(int p, int nb_log2) {
+    const char* e = getenv("DD_FIRST_ONES");
+    if (e && atoi(e) == 0) return false;
+    const char* wg = getenv("DD_FIRST_WG");
+    return nb_log2 >= 1 && !getenv("DD_NO_PRESORT") && !getenv("DD_BUCKET_NO_FIRST") && (!wg || atoi(wg) == 3) && p <= 20;
+}
+
 static int ensure_side_streams(dd_ctx* c, int n) {
     if (!c->side_go) {
         DD_HIP(hipEventCreateWithFlags(&c->side_go, hipEventDisableTiming));
@@ -609,10 +618,13 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         const size_t cur_stride = stride_env ? (size_t)std::max(4, atoi(stride_env)) / 4 * 4 : (size_t)256;
         const size_t cur_bytes = align_up((size_t)nrows * cur_stride, 256);
         const size_t flt_tot = align_up(nhashed * flt_bytes, 256);
-        if ((rc = c->buckets.reserve(tab_bytes + cur_bytes + flt_tot + nareas * (fill_bytes + area_bytes)))) return rc;
+        // (round 5, DD_FIRST_ONES: the first epoch's updates of rho = 1 as one bit per register instead of a record each --
+        // dd_sweep.hip, scatter_first_bin_kernel<.., ONES>; the bits start at zero with the cursors and filters)
+        const size_t ones_bytes = first_ones_form(p, bplan->nb_log2) ? m / 8 : 0, ones_tot = align_up(nhashed * ones_bytes, 256);
+        if ((rc = c->buckets.reserve(tab_bytes + cur_bytes + flt_tot + ones_tot + nareas * (fill_bytes + area_bytes)))) return rc;
         if ((rc = c->stage_rows.reserve(tab_bytes))) return rc;
         char* bb = static_cast<char*>(c->buckets.p);
-        char* fills = bb + tab_bytes + cur_bytes + flt_tot;
+        char* fills = bb + tab_bytes + cur_bytes + flt_tot + ones_tot;
         char* areas = fills + nareas * fill_bytes;
         std::vector<dd::BucketRow> rtab(nrows);
         // (row groups: the slot of a row = the ring half of its group's stream + its place in the group; groups are counted
@@ -643,6 +655,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
                 r.cursor = reinterpret_cast<uint32_t*>(bb + tab_bytes + ((size_t)g * K + kk) * cur_stride);
                 const bool hashed = kk >= first_hashed && kk < first_hashed + hashed_per_genome;
                 r.filter = hashed ? reinterpret_cast<uint8_t*>(bb + tab_bytes + cur_bytes + h * flt_bytes) : nullptr;
+                r.ones = hashed && ones_bytes ? reinterpret_cast<uint32_t*>(bb + tab_bytes + cur_bytes + flt_tot + h * ones_bytes) : nullptr;
                 const size_t slot = hashed ? area_slot(g, kk, h) : 0;
                 r.fill = hashed ? reinterpret_cast<uint32_t*>(fills + slot * fill_bytes) : nullptr;
                 r.seg = hashed ? reinterpret_cast<uint16_t*>(fills + slot * fill_bytes + align_up((size_t)bplan->cap_chunks * 4, 256)) : nullptr;
@@ -650,7 +663,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
                 h += hashed ? 1 : 0;
             }
         // cursors and filters start at zero: nothing handed out, every register's lower bound is 0
-        DD_HIP(hipMemsetAsync(bb + tab_bytes, 0, cur_bytes + flt_tot, st));
+        DD_HIP(hipMemsetAsync(bb + tab_bytes, 0, cur_bytes + flt_tot + ones_tot, st));
         if ((rc = upload(c, c->stage_rows, bb, rtab.data(), sizeof(dd::BucketRow) * nrows, 0))) return rc;
         rows_dev = reinterpret_cast<const dd::BucketRow*>(bb);
         DD_HIP(hipEventRecord(c->stage_free, st));
@@ -720,7 +733,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         // Exact, measured 30 % SLOWER on 64 x 5 Mbp at log2m 20 -- a barrier and a flush every four updates cost the scatter more
         // than a quarter less traffic gives back, and the replay is not bound by its reads: profiles/r05_bucket_path.txt -- A/B knob)
         const int first_wg = getenv("DD_FIRST_WG") ? atoi(getenv("DD_FIRST_WG")) : 3;
-        const int presorted = bplan->nb_log2 >= 1 && !getenv("DD_NO_PRESORT")
+        const int presorted = first_ones_form(p, bplan->nb_log2) ? 5 : bplan->nb_log2 >= 1 && !getenv("DD_NO_PRESORT")
                                   ? (first_wg == 0 ? 1 : (first_wg == 2 ? 2 : (first_wg == 4 && p - bplan->nb_log2 == 16 ? 4 : 3))) : 0;
         const dd::ScatterParams sp{rows_dev, K, bplan->logg, bplan->cap_chunks, unit, bplan->nb_log2, presorted};
         if (side_b && (rc = ensure_side_streams(c, (int)classes.size()))) return rc;

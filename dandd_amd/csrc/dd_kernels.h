@@ -138,6 +138,7 @@ struct BucketRow {              // one per (genome, k) row of the call: table[ge
     uint32_t* fill;             // [cap_chunks] records of each chunk after the sort dropped the null ones
     uint16_t* seg;              // [cap_chunks][16] where each index tile's records start inside a sorted chunk
     uint8_t* filter;            // [m >> logg] lower bound per register group
+    uint32_t* ones;             // [m / 32] first epoch, ScatterParams::presorted 5: bit r = register r saw an update with rho = 1; else null
 };
 struct ScatterParams {
     const BucketRow* rows;
@@ -149,6 +150,8 @@ struct ScatterParams {
     int presorted;              // first-epoch scatter sorts its chunks by index tile itself (rows of several tiles): 1 = every
                                 // wave its own 1024-record chunks, 2 = the workgroup's 16 384-record chunks (one per 16 updates),
                                 // 3 = every tile of tokens binned: 16 fixed regions of 4480 records, counts in seg[chunk][16]
+                                // 4 = the same packed to 3 bytes per record; 5 = 3 without the updates of rho = 1, which set a bit
+                                //     of BucketRow::ones instead
 };
 void launch_scatter(const SweepGenome* genomes_dev, const SweepJob* jobs_dev, int njobs, int kclass,
                     const SweepPlan& plan, const ScatterParams& sp, hipStream_t st, bool first_epoch);

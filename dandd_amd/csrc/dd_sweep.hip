@@ -1580,8 +1580,15 @@ constexpr uint32_t kBinCap = 4480;                        // records per (chunk,
 constexpr uint32_t kBinChunkRecords = 16u * kBinCap;      // 71 680 = 70 x 1024: stream space of one tile of tokens
 constexpr uint32_t kBinPosSlot = 128u;                    // LDS: counters [2][16] at 0, the job's position behind them
 constexpr uint32_t kBinLdsBytes = 256u;
+constexpr int kOnesLog2Max = 19;                          // registers of a row whose rho = 1 updates are bits in LDS (ONES below)
 
-template <int KC, bool CANON>
+// ONES (round 5, ScatterParams::presorted 5): HALF of all updates have rho = 1, and all a register can learn from them is that it
+// is not empty.  They leave no record: the workgroup keeps one bit per register of its row in LDS (m / 8 bytes behind the
+// counters, 64 KiB at most), sets it with a ds_or and ORs the words into the row's bitmap in HBM
+// when its job ends (BucketRow::ones; 32 K atomics per job against the ~330 K four-byte stores they stand for); the replay
+// raises a register that is still 0 behind a set bit to 1 when it writes the tile back.  Exact: max(rho) over a register's
+// updates is 1 iff there is an update and none has rho >= 2.
+template <int KC, bool CANON, bool ONES = false>
 __global__ __launch_bounds__(1024) void scatter_first_bin_kernel(
     const SweepGenome* __restrict__ genomes, const SweepJob* __restrict__ jobs, int p, ScatterParams sp) {
     const SweepJob job = jobs[blockIdx.x];
@@ -1623,6 +1630,11 @@ __global__ __launch_bounds__(1024) void scatter_first_bin_kernel(
     const int cshift = 4 - sp.nb_log2, tile_sh = 32 - sp.nb_log2;
     if (threadIdx.x < 32u) lds32(4u * threadIdx.x) = 0;
     if (threadIdx.x == 0) lds32(kBinPosSlot) = gadd32(row.cursor, (job.tile_end - job.tile_begin) * kBinChunkRecords);
+    // (at most 2^19 bits = 64 KiB, so that two workgroups still share a CU: at log2m 20 only the updates of the lower half of the
+    // row's registers are bits, the others stay records -- one workgroup per CU costs this kernel 6 %, profiles/r05_bucket_path.txt)
+    const uint32_t ones_regs = ONES ? 1u << (p < kOnesLog2Max ? p : kOnesLog2Max) : 0u, ones_words = ones_regs >> 5;
+    if (ONES)
+        for (uint32_t w = threadIdx.x; w < ones_words; w += blockDim.x) lds32(kBinLdsBytes + 4u * w) = 0;
     __syncthreads();
     const uint32_t pos0 = __builtin_amdgcn_readfirstlane(lds32(kBinPosSlot));
     const uint32_t copy = lane & ((1u << cshift) - 1u);
@@ -1646,7 +1658,13 @@ __global__ __launch_bounds__(1024) void scatter_first_bin_kernel(
             auto update = [&](bool valid) {
                 const Probe q = probe(win.template hash<CANON>(k), p);
                 if (!valid) return;
-                const uint32_t rec = (q.hi >> (32 - p)) | (rho_of(q, p) << 24);
+                const uint32_t rho = rho_of(q, p);
+                if (ONES && rho == 1u && (q.hi >> (32 - p)) < ones_regs) {
+                    const uint32_t idx = q.hi >> (32 - p);
+                    atomicOr(&lds32(kBinLdsBytes + ((idx >> 5) << 2)), 1u << (idx & 31u));
+                    return;
+                }
+                const uint32_t rec = (q.hi >> (32 - p)) | (rho << 24);
                 const uint32_t bin0 = (q.hi >> tile_sh) << cshift;  // + copy = the bin
                 uint32_t slot = kBinCap;
                 if (room) slot = atomicAdd(&lds32(ctr + ((bin0 | copy) << 2)), 1u);
@@ -1689,6 +1707,13 @@ __global__ __launch_bounds__(1024) void scatter_first_bin_kernel(
             const uint32_t c = lds32(ctr + 4u * lane);
             lds32(ctr + 4u * lane) = 0;
             if (room) ((DD_GLOBAL uint16_t*)counts)[(size_t)(cpos / kBinChunkRecords) * 16u + lane] = (uint16_t)(c < kBinCap ? c : kBinCap);
+        }
+    }
+    if (ONES) {   // (behind the last tile's barrier: every ds_or of the job is in)
+        uint32_t* const ones = uniform_ptr(row.ones);
+        for (uint32_t w = threadIdx.x; w < ones_words; w += blockDim.x) {
+            const uint32_t v = lds32(kBinLdsBytes + 4u * w);
+            if (v) atomicOr(ones + w, v);
         }
     }
 }
@@ -2033,7 +2058,7 @@ __global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restric
             }
             cur = nxt;
         }
-    } else if (FORM == 3) {
+    } else if (FORM == 3 || FORM == 5) {
         const int cshift = 4 - nb_log2;
         const uint32_t nunits = (nrec / kBinChunkRecords) << cshift;
         const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2188,6 +2213,24 @@ __global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restric
     }
     }
     __syncthreads();
+    if (FORM == 5) {
+        // the updates with rho = 1 left no record, only a bit (scatter_first_bin_kernel<.., ONES>): a register still 0 behind
+        // a set bit becomes 1.  Thread i holds registers 16 i .. 16 i + 15 of the tile = halfword i of the tile's bits.
+        const DD_GLOBAL uint16_t* bits = (const DD_GLOBAL uint16_t*)row.ones + (((size_t)b * tile) >> 4);
+        for (uint32_t i = threadIdx.x; i < (tile >> 4); i += blockDim.x) {
+            const uint32_t h = bits[i];
+            if (!h) continue;
+            uint4 v = l4[i];
+            auto raise = [](uint32_t w, uint32_t nib) {
+                const uint32_t set = ((nib & 0xFu) * 0x00204081u) & 0x01010101u;                 // bit j of the nibble -> byte j
+                const uint32_t zero = (~(w + 0x7F7F7F7Fu) & 0x80808080u) >> 7;                    // 1 in every byte that is 0 (bytes < 128)
+                return w | (set & zero);
+            };
+            v.x = raise(v.x, h), v.y = raise(v.y, h >> 4), v.z = raise(v.z, h >> 8), v.w = raise(v.w, h >> 12);
+            l4[i] = v;
+        }
+        __syncthreads();
+    }
     for (uint32_t i = threadIdx.x; i < (tile >> 4); i += blockDim.x) gstore16(tile_g + (size_t)i * 16, l4[i]);
     // the tile's part of the filter: minimum of every group of 2^logg registers (as a byte, or saturated to 15
     // and packed two to a byte)
@@ -2316,6 +2359,11 @@ void launch_scatter(const SweepGenome* genomes, const SweepJob* jobs, int njobs,
         if (sp.presorted == 4) {                                                                                                   \
             auto kern = scatter_first_pack_kernel<KC, CN>;                                                                         \
             hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3(1024), std::max((size_t)kPackLdsBytes, first_lds_floor), st, genomes, jobs, plan.log2m, sp); \
+        } else if (sp.presorted == 5) {                                                                                            \
+            auto kern = scatter_first_bin_kernel<KC, CN, true>;                                                                    \
+            static std::atomic<unsigned long long> attr_done{0};                                                                   \
+            allow_full_lds(reinterpret_cast<const void*>(kern), attr_done);                                                        \
+            hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3(1024), std::max((size_t)kBinLdsBytes + (((size_t)1 << std::min(plan.log2m, kOnesLog2Max)) >> 3), first_lds_floor), st, genomes, jobs, plan.log2m, sp); \
         } else if (sp.presorted == 3) {                                                                                            \
             auto kern = scatter_first_bin_kernel<KC, CN>;                                                                          \
             hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3(1024), std::max((size_t)kBinLdsBytes, first_lds_floor), st, genomes, jobs, plan.log2m, sp); \
@@ -2401,14 +2449,15 @@ void launch_replay(const BucketRow* rows, int ngenomes, int K, int k0, int nks, 
         hipLaunchKernelGGL(sort_chunks_kernel, dim3((unsigned)rs.nrows * wgs_per_row), dim3(256), 0, st, rows, rs, plan.log2m,
                            plan.nb_log2, plan.cap_chunks, wgs_per_row);
     }
-    static std::atomic<unsigned long long> attr_done[4] = {{0}, {0}, {0}, {0}};
+    static std::atomic<unsigned long long> attr_done[5] = {{0}, {0}, {0}, {0}, {0}};
 #define DD_REPLAY(FORM, SLOT)                                                                                                   \
     do {                                                                                                                        \
         allow_full_lds(reinterpret_cast<const void*>(replay_kernel<FORM>), attr_done[SLOT]);                                    \
         hipLaunchKernelGGL(replay_kernel<FORM>, dim3(blocks), dim3(1024), tile, st, rows, rs, plan.log2m, plan.logg, plan.nb_log2, \
                            plan.cap_chunks, plan.fbits);                                                                        \
     } while (0)
-    if (presorted == 4) DD_REPLAY(4, 3);       // the first epoch's packed bins (3 bytes per record)
+    if (presorted == 5) DD_REPLAY(5, 4);       // the first epoch's binned tiles + the bitmap of its rho = 1 updates
+    else if (presorted == 4) DD_REPLAY(4, 3);  // ... its packed bins (3 bytes per record)
     else if (presorted == 3) DD_REPLAY(3, 2);  // ... its binned tiles (4 bytes per record)
     else if (presorted == 2) DD_REPLAY(2, 1);  // ... or its workgroup chunks
     else DD_REPLAY(0, 0);

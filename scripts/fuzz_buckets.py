@@ -13,7 +13,7 @@ n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 engines = {}
 alph = [np.frombuffer(b"ACGT", np.uint8), np.frombuffer(b"ACGTacgtN", np.uint8), np.frombuffer(b"ACGTACGTACGTRYKMn-* 0>@\r", np.uint8)]
-KNOBS = ["DD_BUCKET_E0", "DD_BUCKET_EMAX", "DD_BUCKET_CAP", "DD_BUCKET_LOGG", "DD_BUCKET_FBITS", "DD_NO_XCD_AFFINITY", "DD_GLOBAL_FROM_P", "DD_BIGMAP_ANY_SIZE", "DD_NO_PRESORT", "DD_BUCKET_UNIT", "DD_BUCKET_NK", "DD_BUCKET_STAGGER", "DD_SIDE_ALWAYS", "DD_BUCKET_TILE_LOG2", "DD_FIRST_WG", "DD_ROW_GROUP_MB"]
+KNOBS = ["DD_BUCKET_E0", "DD_BUCKET_EMAX", "DD_BUCKET_CAP", "DD_BUCKET_LOGG", "DD_BUCKET_FBITS", "DD_NO_XCD_AFFINITY", "DD_GLOBAL_FROM_P", "DD_BIGMAP_ANY_SIZE", "DD_NO_PRESORT", "DD_BUCKET_UNIT", "DD_BUCKET_NK", "DD_BUCKET_STAGGER", "DD_SIDE_ALWAYS", "DD_BUCKET_TILE_LOG2", "DD_FIRST_WG", "DD_ROW_GROUP_MB", "DD_FIRST_ONES"]
 t0 = time.time()
 for it in range(n_cfg):
     for k in KNOBS:
@@ -51,6 +51,8 @@ for it in range(n_cfg):
         os.environ["DD_FIRST_WG"] = str(int(rng.choice([0, 2, 4])))       # (4 = packed bins, round 5; default: 3)
     if rng.integers(0, 6) == 0:
         os.environ["DD_ROW_GROUP_MB"] = "1"
+    if rng.integers(0, 4) == 0:
+        os.environ["DD_FIRST_ONES"] = "0"                                   # (round 5 default: the binned first epoch's rho = 1 updates are bits)
     canon = bool(rng.integers(0, 2))
     k1, k2 = sorted(int(x) for x in rng.integers(1, 65, size=2))
     if k2 - k1 > 6:

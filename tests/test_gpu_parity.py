@@ -120,6 +120,11 @@ BUCKET_KNOBS = {
     "packed_bins_tight": {"DD_FIRST_WG": "4", "DD_BUCKET_CAP": "110", "DD_BUCKET_E0": "3"},     # packed bins take 52.5 chunks of stream per tile of tokens: two fit, the third goes to the registers
     "row_groups": {"DD_ROW_GROUP_MB": "1"},                              # round 5: scatter -> replay per group of 8 rows, record areas a ring
     "row_groups_two_tiles_per_job": {"DD_ROW_GROUP_MB": "1", "DD_ROW_GROUP_TPJ": "2"},
+    # round 5, the default since: the binned first epoch's updates of rho = 1 leave a bit per register, not a record each
+    "all_updates_records": {"DD_FIRST_ONES": "0"},
+    "all_updates_records_epochs": {"DD_FIRST_ONES": "0", "DD_BUCKET_E0": "3"},
+    "ones_bits_tight": {"DD_BUCKET_CAP": "150", "DD_BUCKET_E0": "1"},     # ... with the stream full from the third tile on: records go to the registers, bits stay bits
+    "ones_bits_row_groups": {"DD_ROW_GROUP_MB": "1", "DD_FIRST_ONES": "1"},
 }
 
 
