@@ -178,6 +178,24 @@ def test_packed_bins_on_low_complexity_text(engine_factory, orc, monkeypatch, p)
     _sweep_check(eng_nc, orc, fa, 20, 21, False)
 
 
+@pytest.mark.parametrize("knobs", ["default", "all_updates_records"])
+@pytest.mark.parametrize("p", [17, 18, 20])
+def test_first_epoch_on_low_complexity_text(engine_factory, orc, monkeypatch, p, knobs):
+    """The binned first epoch (with its rho = 1 updates as bits, round 5, and without) over text whose records all land in one bin and
+    one register: 400 000 copies of ONE k-mer of rho 10-12 (TCCG repeated, k 17 / 18; GG..G, k 31 at log2m 20: found with the oracle),
+    homopolymers of small rho (one bit set 200 000 times), a short period inside random text.  == the oracle."""
+    for k, v in BUCKET_KNOBS[knobs].items():
+        monkeypatch.setenv(k, v)
+    eng = engine_factory(p, True)
+    rng = np.random.default_rng(p)
+    mixed = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=150_000))
+    fa = np.frombuffer(b">r\n" + b"TCCG" * 100_000 + b"\n>g\n" + b"G" * 300_000 + b"\n>a\n" + b"A" * 200_000 + b"\n>mix\n" + mixed + b"GGCG" * 30_000 + mixed[:50_000] + b"\n", dtype=np.uint8)
+    _sweep_check(eng, orc, fa, 15, 18, True)
+    _sweep_check(eng, orc, fa, 31, 34, True)
+    eng_nc = engine_factory(p, False)
+    _sweep_check(eng_nc, orc, fa, 17, 18, False)
+
+
 @pytest.mark.parametrize("p", [18, 20])
 def test_row_groups_over_unequal_genomes(engine_factory, torch_cuda, orc, monkeypatch, p):
     """DD_ROW_GROUP_MB (round 5): a single-epoch call's rows go scatter -> replay in groups of 8, on two streams in turn, and the
