@@ -457,6 +457,8 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
                                                      const uint32_t* __restrict__ abase, uint32_t* __restrict__ errors, int pwalk) {
     constexpr bool RAW = MODE != 0;
     constexpr bool WRITES = MODE == 2 || MODE == 3;   // (16-bit symbols)
+    const bool near_ok = !(pwalk & 4);                 // (DD_INFLATE_NEAR=0: matches that may start inside the batch leave the lanes' walk, as in round 4)
+    pwalk &= 3;
     bool too_long = false;                             // MODE 3: the piece does not fit its ranges
     constexpr uint32_t kLit = RAW ? 0x40000000u : 0x80000000u;   // a batch lane's source: a literal (else an offset in the text; RAW: negative = in front of the piece)
     const uint32_t lane = threadIdx.x & 63u;
@@ -506,6 +508,18 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
     uint32_t from = 0;               // this lane's byte: kLit | literal, or its source offset in the text
     auto flush = [&]() {
         if (used) {
+            // A lane whose byte comes from INSIDE the batch (a match that starts fewer bytes back than the batch is long: every
+            // third match of a gzip -1 member of DNA, round 5) takes over its source lane's source, all lanes at once, until
+            // none points into the batch any more: pointer jumping, at most six rounds of one ds_bpermute.  (Round 4 kept such
+            // matches out of the lanes' walk and decoded them one at a time.)
+            if (MODE != 1) {
+                for (;;) {
+                    const bool inside = lane < used && !(from & kLit) && (int)from >= (int)bstart;
+                    if (!__any(inside)) break;
+                    const uint32_t theirs = bperm(inside ? from - bstart : lane, from);
+                    if (inside) from = theirs;
+                }
+            }
             if (MODE == 0) {
                 uint32_t v = from & 0xFFu;
                 // (what the batch copies was stored by earlier batches of this wave: they have landed before it is read --
@@ -589,8 +603,12 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
                 // window follows the chain (one v_readlane and a dozen scalar instructions per symbol) and gives every
                 // symbol on it its place in the output batch; then the lanes of the batch look their symbol up and note
                 // where their byte comes from.  Symbols the lanes cannot finish alone leave the walk to the one-symbol
-                // path below: codes longer than the tables' 10 bits, the end of the block, a match whose source may be
-                // inside the batch (distance < length + 64) or before the text's start, one that does not fit a batch.
+                // path below: codes longer than the tables' 10 bits, the end of the block, a match whose source lies before
+                // the text's start, one that does not fit a batch.  (Round 4 also sent every match there whose source MIGHT
+                // be inside the batch -- distance < length + 64 --: 2 % of the matches of a gzip -6 member of DNA, but 31 % at
+                // gzip -1, whose matcher takes the most recent occurrence.  Now flush() resolves sources inside the batch by
+                // pointer jumping and they stay in the walk: inflate_kernel<3> over gzip -1 members 12-14 -> ~9 ms per batch,
+                // ten 50 Mbp files 8.6 -> 10.9 Gbp/s on one box, 8.6 -> 9.3 on another; DD_INFLATE_NEAR=0 = round 4's rule.)
                 uint32_t q, r, s0, s1, s2, s3, s4;   // the window: bit r of word W[q] = s0; s0..s4 = W[q .. q + 4]
                 {
                     const uint64_t P = b.bit_pos();
@@ -617,7 +635,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
                     // bits 0..5: the symbol's length in bits; 6..14: bytes it makes; 0 = not for the walk
                     uint32_t pk = 0;
                     if (kd == 1u) pk = l1 | (1u << 6);
-                    else if (kd == 3u && e2 != 0u && dv >= v1 + 64u && dv <= at + (RAW ? 32768u : 0u)) pk = (t1 + l2 + ex2) | (v1 << 6);
+                    else if (kd == 3u && e2 != 0u && (near_ok || dv >= v1 + 64u) && dv <= at + (RAW ? 32768u : 0u)) pk = (t1 + l2 + ex2) | (v1 << 6);
                     unsigned long long mark = 0, starts = 0;
                     uint32_t pos = 0, outacc = 0, pks = 0;
                     const uint32_t room = 64u - used;
@@ -724,7 +742,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
                             // the copy: its bytes join the batch (several batches when it is long).  It reads the dist-byte pattern
                             // in front of it; should that reach into the batch itself, the batch leaves first.
                             const uint32_t pat = at - dist, pat_end = pat + (dist < len ? dist : len);   // (RAW: both may be "negative")
-                            if ((int)pat_end > (int)bstart) flush();
+                            if (!near_ok && (int)pat_end > (int)bstart) flush();
                             at += len;
                             auto place = [&](auto src_of) {
                                 uint32_t done = 0;
@@ -1241,7 +1259,8 @@ static void inflate_attributes() {
 // or more, 2 = always (tests)
 static int pwalk_mode() {
     const char* e = getenv("DD_INFLATE_PWALK");
-    return e ? std::max(0, std::min(2, atoi(e))) : 0;
+    const char* near = getenv("DD_INFLATE_NEAR");
+    return (e ? std::max(0, std::min(2, atoi(e))) : 0) | (near && atoi(near) == 0 ? 4 : 0);
 }
 
 void launch_inflate_bgzf(const InflateJob* jobs_dev, int njobs, uint32_t* errors_dev, hipStream_t st) {
