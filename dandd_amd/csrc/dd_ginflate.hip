@@ -1008,6 +1008,23 @@ __global__ __launch_bounds__(64) void find_starts_kernel(const RawFile* __restri
             }
             return ~0ull;
         };
+        // Kraft sum and count of the code-length code's non-zero lengths, three 3-bit lengths at a time: a 512-entry table at the
+        // front of LDS (round 5; the unrolled 19-length sum was ~95 of the scan's ~110 VALU instructions per 64 positions, and the
+        // scan is what this kernel's 5 ms per batch were made of).  full_test() overwrites it with its own tables: rebuilt after.
+        auto build_lut = [&]() {
+            for (uint32_t v = lane; v < 512u; v += 64u) {
+                uint32_t kr = 0, nzv = 0;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const uint32_t l = (v >> (3 * q)) & 7u;
+                    kr += l ? (128u >> l) : 0u;
+                    nzv += l ? 1u : 0u;
+                }
+                l32(kLitInfo + 4u * v) = kr | (nzv << 16);
+            }
+            __builtin_amdgcn_wave_barrier();
+        };
+        build_lut();
         uint32_t nq = 0;
         for (uint64_t base = lo; base < hi && found == ~0ull; base += 64u) {
             // the 96 bits from position base + lane on
@@ -1017,21 +1034,13 @@ __global__ __launch_bounds__(64) void find_starts_kernel(const RawFile* __restri
             const uint32_t x0 = __builtin_amdgcn_alignbit(w1, w0, sh), x1 = __builtin_amdgcn_alignbit(w2, w1, sh), x2 = __builtin_amdgcn_alignbit(w3, w2, sh);
             const uint32_t hclen = ((x0 >> 13) & 15u) + 4u;
             bool cand = pos < hi && ((x0 >> 1) & 3u) == 2u && ((x0 >> 3) & 31u) <= 29u && ((x0 >> 8) & 31u) <= 29u;
-            // Kraft sum of the code-length code (3-bit lengths from bit 17 on) in units of 2^-7
-            uint32_t kraft = 0, nz = 0;
-#pragma unroll
-            for (int i = 0; i < 19; ++i) {
-                const int bp = 17 + 3 * i;
-                uint32_t l;
-                if (bp + 3 <= 32) l = (x0 >> bp) & 7u;
-                else if (bp < 32) l = ((x0 >> bp) | (x1 << (32 - bp))) & 7u;
-                else if (bp + 3 <= 64) l = (x1 >> (bp - 32)) & 7u;
-                else if (bp < 64) l = ((x1 >> (bp - 32)) | (x2 << (64 - bp))) & 7u;
-                else l = (x2 >> (bp - 64)) & 7u;
-                const bool in = (uint32_t)i < hclen && l != 0u;
-                kraft += in ? (128u >> l) : 0u;
-                nz += in ? 1u : 0u;
-            }
+            // Kraft sum of the code-length code (3-bit lengths from bit 17 on, the first hclen of them) in units of 2^-7
+            const uint32_t f_lo = __builtin_amdgcn_alignbit(x1, x0, 17), f_hi = __builtin_amdgcn_alignbit(x2, x1, 17);
+            const uint32_t nbits = 3u * hclen;   // 12 .. 57
+            const uint32_t fa = f_lo & (nbits >= 32u ? ~0u : (1u << (nbits & 31u)) - 1u), fb = f_hi & (nbits > 32u ? (1u << ((nbits - 32u) & 31u)) - 1u : 0u);
+            auto lut = [&](uint32_t nine) { return l32(kLitInfo + 4u * (nine & 511u)); };
+            const uint32_t sum = lut(fa) + lut(fa >> 9) + lut(fa >> 18) + lut((fa >> 27) | (fb << 5)) + lut(fb >> 4) + lut(fb >> 13) + lut(fb >> 22);
+            const uint32_t kraft = sum & 0xFFFFu, nz = sum >> 16;
             cand = cand && (kraft == 128u || nz == 1u);
             const unsigned long long m = __ballot(cand);
             if (m) {
@@ -1041,6 +1050,7 @@ __global__ __launch_bounds__(64) void find_starts_kernel(const RawFile* __restri
                 if (nq >= 64u) {
                     found = full_test(64u);
                     __builtin_amdgcn_wave_barrier();
+                    build_lut();
                     // the rest of the queue moves to the front
                     const uint32_t restv = lane < nq - 64u ? l32(kFindQueue + 4u * (64u + lane)) : 0u;
                     __builtin_amdgcn_wave_barrier();
