@@ -1026,11 +1026,26 @@ __global__ __launch_bounds__(64) void find_starts_kernel(const RawFile* __restri
         };
         build_lut();
         uint32_t nq = 0;
+        // The stream comes in through ONE load per 29 steps: lane l holds word cbase + l of a 64-word chunk, a step takes the six
+        // words its 64 positions span out of it with v_readlane (the step's first word is wave-uniform) and every lane picks its
+        // three by the word its position starts in.  (Four loads per lane and step, each behind a bounds check and a 64-bit
+        // address, were what the scan waited for: round 5, profiles/r05_gunzip.txt.)
+        uint32_t cbase = (uint32_t)(lo >> 5), cw = word_at(cbase + lane);
+        const uint32_t r0 = (uint32_t)lo & 31u;   // (base = lo + 64 n: its bit inside its word never changes)
+        const uint32_t tt = lane + r0, kq = tt >> 5, sh = tt & 31u;
         for (uint64_t base = lo; base < hi && found == ~0ull; base += 64u) {
             // the 96 bits from position base + lane on
             const uint64_t pos = base + lane;
-            const uint32_t wq = (uint32_t)(pos >> 5), sh = (uint32_t)pos & 31u;
-            const uint32_t w0 = word_at(wq), w1 = word_at(wq + 1u), w2 = word_at(wq + 2u), w3 = word_at(wq + 3u);
+            uint32_t qrel = (uint32_t)(base >> 5) - cbase;
+            if (qrel + 5u > 63u) {
+                cbase += qrel;
+                cw = word_at(cbase + lane);
+                qrel = 0;
+            }
+            const uint32_t s0 = lane_value(cw, qrel), s1 = lane_value(cw, qrel + 1u), s2 = lane_value(cw, qrel + 2u), s3 = lane_value(cw, qrel + 3u),
+                           s4 = lane_value(cw, qrel + 4u), s5 = lane_value(cw, qrel + 5u);
+            const uint32_t w0 = kq == 0u ? s0 : (kq == 1u ? s1 : s2), w1 = kq == 0u ? s1 : (kq == 1u ? s2 : s3), w2 = kq == 0u ? s2 : (kq == 1u ? s3 : s4),
+                           w3 = kq == 0u ? s3 : (kq == 1u ? s4 : s5);
             const uint32_t x0 = __builtin_amdgcn_alignbit(w1, w0, sh), x1 = __builtin_amdgcn_alignbit(w2, w1, sh), x2 = __builtin_amdgcn_alignbit(w3, w2, sh);
             const uint32_t hclen = ((x0 >> 13) & 15u) + 4u;
             bool cand = pos < hi && ((x0 >> 1) & 3u) == 2u && ((x0 >> 3) & 31u) <= 29u && ((x0 >> 8) & 31u) <= 29u;
