@@ -117,9 +117,6 @@ def convert_main(argv):
     return 2
 
 
-# sketches a backend keeps in memory after reading or writing their files (MiB; `dandd serve` raises it: host/cli.py)
-DEFAULT_SKETCH_CACHE_MB = 1024
-
 class StaleGenome(FileNotFoundError):
     """A member's file is where it was recorded, but is not the file it was: another size."""
 
@@ -252,7 +249,7 @@ class HipBackend:
         # only trusted while its file is still there with the size and modification time it had then.
         self._recent = OrderedDict()  # path -> (registers, k, (file size, mtime))
         self._recent_bytes = 0
-        self._recent_limit = int(os.environ.get("DANDD_SKETCH_CACHE_MB", str(DEFAULT_SKETCH_CACHE_MB))) << 20
+        self._recent_limit = int(os.environ.get("DANDD_SKETCH_CACHE_MB", "1024")) << 20
 
     def _remember(self, path, regs, k):
         if self._recent_limit <= 0:

@@ -126,17 +126,6 @@ def serve_command(args):
     srv.bind(path)
     os.chmod(path, 0o600)      # the socket runs commands as this user: nobody else may connect
     srv.listen(8)
-    # A resident process is what the backends' sketch cache (files this process read or wrote last, checked against size and
-    # mtime before every use) is for: `kij` after `tree` on 64 genomes at -r 20 asks for 2 368 one-MiB sketches again, 2.4 GB --
-    # more than the one-shot default of 1 GiB, and an LRU that is smaller than its scan never hits.  A quarter of the RAM, 16 GiB
-    # at most, unless the client's DANDD_SKETCH_CACHE_MB says otherwise.
-    # (a default, not an environment variable: a command runs with its CLIENT's DANDD_* environment)
-    try:
-        from . import backend as _backend
-        ram_mb = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") >> 20
-        _backend.DEFAULT_SKETCH_CACHE_MB = max(1024, min(16384, ram_mb // 4))
-    except (ValueError, OSError):
-        pass
     if args.warm:              # bring a backend up before the first command arrives: "<registers>[,nc]"
         for spec in args.warm:
             regs, _, flag = spec.partition(",")
