@@ -643,6 +643,7 @@ def test_single_member_gzip_files_are_inflated_on_the_device(engine_factory, orc
     eng = engine_factory(14, True)
     uniform, real = orc.synth_fasta(SEED, 0, 3_000_000, 4).tobytes(), orc.synth_realistic(SEED, 1, 2_500_000).tobytes()
     lowent = (b">x\n" + b"ACGT" * 20 + b"\n") * 30000 + uniform[:200_000]
+    runs = b">r\n" + b"A" * 150_000 + b"\n" + b"AC" * 60_000 + b"\n" + b"ACG" * 40_000 + b"\n" + uniform[:300_000] + b"N" * 90_000 + uniform[300_000:500_000] + b"T" * 70 + b"\n"
 
     def member(raw, level=6, strategy=0, name=None):
         if name is not None:
@@ -657,6 +658,10 @@ def test_single_member_gzip_files_are_inflated_on_the_device(engine_factory, orc
              ("named", real[:1_500_000], member(real[:1_500_000], 6, name="genome.fa")), ("stored", uniform[:600_000], member(uniform[:600_000], 0)),
              ("fixed", uniform[:300_000], member(uniform[:300_000], 6, zlib.Z_FIXED)), ("huff", uniform[:500_000], member(uniform[:500_000], 6, zlib.Z_HUFFMAN_ONLY)),
              ("rle", real[:500_000], member(real[:500_000], 6, zlib.Z_RLE)), ("lowent", lowent, member(lowent, 9)),
+             # round 5: matches whose source lies inside the 64-byte batch under assembly stay in the lanes' walk and are resolved by
+             # pointer jumping -- runs (distance 1, length 258), period 2 and 3, an N run inside text, at the level whose matcher
+             # takes the nearest occurrence and at the one that looks furthest
+             ("runs_l1", runs, member(runs, 1)), ("runs_l9", runs, member(runs, 9)),
              # round 5: SEVERAL members (`cat a.fa.gz b.fa.gz`; each found by its header, decoded as a stream of its own, the texts one
              # behind the other) -- two of different levels, three with a named header in the middle and a stored-only one at the end
              ("two_members", uniform[:1_500_000], member(uniform[:800_000], 6) + member(uniform[800_000:1_500_000], 1)),
