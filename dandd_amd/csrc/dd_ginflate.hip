@@ -387,8 +387,10 @@ DD_D bool piece_of(const RawFile* files, int nfiles, const uint64_t* starts, uin
 // ten gzip -1 files 7.98 / 7.90 / 7.87 Gbp/s with the scalar walk / this one behind windows of five symbols or more / this one
 // always, BGZF 16.6-17.1 all three: gzip -1 DNA is not literal runs but SHORT MATCHES (2.3 bits per base: ~3 symbols per window,
 // where the two walks cost the same), and swapping 66 scalar instructions for 70 vector ones changes nothing because the kernel
-// is bound by neither unit's issue rate but by its waves' serial chains.  Kept behind DD_INFLATE_PWALK (default 0) for texts
-// that ARE literal runs; bit-exact in all three modes (strict tests, scripts/fuzz_inflate.py).
+// is bound by neither unit's issue rate but by its waves' serial chains.  -- That was with a third of a gzip -1 member's matches
+// kept OUT of the walk (their source might lie inside the batch).  Since flush() resolves those (same round) a window's walkable
+// symbols doubled, and this walk became the default: inflate_kernel<3> 9.16 -> 7.73 ms per batch of five gzip -1 members, 9.18 ->
+// 8.23 at gzip -6 (rocprofv3; DD_INFLATE_PWALK=0 | 1 | 2).  Bit-exact in all three modes (strict tests, scripts/fuzz_inflate.py).
 template <int CTRL, int ROW_MASK>
 DD_D uint32_t dpp_add(uint32_t x) {
     return x + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, false);
@@ -1311,12 +1313,14 @@ static void inflate_attributes() {
     done.fetch_or(bit, std::memory_order_relaxed);
 }
 
-// DD_INFLATE_PWALK: 0 = the scalar walk only (default: round 4's), 1 = the lanes' walk for windows behind a window of five symbols
-// or more, 2 = always (tests)
+// DD_INFLATE_PWALK: 0 = the scalar walk only (round 4's), 1 = the lanes' walk for windows behind a window of five symbols or more,
+// 2 = always -- the default since matches that start inside the batch stay in the walk (round 5): a gzip -1 window then holds ~6
+// walkable symbols instead of ~3 and the lanes' walk, whose cost does not depend on their number, takes inflate_kernel<3> from
+// 9.16 to 7.73 ms per batch of five 50 Mbp gzip -1 members (gzip -6: 9.18 -> 8.23); before that change it measured neutral
 static int pwalk_mode() {
     const char* e = getenv("DD_INFLATE_PWALK");
     const char* near = getenv("DD_INFLATE_NEAR");
-    return (e ? std::max(0, std::min(2, atoi(e))) : 0) | (near && atoi(near) == 0 ? 4 : 0);
+    return (e ? std::max(0, std::min(2, atoi(e))) : 2) | (near && atoi(near) == 0 ? 4 : 0);
 }
 
 void launch_inflate_bgzf(const InflateJob* jobs_dev, int njobs, uint32_t* errors_dev, hipStream_t st) {

@@ -535,7 +535,7 @@ def test_bgzf_files_are_inflated_on_the_device(engine_factory, orc, tmp_path, mo
         cases.append((name, str(path), np.frombuffer(raw, dtype=np.uint8)))
     monkeypatch.setenv("DD_INFLATE_STRICT", "1")                 # a block the device refuses fails the call: no silent host fallback here
     got = eng.sketch_files([p for _, p, _ in cases], 19, 21)
-    for mode in ("1", "2"):                                      # the walk over a window's symbols by all lanes at once (round 5 knob): same registers, same bytes
+    for mode in ("0", "1"):                                      # the walk over a window's symbols by all lanes at once is the default (2) since round 5: the scalar walk and the adaptive mix give the same registers, the same bytes
         monkeypatch.setenv("DD_INFLATE_PWALK", mode)
         assert np.array_equal(eng.sketch_files([p for _, p, _ in cases], 19, 21), got), mode
         for (name, path, fa), text in zip(cases, eng.inflate_files([p for _, p, _ in cases])):
