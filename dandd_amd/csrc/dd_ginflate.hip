@@ -8,11 +8,13 @@
 //
 // One wave per block.  A deflate stream is a serial thing -- every Huffman code starts where the previous one ended --,
 // but the wave does not walk it one symbol at a time: LANE i DECODES THE SYMBOL THAT WOULD START AT BIT i of a 64-bit
-// window (literal/length code, extra bits, distance code, extra bits: two table gathers from LDS), a scalar walk follows
-// the chain of symbols that really are there (one v_readlane each), and the lanes of the 64-byte output batch look up the
-// symbol they belong to and note where their byte comes from -- a literal, or an earlier position of the text.  A batch
-// costs ONE load and ONE contiguous store.  Block headers, code tables (built code by code, the replicas of a code spread
-// over the lanes), codes longer than the tables' 10 bits, overlapping and near copies go one symbol at a time.
+// window (literal/length code, extra bits, distance code, extra bits: two table gathers from LDS), a walk follows the
+// chain of symbols that really are there (round 4: scalar, one v_readlane each; round 5: by all lanes at once, pointer
+// jumping -- parallel_walk), and the lanes of the 64-byte output batch look up the symbol they belong to and note where
+// their byte comes from -- a literal, or an earlier position of the text, which may lie inside the batch itself (resolved
+// by pointer jumping when the batch leaves, round 5).  A batch costs ONE load and ONE contiguous store.  Block headers,
+// code tables (built code by code, the replicas of a code spread over the lanes), codes longer than the tables' 10 bits
+// and copies that do not fit what is left of a batch go one symbol at a time.
 // The block's TEXT lives where it is going -- the FASTA buffer in HBM --, not in LDS: a wave needs 9.25 KiB of LDS (its
 // code tables), seventeen waves share a CU, and the serial chain of one block hides behind sixteen others.  What bounds a
 // launch is the CU's scalar issue slot: instructions per symbol (profiles/r04_bgzf.txt: 10 ms per block -> 3.1).
@@ -23,13 +25,14 @@
 // launch's error count and the caller runs the call again with the host decoder (dd_inflate.h), which words the error.
 //
 // ORDINARY .gz files (ONE gzip member: what `gzip` and the sequence archives write) take the second half of this file
-// (launch_gunzip_members): find_starts_kernel finds deflate block starts by trial, one per 32-128 KiB range of the
+// (launch_gunzip_members): find_starts_kernel finds deflate block starts by trial, one per 16-128 KiB range of the
 // compressed file; the same decoder (inflate_kernel<3>) decodes every piece between two starts WITHOUT the 32 KiB in
 // front of it, into 16-bit symbols -- a byte, or "position p of that unknown window"; piece_maps_kernel /
 // group_windows_kernel compose the pieces' window-to-window maps in two levels; translate_kernel turns symbols into text
 // in the buffer K0 reads; chunk_crc_kernel checks it against the member's CRC-32 (the host combines the chunks).
 // Ten 50 Mbp .gz: 12 Gbp/s through dd_sketch_files against 6 with the host decoder; one 3 Gbp .gz: 14.9 against 4.6
-// (profiles/r04_gunzip.txt).
+// (profiles/r04_gunzip.txt).  Round 5 (profiles/r05_gunzip.txt): several members per file, four-line FASTQ (dd_fastq.hip),
+// gzip -1 from 6.7 to 10.7-12.9 Gbp/s, one 400 Mbp member from 8.0 to 11.
 #include "dd_common.h"
 #include "dd_kernels.h"
 
