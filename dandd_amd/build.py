@@ -46,6 +46,26 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# `dashing`: the reference's command-line contract over the C ABI (csrc/dd_cli.c, plain C99, no Python)
+BINDIR = os.path.join(HERE, "bin")
+CLI = os.path.join(BINDIR, "dashing")
+CLI_SRC = os.path.join(CSRC, "dd_cli.c")
+
+
+def build_cli(force=False):
+    """gcc, C99, linked against the library next to it (rpath $ORIGIN/../lib); needs build() to have run."""
+    inc = os.path.join(HERE, "..", "include")
+    deps = [CLI_SRC, os.path.join(inc, "dandd_hip.h"), LIB]
+    if not force and os.path.exists(CLI) and all(os.path.getmtime(d) <= os.path.getmtime(CLI) for d in deps):
+        return CLI
+    os.makedirs(BINDIR, exist_ok=True)
+    cmd = [os.environ.get("CC", "gcc"), "-std=c99", "-O2", "-Wall", "-Wextra", "-pedantic", "-I" + inc, CLI_SRC, "-o", CLI + ".tmp",
+           "-L" + LIBDIR, "-ldandd_hip", "-lz", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link," + LIBDIR]
+    subprocess.check_call(cmd)
+    os.replace(CLI + ".tmp", CLI)
+    return CLI
+
+
 def _stale(obj, src):
     if not os.path.exists(obj):
         return True
@@ -96,3 +116,4 @@ if __name__ == "__main__":
         extra += ["-save-temps=obj"]
     build(force="--force" in sys.argv, extra=extra, verbose=True)
     print(LIB)
+    print(build_cli(force="--force" in sys.argv))

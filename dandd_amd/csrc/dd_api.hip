@@ -960,6 +960,9 @@ static bool bgzf_parse(const uint8_t* data, size_t n, std::vector<BgzfBlock>& bl
         p += bs;
     }
     if (blks.empty()) return false;
+    // (the text rules of dd_fastq.hip and TextJob hold offsets in 32 bits, as the gzip path's do: a text of 4 GiB or more is
+    // for the host decoder -- the same bound as gzip_members_parse's)
+    if (total >= ((uint64_t)1 << 32) - 65536) return false;
     // FASTQ (reads, not assemblies) starts with '@': look at the first block's text
     {
         uint8_t first[256];
@@ -1564,6 +1567,12 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
                 if (!(sj.dev_inflate || sj.dev_gunzip) || !sizes[j]) continue;
                 dd::TextJob t{};
                 t.text = const_cast<uint8_t*>(ptrs[j]);
+                if (sizes[j] >= ((uint64_t)1 << 32)) {   // (bgzf_parse / gzip_members_parse refuse such files: never reached)
+                    rc = fail(DD_EINVAL, "a device-inflated text of %zu bytes does not fit the text rules' 32-bit offsets", (size_t)sizes[j]);
+                    first_err = g_err;
+                    e = hipErrorInvalidValue;
+                    break;
+                }
                 t.n = (uint32_t)sizes[j];
                 t.fastq = sj.fastq ? 1u : 0u;
                 t.block0 = (uint32_t)blocks;
@@ -1580,7 +1589,7 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
                 }
                 tj.push_back(t);
             }
-            if (!tj.empty()) {
+            if (!tj.empty() && e == hipSuccess) {
                 const size_t tab = align_up(tj.size() * sizeof(dd::TextJob), 256);
                 if ((rc = c->pipe_txt[set].reserve(tab + words * 4 + 256)) != DD_OK || (rc = c->pipe_txt_host[set].reserve(tab)) != DD_OK) {
                     first_err = g_err;
@@ -2217,12 +2226,15 @@ RcclApi* rccl() {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char* names[] = {getenv("DD_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // DD_RCCL_LIB names THE copy to use (nothing else is tried when it is set)
+        const char* named = getenv("DD_RCCL_LIB");
+        const char* names[] = {named, named ? nullptr : "librccl.so.1", named ? nullptr : "librccl.so", named ? nullptr : "/opt/rocm/lib/librccl.so.1"};
         for (int pass = 0; pass < 2 && !api.lib; ++pass)      // pass 0: a copy that is already mapped (RTLD_NOLOAD)
             for (const char* n : names)
                 if (n && !api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
         if (!api.lib) {
-            api.why = std::string("librccl.so not found (") + (dlerror() ? dlerror() : "?") + "); set DD_RCCL_LIB";
+            const char* e = dlerror();                        // one call: dlerror() clears its state when read
+            api.why = std::string("librccl.so not found (") + (e ? e : "?") + "); set DD_RCCL_LIB";
             return;
         }
         auto sym = [&](const char* n) {

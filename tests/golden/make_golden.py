@@ -30,16 +30,21 @@ REF = "/root/reference/lib/dandd"
 sys.path.insert(0, ROOT)
 
 DASHING_SHIM = r'''#!/usr/bin/env python3
-import json, os, sys
+import hashlib, json, os, sys
 sys.path.insert(0, %(root)r)
 import numpy as np
 from oracle import dd_oracle as orc
 BACKEND = os.environ.get("DD_SHIM_BACKEND", "hll")
 LOG = os.environ.get("DD_SHIM_LOG")
 a = sys.argv[1:]
-if LOG:
-    with open(LOG, "a") as f:
-        f.write("dashing " + " ".join(a) + "\n")
+def log(**extra):
+    # one JSON line per external command the reference issued: its argv as given, what `card` answered, and a digest of the
+    # registers `sketch` / `union` left behind (the command trace tests/test_gpu_cli.py replays through the product's `dashing`)
+    if LOG:
+        with open(LOG, "a") as f:
+            f.write(json.dumps(dict(argv=["dashing"] + a, **extra)) + "\n")
+def digest(obj):
+    return {"regs_sha256": hashlib.sha256(np.array(obj["regs"], dtype=np.uint8).tobytes()).hexdigest()} if "regs" in obj else {}
 def load(p):
     with open(p, "rb") as f:
         return json.loads(f.read())
@@ -64,6 +69,7 @@ if cmd == "sketch":
         fa = np.fromfile(fasta, dtype=np.uint8)
         obj["regs"] = orc.sketch(fa, k, S, canon).tolist()
     save(out, obj)
+    log(out=out, **digest(obj))
 elif cmd == "union":
     assert a[1] == "-z" and a[2] == "-o"
     out, ins = a[3], [load(p) for p in a[4:]]
@@ -72,9 +78,11 @@ elif cmd == "union":
     if BACKEND == "hll":
         obj["regs"] = orc.union(*[np.array(s["regs"], dtype=np.uint8) for s in ins]).tolist()
     save(out, obj)
+    log(out=out, **digest(obj))
 elif cmd == "card":
     assert a[1] == "--presketched"
     print("#Path\tSize (est.)")
+    cards = {}
     for p in a[2:]:
         s = load(p)
         if BACKEND == "hll":
@@ -82,6 +90,8 @@ elif cmd == "card":
         else:
             v = float(orc.exact_count([np.fromfile(f, dtype=np.uint8) for f in s["fastas"]], s["k"], s["canon"]))
         print("%%s\t%%r" %% (p, v))
+        cards[p] = repr(v)
+    log(cards=cards)
 else:
     sys.exit("dashing shim: unknown command " + cmd)
 '''
@@ -246,7 +256,29 @@ def scenario(backend, fdir, registers):
         out["tree_flist_label_fast"] = read_csv(os.path.join(o11, "gold_lab_4_dashing_deltas.csv"))
         out["tree_flist_label_fast_files"] = sorted(os.listdir(o11))
         with open(os.path.join(work, "trace.log")) as f:
-            out["_n_external_commands"] = sum(1 for _ in f)
+            trace = [json.loads(line) for line in f]
+        out["_n_external_commands"] = len(trace)
+        if backend == "hll":
+            # The command trace itself: every `dashing ...` line the unmodified reference issued (after the `parallel` shim put
+            # the k in), in order, with the scenario directory written as @W@; what each `card` printed; a digest of the registers
+            # each `sketch` / `union` wrote; and the reference's own cardinality caches at the end (lib/species_specifics.py:78-89).
+            def rel(x):
+                if isinstance(x, str):
+                    return x.replace(work, "@W@")
+                if isinstance(x, list):
+                    return [rel(v) for v in x]
+                if isinstance(x, dict):
+                    return {rel(k): rel(v) for k, v in x.items()}
+                return x
+            caches = {}
+            for dirpath, _, files in sorted(os.walk(work)):
+                for fn in sorted(files):
+                    if fn.endswith("_dashing_cardinalities.pickle"):
+                        with open(os.path.join(dirpath, fn), "rb") as f:
+                            caches[rel(os.path.join(dirpath, fn))] = {rel(k): repr(v) for k, v in sorted(pickle.load(f).items())}
+            with open(os.path.join(HERE, "ref_trace_hll.json"), "w") as f:
+                json.dump({"registers": registers, "fastas": sorted(os.listdir(data)), "data": "@W@/data",
+                           "commands": rel(trace), "cardinality_caches": caches}, f, indent=0, sort_keys=True)
         return out
     finally:
         shutil.rmtree(work, ignore_errors=True)

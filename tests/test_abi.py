@@ -111,3 +111,21 @@ def test_header_is_plain_c_and_links_from_c(lib, tmp_path):
     env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
     r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "abi_consumer: ok" in r.stdout, (r.returncode, r.stdout, r.stderr[-2000:])
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash(lib):
+    """dd_comm_unique_id on a machine whose librccl cannot be opened returns DD_ENODEV with a message (the advisor's round-5 finding:
+    the message was built from two dlerror() calls, the second of which returns NULL)."""
+    code = (
+        "import ctypes, sys; sys.path.insert(0, %r)\n"
+        "from dandd_amd import engine\n"
+        "l = engine.load_library()\n"
+        "buf = (ctypes.c_uint8 * 128)()\n"
+        "rc = l.dd_comm_unique_id(buf)\n"
+        "l.dd_last_error.restype = ctypes.c_char_p\n"
+        "print('RC', rc, l.dd_last_error().decode())\n" % ROOT
+    )
+    env = dict(os.environ, DD_RCCL_LIB="/nonexistent/librccl.so", HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr[-2000:])
+    assert "RC -2" in out.stdout and "librccl.so not found" in out.stdout and "DD_RCCL_LIB" in out.stdout, out.stdout

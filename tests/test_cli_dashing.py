@@ -1,0 +1,214 @@
+"""`dandd_amd/bin/dashing` (dandd_amd/csrc/dd_cli.c): the reference's real plugin API -- the `dashing sketch | union | card` argv +
+files + stdout contract of /root/reference/lib/sketch_classes.py:306-321,351-373 and lib/huffman_dandd.py:214-218 -- as a plain C
+program over the C ABI.
+
+GPU: the command trace the UNMODIFIED reference issued (tests/golden/ref_trace_hll.json, captured by tests/golden/make_golden.py
+with oracle-backed shims on PATH) is replayed line by line through the product's executable; every `card` answer must be the
+cardinality the reference cached, every `.hll` payload the oracle's registers.
+CPU: the executable builds, refuses to run without a GPU (no fallback), rejects bad command lines, and its resident form answers."""
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(HERE, "golden")
+NATIVE_HEAD = 12
+
+
+@pytest.fixture(scope="module")
+def dashing():
+    from dandd_amd import build
+    build.build()
+    return build.build_cli()
+
+
+def _trace():
+    with open(os.path.join(GOLD, "ref_trace_hll.json")) as f:
+        return json.load(f)
+
+
+def _start_server(dashing, sock, env):
+    srv = subprocess.Popen([dashing, "serve", "--socket", sock, "--idle-exit", "600"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    line = srv.stdout.readline()
+    assert "listening" in line, (line, srv.stderr.read() if srv.poll() is not None else "")
+    return srv
+
+
+def test_trace_fixture_is_the_reference_grammar():
+    """the fixture holds only the three command shapes SURVEY.md section 8(b) lists, and a cached cardinality for every sketch"""
+    t = _trace()
+    assert len(t["commands"]) > 700
+    printed = {}
+    for c in t["commands"]:
+        a = c["argv"]
+        assert a[0] == "dashing" and a[1] in ("sketch", "union", "card")
+        if a[1] == "sketch":
+            rest = [x for x in a[2:] if x != "--no-canon"]
+            assert rest[0].startswith("-k") and rest[1] == "-S" and rest[3] == "--prefix" and len(rest) == 6
+            assert os.path.basename(c["out"]) == f"{os.path.basename(rest[5])}.w.{rest[0][2:]}.spacing.{rest[2]}.hll"
+        elif a[1] == "union":
+            assert a[2:4] == ["-z", "-o"] and len(a) >= 6 and c["out"] == a[4]
+        else:
+            assert a[2] == "--presketched" and len(a) == 4      # (always ONE path: SURVEY.md section 8a, row a4)
+            printed.update(c["cards"])
+    cached = {}
+    for table in t["cardinality_caches"].values():
+        cached.update(table)
+    assert cached and all(printed.get(p) == v for p, v in cached.items())
+
+
+def test_cli_without_gpu_fails_loudly(dashing, tmp_path):
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    env.pop("DANDD_DASHING_SERVER", None)
+    r = subprocess.run([dashing, "sketch", "-k9", "-S", "12", "--prefix", str(tmp_path), os.path.join(GOLD, "fasta", "g0.fasta")],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "no CPU path" in r.stderr, (r.returncode, r.stderr)
+    assert not os.listdir(tmp_path)                               # nothing half-written takes a sketch's name
+    for bad in (["frobnicate"], ["sketch", "-k9", "--prefix", str(tmp_path)], ["sketch", "-k99", "-S", "12", "x.fa"], ["union", "-o"],
+                ["card", "--frob", "x"], []):
+        r = subprocess.run([dashing] + bad, env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 64 and r.stderr, (bad, r.returncode, r.stderr)
+    r = subprocess.run([dashing, "card", "--presketched", os.path.join(GOLD, "fasta", "g0.fasta")], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "neither a dandd_amd nor a Dashing sketch file" in r.stderr
+    assert r.stdout == "#Path\tSize (est.)\n"
+
+
+def test_resident_form_answers_and_survives_bad_clients(dashing, tmp_path):
+    """`dashing serve`: ping, a command that fails (no GPU here) with its message sent back, a client that hangs up mid-request, shutdown"""
+    import socket
+    sock = str(tmp_path / "d.sock")
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    env.pop("DANDD_DASHING_SERVER", None)
+    srv = _start_server(dashing, sock, env)
+    try:
+        cenv = dict(env, DANDD_DASHING_SERVER=sock, DANDD_SERVER_REQUIRED="1")
+        assert oct(os.stat(sock).st_mode & 0o777) == "0o600"
+        r = subprocess.run([dashing, "ping"], env=cenv, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and int(r.stdout) == srv.pid
+        for junk in (b"", b"\x02\x00", b"\xff\xff\xff\xff", b"\x01\x00\x00\x00\x10\x00\x00\x00abc"):
+            s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            s.connect(sock)
+            s.sendall(junk)
+            s.close()
+        r = subprocess.run([dashing, "card", "--presketched", "no/such.hll"], env=cenv, capture_output=True, text=True, timeout=60, cwd=str(tmp_path))
+        assert r.returncode == 1 and "no/such.hll" in r.stderr and r.stdout == "#Path\tSize (est.)\n"
+        r = subprocess.run([dashing, "sketch", "-k9", "-S", "12", "--prefix", ".", os.path.join(GOLD, "fasta", "g0.fasta")], env=cenv,
+                           capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
+        assert r.returncode == 1 and "no CPU path" in r.stderr
+        r = subprocess.run([dashing, "shutdown"], env=cenv, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0
+        assert srv.wait(timeout=30) == 0 and not os.path.exists(sock)
+        r = subprocess.run([dashing, "ping"], env=cenv, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 111 and "no server" in r.stderr
+    finally:
+        if srv.poll() is None:
+            srv.kill()
+
+
+def _replay(dashing, work, commands, env, orc, check_oracle):
+    """run every traced line in `work`; -> number of commands run"""
+    regs_of = {}                                                   # output path -> registers, for checking unions against their inputs
+    for c in commands:
+        argv = [x.replace("@W@", work) for x in c["argv"]]
+        if argv[1] == "sketch":
+            os.makedirs(argv[argv.index("--prefix") + 1], exist_ok=True)     # (the reference makes the per-k directories itself: lib/huffman_dandd.py:171-174)
+        elif argv[1] == "union":
+            os.makedirs(os.path.dirname(argv[argv.index("-o") + 1]), exist_ok=True)
+        r = subprocess.run([dashing] + argv[1:], env=env, capture_output=True, text=True, timeout=300, cwd=work)
+        assert r.returncode == 0, (argv, r.returncode, r.stdout, r.stderr)
+        if argv[1] == "card":
+            lines = r.stdout.splitlines()
+            assert lines[0] == "#Path\tSize (est.)" and len(lines) == 1 + len(c["cards"])
+            for line, (path, want) in zip(lines[1:], c["cards"].items()):
+                got_path, got = line.split("\t")
+                assert got_path == path.replace("@W@", work)
+                assert float(got) == float(want), (argv, got, want)      # the double the reference put in its cardkey (lib/sketch_classes.py:318-321)
+            continue
+        out = c["out"].replace("@W@", work)
+        raw = np.fromfile(out, dtype=np.uint8)
+        assert raw[:8].tobytes() == b"DDHLL\x01\x00\x00"
+        regs = raw[NATIVE_HEAD:]
+        assert hashlib.sha256(regs.tobytes()).hexdigest() == c["regs_sha256"], argv
+        regs_of[out] = regs
+        if check_oracle:
+            if argv[1] == "sketch":
+                rest = [x for x in argv[2:] if x != "--no-canon"]
+                k, p, fasta = int(rest[0][2:]), int(rest[2]), rest[5]
+                want = orc.sketch(np.fromfile(fasta, dtype=np.uint8), k, p, "--no-canon" not in argv)
+                assert raw[8] == p and raw[9] == k and raw[10] == int("--no-canon" not in argv)
+            else:
+                ins = argv[argv.index("-o") + 2:]
+                want = np.maximum.reduce([regs_of[i] if i in regs_of else np.fromfile(i, dtype=np.uint8)[NATIVE_HEAD:] for i in ins])
+            assert np.array_equal(regs, want), argv
+    return len(commands)
+
+
+@pytest.mark.gpu
+def test_reference_command_trace_replayed_through_the_product(dashing, tmp_path, orc, torch_cuda):
+    """Every command line the unmodified reference issued over eleven CLI scenarios (742 of them), through the resident form
+    (one process keeps the GPU contexts; the traced argv is what a client process sends), in a directory laid out as the
+    reference laid it out.  Then the reference's own cardinality caches, asked for again in one multi-path `card`."""
+    t = _trace()
+    work = str(tmp_path / "w")
+    shutil.copytree(os.path.join(GOLD, "fasta"), os.path.join(work, "data"))
+    sock = str(tmp_path / "d.sock")
+    env = dict(os.environ)
+    env.pop("DANDD_DASHING_SERVER", None)
+    env.pop("DANDD_SKETCH_FORMAT", None)
+    srv = _start_server(dashing, sock, env)
+    try:
+        cenv = dict(env, DANDD_DASHING_SERVER=sock, DANDD_SERVER_REQUIRED="1")
+        t0 = time.perf_counter()
+        n = _replay(dashing, work, t["commands"], cenv, orc, check_oracle=True)
+        dt = time.perf_counter() - t0
+        print(f"replayed {n} traced commands through `dashing serve` in {dt:.1f} s ({1e3 * dt / n:.1f} ms per command, checks included)")
+        for cache, table in t["cardinality_caches"].items():
+            paths = [p.replace("@W@", work) for p in table]
+            r = subprocess.run([dashing, "card", "--presketched"] + paths, env=cenv, capture_output=True, text=True, timeout=300, cwd=work)
+            assert r.returncode == 0, r.stderr
+            got = dict(line.split("\t") for line in r.stdout.splitlines()[1:])
+            assert {p: float(v) for p, v in got.items()} == {p.replace("@W@", work): float(v) for p, v in table.items()}, cache
+        r = subprocess.run([dashing, "shutdown"], env=cenv, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and int(r.stdout) >= n
+        assert srv.wait(timeout=60) == 0
+    finally:
+        if srv.poll() is None:
+            srv.kill()
+
+
+@pytest.mark.gpu
+def test_one_process_per_command_like_the_reference(dashing, tmp_path, orc, torch_cuda):
+    """The literal contract: no server, a fresh process (and a fresh GPU context) per traced line -- the first scenario's hill-climb
+    on the first leaf and what follows it (sketch x3 under `parallel`, card x3, ...), in both sketch containers."""
+    t = _trace()
+    env = dict(os.environ)
+    env.pop("DANDD_DASHING_SERVER", None)
+    env.pop("DANDD_SKETCH_FORMAT", None)
+    work = str(tmp_path / "w")
+    shutil.copytree(os.path.join(GOLD, "fasta"), os.path.join(work, "data"))
+    first = t["commands"][:24]
+    assert {c["argv"][1] for c in first} >= {"sketch", "card"}
+    _replay(dashing, work, first, env, orc, check_oracle=True)
+    # a union of the leaves sketched above, written in Dashing's container as recalled (gzip), read back by `card` and by the store
+    sk = [c["out"].replace("@W@", work) for c in first if c["argv"][1] == "sketch"]
+    k = int(first[0]["argv"][2][2:])
+    same_k = [s for s in sk if f".w.{k}.spacing." in s]
+    out = os.path.join(work, f"u_12n{len(same_k)}k{k}.hll")
+    denv = dict(env, DANDD_SKETCH_FORMAT="dashing")
+    r = subprocess.run([dashing, "union", "-z", "-o", out] + same_k, env=denv, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    with open(out, "rb") as f:
+        assert f.read(2) == b"\x1f\x8b"
+    from dandd_amd.host.backend import read_sketch_file
+    regs, log2m, kk, canon = read_sketch_file(out)
+    want = np.maximum.reduce([np.fromfile(s, dtype=np.uint8)[NATIVE_HEAD:] for s in same_k])
+    assert np.array_equal(regs, want) and (log2m, kk, canon) == (12, k, True)
+    r = subprocess.run([dashing, "card", "--presketched", out], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and float(r.stdout.splitlines()[1].split("\t")[1]) == orc.card(want, 12)
