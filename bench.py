@@ -1013,7 +1013,7 @@ def main():
         if cfg["extra"] == "pairwise" and path == "pairwise_gram":
             ns = (n + 63) // 64
             blocks = ns * 3 + ns * (ns - 1) // 2 * 4                      # 32 x 32 blocks per (k, threshold, 32 registers)
-            if n > 64 and os.environ.get("DD_GRAM_DIAG2", "1") != "0":    # 128-row diagonal units (10 blocks) hold the pairs (2u, 2u + 1)
+            if n > 64:    # 128-row diagonal units (10 blocks) hold the pairs (2u, 2u + 1)
                 blocks = (ns + 1) // 2 * 10 + (ns * (ns - 1) // 2 - ns // 2) * 4
             mfma = sum(thresholds) * (m // 32) * blocks
             tops = 2.0 * 32 * 32 * 32 * mfma / (k2_ms / 1e3) / 1e12

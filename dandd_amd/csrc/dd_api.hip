@@ -169,7 +169,7 @@ struct dd_ctx {
                                          //     the decoder did its work, the FILE -- damaged trailer, two members, text beyond 4 GiB -- is not for it)
     hipEvent_t pipe_h2d[2] = {nullptr, nullptr}, pipe_done[2] = {nullptr, nullptr}, pipe_d2h[2] = {nullptr, nullptr};
     hipStream_t side[8] = {};  // k classes of a small call run side by side
-    hipEvent_t side_done[8] = {}, side_go = nullptr, side_stagger = nullptr;
+    hipEvent_t side_done[8] = {}, side_go = nullptr;
     int ingest_calls = 0;
     // HBM the record streams of one log2m >= 17 call may take: a sixth of the device (48 GiB of 288), 16 GiB at least
     size_t bucket_budget = (size_t)16 << 30;
@@ -372,7 +372,6 @@ void dd_destroy(dd_ctx* c) {
         }
     if (c->side_go) {
         (void)hipEventDestroy(c->side_go);
-        (void)hipEventDestroy(c->side_stagger);
     }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->copy_stream_b) (void)hipStreamDestroy(c->copy_stream_b);
@@ -405,33 +404,12 @@ int dd_synchronize(dd_ctx* c) {
 
 // ------------------------------------------------------------------------------ sketch
 // The side streams the k classes of a call run on: `n` of them (at most 8), made when first asked for -- a stream
-// costs 2 ms to create (4 with a priority) and as much again to destroy, which a one-shot process pays in full.
-// DD_SIDE_PRIO (experiments): one digit per stream, 0 = the device's highest queue priority, 1 = normal, 2 = lowest.
-// first epoch of the log2m >= 17 path with its rho = 1 updates as bits (ScatterParams::presorted 5): the binned form must be the
-// one that runs and a row's bits must fit LDS beside its counters
-static bool first_ones_form(int p, int nb_log2) {
-    const char* e = getenv("DD_FIRST_ONES");
-    if (e && atoi(e) == 0) return false;
-    const char* wg = getenv("DD_FIRST_WG");
-    return nb_log2 >= 1 && !getenv("DD_NO_PRESORT") && !getenv("DD_BUCKET_NO_FIRST") && (!wg || atoi(wg) == 3) && p <= 20;
-}
-
+// costs 2 ms to create and as much again to destroy, which a one-shot process pays in full.
 static int ensure_side_streams(dd_ctx* c, int n) {
-    if (!c->side_go) {
-        DD_HIP(hipEventCreateWithFlags(&c->side_go, hipEventDisableTiming));
-        DD_HIP(hipEventCreateWithFlags(&c->side_stagger, hipEventDisableTiming));
-    }
-    const char* prio = getenv("DD_SIDE_PRIO");
-    const size_t np = prio ? strlen(prio) : 0;
+    if (!c->side_go) DD_HIP(hipEventCreateWithFlags(&c->side_go, hipEventDisableTiming));
     for (int i = 0; i < std::min(n, 8); ++i) {
         if (c->side[i]) continue;
-        if ((size_t)i < np && (prio[i] == '0' || prio[i] == '2')) {
-            int lo = 0, hi = 0;  // (numerically: hi <= lo)
-            DD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            DD_HIP(hipStreamCreateWithPriority(&c->side[i], hipStreamNonBlocking, prio[i] == '0' ? hi : lo));
-        } else {
-            DD_HIP(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
-        }
+        DD_HIP(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
         DD_HIP(hipEventCreateWithFlags(&c->side_done[i], hipEventDisableTiming));
     }
     return DD_OK;
@@ -481,7 +459,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     char* sb = static_cast<char*>(c->scratch.p);
 
     // presence bitmaps for the small-k class (k <= 9), zeroed per call
-    const bool use_bitmaps = kmin <= dd::kBitmapMaxK && dd::PlanKnobs::from_env().use_bitmaps;
+    const bool use_bitmaps = kmin <= dd::kBitmapMaxK;
     uint32_t* bitmap_base = nullptr;
     if (use_bitmaps) {
         const size_t bbytes = (size_t)ngenomes * dd::kBitmapStride * sizeof(uint32_t);
@@ -586,15 +564,14 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     char* jdev = static_cast<char*>(pc.jobtab.p);
     DD_HIP(hipEventRecord(c->stage_free, st));
 
-    // ---- bucket mode (log2m >= 18): row table, cursors, filters and record areas ----------------
+    // ---- bucket mode (log2m >= 17): row table, cursors, filters and record areas ----------------
     const dd::SweepPlan* bplan = nullptr;
     for (const dd::SweepClass& sc : classes)
         if (sc.plan.mode == dd::kBucketMode) bplan = &sc.plan;
     const dd::BucketRow* rows_dev = nullptr;
     const int nrows = ngenomes * K;
-    std::vector<int> group_base(classes.size(), 0);   // row groups: the number of a class's first group, counted through the call
     if (bplan) {
-        const size_t flt_bytes = align_up((m >> bplan->logg) * bplan->fbits / 8, 16), area_bytes = (size_t)bplan->cap_chunks * 4096;  // 1024 records per chunk
+        const size_t flt_bytes = align_up((m >> bplan->logg) / 2, 16), area_bytes = (size_t)bplan->cap_chunks * 4096;  // 4-bit filter entries; 1024 records per chunk
         const size_t fill_bytes = align_up((size_t)bplan->cap_chunks * 4, 256) + align_up((size_t)bplan->cap_chunks * 32, 256);  // fill + seg
         int first_hashed = K, hashed_per_genome = 0;  // rows of a genome that belong to a bucket class
         for (const dd::SweepClass& sc : classes)
@@ -603,50 +580,21 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
                 hashed_per_genome += sc.klast - sc.kfirst + 1;
             }
         const size_t nhashed = (size_t)ngenomes * hashed_per_genome;
-        // row groups (DD_ROW_GROUP_MB, single-epoch calls): group after group on two alternating streams, the record areas
-        // of a stream's successive groups are the same ring of `group_rows` slots -- written, read back at once, written again
-        int group_rows = 0;
-        for (const dd::SweepClass& sc : classes)
-            if (sc.plan.mode == dd::kBucketMode && sc.group_rows) group_rows = std::max(group_rows, sc.group_rows);
-        if (getenv("DD_SIDE_ALWAYS") && !getenv("DD_NO_SIDE_STREAMS")) group_rows = 0;   // (class pipelines on side streams: every row its own area)
-        // (both halves of the ring whatever the number of rows: a call of two small classes puts the second's only group in the second half)
-        const size_t nareas = group_rows ? (size_t)2 * group_rows : nhashed;
         const size_t tab_bytes = align_up(sizeof(dd::BucketRow) * nrows, 256);
-        // one cursor per row, each in a 256-byte slot of its own: every 64-record block of a row is reserved by one
-        // atomic add on it, and neighbouring rows are written from other XCDs
-        const char* stride_env = getenv("DD_CURSOR_STRIDE");
-        const size_t cur_stride = stride_env ? (size_t)std::max(4, atoi(stride_env)) / 4 * 4 : (size_t)256;
+        // one cursor per row, each in a 256-byte slot of its own: every block of a row is reserved by an atomic add on it,
+        // and neighbouring rows are written from other XCDs
+        const size_t cur_stride = 256;
         const size_t cur_bytes = align_up((size_t)nrows * cur_stride, 256);
         const size_t flt_tot = align_up(nhashed * flt_bytes, 256);
-        // (round 5, DD_FIRST_ONES: the first epoch's updates of rho = 1 as one bit per register instead of a record each --
-        // dd_sweep.hip, scatter_first_bin_kernel<.., ONES>; the bits start at zero with the cursors and filters)
-        const size_t ones_bytes = first_ones_form(p, bplan->nb_log2) ? m / 8 : 0, ones_tot = align_up(nhashed * ones_bytes, 256);
-        if ((rc = c->buckets.reserve(tab_bytes + cur_bytes + flt_tot + ones_tot + nareas * (fill_bytes + area_bytes)))) return rc;
+        // the first epoch's updates of rho = 1: one bit per register instead of a record each (dd_sweep.hip,
+        // scatter_first_bin_kernel); the bits start at zero with the cursors and filters
+        const size_t ones_bytes = m / 8, ones_tot = align_up(nhashed * ones_bytes, 256);
+        if ((rc = c->buckets.reserve(tab_bytes + cur_bytes + flt_tot + ones_tot + nhashed * (fill_bytes + area_bytes)))) return rc;
         if ((rc = c->stage_rows.reserve(tab_bytes))) return rc;
         char* bb = static_cast<char*>(c->buckets.p);
         char* fills = bb + tab_bytes + cur_bytes + flt_tot + ones_tot;
-        char* areas = fills + nareas * fill_bytes;
+        char* areas = fills + nhashed * fill_bytes;
         std::vector<dd::BucketRow> rtab(nrows);
-        // (row groups: the slot of a row = the ring half of its group's stream + its place in the group; groups are counted
-        // through the classes in launch order)
-        {
-            int gc = 0;
-            for (size_t i = 0; i < classes.size(); ++i) {
-                group_base[i] = gc;
-                if (classes[i].plan.mode == dd::kBucketMode && classes[i].group_rows) gc += (int)classes[i].group_begin.size() - 1;
-            }
-        }
-        auto area_slot = [&](int g, int kk, size_t dense) -> size_t {
-            if (!group_rows) return dense;
-            for (size_t i = 0; i < classes.size(); ++i) {
-                const dd::SweepClass& sc = classes[i];
-                if (sc.plan.mode != dd::kBucketMode || kk < sc.kfirst - kmin || kk > sc.klast - kmin) continue;
-                const int nks = sc.klast - sc.kfirst + 1, local = g * nks + (kk - (sc.kfirst - kmin));
-                const int grp = group_base[i] + local / sc.group_rows;
-                return (size_t)(grp & 1) * group_rows + (size_t)(local % sc.group_rows);
-            }
-            return dense;
-        };
         size_t h = 0;
         for (int g = 0; g < ngenomes; ++g)
             for (int kk = 0; kk < K; ++kk) {
@@ -655,14 +603,13 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
                 r.cursor = reinterpret_cast<uint32_t*>(bb + tab_bytes + ((size_t)g * K + kk) * cur_stride);
                 const bool hashed = kk >= first_hashed && kk < first_hashed + hashed_per_genome;
                 r.filter = hashed ? reinterpret_cast<uint8_t*>(bb + tab_bytes + cur_bytes + h * flt_bytes) : nullptr;
-                r.ones = hashed && ones_bytes ? reinterpret_cast<uint32_t*>(bb + tab_bytes + cur_bytes + flt_tot + h * ones_bytes) : nullptr;
-                const size_t slot = hashed ? area_slot(g, kk, h) : 0;
-                r.fill = hashed ? reinterpret_cast<uint32_t*>(fills + slot * fill_bytes) : nullptr;
-                r.seg = hashed ? reinterpret_cast<uint16_t*>(fills + slot * fill_bytes + align_up((size_t)bplan->cap_chunks * 4, 256)) : nullptr;
-                r.area = hashed ? reinterpret_cast<uint32_t*>(areas + slot * area_bytes) : nullptr;
+                r.ones = hashed ? reinterpret_cast<uint32_t*>(bb + tab_bytes + cur_bytes + flt_tot + h * ones_bytes) : nullptr;
+                r.fill = hashed ? reinterpret_cast<uint32_t*>(fills + h * fill_bytes) : nullptr;
+                r.seg = hashed ? reinterpret_cast<uint16_t*>(fills + h * fill_bytes + align_up((size_t)bplan->cap_chunks * 4, 256)) : nullptr;
+                r.area = hashed ? reinterpret_cast<uint32_t*>(areas + h * area_bytes) : nullptr;
                 h += hashed ? 1 : 0;
             }
-        // cursors and filters start at zero: nothing handed out, every register's lower bound is 0
+        // cursors, filters and bits start at zero: nothing handed out, every register's lower bound is 0
         DD_HIP(hipMemsetAsync(bb + tab_bytes, 0, cur_bytes + flt_tot + ones_tot, st));
         if ((rc = upload(c, c->stage_rows, bb, rtab.data(), sizeof(dd::BucketRow) * nrows, 0))) return rc;
         rows_dev = reinterpret_cast<const dd::BucketRow*>(bb);
@@ -670,6 +617,19 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     }
 
     // ---- K1 launches -------------------------------------------------------------------
+    auto launch_lds_class = [&](const dd::SweepClass& sc, size_t i, hipStream_t ks) {
+        const dd::SweepGenome* gt = reinterpret_cast<const dd::SweepGenome*>(tdev);
+        const dd::SweepJob* jt = reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]);
+        if (sc.kclass == dd::kBitmapClass) {
+            dd::launch_bitmap(gt, jt, (int)sc.jobs.size(), sc.kfirst, sc.klast, c->canonical, ks);
+            dd::launch_bitmap_finish(gt, ngenomes, sc.kfirst, sc.klast, kmin, p, ks);
+        } else if (sc.kclass == dd::kBigmapClass) {
+            dd::launch_bigmap(gt, jt, (int)sc.jobs.size(), c->canonical, ks);
+            dd::launch_bigmap_finish(gt, ngenomes, sc.kfirst, sc.klast, kmin, p, c->canonical, ks);
+        } else {
+            dd::launch_sweep(gt, jt, (int)sc.jobs.size(), sc.kclass, sc.plan, ks);
+        }
+    };
     // The k classes are independent.  On a big call they are launched back to back (running them side by side
     // was measured neutral to slightly slower: they compete for the same VALUs).  On a SMALL call -- one batch of
     // the ingestion pipeline, a single genome -- every class is only a few rounds of workgroups long and ends
@@ -679,13 +639,13 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
     int lds_classes = 0;
     for (const dd::SweepClass& sc : classes)
         if (sc.plan.mode != dd::kBucketMode) lds_jobs += sc.jobs.size(), ++lds_classes;
-    const bool side = lds_classes > 1 && (lds_jobs < 12000 || getenv("DD_SIDE_ALWAYS")) && !getenv("DD_NO_SIDE_STREAMS");
+    const bool side = lds_classes > 1 && lds_jobs < 12000;
     if (side && (rc = ensure_side_streams(c, lds_classes))) return rc;
     // log2m >= 17, see below.  A call whose only epoch is the unfiltered first one (many small genomes: 64 x 5 Mbp at
     // log2m 20) runs its classes one after the other instead: its scatter (returning LDS atomics, 4-byte stores) and
     // its replay (HBM reads at 5 TB/s) each have the chip to themselves then -- 24.4 -> 22.9 ms with round 4's kernels
     // (profiles/r04_bucket_path.txt); calls with filtered epochs keep the side streams (26.8 against 24.9 ms without).
-    const bool side_b = bplan && (bplan->nepochs > 1 || getenv("DD_SIDE_ALWAYS")) && !getenv("DD_NO_SIDE_STREAMS");
+    const bool side_b = bplan && bplan->nepochs > 1;
     // (launches that run side by side are timed as ONE span on the caller's stream: per-launch spans would overlap)
     std::unique_ptr<Span> phase((side || side_b) ? new Span(c, DD_KERNEL_SWEEP) : nullptr);
     if (side) DD_HIP(hipEventRecord(c->side_go, st));
@@ -699,21 +659,7 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
             DD_HIP(hipStreamWaitEvent(ks, c->side_go, 0));
         }
         Span sp(c, DD_KERNEL_SWEEP, !side);
-        if (sc.kclass == dd::kBitmapClass) {
-            dd::launch_bitmap(reinterpret_cast<const dd::SweepGenome*>(tdev),
-                              reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]),
-                              (int)sc.jobs.size(), sc.kfirst, sc.klast, c->canonical, ks);
-            dd::launch_bitmap_finish(reinterpret_cast<const dd::SweepGenome*>(tdev), ngenomes, sc.kfirst, sc.klast,
-                                     kmin, p, ks);
-        } else if (sc.kclass == dd::kBigmapClass) {
-            dd::launch_bigmap(reinterpret_cast<const dd::SweepGenome*>(tdev), reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]),
-                              (int)sc.jobs.size(), c->canonical, ks);
-            dd::launch_bigmap_finish(reinterpret_cast<const dd::SweepGenome*>(tdev), ngenomes, sc.kfirst, sc.klast, kmin, p, c->canonical, ks);
-        } else {
-            dd::launch_sweep(reinterpret_cast<const dd::SweepGenome*>(tdev),
-                             reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]),
-                             (int)sc.jobs.size(), sc.kclass, sc.plan, ks);
-        }
+        launch_lds_class(sc, i, ks);
         if (side) {
             DD_HIP(hipEventRecord(c->side_done[lane_no & 7], ks));
             DD_HIP(hipStreamWaitEvent(st, c->side_done[lane_no & 7], 0));
@@ -722,33 +668,14 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
         blocks += (int)sc.jobs.size();
     }
     if (bplan) {
-        // epoch by epoch: scatter launches of every k class (independent rows: side by side on side streams, so the
-        // tail of one overlaps the body of another), then one sort + replay over all rows
-        const char* unit_env = getenv("DD_BUCKET_UNIT");
-        const unsigned unit = unit_env ? (unsigned)std::max(1, std::min(16, atoi(unit_env))) * 64u : 256u;
-        // first-epoch chunks leave the scatter sorted by index tile: 2 = one 16 384-record chunk per workgroup and 16
-        // updates (round 4), 1 = every wave its own 1024-record chunks (DD_FIRST_WG=0), 0 = sorted by a pass of their own
-        // (DD_FIRST_WG: 3 = binned tiles of tokens, the default; 2 = 16 384-record sorted chunks; 0 = per-wave chunks)
-        // (round 5: 4 = the bins PACKED to 3 bytes per record through an LDS ring -- needs 64 KiB index tiles: 16 bits of index.
-        // Exact, measured 30 % SLOWER on 64 x 5 Mbp at log2m 20 -- a barrier and a flush every four updates cost the scatter more
-        // than a quarter less traffic gives back, and the replay is not bound by its reads: profiles/r05_bucket_path.txt -- A/B knob)
-        const int first_wg = getenv("DD_FIRST_WG") ? atoi(getenv("DD_FIRST_WG")) : 3;
-        const int presorted = first_ones_form(p, bplan->nb_log2) ? 5 : bplan->nb_log2 >= 1 && !getenv("DD_NO_PRESORT")
-                                  ? (first_wg == 0 ? 1 : (first_wg == 2 ? 2 : (first_wg == 4 && p - bplan->nb_log2 == 16 ? 4 : 3))) : 0;
-        const dd::ScatterParams sp{rows_dev, K, bplan->logg, bplan->cap_chunks, unit, bplan->nb_log2, presorted};
+        // Every k class is a pipeline of its own -- scatter(e), (sort(e),) replay(e), scatter(e+1) ... over its own rows --
+        // so, when there are filtered epochs, each gets a side stream: the tails of one class's launches are filled by the
+        // others' work.  (Starting the pipelines one first-epoch scatter apart, and streams of different priorities, were
+        // measured and lost: profiles/r03_bucket_path.txt, r04_bucket_path.txt.)
+        const dd::ScatterParams sp{rows_dev, K, bplan->logg, bplan->cap_chunks, bplan->nb_log2};
         if (side_b && (rc = ensure_side_streams(c, (int)classes.size()))) return rc;
-        // Every k class is a pipeline of its own -- scatter(e), sort(e), replay(e), scatter(e+1) ... over its own rows
-        // -- so each gets a side stream: the tails of one class's launches are filled by the others' work.
         if (side_b) DD_HIP(hipEventRecord(c->side_go, st));
         int lane_b = 0;
-        // The class pipelines start one first-epoch scatter apart (class i + 1's first scatter waits for class i's):
-        // a class's replay (HBM reads, LDS compare-and-swaps) then runs beside the next class's scatter (VALU issue)
-        // instead of every scatter running beside every other and the replays likewise.  64 x 5 Mbp at log2m 20:
-        // 33.4 -> 31.7 ms; 10 x 50 Mbp and log2m 18 unchanged (profiles/r03_bucket_path.txt).
-        // (round 4: with the first epoch binned straight from the hash the stagger LOSES -- 64 x 5 Mbp 25.6 against 24.4 ms,
-        // 10 x 50 Mbp 25.6 against 24.9 at log2m 20, equal at 18 -- and is off; DD_BUCKET_STAGGER=1 brings it back)
-        const bool stagger = side_b && getenv("DD_BUCKET_STAGGER") && atoi(getenv("DD_BUCKET_STAGGER")) == 1;
-        int staggered = 0;
         for (size_t i = 0; i < classes.size(); ++i) {
             const dd::SweepClass& sc = classes[i];
             hipStream_t ks = st;
@@ -758,54 +685,17 @@ int dd_sketch_device(dd_ctx* c, const uint8_t* const* fasta_dev, const size_t* n
             }
             if (sc.plan.mode != dd::kBucketMode) {
                 if (!side_b) continue;  // (already launched above)
-                // the small-k class (its rows are not bucketed) runs beside the pipelines
-                if (sc.kclass == dd::kBitmapClass) {
-                    dd::launch_bitmap(reinterpret_cast<const dd::SweepGenome*>(tdev), reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]),
-                                      (int)sc.jobs.size(), sc.kfirst, sc.klast, c->canonical, ks);
-                    dd::launch_bitmap_finish(reinterpret_cast<const dd::SweepGenome*>(tdev), ngenomes, sc.kfirst, sc.klast, kmin, p, ks);
-                } else if (sc.kclass == dd::kBigmapClass) {
-                    dd::launch_bigmap(reinterpret_cast<const dd::SweepGenome*>(tdev), reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]),
-                                      (int)sc.jobs.size(), c->canonical, ks);
-                    dd::launch_bigmap_finish(reinterpret_cast<const dd::SweepGenome*>(tdev), ngenomes, sc.kfirst, sc.klast, kmin, p, c->canonical, ks);
-                } else {
-                    dd::launch_sweep(reinterpret_cast<const dd::SweepGenome*>(tdev), reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]),
-                                     (int)sc.jobs.size(), sc.kclass, sc.plan, ks);
-                }
+                launch_lds_class(sc, i, ks);   // the small-k classes (their rows are not bucketed) run beside the pipelines
                 blocks += (int)sc.jobs.size();
-            }
-            if (sc.plan.mode == dd::kBucketMode && sc.group_rows && !side_b) {
-                // row groups: group after group, scatter -> replay at once, on two streams in turn (group i + 1's scatter --
-                // VALU issue -- runs beside group i's replay -- record reads); what a group writes it reads back ~100 us later
-                if ((rc = ensure_side_streams(c, 2))) return rc;
-                if (!phase) phase.reset(new Span(c, DD_KERNEL_SWEEP));
-                DD_HIP(hipEventRecord(c->side_go, st));
-                const int nks = sc.klast - sc.kfirst + 1, ngroups = (int)sc.group_begin.size() - 1;
-                for (int s2 = 0; s2 < 2; ++s2) DD_HIP(hipStreamWaitEvent(c->side[s2], c->side_go, 0));
-                for (int gi = 0; gi < ngroups; ++gi) {
-                    hipStream_t gs = c->side[(group_base[i] + gi) & 1];
-                    const size_t j0 = sc.group_begin[gi], j1 = sc.group_begin[gi + 1];
-                    dd::launch_scatter(reinterpret_cast<const dd::SweepGenome*>(tdev), reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]) + j0,
-                                       (int)(j1 - j0), sc.kclass, sc.plan, sp, gs, true);
-                    dd::launch_replay(rows_dev, ngenomes, K, sc.kfirst - kmin, nks, *bplan, gs, presorted, gi * sc.group_rows, sc.group_rows);
-                    blocks += (int)(j1 - j0);
-                }
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    DD_HIP(hipEventRecord(c->side_done[s2], c->side[s2]));
-                    DD_HIP(hipStreamWaitEvent(st, c->side_done[s2], 0));
-                }
-                continue;
             }
             for (int e = 0; sc.plan.mode == dd::kBucketMode && e < bplan->nepochs; ++e) {
                 const size_t j0 = sc.epoch_begin[e], j1 = sc.epoch_begin[e + 1];
                 if (j1 == j0) continue;
                 Span span(c, DD_KERNEL_SWEEP, !side_b);
-                const bool first = e == 0 && !getenv("DD_BUCKET_NO_FIRST");
-                if (stagger && e == 0 && staggered++) DD_HIP(hipStreamWaitEvent(ks, c->side_stagger, 0));
                 dd::launch_scatter(reinterpret_cast<const dd::SweepGenome*>(tdev),
                                    reinterpret_cast<const dd::SweepJob*>(jdev + job_off[i]) + j0, (int)(j1 - j0),
-                                   sc.kclass, sc.plan, sp, ks, first);
-                if (stagger && e == 0) DD_HIP(hipEventRecord(c->side_stagger, ks));
-                dd::launch_replay(rows_dev, ngenomes, K, sc.kfirst - kmin, sc.klast - sc.kfirst + 1, *bplan, ks, first ? presorted : 0);
+                                   sc.kclass, sc.plan, sp, ks, e == 0);
+                dd::launch_replay(rows_dev, ngenomes, K, sc.kfirst - kmin, sc.klast - sc.kfirst + 1, *bplan, ks, e == 0);
                 blocks += (int)(j1 - j0);
             }
             if (side_b) {
@@ -1057,7 +947,7 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
                                         : (c->p >= 17 ? (c->ingest_calls == 0 ? 128 : 512) : (any_gz && gpu_inflate ? 320 : 128))) << 20;
     // (at most 256 files per launch: the loaders' window is two batches of host buffers of 2 MiB at least; with 64,
     // a thousand 100 kbp plasmids took 23 launches of ~3 ms each)
-    const size_t kMaxBatchFiles = getenv("DD_BATCH_FILES") ? (size_t)std::max(1, atoi(getenv("DD_BATCH_FILES"))) : 256;
+    const size_t kMaxBatchFiles = 256;
     int batch_files = (int)std::max<size_t>(1, std::min<size_t>(kMaxBatchFiles, kBatchBytes / avg));
     const bool full_batches = any_gz && gpu_inflate;
     if (full_batches && nfiles >= 2) {
@@ -1066,7 +956,7 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
         // -- ten gzip -1 files went out as 4 + 4 at t = 4 ms and 2 at t = 40 ms, whose find + inflate + sweep then ran alone
         // for the call's last 22 of 62 ms (DD_TRACE_FILES; profiles/r05_gunzip.txt)
         int nb = (nfiles + batch_files - 1) / batch_files;
-        if (nb == 3 && nfiles * 2 <= batch_files * 5 && !getenv("DD_TAIL_BATCH")) nb = 2;
+        if (nb == 3 && nfiles * 2 <= batch_files * 5) nb = 2;
         nb = std::max(nb, 2);
         batch_files = (nfiles + nb - 1) / nb;
     }
@@ -1119,7 +1009,7 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
     };
     std::vector<Item> items;
     const size_t kPiece = (size_t)8 << 20;
-    const size_t kFirstPiece = (size_t)(getenv("DD_FIRST_PIECE_MB") ? std::max(1, atoi(getenv("DD_FIRST_PIECE_MB"))) : 2) << 20;
+    const size_t kFirstPiece = (size_t)2 << 20;
     for (int i = 0; i < nfiles; ++i) {
         struct stat sb;
         unsigned char magic[18] = {0};
@@ -1344,7 +1234,7 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return slots[i].done; });
             if (full_batches)
-                cv.wait_for(lk, std::chrono::milliseconds(getenv("DD_BATCH_WAIT_MS") ? std::max(0, atoi(getenv("DD_BATCH_WAIT_MS"))) : 3), [&] {
+                cv.wait_for(lk, std::chrono::milliseconds(3), [&] {
                     for (int j = i; j < std::min(nfiles, i + batch_files); ++j)
                         if (!slots[j].done) return false;
                     return true;
@@ -1355,7 +1245,7 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             // (device-inflated batches: no small batch at the end -- a launch of the inflate kernel over two files' pieces takes as
             // long as one over five, with a quarter of the chip: ten gzip -1 files went out as 4 + 4 + 2 and the last two cost
             // 22 of the call's 60 ms.  What would be left is fewer than half a batch: it joins this one, waited for.)
-            if (full_batches && i + count < nfiles && nfiles - (i + count) < (batch_files + 1) / 2 && !getenv("DD_TAIL_BATCH")) {
+            if (full_batches && i + count < nfiles && nfiles - (i + count) < (batch_files + 1) / 2) {
                 cv.wait(lk, [&] {
                     for (int j = i + count; j < nfiles; ++j)
                         if (!slots[j].done) return false;
@@ -1476,7 +1366,7 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             continue;
         }
         hipError_t e = hipSuccess;
-        hipStream_t cs = ((njobs || nmem) && set && !getenv("DD_ONE_COPY_STREAM")) ? c->copy_stream_b : c->copy_stream;
+        hipStream_t cs = ((njobs || nmem) && set) ? c->copy_stream_b : c->copy_stream;
         std::vector<const uint8_t*> ptrs(count);
         dd::InflateJob* jobs_host = njobs ? static_cast<dd::InflateJob*>(c->pipe_jobs_host[set].p) : nullptr;
         size_t nj = 0;

@@ -393,7 +393,7 @@ DD_D bool piece_of(const RawFile* files, int nfiles, const uint64_t* starts, uin
 // is bound by neither unit's issue rate but by its waves' serial chains.  -- That was with a third of a gzip -1 member's matches
 // kept OUT of the walk (their source might lie inside the batch).  Since flush() resolves those (same round) a window's walkable
 // symbols doubled, and this walk became the default: inflate_kernel<3> 9.16 -> 7.73 ms per batch of five gzip -1 members, 9.18 ->
-// 8.23 at gzip -6 (rocprofv3; DD_INFLATE_PWALK=0 | 1 | 2).  Bit-exact in all three modes (strict tests, scripts/fuzz_inflate.py).
+// 8.23 at gzip -6 (rocprofv3).  The scalar walk and the mixed mode are gone from the build (round 6); git history has them.
 template <int CTRL, int ROW_MASK>
 DD_D uint32_t dpp_add(uint32_t x) {
     return x + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, false);
@@ -459,11 +459,9 @@ DD_D void parallel_walk(uint32_t pk, uint32_t lane, uint32_t used, unsigned long
 template <int MODE>
 __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restrict__ jobs, const RawFile* __restrict__ files, int nfiles,
                                                      const uint64_t* __restrict__ starts, uint32_t* __restrict__ lens, uint32_t* __restrict__ over,
-                                                     const uint32_t* __restrict__ abase, uint32_t* __restrict__ errors, int pwalk) {
+                                                     const uint32_t* __restrict__ abase, uint32_t* __restrict__ errors) {
     constexpr bool RAW = MODE != 0;
     constexpr bool WRITES = MODE == 2 || MODE == 3;   // (16-bit symbols)
-    const bool near_ok = !(pwalk & 4);                 // (DD_INFLATE_NEAR=0: matches that may start inside the batch leave the lanes' walk, as in round 4)
-    pwalk &= 3;
     bool too_long = false;                             // MODE 3: the piece does not fit its ranges
     constexpr uint32_t kLit = RAW ? 0x40000000u : 0x80000000u;   // a batch lane's source: a literal (else an offset in the text; RAW: negative = in front of the piece)
     const uint32_t lane = threadIdx.x & 63u;
@@ -613,7 +611,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
                 // be inside the batch -- distance < length + 64 --: 2 % of the matches of a gzip -6 member of DNA, but 31 % at
                 // gzip -1, whose matcher takes the most recent occurrence.  Now flush() resolves sources inside the batch by
                 // pointer jumping and they stay in the walk: inflate_kernel<3> over gzip -1 members 12-14 -> ~9 ms per batch,
-                // ten 50 Mbp files 8.6 -> 10.9 Gbp/s on one box, 8.6 -> 9.3 on another; DD_INFLATE_NEAR=0 = round 4's rule.)
+                // ten 50 Mbp files 8.6 -> 10.9 Gbp/s on one box, 8.6 -> 9.3 on another.)
                 uint32_t q, r, s0, s1, s2, s3, s4;   // the window: bit r of word W[q] = s0; s0..s4 = W[q .. q + 4]
                 {
                     const uint64_t P = b.bit_pos();
@@ -623,7 +621,6 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
                     s0 = b.word(), s1 = b.word(), s2 = b.word(), s3 = b.word(), s4 = b.word();
                 }
                 uint32_t osv = 0;   // a symbol's lane: the batch slot of its first byte
-                bool many_symbols = false;   // the window before held five symbols or more: the walk goes to all lanes at once
                 for (;;) {
                     // lane i: the 64 bits from bit r + i on
                     const uint32_t t = lane + r, kq = t >> 5, sh = t & 31u;
@@ -640,33 +637,16 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
                     // bits 0..5: the symbol's length in bits; 6..14: bytes it makes; 0 = not for the walk
                     uint32_t pk = 0;
                     if (kd == 1u) pk = l1 | (1u << 6);
-                    else if (kd == 3u && e2 != 0u && (near_ok || dv >= v1 + 64u) && dv <= at + (RAW ? 32768u : 0u)) pk = (t1 + l2 + ex2) | (v1 << 6);
+                    else if (kd == 3u && e2 != 0u && dv <= at + (RAW ? 32768u : 0u)) pk = (t1 + l2 + ex2) | (v1 << 6);
                     unsigned long long mark = 0, starts = 0;
                     uint32_t pos = 0, outacc = 0, pks = 0;
-                    const uint32_t room = 64u - used;
-                    if (pwalk == 2 || (pwalk == 1 && many_symbols)) {
-                        parallel_walk(pk, lane, used, mark, pos, outacc, pks, osv);
-                        // which slots of the batch start a symbol: the symbols' lanes say so in LDS, the slots' lanes read it back
-                        g_lds[kLens + 512u + lane] = 0;
-                        __builtin_amdgcn_wave_barrier();
-                        if ((mark >> lane) & 1ull) g_lds[kLens + 512u + osv] = 1;
-                        __builtin_amdgcn_wave_barrier();
-                        starts = __ballot(g_lds[kLens + 512u + lane] != 0);
-                    } else {
-                        do {
-                            pks = (uint32_t)__builtin_amdgcn_readlane((int)pk, (int)pos);
-                            const uint32_t ol = pks >> 6;
-                            if (!pks || outacc + ol > room) break;
-                            const uint32_t slot = used + outacc;
-                            mark |= 1ull << pos;
-                            starts |= 1ull << slot;
-                            if (lane == pos) osv = slot;
-                            outacc += ol;
-                            pos += pks & 63u;
-                            pks = 1;
-                        } while (pos < 64u);
-                    }
-                    many_symbols = __builtin_popcountll(mark) >= 5;
+                    parallel_walk(pk, lane, used, mark, pos, outacc, pks, osv);
+                    // which slots of the batch start a symbol: the symbols' lanes say so in LDS, the slots' lanes read it back
+                    g_lds[kLens + 512u + lane] = 0;
+                    __builtin_amdgcn_wave_barrier();
+                    if ((mark >> lane) & 1ull) g_lds[kLens + 512u + osv] = 1;
+                    __builtin_amdgcn_wave_barrier();
+                    starts = __ballot(g_lds[kLens + 512u + lane] != 0);
                     if (outacc) {
                         if (at + outacc > out_len) { ok = false, too_long = true; break; }
                         // the symbols' lanes say where their bytes come from; the batch's lanes find their symbol by counting
@@ -746,8 +726,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob* __restric
                             if (at + len > out_len) { ok = false, too_long = true; break; }
                             // the copy: its bytes join the batch (several batches when it is long).  It reads the dist-byte pattern
                             // in front of it; should that reach into the batch itself, the batch leaves first.
-                            const uint32_t pat = at - dist, pat_end = pat + (dist < len ? dist : len);   // (RAW: both may be "negative")
-                            if (!near_ok && (int)pat_end > (int)bstart) flush();
+                            const uint32_t pat = at - dist;   // (RAW: may be "negative")
                             at += len;
                             auto place = [&](auto src_of) {
                                 uint32_t done = 0;
@@ -1316,20 +1295,10 @@ static void inflate_attributes() {
     done.fetch_or(bit, std::memory_order_relaxed);
 }
 
-// DD_INFLATE_PWALK: 0 = the scalar walk only (round 4's), 1 = the lanes' walk for windows behind a window of five symbols or more,
-// 2 = always -- the default since matches that start inside the batch stay in the walk (round 5): a gzip -1 window then holds ~6
-// walkable symbols instead of ~3 and the lanes' walk, whose cost does not depend on their number, takes inflate_kernel<3> from
-// 9.16 to 7.73 ms per batch of five 50 Mbp gzip -1 members (gzip -6: 9.18 -> 8.23); before that change it measured neutral
-static int pwalk_mode() {
-    const char* e = getenv("DD_INFLATE_PWALK");
-    const char* near = getenv("DD_INFLATE_NEAR");
-    return (e ? std::max(0, std::min(2, atoi(e))) : 2) | (near && atoi(near) == 0 ? 4 : 0);
-}
-
 void launch_inflate_bgzf(const InflateJob* jobs_dev, int njobs, uint32_t* errors_dev, hipStream_t st) {
     if (njobs <= 0) return;
     inflate_attributes();
-    hipLaunchKernelGGL(inflate_kernel<0>, dim3((unsigned)njobs), dim3(64), kInflateLds, st, jobs_dev, nullptr, 0, nullptr, nullptr, nullptr, nullptr, errors_dev, pwalk_mode());
+    hipLaunchKernelGGL(inflate_kernel<0>, dim3((unsigned)njobs), dim3(64), kInflateLds, st, jobs_dev, nullptr, 0, nullptr, nullptr, nullptr, nullptr, errors_dev);
 }
 
 // Single-member gzip files on the device: block starts -> piece lengths -> offsets -> symbols -> windows -> text -> CRCs.
@@ -1340,12 +1309,11 @@ void launch_gunzip_members(const RawFile* files_dev, int nfiles, int npieces, in
     inflate_attributes();
     uint32_t *lens = tables_dev, *offs = tables_dev + stride, *over = tables_dev + 2 * stride, *abase = tables_dev + 3 * stride;
     const dim3 grid((unsigned)npieces), wave(64);
-    const int pw = pwalk_mode();
     hipLaunchKernelGGL(find_starts_kernel, grid, wave, kFindLds, st, files_dev, nfiles, starts);
-    hipLaunchKernelGGL(inflate_kernel<3>, grid, wave, kInflateLds, st, nullptr, files_dev, nfiles, starts, lens, over, nullptr, errors_dev, pw);
-    hipLaunchKernelGGL(inflate_kernel<1>, grid, wave, kInflateLds, st, nullptr, files_dev, nfiles, starts, lens, over, nullptr, errors_dev, pw);   // (the pieces marked in `over` only)
+    hipLaunchKernelGGL(inflate_kernel<3>, grid, wave, kInflateLds, st, nullptr, files_dev, nfiles, starts, lens, over, nullptr, errors_dev);
+    hipLaunchKernelGGL(inflate_kernel<1>, grid, wave, kInflateLds, st, nullptr, files_dev, nfiles, starts, lens, over, nullptr, errors_dev);   // (the pieces marked in `over` only)
     hipLaunchKernelGGL(piece_offsets_kernel, dim3((unsigned)nfiles), wave, 0, st, files_dev, lens, over, offs, abase, errors_dev);
-    hipLaunchKernelGGL(inflate_kernel<2>, grid, wave, kInflateLds, st, nullptr, files_dev, nfiles, starts, lens, over, abase, errors_dev, pw);
+    hipLaunchKernelGGL(inflate_kernel<2>, grid, wave, kInflateLds, st, nullptr, files_dev, nfiles, starts, lens, over, abase, errors_dev);
     hipLaunchKernelGGL(piece_maps_kernel, dim3((unsigned)ngroups), dim3(1024), 131072, st, files_dev, nfiles, lens, over, abase, errors_dev);
     hipLaunchKernelGGL(group_windows_kernel, dim3((unsigned)nfiles), dim3(1024), 65536, st, files_dev, errors_dev);
     if (nchunks > 0) {

@@ -434,12 +434,8 @@ static int gram_len(int nsp, int K, int p) {
     return (int)len;
 }
 
-// n > 64: the diagonal is covered by 128-row units (kDiag2) and the off-diagonal launch skips the 64 x 64 pairs inside them;
-// DD_GRAM_DIAG2=0 keeps round 4's 64-row diagonal units
-static bool gram_diag2(int n) {
-    const char* knob = getenv("DD_GRAM_DIAG2");
-    return n > 64 && !(knob && atoi(knob) == 0);
-}
+// n > 64: the diagonal is covered by 128-row units (kDiag2) and the off-diagonal launch skips the 64 x 64 pairs inside them
+static bool gram_diag2(int n) { return n > 64; }
 
 size_t gram_scratch_bytes(int n, int K, int p, int* sp_per_launch) {
     const int ns = (n + 63) / 64;

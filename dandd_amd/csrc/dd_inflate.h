@@ -537,7 +537,7 @@ inline int gunzip_member_parallel(const uint8_t* in, size_t n, Buf& out, int nth
     using namespace inflate_detail;
     const size_t hdr = gzip_header_len(in, n);
     if (!hdr || n < hdr + 8 + 2 * min_piece || nthreads < 2) return 0;
-    const bool trace = getenv("DD_INFLATE_TRACE") != nullptr;
+    const bool trace = getenv("DD_TRACE_FILES") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
     const size_t body_end = n - 8;   // if the file is ONE member, its trailer sits here (checked at the end)

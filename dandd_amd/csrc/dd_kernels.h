@@ -94,19 +94,15 @@ struct SweepJob {               // one per workgroup, device-resident table
     int slice;                  // big-bitmap jobs: which 2^20-bit slice of k's index space the workgroup records
 };
 constexpr int kBucketMode = 5;
+constexpr int kBucketFromLog2m = 17;  // registers stay in HBM (scatter + replay) from this log2m on
 struct SweepPlan {
     int log2m;
     int canonical;
     int threads;                // workgroup size
     int lds_bytes;              // dynamic LDS per workgroup
-    int mode;                   // 0: registers in LDS; 1: in HBM, every update checked there;
-                                // 2..4: in HBM behind an LDS filter byte per 2^mode registers (one k per job);
-                                // 5 (kBucketMode): in HBM, scatter to buckets + replay (below)
+    int mode;                   // 0: registers in LDS (log2m <= 16); 5 (kBucketMode): in HBM, scatter to buckets + replay (below)
     // kBucketMode only
-    int logg = 0;               // one filter entry per 2^logg registers
-    int fbits = 8;              // bits per filter entry: 8, or 4 (bounds saturate at 15, two entries per byte)
-    int nk_job = 1;             // ks per scatter job
-    int probe = 0;              // second-level filter: queued candidates are checked against the row itself
+    int logg = 0;               // one 4-bit filter entry (bounds saturate at 15, two entries per byte) per 2^logg registers
     int nb_log2 = 0;            // 2^nb_log2 index tiles of 64 KiB per row (replay)
     unsigned cap_chunks = 0;    // 1024-record chunks per row and epoch
     int nepochs = 0;
@@ -121,8 +117,9 @@ void launch_sweep(const SweepGenome* genomes_dev, const SweepJob* jobs_dev, int 
 //            for its register group is dropped, the others are queued per wave in LDS, checked 64 at a time
 //            against the row itself, and what survives leaves as 4-byte records (idx | rho << 24), one 256-byte
 //            block at a time, for the ROW's record stream -- a dense stream: waves reserve 256 records per atomic
-//            add on the row's cursor.  The first epoch (registers all zero) has no filter and no queues: its waves
-//            collect 1024 records and store them as a chunk already sorted by index tile.
+//            add on the row's cursor.  The first epoch (registers all zero) has no filter and no queues: a record goes
+//            straight from the hash into the bin of its index tile (16 fixed regions of 4480 records per tile of tokens,
+//            counts in seg[chunk][16]), except the updates of rho = 1 -- half of them --, which set a bit of BucketRow::ones.
 //   sort   : every 1024-record chunk is sorted by index tile in place (HBM-bound streaming pass; not needed
 //            after the first epoch).
 //   replay : one workgroup per (row, 64 KiB index tile): tile into LDS, apply the tile's segment of every
@@ -138,27 +135,20 @@ struct BucketRow {              // one per (genome, k) row of the call: table[ge
     uint32_t* fill;             // [cap_chunks] records of each chunk after the sort dropped the null ones
     uint16_t* seg;              // [cap_chunks][16] where each index tile's records start inside a sorted chunk
     uint8_t* filter;            // [m >> logg] lower bound per register group
-    uint32_t* ones;             // [m / 32] first epoch, ScatterParams::presorted 5: bit r = register r saw an update with rho = 1; else null
+    uint32_t* ones;             // [m / 32] first epoch: bit r = register r saw an update with rho = 1
 };
 struct ScatterParams {
     const BucketRow* rows;
     int K;                      // rows per genome
     int logg;
     unsigned cap_chunks;
-    unsigned unit;              // records a wave reserves per atomic add on the row's cursor (multiple of 64)
     int nb_log2;                // index tiles per row (log2)
-    int presorted;              // first-epoch scatter sorts its chunks by index tile itself (rows of several tiles): 1 = every
-                                // wave its own 1024-record chunks, 2 = the workgroup's 16 384-record chunks (one per 16 updates),
-                                // 3 = every tile of tokens binned: 16 fixed regions of 4480 records, counts in seg[chunk][16]
-                                // 4 = the same packed to 3 bytes per record; 5 = 3 without the updates of rho = 1, which set a bit
-                                //     of BucketRow::ones instead
 };
 void launch_scatter(const SweepGenome* genomes_dev, const SweepJob* jobs_dev, int njobs, int kclass,
                     const SweepPlan& plan, const ScatterParams& sp, hipStream_t st, bool first_epoch);
-// sort + replay + cursor reset of rows k0 .. k0+nks-1 (indices into a genome's K rows) of every genome
-// (presorted: the form of the chunks the scatter left, ScatterParams::presorted; 0 = unsorted: the sort pass runs first)
-void launch_replay(const BucketRow* rows_dev, int ngenomes, int K, int k0, int nks, const SweepPlan& plan, hipStream_t st,
-                   int presorted = 0, int row0 = 0, int nrows = -1 /* a row group of the class (dd_plan.h); -1: every row */);
+// (sort +) replay + cursor reset of rows k0 .. k0+nks-1 (indices into a genome's K rows) of every genome; first_epoch: the
+// records are the binned tiles the first epoch's scatter left (no sort pass)
+void launch_replay(const BucketRow* rows_dev, int ngenomes, int K, int k0, int nks, const SweepPlan& plan, hipStream_t st, bool first_epoch);
 int sweep_max_lds_bytes();
 // small-k class: jobs carry ks <= kBitmapMaxK; records k-mer presence in genome.bitmap
 // (kfirst..klast: the ks of the class; the LDS image covers exactly their bitmaps)

@@ -21,42 +21,20 @@ struct SweepClass {
     // bucket mode (plan.mode == kBucketMode): the jobs of epoch e are jobs[epoch_begin[e] .. epoch_begin[e+1]);
     // one scatter launch per (class, epoch), one replay launch per epoch over the rows of all classes
     std::vector<size_t> epoch_begin;
-    // row groups (knobs.row_group_mb; single-epoch calls only): the class's rows -- numbered genome * nks + (k - kfirst) --
-    // in groups of group_rows; the scatter jobs of group i are jobs[group_begin[i] .. group_begin[i+1]), and the group's
-    // replay follows them at once, while its records are still in the 256 MiB memory-side cache.  Empty = one launch per epoch.
-    std::vector<size_t> group_begin;
-    int group_rows = 0;
 };
 
-// development knobs, read from the environment by from_env() (README.md lists them)
+// What the environment may change about a plan (README.md lists every knob): capacities, and the switches the tests use to
+// reach, on small inputs, the paths large inputs take (several epochs, a full record stream, the exact-set class).
 struct PlanKnobs {
-    size_t lds_budget = 80 * 1024;  // per workgroup: two 1024-thread workgroups (8 waves/SIMD) per CU
-    bool lds_budget_forced = false;
-    size_t jobs_per_cu = 32;
-    size_t jobs_per_row = 0;        // filtered mode; 0 = heuristic
-    int global_from_p = 17;         // registers stay in HBM from this log2m on (17: 22.8 Gbp/s through scatter + replay, 18.7 with one 128 KiB row per workgroup in LDS)
-    bool use_bitmaps = true, use_bigmaps = true, filter = true, xcd_affinity = true, taper = true;
-    bool bigmap_any_size = false;   // tests: the exact-set class whatever the genomes' sizes
-    // registers in HBM, two-phase: scatter (idx, rho) records into per-(row, index tile) buckets, replay
-    // each bucket into an LDS-resident tile (no global atomics); off = the filtered compare-and-swap path
-    bool buckets = true;
-    size_t bucket_e0_tiles = 0;     // tiles in the first epoch; 0 = four tokens per register (4 m / 65536), at least 8
-    size_t bucket_emax_tiles = 0;   // longest epoch; 0 = what the budget below allows, at most 256 tiles
-    size_t bucket_cap_chunks = 0;   // 64-record chunks per bucket; 0 = every token of the longest epoch fits
-    int bucket_logg = 0;            // registers per filter entry (log2) PLUS ONE; 0 = default (a 64 KiB filter)
-    int bucket_fbits = 0;           // bits per filter entry (8 or 4); 0 = 4
-    int bucket_probe = -1;          // second-level filter against the row itself: 1 / 0; -1 = default
-    size_t bucket_budget = (size_t)16 << 30;  // HBM for the record areas of one call
-    size_t bucket_slots = 8192;     // scatter jobs per (class, epoch) aimed at
-    size_t row_group_mb = 0;        // > 0: scatter -> replay per group of rows whose record areas sum to <= this (DD_ROW_GROUP_MB)
+    size_t bucket_e0_tiles = 0;     // DD_BUCKET_E0: tiles in the first epoch; 0 = four tokens per register (4 m / 65536), at least 8
+    size_t bucket_emax_tiles = 0;   // DD_BUCKET_EMAX: longest epoch; 0 = what the budget below allows, at most 256 tiles
+    size_t bucket_cap_chunks = 0;   // DD_BUCKET_CAP: 1024-record chunks per row's stream; 0 = every token of the first epoch fits
+    size_t bucket_budget = (size_t)16 << 30;  // DD_BUCKET_GB: HBM for the record areas of one call
+    bool bigmap_any_size = false;   // DD_BIGMAP_ANY_SIZE (tests): the exact-set class whatever the genomes' sizes
     static PlanKnobs from_env();
     bool operator==(const PlanKnobs& o) const {
-        return lds_budget == o.lds_budget && lds_budget_forced == o.lds_budget_forced && jobs_per_cu == o.jobs_per_cu &&
-               jobs_per_row == o.jobs_per_row && global_from_p == o.global_from_p && use_bitmaps == o.use_bitmaps && use_bigmaps == o.use_bigmaps && bigmap_any_size == o.bigmap_any_size &&
-               filter == o.filter && xcd_affinity == o.xcd_affinity && taper == o.taper && buckets == o.buckets &&
-               bucket_e0_tiles == o.bucket_e0_tiles && bucket_emax_tiles == o.bucket_emax_tiles &&
-               bucket_cap_chunks == o.bucket_cap_chunks && bucket_logg == o.bucket_logg && bucket_fbits == o.bucket_fbits && bucket_probe == o.bucket_probe &&
-               bucket_budget == o.bucket_budget && bucket_slots == o.bucket_slots && row_group_mb == o.row_group_mb;
+        return bucket_e0_tiles == o.bucket_e0_tiles && bucket_emax_tiles == o.bucket_emax_tiles && bucket_cap_chunks == o.bucket_cap_chunks &&
+               bucket_budget == o.bucket_budget && bigmap_any_size == o.bigmap_any_size;
     }
 };
 

@@ -65,11 +65,9 @@ DD_D void bit_slice(const uint32_t (&w)[8], uint32_t (&pl)[6]) {
 // fold of the current eight measured 2.43 ms where the d-major two-workgroup form took 2.11 and this one takes 1.82.)
 // DG: 16-byte groups of plane words a lane folds per prefix before it moves to the next prefix (one row address per DG
 // reads).
-// AHEAD: the waves that hold no chain -- (512 - orderings x thresholds) / 64 of the eight; the host asks for at least
-// two -- convert tile t + 1 into a second set of planes WHILE the chain waves scan tile t: one barrier per tile instead of
-// two, and the conversion (a quarter of the kernel's instructions, all VALU) runs under the scan (bound by what the LDS
-// returns, profiles/r04_k2_pscan_lds.txt).  The planes take twice the LDS, so tiles are half as long.
-template <int NMAX, int UPT, int DG, bool AHEAD>
+// (Converter waves running a tile ahead of the scan on a second set of planes were built and measured no better --
+// profiles/r04_k2_pscan_lds.txt; the kernel converts, then scans, a tile at a time.)
+template <int NMAX, int UPT, int DG>
 __global__ __launch_bounds__(PS_THREADS, 4) void pscan_kernel(const uint8_t* __restrict__ leaf, int n, int K, int p,
                                                            const int32_t* __restrict__ ord, int no, const uint32_t* __restrict__ rng,
                                                            int RR, int tiles_per_range, int D, int chain_pitch,
@@ -83,7 +81,7 @@ __global__ __launch_bounds__(PS_THREADS, 4) void pscan_kernel(const uint8_t* __r
     const int DP = D + 4;                        // words per (leaf, threshold) row: 16 consecutive rows start on 16 different banks
     uint32_t* planes = lds;
     const uint32_t set_words = (uint32_t)n * (uint32_t)T * (uint32_t)DP;      // one set of planes
-    uint8_t* ord_s = reinterpret_cast<uint8_t*>(lds + (size_t)set_words * (AHEAD ? 2 : 1));
+    uint8_t* ord_s = reinterpret_cast<uint8_t*>(lds + (size_t)set_words);
     for (int i = threadIdx.x; i < no * n; i += PS_THREADS) ord_s[i] = (uint8_t)ord[i];
     __syncthreads();
     // this lane's chain
@@ -106,35 +104,33 @@ __global__ __launch_bounds__(PS_THREADS, 4) void pscan_kernel(const uint8_t* __r
     const int tiles_total = tiles_per_range;     // (argument reused: all tiles of a row)
     const int tile0 = (int)(((long long)tiles_total * rr) / RR), ntiles = (int)(((long long)tiles_total * (rr + 1)) / RR) - tile0;
     const size_t reg0 = (size_t)tile0 * tile_regs;
-    // AHEAD: the converter waves are the last ones; converter thread x of nconv takes units x, x + nconv, ..
-    const int scan_waves = AHEAD ? (no * T + 63) / 64 : 0;
-    const int nconv = AHEAD ? PS_THREADS - 64 * scan_waves : PS_THREADS;
-    const int cx = AHEAD ? (int)threadIdx.x - 64 * scan_waves : (int)threadIdx.x;   // < 0: a chain wave
-    const bool converter = cx >= 0;
+    // every thread converts: thread x takes units x, x + PS_THREADS, ..
+    constexpr int nconv = PS_THREADS;
+    const int cx = (int)threadIdx.x;
     uint4 cur[UPT][2];
     auto load1 = [&](int q, int tile) {   // unit q of this thread, of `tile`
         // (threads past the last unit load the last unit again: with every load unconditional the compiler can count
         // them, and waits for the current tile's bytes with the next tile's loads still in flight)
-        int u = (converter ? cx : 0) + q * nconv;
+        int u = cx + q * nconv;
         u = u < units ? u : units - 1;
         const int g = u / D, d = u % D;
         const uint8_t* src = leaf + (((size_t)g * K + k) << p) + reg0 + (size_t)tile * tile_regs + (size_t)d * 32;
         cur[q][0] = gload16(src);
         cur[q][1] = gload16(src + 16);
     };
-    // ---- convert: bytes -> threshold planes of `tile` into plane set `set`
-    auto convert = [&](int tile, uint32_t set) {
+    // ---- convert: bytes -> threshold planes of `tile`
+    auto convert = [&](int tile) {
 #pragma unroll
         for (int q = 0; q < UPT; ++q) {
             const int u = cx + q * nconv;
-            if (converter && u < units) {
+            if (u < units) {
                 const uint32_t w[8] = {cur[q][0].x, cur[q][0].y, cur[q][0].z, cur[q][0].w, cur[q][1].x, cur[q][1].y, cur[q][1].z, cur[q][1].w};
                 uint32_t x[6], nx[6];
                 bit_slice(w, x);
                 load1(q, tile + 1 < ntiles ? tile + 1 : tile);   // (the bytes are sliced: their registers take those of the tile this thread converts next)
 #pragma unroll
                 for (int b = 0; b < 6; ++b) nx[b] = ~x[b];
-                uint32_t* dst = planes + (size_t)set * set_words + (size_t)(u / D) * T * DP + (u % D);   // [g][.][d]
+                uint32_t* dst = planes + (size_t)(u / D) * T * DP + (u % D);   // [g][.][d]
                 uint32_t le = 0;
 #pragma unroll
                 for (int v = 0; v < 64; ++v) {
@@ -150,19 +146,11 @@ __global__ __launch_bounds__(PS_THREADS, 4) void pscan_kernel(const uint8_t* __r
             }
         }
     };
-    if (converter) {
 #pragma unroll
-        for (int q = 0; q < UPT; ++q) load1(q, 0);
-    }
-    if (AHEAD) {
-        convert(0, 0);   // (tile 0 is converted with nothing to scan beside it)
-        __syncthreads();
-    }
+    for (int q = 0; q < UPT; ++q) load1(q, 0);
     for (int tile = 0; tile < ntiles; ++tile) {
-        const uint32_t set = AHEAD ? (uint32_t)(tile & 1) : 0u;
-        if (!AHEAD) convert(tile, 0);
-        else if (tile + 1 < ntiles) convert(tile + 1, set ^ 1u);   // (chain waves fall through: they have no units)
-        if (!AHEAD) __syncthreads();
+        convert(tile);
+        __syncthreads();
         // ---- scan: running AND along the ordering, one popcount per prefix
         // Prefix-major over chunks of DG 16-byte groups: a prefix's row address is computed once per chunk and its DG
         // reads carry their word offsets as immediates (the d-major form paid the byte extraction, a 64-bit multiply-add
@@ -176,7 +164,7 @@ __global__ __launch_bounds__(PS_THREADS, 4) void pscan_kernel(const uint8_t* __r
                 // (rows are read at their absolute LDS byte address -- the kernel's only LDS is the dynamic array, which
                 // then starts at 0, checked at the top -- so a row's address is ONE 24-bit multiply-add, full rate, where
                 // pointer arithmetic took a quarter-rate v_mul_lo_u32, a shift and an add)
-                const uint32_t at0 = 4u * (set * set_words + tDP + (uint32_t)d0), row_bytes = 4u * rowDP;
+                const uint32_t at0 = 4u * (tDP + (uint32_t)d0), row_bytes = 4u * rowDP;
                 auto row = [&](int j) {
                     uint32_t g = (gp[j >> 2] >> (8 * (j & 3))) & 0xffu;
                     asm volatile("" : "+v"(g));   // (keeps the 32 row offsets from being hoisted into 32 registers again)
@@ -265,11 +253,8 @@ static int pscan_words(int n, int T, size_t lds_limit) {
 
 // n <= 32: a lane keeps one count per prefix in registers; longer orderings take the streaming kernel.  log2m >= 18:
 // below that the streaming kernel is the faster one (10 orderings x 30 prefixes x 37 k, same box: 0.10 / 0.22 / 0.34 ms
-// against 0.17 / 0.21 / 0.35 at log2m 15 / 16 / 17; 0.70 / 1.57 / 3.15 against 0.61 / 1.07 / 2.11 at 18 / 19 / 20) --
-// DD_PROGRESSIVE_PSCAN=1 takes this path from log2m 12 on (tests).
-bool pscan_usable(int n, int no, int p) {
-    return p >= (getenv("DD_PROGRESSIVE_PSCAN") ? 12 : 18) && n >= 2 && n <= 32 && no >= 1;
-}
+// against 0.17 / 0.21 / 0.35 at log2m 15 / 16 / 17; 0.70 / 1.57 / 3.15 against 0.61 / 1.07 / 2.11 at 18 / 19 / 20).
+bool pscan_usable(int n, int no, int p) { return p >= 18 && n >= 2 && n <= 32 && no >= 1; }
 
 // scratch: the range pairs of every k, then the partial counts [k][range][prefix][chain]
 size_t pscan_scratch_bytes(int n, int K, int p, int no) {
@@ -290,14 +275,8 @@ bool launch_progressive_pscan(const uint8_t* leaf_dev, int n, int K, int p, cons
     if (fit < 1) return false;
     const int launches = (norder + fit - 1) / fit;
     const int group = (norder + launches - 1) / launches;
-    // DD_PSCAN_AHEAD=1|2: converter waves a tile ahead of the scan (1: two workgroups per CU, short tiles; 2: one workgroup per CU)
-    const int ahead = getenv("DD_PSCAN_AHEAD") ? atoi(getenv("DD_PSCAN_AHEAD")) : 0;
-    const int scan_waves = (group * Tmax + 63) / 64, nconv = PS_THREADS - 64 * scan_waves;
-    const bool use_ahead = ahead > 0 && nconv >= 128;
-    int D = pscan_words(n, Tmax, use_ahead ? (ahead == 2 ? (size_t)75 << 10 : (size_t)37 << 10) : (size_t)76 << 10);   // (two sets of planes when ahead)
-    if (use_ahead)
-        while (D > 4 && n * D > 3 * nconv) D >>= 1;   // at most three (leaf, word) units per converter thread
-    const size_t lds_bytes = (size_t)n * (D + 4) * Tmax * 4 * (use_ahead ? 2 : 1) + (((size_t)group * n + 15) & ~(size_t)15);
+    const int D = pscan_words(n, Tmax, (size_t)76 << 10);
+    const size_t lds_bytes = (size_t)n * (D + 4) * Tmax * 4 + (((size_t)group * n + 15) & ~(size_t)15);
     if (lds_bytes > ((size_t)158 << 10)) return false;
     const size_t m = (size_t)1 << p;
     const int tiles = (int)(m / ((size_t)32 * D));
@@ -311,27 +290,16 @@ bool launch_progressive_pscan(const uint8_t* leaf_dev, int n, int K, int p, cons
     const int pitch = PS_THREADS;
     for (int o0 = 0; o0 < norder; o0 += group) {
         const int no = std::min(group, norder - o0);
-#define DD_PSCAN_LAUNCH(NMAX, UPT, DG, AH)                                                                                                     \
+#define DD_PSCAN_LAUNCH(NMAX, UPT, DG)                                                                                                         \
     do {                                                                                                                                      \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pscan_kernel<NMAX, UPT, DG, AH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
-        hipLaunchKernelGGL((pscan_kernel<NMAX, UPT, DG, AH>), dim3((unsigned)(K * RR)), dim3(PS_THREADS), lds_bytes, st, leaf_dev, n, K, p,    \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pscan_kernel<NMAX, UPT, DG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+        hipLaunchKernelGGL((pscan_kernel<NMAX, UPT, DG>), dim3((unsigned)(K * RR)), dim3(PS_THREADS), lds_bytes, st, leaf_dev, n, K, p,        \
                            ord_dev + (size_t)o0 * n, no, rng, RR, tiles_per_range, D, pitch, part);                                           \
     } while (0)
         // (D = 4, 8, 16 or 32 plane words per row: one or two 16-byte groups per chunk of the scan; four groups -- 16
         // running ANDs beside the 32 counts -- spill)
-        if (use_ahead) {
-            const int upt = (n * D + nconv - 1) / nconv;
-            if (D >= 8) {
-                if (upt <= 1) DD_PSCAN_LAUNCH(32, 1, 2, true);
-                else if (upt == 2) DD_PSCAN_LAUNCH(32, 2, 2, true);
-                else DD_PSCAN_LAUNCH(32, 3, 2, true);
-            } else {
-                if (upt <= 1) DD_PSCAN_LAUNCH(32, 1, 1, true);
-                else if (upt == 2) DD_PSCAN_LAUNCH(32, 2, 1, true);
-                else DD_PSCAN_LAUNCH(32, 3, 1, true);
-            }
-        } else if (D >= 8) DD_PSCAN_LAUNCH(32, 1, 2, false);
-        else DD_PSCAN_LAUNCH(32, 1, 1, false);
+        if (D >= 8) DD_PSCAN_LAUNCH(32, 1, 2);
+        else DD_PSCAN_LAUNCH(32, 1, 1);
 #undef DD_PSCAN_LAUNCH
         const size_t jobs = (size_t)no * n * K;
         hipLaunchKernelGGL(pscan_finish_kernel, dim3((unsigned)((jobs + 3) / 4)), dim3(256), 0, st, part, n, K, p, no, rng, RR, pitch,

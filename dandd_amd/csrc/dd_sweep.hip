@@ -160,94 +160,13 @@ DD_D void raise(const R&, typename R::Addr a, const Probe& q, int p) {
     (void)cas_raise<R>(a, R::load32(a), rho_of(q, p));
 }
 
-// ---- log2m >= 18: registers in HBM behind an LDS filter and a candidate queue -----------------------
-// One array (256 KiB .. 1 MiB) no longer fits LDS, and checking every update against HBM/L2 costs one
-// L2 request per LANE (a wave's 64 registers are 64 different lines): measured 243 cycles per
-// wave-update per CU, 7x the VALU time.  Registers only ever rise, so ANY value a register group was
-// once seen to have is a lower bound for ever: LDS keeps, per group of G = 2^LOGG adjacent registers
-// (4..16: one aligned 4..16-byte load), the minimum the group was last seen with.  rho <= that bound
-// proves the update changes nothing -- the common case touches LDS only.
-// The few updates that pass the filter are not applied on the spot (a 2 us memory round trip for one
-// or two lanes of the wave, once per token: measured latency-bound at 600 cycles per update) but
-// queued per wave in LDS as (register, rho); whenever 64 are waiting the whole wave applies them at
-// once: each lane loads its group (one request), raises its register by CAS if needed, and stores the
-// group's new minimum.  A stale or racing bound is merely lower than it could be, never wrong.
-constexpr uint32_t kQueueEntries = 128;  // per wave; a push adds <= 64 to < 64 waiting
+// (log2m >= 17: the registers stay in HBM and are reached through record streams -- scatter + sort + replay, below)
+constexpr uint32_t kQueueEntries = 128;  // per wave and queue (scatter_kernel); a push adds <= 64 to < 64 waiting
 DD_D uint32_t min4(uint32_t w) {  // smallest byte
     const uint32_t a = w & 0xFFu, b = (w >> 8) & 0xFFu, c = (w >> 16) & 0xFFu, d = w >> 24;
     const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
     return ab < cd ? ab : cd;
 }
-template <int LOGG>
-struct RegsFiltered {
-    uint8_t* base;    // the k's register row in HBM, 16-byte aligned; filter byte i covers registers i<<LOGG ..
-    uint32_t queue;   // byte offset of this wave's candidate queue in g_lds
-};
-// apply one (register, rho): exact byte-max in HBM, then raise the group's bound
-template <int LOGG>
-DD_D void filtered_apply(const RegsFiltered<LOGG>& regs, uint32_t idx, uint32_t rho) {
-    constexpr uint32_t G = 1u << LOGG, NW = G / 4;
-    uint8_t* const grp = regs.base + (idx & ~(G - 1u));
-    uint32_t w[NW];
-    // Plain loads, served by this XCD's L2 (the job order gives every row to one XCD): a quarter of the
-    // latency of a memory-side read.  Should the line be stale the values are only LOWER than the truth:
-    // the CAS then fails once and returns the real word, and the bound stored below is still a bound.
-    if (NW == 1) {
-        w[0] = gload4(grp);
-    } else if (NW == 2) {
-        const uint2 v = gload8(grp);
-        w[0] = v.x, w[1] = v.y;
-    } else {
-        const uint4 v = gload16(grp);
-        w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
-    }
-    const uint32_t wi = (idx & (G - 1u)) >> 2;  // this lane's word inside the group
-    uint32_t mine = w[0];
-#pragma unroll
-    for (uint32_t i = 1; i < NW; ++i) mine = (wi == i) ? w[i] : mine;
-    const uint32_t fin = cas_raise<RegsGlobal>(regs.base + idx, mine, rho);  // the register afterwards, >= rho
-    // group minimum with this register at its new value (the others as just seen: still lower bounds)
-    const uint32_t sh = (idx & 3u) * 8u;
-    const uint32_t upd = (mine & ~(0xFFu << sh)) | (fin << sh);
-    uint32_t lo = 0xFFu;
-#pragma unroll
-    for (uint32_t i = 0; i < NW; ++i) {
-        const uint32_t m = min4(wi == i ? upd : w[i]);
-        lo = m < lo ? m : lo;
-    }
-    if (lo > g_lds[idx >> LOGG]) g_lds[idx >> LOGG] = (uint8_t)lo;
-}
-// lanes 0..n-1 apply queue entries first..first+n-1 (called with the whole wave converged)
-template <int LOGG>
-DD_D void filtered_drain(const RegsFiltered<LOGG>& regs, uint32_t first, uint32_t n) {
-    const uint32_t lane = threadIdx.x & 63u;
-    if (lane < n) {
-        const uint32_t e = *reinterpret_cast<const uint32_t*>(g_lds + regs.queue + 4u * (first + lane));
-        const uint32_t idx = e & 0xFFFFFFu, rho = e >> 24;
-        if (rho > g_lds[idx >> LOGG]) filtered_apply(regs, idx, rho);  // the bound may have risen since
-    }
-}
-// One update; must be reached by every lane of the wave (`valid` says whether the lane has a k-mer):
-// `waiting` (entries in this wave's queue) has to stay wave-uniform.
-template <int LOGG>
-DD_D void filtered_update(const RegsFiltered<LOGG>& regs, uint32_t& waiting, uint64_t h, int p, bool valid) {
-    const Probe q = probe(h, p);
-    const uint32_t idx = q.hi >> (32 - p);
-    const bool cand = valid && q.lz >= g_lds[idx >> LOGG];  // rho > bound, or hiw == 0
-    const unsigned long long mask = __ballot(cand);
-    if (mask) {
-        if (cand) {
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            *reinterpret_cast<uint32_t*>(g_lds + regs.queue + 4u * (waiting + rank)) = idx | (rho_of(q, p) << 24);
-        }
-        waiting += (uint32_t)__builtin_popcountll(mask);
-        if (waiting >= 64u) {
-            waiting -= 64u;
-            filtered_drain(regs, waiting, 64u);
-        }
-    }
-}
-
 // reg[h >> (64-p)] = max(., rho(h)); the common case (no change) is one byte read + compare.
 template <typename R>
 DD_D void hll_update(const R& regs, uint64_t h, int p) {
@@ -281,7 +200,7 @@ DD_D uint64_t pack64(uint32_t hi, uint32_t lo) { return ((uint64_t)hi << 32) | l
 // words), computed with a handful of bit operations instead of 64 pushes.  The reverse-complement
 // window holds tokens in stream order, newest on top, so it is simply the complement of the words.
 //   KC 0: k <= 16 (32-bit windows)   KC 1: 16 <= k <= 32 (64-bit)   KC 3: 33 <= k <= 48 (96-bit: 64 + 32)
-//   KC 2: 49 <= k <= 64 (128-bit)
+//   KC 2: 49 <= k <= 64 (128-bit: Windows<7>, four 32-bit words)
 template <int KC>
 struct Windows;
 
@@ -353,39 +272,6 @@ struct Windows<5> {
         if (!CANON) return wang64_fast<false>(f);
         const uint64_t r = pack64(rh, rl) >> (64 - 2 * k);
         return wang64_fast<false>(f < r ? f : r);
-    }
-};
-
-template <>
-struct Windows<2> {
-    uint64_t fh = 0, fl = 0, rh = 0, rl = 0;
-    DD_D void prime(const uint4& hc) {
-        fl = pack64(pairrev32(hc.z), pairrev32(hc.w));
-        fh = pack64(pairrev32(hc.x), pairrev32(hc.y));
-        rh = ~pack64(hc.w, hc.z);
-        rl = ~pack64(hc.y, hc.x);
-    }
-    DD_D void push(uint32_t c) {
-        fh = (fh << 2) | (fl >> 62);
-        fl = (fl << 2) | c;
-        rl = (rl >> 2) | (rh << 62);
-        rh = (rh >> 2) | ((uint64_t)(3u - c) << 62);
-    }
-    template <bool CANON>
-    DD_D uint64_t hash(int k) const {  // 49 <= k <= 64 (33..48 is Windows<3>)
-        // the k-mer covers all of fl and the low word of fh: only the top word is masked, and the
-        // reverse complement comes down by 128 - 2k <= 30 bits: one 32-bit funnel shift per word
-        const int hb = 2 * k - 96;  // bits of the k-mer in the top word, 2..32
-        const uint32_t mh = (hb == 32) ? ~0u : ((1u << hb) - 1u);
-        const uint64_t ah = pack64((uint32_t)(fh >> 32) & mh, (uint32_t)fh);
-        const uint64_t al = fl;
-        if (!CANON) return wang64_fast<false>(fold128(ah, al));
-        const uint32_t s = 128u - 2u * (uint32_t)k;  // 0..30
-        const uint32_t r3 = (uint32_t)(rh >> 32), r2 = (uint32_t)rh, r1 = (uint32_t)(rl >> 32), r0 = (uint32_t)rl;
-        const uint64_t bh = pack64(r3 >> s, __builtin_amdgcn_alignbit(r3, r2, s));
-        const uint64_t bl = pack64(__builtin_amdgcn_alignbit(r2, r1, s), __builtin_amdgcn_alignbit(r1, r0, s));
-        const bool f_lt = (ah < bh) | ((ah == bh) & (al < bl));  // bitwise: no exec-mask short circuit
-        return wang64_fast<false>(fold128(f_lt ? ah : bh, f_lt ? al : bl));
     }
 };
 
@@ -499,7 +385,7 @@ struct Windows<7> {
         r3 = (r3 >> 2) | ((3u - c) << 30);
     }
     template <bool CANON>
-    DD_D uint64_t hash(int k) const {  // 49 <= k <= 64, as Windows<2>
+    DD_D uint64_t hash(int k) const {  // 49 <= k <= 64
         const int hb = 2 * k - 96;  // bits of the k-mer in the top word, 2..32
         const uint32_t mh = (hb == 32) ? ~0u : ((1u << hb) - 1u);
         const uint64_t ah = pack64(f3 & mh, f2);
@@ -530,11 +416,8 @@ DD_D void sweep_token(const Win& win, int run, int kfirst, int nk, int p, const 
     if (j < nk && (!CHECK || run >= kfirst + j)) hll_update(slot(j), win.template hash<CANON>(kfirst + j), p);
 }
 
-// MODE 0      : registers of the group live in LDS (2^p * nk bytes <= 160 KiB).
-// MODE 1      : registers are updated in place in the genome's HBM slab, every update checked there.
-// MODE 2, 3, 4: in place behind an LDS filter of one byte per 2^MODE registers (RegsFiltered), one k
-//               per workgroup.
-template <int KC, bool CANON, int MODE>
+// The registers of the job's k-group live in LDS (2^p * nk bytes <= 160 KiB): log2m <= 16.
+template <int KC, bool CANON>
 __global__ __launch_bounds__(1024) void sweep_kernel(const SweepGenome* __restrict__ genomes,
                                                     const SweepJob* __restrict__ jobs, int p) {
     lds_starts_at_zero();
@@ -571,23 +454,7 @@ __global__ __launch_bounds__(1024) void sweep_kernel(const SweepGenome* __restri
     TileIn next;
     fetch(job.tile_begin, next);
 
-    if (MODE >= 2) {
-        // filter = per-group minimum of the row as it stands (any snapshot is a valid lower bound)
-        constexpr int LOGG = MODE >= 2 ? MODE : 2;
-        for (uint32_t i = threadIdx.x; i < (m >> 4); i += blockDim.x) {
-            const uint4 v = load16_fresh(slab + (size_t)i * 16);
-            const uint32_t m0 = min4(v.x), m1 = min4(v.y), m2 = min4(v.z), m3 = min4(v.w);
-            if (LOGG == 2) {
-                reinterpret_cast<uint32_t*>(g_lds)[i] = m0 | (m1 << 8) | (m2 << 16) | (m3 << 24);
-            } else if (LOGG == 3) {
-                reinterpret_cast<uint16_t*>(g_lds)[i] = (uint16_t)((m0 < m1 ? m0 : m1) | ((m2 < m3 ? m2 : m3) << 8));
-            } else {
-                const uint32_t a = m0 < m1 ? m0 : m1, b = m2 < m3 ? m2 : m3;
-                g_lds[i] = (uint8_t)(a < b ? a : b);
-            }
-        }
-    }
-    if (MODE == 0) {
+    {
         // Warm start: begin from whatever earlier jobs have already merged into the slab.  Any
         // (possibly stale) snapshot is a valid lower bound of the final registers, and a warm
         // array makes the "register rises" path rare: after T tokens have been absorbed only
@@ -603,18 +470,11 @@ __global__ __launch_bounds__(1024) void sweep_kernel(const SweepGenome* __restri
 
     const int kmaxg = kfirst + nk - 1;
     auto lds_slot = [](int j) { return RegsLds{(uint32_t)j}; };
-    auto glb_slot = [slab, p](int j) { return RegsGlobal{slab + ((size_t)j << p)}; };
-    // filtered mode: one k per job; LDS = filter (m >> LOGG bytes) then one candidate queue per wave
-    constexpr int LOGG = MODE >= 2 ? MODE : 2;
-    const RegsFiltered<LOGG> flt{slab, (m >> LOGG) + (threadIdx.x >> 6) * (kQueueEntries * 4u)};
-    uint32_t waiting = 0;
 
     for (unsigned tile = job.tile_begin; tile < job.tile_end; ++tile) {
         const TileIn cur = next;
         fetch(tile + 1, next);
-        // (filtered mode keeps dead lanes in the loop, as all-BREAK segments: its queue counter must
-        // stay wave-uniform)
-        if (!cur.live && MODE < 2) continue;
+        if (!cur.live) continue;
         const uint4 hc = cur.hc, sc = cur.sc;
         const uint2 hb = cur.hb, sb = cur.sb;
         const uint32_t cw[4] = {sc.x, sc.y, sc.z, sc.w};
@@ -630,9 +490,7 @@ __global__ __launch_bounds__(1024) void sweep_kernel(const SweepGenome* __restri
 #pragma unroll 1
                 for (int i = 0; i < 16; ++i) {
                     win.push((cw[w] >> (2 * i)) & 3u);
-                    if (MODE >= 2) filtered_update(flt, waiting, win.template hash<CANON>(kfirst), p, true);
-                    else if (MODE == 1) sweep_token<KC, CANON, false>(win, 0, kfirst, nk, p, glb_slot);
-                    else sweep_token<KC, CANON, false>(win, 0, kfirst, nk, p, lds_slot);
+                    sweep_token<KC, CANON, false>(win, 0, kfirst, nk, p, lds_slot);
                 }
             }
             continue;
@@ -648,41 +506,31 @@ __global__ __launch_bounds__(1024) void sweep_kernel(const SweepGenome* __restri
                 run = ((bw >> i) & 1u) ? 0 : run + 1;
                 win.push(c);
                 // wave-uniform fast path: no lane of the wave is within kmaxg tokens of a BREAK
-                if (__all(run >= kmaxg)) {
-                    if (MODE >= 2) filtered_update(flt, waiting, win.template hash<CANON>(kfirst), p, true);
-                    else if (MODE == 1) sweep_token<KC, CANON, false>(win, run, kfirst, nk, p, glb_slot);
-                    else sweep_token<KC, CANON, false>(win, run, kfirst, nk, p, lds_slot);
-                } else {
-                    if (MODE >= 2) filtered_update(flt, waiting, win.template hash<CANON>(kfirst), p, run >= kfirst);
-                    else if (MODE == 1) sweep_token<KC, CANON, true>(win, run, kfirst, nk, p, glb_slot);
-                    else sweep_token<KC, CANON, true>(win, run, kfirst, nk, p, lds_slot);
-                }
+                if (__all(run >= kmaxg)) sweep_token<KC, CANON, false>(win, run, kfirst, nk, p, lds_slot);
+                else sweep_token<KC, CANON, true>(win, run, kfirst, nk, p, lds_slot);
             }
         }
     }
-    if (MODE >= 2) filtered_drain(flt, 0u, waiting);  // what is still queued (< 64 entries)
     __syncthreads();
 
     // merge the group's registers into the genome's slab (rows krow .. krow+nk-1 are contiguous)
-    if (MODE == 0) {
-        const uint4* l4 = reinterpret_cast<const uint4*>(g_lds);
-        uint32_t* gw = reinterpret_cast<uint32_t*>(slab);
-        const uint32_t n16 = (uint32_t)nk * (m >> 4);
-        for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) {
-            const uint4 lv = l4[i];
-            const uint4 gv = load16_fresh(slab + (size_t)i * 16);
-            const uint32_t l[4] = {lv.x, lv.y, lv.z, lv.w};
-            const uint32_t o[4] = {gv.x, gv.y, gv.z, gv.w};
+    const uint4* l4 = reinterpret_cast<const uint4*>(g_lds);
+    uint32_t* gw = reinterpret_cast<uint32_t*>(slab);
+    const uint32_t n16 = (uint32_t)nk * (m >> 4);
+    for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) {
+        const uint4 lv = l4[i];
+        const uint4 gv = load16_fresh(slab + (size_t)i * 16);
+        const uint32_t l[4] = {lv.x, lv.y, lv.z, lv.w};
+        const uint32_t o[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                uint32_t old = o[q];
-                uint32_t mx = bmax4(old, l[q]);
-                while (mx != old) {
-                    uint32_t prev = gcas32(&gw[4 * i + q], old, mx);
-                    if (prev == old) break;
-                    old = prev;
-                    mx = bmax4(old, l[q]);
-                }
+        for (int q = 0; q < 4; ++q) {
+            uint32_t old = o[q];
+            uint32_t mx = bmax4(old, l[q]);
+            while (mx != old) {
+                uint32_t prev = gcas32(&gw[4 * i + q], old, mx);
+                if (prev == old) break;
+                old = prev;
+                mx = bmax4(old, l[q]);
             }
         }
     }
@@ -1033,39 +881,32 @@ struct RowSet {
 constexpr uint32_t kChunkRecords = 1024;         // 4 KiB; one global atomic hands out one chunk of the row's stream
 
 struct Scatter {
-    uint32_t queue;        // byte offset in g_lds of this wave's record queue (kQueueEntries x 4 B)
+    uint32_t queue;        // byte offset in g_lds of this wave's two record queues (2 x kQueueEntries x 4 B)
     uint32_t* area;        // the row's record stream, chunk c at area + c * kChunkRecords
     uint32_t* cursor;      // records reserved so far (may run past the capacity: readers clamp)
-    uint32_t* fill;        // first epoch, chunks sorted on the way out: non-null records per chunk ...
-    uint16_t* seg;         // ... and where each index tile's segment starts (as sort_chunks_kernel leaves them)
-    int tshift, nb, nb_log2;  // index tile of a record = idx >> tshift; tiles per row
-    uint8_t* regs;         // the row itself: where records go when the stream is full
+    uint8_t* regs;         // the row itself: what candidates are probed against, and where records go when the stream is full
     uint32_t cap_chunks;
-    uint32_t unit;         // records a wave reserves at a time (a multiple of 64)
     int fshift;            // hash high word >> fshift = index of the register group's filter entry (32 - p + logg)
     int ishift;            // hash high word >> ishift = register index (32 - p)
     uint32_t himask;       // the index bits of the hash high word
-    uint32_t fbase;        // byte offset in g_lds of this k's filter
 };
+constexpr uint32_t kScatterUnit = 256;  // records a wave reserves at a time (a multiple of 64)
 DD_D uint32_t& lds32(uint32_t off) { return *reinterpret_cast<uint32_t*>(g_lds + off); }
 DD_D uint32_t gadd32(void* p, uint32_t v) {
     return __hip_atomic_fetch_add((DD_GLOBAL uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // 64 records (one per lane; null records have rho 0) leave for the row's stream.  The stream is DENSE: the row's
-// cursor counts records, every block is reserved by one atomic add of its own 64 (first epoch: 1024 at a time,
-// `cur` / `left` = the wave's reservation), so the 1024-record chunks the sort and the replay work on are all
-// full whatever the job sizes were.  (Round 2's first form gave every wave of every job a chunk of its own:
-// 4.4 M chunks per log2m 20 step for 1.7 G records, i.e. 38 % full, and the replay's per-tile segments 30 records
-// long.)  Whole waves, uniform state.
-template <bool FIRST>
+// cursor counts records, a wave reserves kScatterUnit of them with one atomic add (`cur` / `left` = its reservation), so
+// the 1024-record chunks the sort and the replay work on are all full whatever the job sizes were.  (Round 2's first
+// form gave every wave of every job a chunk of its own: 4.4 M chunks per log2m 20 step for 1.7 G records, i.e. 38 % full,
+// and the replay's per-tile segments 30 records long.)  Whole waves, uniform state.
 DD_D void scatter_block(const Scatter& s, uint32_t rec, uint32_t& cur, uint32_t& left) {
     const uint32_t lane = threadIdx.x & 63u;
     if (left == 0u) {
-        const uint32_t unit = FIRST ? kChunkRecords : s.unit;
         uint32_t c = 0;
-        if (lane == 0) c = gadd32(s.cursor, unit);
+        if (lane == 0) c = gadd32(s.cursor, kScatterUnit);
         cur = __builtin_amdgcn_readfirstlane(c);
-        left = unit / 64u;
+        left = kScatterUnit / 64u;
     }
     const uint32_t pos = cur;
     cur += 64u;
@@ -1080,69 +921,7 @@ DD_D void scatter_block(const Scatter& s, uint32_t rec, uint32_t& cur, uint32_t&
     }
     gstore4(s.area + pos + lane, rec);
 }
-// First epoch, rows of several index tiles: the wave collects its records in LDS (4 KiB at `s.queue`, 256 bytes of
-// counters behind it) and sends every 1024 of them out as one chunk ALREADY sorted by index tile, segment table
-// and record count included -- what sort_chunks_kernel would otherwise do in a pass of its own that reads and
-// writes every record once more (the first epoch holds 60 % of a 10 x 50 Mbp call's records at log2m 20 and
-// nearly all of a 64 x 5 Mbp call's, and those calls are bound by the records' HBM traffic).
-DD_D void scatter_flush_sorted(const Scatter& s, uint32_t& n) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t have = n;
-    n = 0;
-    uint32_t pos = 0;
-    if (lane == 0) pos = gadd32(s.cursor, kChunkRecords);
-    pos = __builtin_amdgcn_readfirstlane(pos);
-    auto record = [&](int i) { return ((uint32_t)i * 64u + lane < have) ? lds32(s.queue + 4u * ((uint32_t)i * 64u + lane)) : 0u; };
-    if (pos + kChunkRecords > s.cap_chunks * kChunkRecords) {
-        // the stream is full: the records go to their registers directly (exact, slow, rare)
-#pragma unroll 1
-        for (int i = 0; i < 16; ++i) {
-            const uint32_t e = record(i);
-            if (e >> 24) {
-                uint8_t* a = s.regs + (e & 0xFFFFFFu);
-                (void)cas_raise<RegsGlobal>(a, RegsGlobal::load32(a), e >> 24);
-            }
-        }
-        if (lane < 16) lds32(s.queue + kChunkRecords * 4u + 4u * lane) = 0;
-        __builtin_amdgcn_wave_barrier();
-        return;
-    }
-    // (two passes over the collection area, a record in flight at a time: holding all 16 of a lane in registers,
-    // as sort_chunks_kernel does, costs this kernel its second workgroup per CU)
-    // 16 counters = (tile, copy): with fewer than 16 tiles per row a lane counts in copy `lane % (16 / tiles)`, so the
-    // 64 lanes of an LDS atomic always spread over 16 addresses (same-address lanes are served one after the other:
-    // 4 tiles = 4 addresses cost 64 x 5 Mbp at log2m 18 6 %; 64 addresses, tried at log2m 20, were SLOWER than 16)
-    const uint32_t hist = s.queue + kChunkRecords * 4u;
-    const int cshift = 4 - s.nb_log2;  // log2 copies
-    const uint32_t copy = lane & ((1u << cshift) - 1u);
-    __builtin_amdgcn_wave_barrier();  // (the counters were kept by scatter_update as the records came in)
-    const uint32_t mine = lane < 16 ? lds32(hist + 4u * lane) : 0u;  // entry `lane` = (tile lane >> cshift, copy)
-    uint32_t incl = mine;
-#pragma unroll
-    for (int d = 1; d < 16; d <<= 1) {
-        const uint32_t up = __shfl_up(incl, d);
-        if (lane >= (uint32_t)d) incl += up;
-    }
-    const uint32_t total = __shfl(incl, 15);
-    const uint32_t chunk = pos / kChunkRecords;
-    __builtin_amdgcn_wave_barrier();
-    if (lane < 16) {
-        lds32(hist + 4u * lane) = incl - mine;
-        if (copy == 0u) ((DD_GLOBAL uint16_t*)s.seg)[(size_t)chunk * 16u + (lane >> cshift)] = (uint16_t)(incl - mine);
-    }
-    __builtin_amdgcn_wave_barrier();
-    // the chunk's 4 KiB are written by this wave within a few hundred cycles: the 4-byte stores meet in the L2
-#pragma unroll 4
-    for (int i = 0; i < 16; ++i) {
-        const uint32_t e = record(i);
-        if (e >> 24) gstore4(s.area + pos + atomicAdd(&lds32(hist + 4u * ((((e & 0xFFFFFFu) >> s.tshift) << cshift) | copy)), 1u), e);
-    }
-    if (lane == 0) gstore4(s.fill + chunk, total);
-    __builtin_amdgcn_wave_barrier();
-    if (lane < 16) lds32(hist + 4u * lane) = 0;  // for the next chunk's records
-    __builtin_amdgcn_wave_barrier();
-}
-// Second-level filter (PROBE): 64 queued candidates are checked against the ROW ITSELF -- one byte load per
+// Second-level filter: 64 queued candidates are checked against the ROW ITSELF -- one byte load per
 // lane from the registers as the last replay left them (the row of the jobs an XCD is running stays in that
 // XCD's L2: job order, dd_plan.hip) -- and only those that really exceed their register move on to a second
 // queue and, 64 at a time, to the stream.  The group-minimum filter lets ~25 % of the updates through at log2m
@@ -1164,67 +943,40 @@ DD_D void scatter_probe(const Scatter& s, uint32_t cand, uint32_t& waiting2, uin
         waiting2 += (uint32_t)__builtin_popcountll(mask);
         if (waiting2 >= 64u) {
             waiting2 -= 64u;
-            scatter_block<false>(s, lds32(s.queue + kQueueEntries * 4u + 4u * (waiting2 + (threadIdx.x & 63u))), cur, left);
+            scatter_block(s, lds32(s.queue + kQueueEntries * 4u + 4u * (waiting2 + (threadIdx.x & 63u))), cur, left);
         }
     }
 }
 // One update.  Reached by whole waves (`valid`: the lane has a k-mer); `waiting`, `waiting2`, `cur` are wave-uniform.
-// NIB: the filter holds 4-bit bounds (saturating at 15), two register groups per byte -- twice the resolution
-// in the same 64 KiB of LDS for three more instructions per update.
-// FIRST: the call's first epoch -- every register is still zero, so every update is a record: no filter, no
-// queues, the wave's 64 records (null where a lane has no k-mer) leave as a block at once.
-template <bool NIB, bool PROBE, bool FIRST>
+// The filter holds 4-bit bounds (saturating at 15), two register groups per byte: twice the resolution of byte entries
+// in the same 64 KiB of LDS for three more instructions per update (measured better at log2m 18, 19 and 20).
 DD_D void scatter_update(const Scatter& s, uint32_t& waiting, uint32_t& waiting2, uint32_t& cur, uint32_t& left, uint64_t h, int p, bool valid) {
     const Probe q = probe(h, p);
-    if (FIRST) {
-        const uint32_t rec = valid ? (q.hi >> (32 - p)) | (rho_of(q, p) << 24) : 0u;
-        if (NIB) {  // (first-epoch kernels have no filter: the flag selects chunks sorted on the way out, `cur` = records collected)
-            lds32(s.queue + 4u * (cur + (threadIdx.x & 63u))) = rec;
-            // counted here, between the hashes, rather than in a pass of the flush: the same LDS atomics, but not in one
-            // burst with every other wave of the CU doing the same, and without re-reading the records
-            if (valid) atomicAdd(&lds32(s.queue + kChunkRecords * 4u + 4u * (((q.hi >> (32 - p + s.tshift)) << (4 - s.nb_log2)) | ((threadIdx.x & 63u) & ((1u << (4 - s.nb_log2)) - 1u)))), 1u);
-            cur += 64u;
-            if (cur == kChunkRecords) scatter_flush_sorted(s, cur);
-        } else {
-            scatter_block<true>(s, rec, cur, left);
-        }
-        return;
-    }
-    uint32_t bound;
-    if (NIB) {
-        // entry e = hi >> fshift sits in nibble e & 1 of byte e >> 1: address and nibble shift straight from hi (three
-        // instructions instead of five; fshift >= 32 - 20 + 1).  The byte is read at its absolute LDS address: this
-        // kernel has no static LDS, so the dynamic array starts at 0 (checked when the job starts), and going through
-        // the g_lds symbol costs a v_add of its link-time address, 0, on every update.
-        const uint32_t at = s.fbase + (q.hi >> (s.fshift + 1));
-        bound = __builtin_amdgcn_ubfe((uint32_t)*(const __attribute__((address_space(3))) uint8_t*)(uintptr_t)at, (q.hi >> (s.fshift - 2)) & 4u, 4u);
-    } else {
-        bound = g_lds[s.fbase + (q.hi >> s.fshift)];
-    }
+    // entry e = hi >> fshift sits in nibble e & 1 of byte e >> 1: address and nibble shift straight from hi (three
+    // instructions instead of five; fshift >= 32 - 20 + 1).  The byte is read at its absolute LDS address: this
+    // kernel has no static LDS, so the dynamic array starts at 0 (checked when the job starts), and going through
+    // the g_lds symbol costs a v_add of its link-time address, 0, on every update.
+    const uint32_t at = q.hi >> (s.fshift + 1);
+    const uint32_t bound = __builtin_amdgcn_ubfe((uint32_t)*(const __attribute__((address_space(3))) uint8_t*)(uintptr_t)at, (q.hi >> (s.fshift - 2)) & 4u, 4u);
     const bool cand = valid && q.lz >= bound;  // rho > bound (or hiw == 0: rho >= 33)
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(cand);
     if (mask) {
         if (cand) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            lds32(s.queue + 4u * (waiting + rank)) = PROBE ? (q.hi & s.himask) | (rho_of(q, p) - 1u)  // (scatter_probe's form)
-                                                           : (q.hi >> (32 - p)) | (rho_of(q, p) << 24);
+            lds32(s.queue + 4u * (waiting + rank)) = (q.hi & s.himask) | (rho_of(q, p) - 1u);  // (scatter_probe's form)
         }
         waiting += (uint32_t)__builtin_popcountll(mask);
         if (waiting >= 64u) {
             waiting -= 64u;
-            const uint32_t rec = lds32(s.queue + 4u * (waiting + (threadIdx.x & 63u)));
-            if (PROBE) scatter_probe(s, rec, waiting2, cur, left);
-            else scatter_block<false>(s, rec, cur, left);
+            scatter_probe(s, lds32(s.queue + 4u * (waiting + (threadIdx.x & 63u))), waiting2, cur, left);
         }
     }
 }
 
-// NK = ks per job.  NK = 1 is what runs: two consecutive ks per job (shared token loads and window push, 7 of the
-// ~50 VALU instructions of an update) measured SLOWER on MI355X both with two 64 KiB filters = one workgroup per CU
-// (35.1 / 40.7 / 49.4 ms against 28.2 / 33.2 / 43.3 at log2m 18 / 19 / 20, profiles/r02_bucket_path.txt) and with
-// two 16 KiB filters at two workgroups per CU (29.2 against 27.4 ms at log2m 20, profiles/r03_bucket_path.txt).
-// NK = 2 is instantiated for nibble filter + row probe only and reached through DD_BUCKET_NK=2 (A/B runs, tests).
-template <int KC, bool CANON, bool NIB, bool PROBE, int NK, bool FIRST = false>
+// The filtered epochs' scatter: one k per job.  (Two consecutive ks per job -- shared token loads and window push, 7 of the
+// ~50 VALU instructions of an update -- measured SLOWER on MI355X both with two 64 KiB filters = one workgroup per CU and
+// with two 16 KiB filters at two workgroups per CU: profiles/r02_bucket_path.txt, profiles/r03_bucket_path.txt.)
+template <int KC, bool CANON>
 __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __restrict__ genomes,
                                                       const SweepJob* __restrict__ jobs, int p, ScatterParams sp) {
     const SweepJob job = jobs[blockIdx.x];
@@ -1232,10 +984,9 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
     lds_starts_at_zero();  // scatter_update reads the filter at absolute LDS addresses
     const SweepGenome g = genomes[job.genome];
     const int k = job.kfirst;
-    const bool two = NK == 2 && job.nk == 2;
     const uint32_t m = 1u << p;
     const unsigned long long ntok = gload8u(g.ntok);
-    const uint32_t nflt = (m >> sp.logg) >> (NIB ? 1 : 0);  // bytes per filter
+    const uint32_t nflt = (m >> sp.logg) >> 1;  // bytes of the filter
 
     struct TileIn {
         uint4 hc, sc;
@@ -1260,38 +1011,23 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
     TileIn next;
     fetch(job.tile_begin, next);
 
-    // each row's filter as the previous epoch's replay left it (plain loads: written by an earlier kernel),
+    // the row's filter as the previous epoch's replay left it (plain loads: written by an earlier kernel) at LDS offset 0,
     // then the per-wave queues
-    Scatter s[NK];
-    uint32_t waiting[NK], waiting2[NK], cur[NK], left[NK];
-#pragma unroll
-    for (int j = 0; j < NK; ++j) {
-        const BucketRow row = sp.rows[(size_t)job.genome * sp.K + job.krow + ((j == 0 || two) ? j : 0)];
-        if (!FIRST && (j == 0 || two)) {
-            uint4* f4 = reinterpret_cast<uint4*>(g_lds + (uint32_t)j * nflt);
-            for (uint32_t i = threadIdx.x; i < (nflt >> 4); i += blockDim.x) f4[i] = gload16(row.filter + (size_t)i * 16);
-        }
-        s[j].fbase = NK == 1 ? 0u : (uint32_t)j * nflt;
-        s[j].queue = (uint32_t)NK * nflt + ((threadIdx.x >> 6) * NK + j) * (kQueueEntries * 4u * (PROBE ? 2u : 1u));
-        if (FIRST) {
-            s[j].queue = (threadIdx.x >> 6) * (kChunkRecords * 4u + 256u);  // (sorted chunks: the wave's collection area + counters)
-            if (NIB && (threadIdx.x & 63u) < 16u) lds32(s[j].queue + kChunkRecords * 4u + 4u * (threadIdx.x & 63u)) = 0;
-        }
-        s[j].fill = row.fill;
-        s[j].seg = row.seg;
-        s[j].tshift = p - sp.nb_log2;
-        s[j].nb = 1 << sp.nb_log2;
-        s[j].nb_log2 = sp.nb_log2;
-        s[j].area = row.area;
-        s[j].cursor = row.cursor;
-        s[j].regs = row.regs;
-        s[j].cap_chunks = sp.cap_chunks;
-        s[j].fshift = 32 - p + sp.logg;
-        s[j].ishift = 32 - p;
-        s[j].himask = ~((1u << (32 - p)) - 1u);
-        waiting[j] = waiting2[j] = cur[j] = left[j] = 0;
-        s[j].unit = sp.unit;
+    const BucketRow row = sp.rows[(size_t)job.genome * sp.K + job.krow];
+    {
+        uint4* f4 = reinterpret_cast<uint4*>(g_lds);
+        for (uint32_t i = threadIdx.x; i < (nflt >> 4); i += blockDim.x) f4[i] = gload16(row.filter + (size_t)i * 16);
     }
+    Scatter s;
+    s.queue = nflt + (threadIdx.x >> 6) * (kQueueEntries * 4u * 2u);
+    s.area = row.area;
+    s.cursor = row.cursor;
+    s.regs = row.regs;
+    s.cap_chunks = sp.cap_chunks;
+    s.fshift = 32 - p + sp.logg;
+    s.ishift = 32 - p;
+    s.himask = ~((1u << (32 - p)) - 1u);
+    uint32_t waiting = 0, waiting2 = 0, cur = 0, left = 0;
     __syncthreads();
 
     for (unsigned tile = job.tile_begin; tile < job.tile_end; ++tile) {
@@ -1303,7 +1039,7 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
         const uint4 hc = in.hc, sc = in.sc;
         const uint2 hb = in.hb, sb = in.sb;
         const uint32_t cw[4] = {sc.x, sc.y, sc.z, sc.w};
-                Windows<KC == 1 ? 5 : (KC == 3 ? 6 : (KC == 2 ? 7 : KC))> win;
+        Windows<KC == 1 ? 5 : (KC == 3 ? 6 : (KC == 2 ? 7 : KC))> win;
         win.prime(hc);
         if (__all((hb.x | hb.y | sb.x | sb.y) == 0u)) {
 #pragma unroll
@@ -1311,8 +1047,7 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
 #pragma unroll 1
                 for (int i = 0; i < 16; ++i) {
                     win.push((cw[w] >> (2 * i)) & 3u);
-                    scatter_update<NIB, PROBE, FIRST>(s[0], waiting[0], waiting2[0], cur[0], left[0], win.template hash<CANON>(k), p, true);
-                    if (NK == 2 && two) scatter_update<NIB, PROBE, FIRST>(s[NK - 1], waiting[NK - 1], waiting2[NK - 1], cur[NK - 1], left[NK - 1], win.template hash<CANON>(k + 1), p, true);
+                    scatter_update(s, waiting, waiting2, cur, left, win.template hash<CANON>(k), p, true);
                 }
             }
             continue;
@@ -1326,49 +1061,17 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const SweepGenome* __rest
                 const uint32_t c = (cw[w] >> (2 * i)) & 3u;
                 run = ((bw >> i) & 1u) ? 0 : run + 1;
                 win.push(c);
-                scatter_update<NIB, PROBE, FIRST>(s[0], waiting[0], waiting2[0], cur[0], left[0], win.template hash<CANON>(k), p, run >= k);
-                if (NK == 2 && two) scatter_update<NIB, PROBE, FIRST>(s[NK - 1], waiting[NK - 1], waiting2[NK - 1], cur[NK - 1], left[NK - 1], win.template hash<CANON>(k + 1), p, run >= k + 1);
+                scatter_update(s, waiting, waiting2, cur, left, win.template hash<CANON>(k), p, run >= k);
             }
         }
     }
-    // what still waits leaves as a block padded with null records; the first epoch's waves fill what is left of
-    // their last reservation with null blocks (the stream has no holes: sort and replay read all of it)
-#pragma unroll
-    for (int j = 0; j < NK; ++j) {
-        if (j && !two) break;
-        const uint32_t lane = threadIdx.x & 63u;
-        if (FIRST) {
-            if (NIB && cur[j]) scatter_flush_sorted(s[j], cur[j]);
-        } else if (PROBE) {
-            if (waiting[j]) scatter_probe(s[j], lane < waiting[j] ? lds32(s[j].queue + 4u * lane) : 0xFFu, waiting2[j], cur[j], left[j]);
-            if (waiting2[j]) scatter_block<false>(s[j], lane < waiting2[j] ? lds32(s[j].queue + kQueueEntries * 4u + 4u * lane) : 0u, cur[j], left[j]);
-        } else if (waiting[j]) {
-            scatter_block<false>(s[j], lane < waiting[j] ? lds32(s[j].queue + 4u * lane) : 0u, cur[j], left[j]);
-        }
-        while (left[j]) scatter_block<FIRST>(s[j], 0u, cur[j], left[j]);  // what is left of the last reservation
-    }
+    // what still waits leaves as a block padded with null records, and what is left of the wave's last reservation is
+    // filled with null blocks (the stream has no holes: sort and replay read all of it)
+    const uint32_t lane = threadIdx.x & 63u;
+    if (waiting) scatter_probe(s, lane < waiting ? lds32(s.queue + 4u * lane) : 0xFFu, waiting2, cur, left);
+    if (waiting2) scatter_block(s, lane < waiting2 ? lds32(s.queue + kQueueEntries * 4u + 4u * lane) : 0u, cur, left);
+    while (left) scatter_block(s, 0u, cur, left);
 }
-
-// ---- first epoch, WORKGROUP chunks (round 4) ------------------------------------------------------------
-// The 16 waves of a first-epoch workgroup fill their 4 KiB collection areas in lockstep: every update adds 64
-// entries (null ones included) to each, so after every 16 updates the workgroup holds exactly 16 384 records and
-// sends them out as ONE chunk sorted by index tile -- the segment of an index tile is then 16 times as long as in a
-// wave's own 1024-record chunk (4 KiB instead of 256 B at log2m 20), and the replay reads it with 16-byte loads.
-//   LDS: [wave][1024] records | two count tables [wave][16] used alternately | [wave][16] placement offsets | slot
-//   per update : record to the wave's area, one LDS atomic on the wave's (tile, copy) counter -- as before
-//   per round  : ONE workgroup barrier; every wave then reads all 256 counts of the round in (tile, wave, copy)
-//                order (four per lane), scans them across the wave, keeps the 16 offsets that are its own, and
-//                places its records with returning atomics on those -- no second barrier: the next round counts
-//                into the other table, which each wave clears (its own 16 entries) right after the barrier, when
-//                every wave is known to have finished reading it.
-//   per job    : ONE atomic add on the row's cursor reserves the chunks of all its rounds (4 per tile).
-// A wave whose segments all lie behind the end of the stream still takes part in the four rounds of the tile.
-constexpr uint32_t kWgChunkRecords = 16u * kChunkRecords;
-constexpr uint32_t kWgAreaBytes = 16u * kChunkRecords * 4u;          // 64 KiB: the waves' collection areas
-constexpr uint32_t kWgTableBytes = 16u * 16u * 4u;                   // one count table
-constexpr uint32_t kWgOffsets = kWgAreaBytes + 2u * kWgTableBytes;   // placement offsets [wave][16]
-constexpr uint32_t kWgPosSlot = kWgOffsets + kWgTableBytes;          // the job's first record position
-constexpr uint32_t kWgLdsBytes = kWgPosSlot + 16u;
 
 // a wave-uniform value that arrived through a vector load (a table entry): moved to scalar registers
 DD_D uint64_t uniform64(uint64_t v) {
@@ -1378,191 +1081,6 @@ DD_D uint64_t uniform64(uint64_t v) {
 }
 template <typename T>
 DD_D T* uniform_ptr(T* q) { return reinterpret_cast<T*>(uniform64(reinterpret_cast<uint64_t>(q))); }
-
-struct ScatterWg {
-    uint32_t* area;
-    uint32_t* fill;
-    uint16_t* seg;
-    uint8_t* regs;
-    uint32_t cap_records;
-    int nb_log2, tshift, cshift;
-};
-// one round's records of the workgroup leave as a sorted chunk at record position `pos` of the row's stream;
-// `have` = 1024 for a wave that hashed this round, 0 for one that is beyond the stream
-DD_D void scatter_flush_wg(const ScatterWg& s, uint32_t wave, uint32_t tbl, uint32_t done, uint32_t have) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t queue = wave * (kChunkRecords * 4u);
-    const uint32_t mine = kWgAreaBytes + tbl * kWgTableBytes, other = kWgAreaBytes + (tbl ^ 1u) * kWgTableBytes;
-    const uint32_t off = kWgOffsets + wave * 64u;
-    __syncthreads();  // every count of this round is in; nobody reads the other table any more
-    if (lane < 16u) lds32(other + wave * 64u + 4u * lane) = 0;
-    const uint32_t pos = lds32(kWgPosSlot) + done;
-    if (pos + kWgChunkRecords > s.cap_records) {
-        // the stream is full: the records go to their registers directly (exact, slow, rare)
-        if (have) {
-#pragma unroll 1
-            for (int i = 0; i < 16; ++i) {
-                const uint32_t e = lds32(queue + 4u * ((uint32_t)i * 64u + lane));
-                if (e >> 24) {
-                    uint8_t* a = s.regs + (e & 0xFFFFFFu);
-                    (void)cas_raise<RegsGlobal>(a, RegsGlobal::load32(a), e >> 24);
-                }
-            }
-        }
-        return;
-    }
-    // keys 4 lane .. 4 lane + 3 in (tile, wave, copy) order; a wave's counter j = tile << cshift | copy
-    // (key -> table entry computed twice rather than kept: the kernel has 64 VGPRs)
-    const uint32_t cmask = (1u << s.cshift) - 1u;
-    auto entry = [&](uint32_t key, uint32_t& w, uint32_t& slot) {
-        w = (key >> s.cshift) & 15u;
-        slot = ((key >> (4 + s.cshift)) << s.cshift) | (key & cmask);
-    };
-    uint32_t cnt[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        uint32_t w, slot;
-        entry(4u * lane + (uint32_t)j, w, slot);
-        cnt[j] = lds32(mine + w * 64u + 4u * slot);
-    }
-    uint32_t at = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-    {
-        const uint32_t sum = at;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(at, d);
-            if (lane >= (uint32_t)d) at += up;
-        }
-        if (wave == 0u && lane == 63u) gstore4(s.fill + pos / kChunkRecords, at);  // the chunk's non-null records
-        at -= sum;
-    }
-    const uint32_t chunk = pos / kChunkRecords;  // (tables are indexed by 1024-record chunk: this one owns 16 entries)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        uint32_t w, slot;
-        entry(4u * lane + (uint32_t)j, w, slot);
-        if (w == wave) lds32(off + 4u * slot) = at;
-        if (wave == 0u && w == 0u && (slot & cmask) == 0u)
-            ((DD_GLOBAL uint16_t*)s.seg)[(size_t)chunk * 16u + (slot >> s.cshift)] = (uint16_t)at;
-        at += cnt[j];
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (have) {
-        const uint32_t copy = lane & cmask;
-#pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            const uint32_t e = lds32(queue + 4u * ((uint32_t)i * 64u + lane));
-            if (e >> 24) gstore4(s.area + pos + atomicAdd(&lds32(off + 4u * ((((e & 0xFFFFFFu) >> s.tshift) << s.cshift) | copy)), 1u), e);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-}
-
-template <int KC, bool CANON>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(KC == 2 ? 4 : 8, 8))) void scatter_first_wg_kernel(const SweepGenome* __restrict__ genomes,
-                                                               const SweepJob* __restrict__ jobs, int p, ScatterParams sp) {
-    const SweepJob job = jobs[blockIdx.x];
-    if (job.tile_begin >= job.tile_end) return;  // filler of the XCD-affine order
-    lds_starts_at_zero();
-    const SweepGenome g = genomes[job.genome];
-    const int k = job.kfirst;
-    const unsigned long long ntok = uniform64(gload8u(g.ntok));
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-
-    struct TileIn {
-        uint4 hc, sc;
-        uint2 hb, sb;
-        bool live;
-    };
-    auto fetch = [&](unsigned tile, TileIn& t) {
-        const unsigned long long seg = (unsigned long long)tile * blockDim.x + threadIdx.x;
-        t.live = tile < job.tile_end && seg * kSegTokens < ntok;
-        t.hc = make_uint4(0, 0, 0, 0);
-        t.hb = make_uint2(~0u, ~0u);
-        t.sc = make_uint4(0, 0, 0, 0);
-        t.sb = make_uint2(~0u, ~0u);
-        if (!t.live) return;
-        if (seg > 0) {
-            t.hc = gload16(g.codes + (seg - 1) * 4);
-            t.hb = gload8(g.bad + (seg - 1) * 2);
-        }
-        t.sc = gload16(g.codes + seg * 4);
-        t.sb = gload8(g.bad + seg * 2);
-    };
-    TileIn next;
-    fetch(job.tile_begin, next);
-
-    const BucketRow row = sp.rows[(size_t)job.genome * sp.K + job.krow];
-    ScatterWg s;
-    s.area = uniform_ptr(row.area);
-    s.fill = uniform_ptr(row.fill);
-    s.seg = uniform_ptr(row.seg);
-    s.regs = uniform_ptr(row.regs);
-    s.cap_records = sp.cap_chunks * kChunkRecords;
-    s.nb_log2 = sp.nb_log2;
-    s.tshift = p - sp.nb_log2;
-    s.cshift = 4 - sp.nb_log2;
-    // the chunks of every round of the job in one reservation; the position is first read behind a barrier
-    if (threadIdx.x == 0) lds32(kWgPosSlot) = gadd32(row.cursor, (job.tile_end - job.tile_begin) * 4u * kWgChunkRecords);
-    if (lane < 32u) lds32(kWgAreaBytes + (lane >> 4) * kWgTableBytes + wave * 64u + 4u * (lane & 15u)) = 0;
-    __builtin_amdgcn_wave_barrier();
-
-    const uint32_t queue = wave * (kChunkRecords * 4u) + 4u * lane;
-    const uint32_t copy = lane & ((1u << s.cshift) - 1u);
-    const int tile_sh = 32 - sp.nb_log2;  // hash high word >> tile_sh = index tile
-    uint32_t tbl = 0, done = 0;
-    for (unsigned tile = job.tile_begin; tile < job.tile_end; ++tile) {
-        const TileIn in = next;
-        fetch(tile + 1, next);
-        if (!__any(in.live)) {
-            // nothing to hash for this wave, but the workgroup's four rounds of the tile need its barriers
-#pragma unroll 1
-            for (int w = 0; w < 4; ++w) {
-                scatter_flush_wg(s, wave, tbl, done, 0u);
-                tbl ^= 1u;
-                done += kWgChunkRecords;
-            }
-            continue;
-        }
-        const uint4 hc = in.hc, sc = in.sc;
-        const uint2 hb = in.hb, sb = in.sb;
-                Windows<KC == 1 ? 5 : (KC == 3 ? 6 : (KC == 2 ? 7 : KC))> win;
-        win.prime(hc);
-        auto update = [&](uint32_t cnt_base, int i, bool valid) {
-            const Probe q = probe(win.template hash<CANON>(k), p);
-            const uint32_t rec = valid ? (q.hi >> (32 - p)) | (rho_of(q, p) << 24) : 0u;
-            lds32(queue + 256u * (uint32_t)i) = rec;
-            if (valid) atomicAdd(&lds32(cnt_base + (((q.hi >> tile_sh) << s.cshift) << 2)), 1u);
-        };
-        const bool clean = __all((hb.x | hb.y | sb.x | sb.y) == 0u);
-        int run = hb.y ? __builtin_clz(hb.y) : 32 + (hb.x ? __builtin_clz(hb.x) : 32);
-#pragma unroll 1
-        for (int w = 0; w < 4; ++w) {
-            const uint32_t cbase = kWgAreaBytes + tbl * kWgTableBytes + wave * 64u + 4u * copy;
-            // (the round's code word picked by selects: a register array indexed by the loop counter would go to scratch,
-            // and unrolling the four rounds quadruples the kernel)
-            const uint32_t cwd = w == 0 ? sc.x : (w == 1 ? sc.y : (w == 2 ? sc.z : sc.w));
-            if (clean) {
-#pragma unroll 1
-                for (int i = 0; i < 16; ++i) {
-                    win.push((cwd >> (2 * i)) & 3u);
-                    update(cbase, i, true);
-                }
-            } else {
-                const uint32_t bw = ((w & 2) ? sb.y : sb.x) >> ((w & 1) * 16);
-#pragma unroll 1
-                for (int i = 0; i < 16; ++i) {
-                    run = ((bw >> i) & 1u) ? 0 : run + 1;
-                    win.push((cwd >> (2 * i)) & 3u);
-                    update(cbase, i, run >= k);
-                }
-            }
-            scatter_flush_wg(s, wave, tbl, done, kChunkRecords);
-            tbl ^= 1u;
-            done += kWgChunkRecords;
-        }
-    }
-}
 
 // ---- first epoch, BINNED tiles of tokens (round 4, what runs) ----------------------------------------------------
 // Sorting 16 384 records per workgroup still costs two LDS atomics per record (count, then place) plus the pass over
@@ -1580,15 +1098,15 @@ constexpr uint32_t kBinCap = 4480;                        // records per (chunk,
 constexpr uint32_t kBinChunkRecords = 16u * kBinCap;      // 71 680 = 70 x 1024: stream space of one tile of tokens
 constexpr uint32_t kBinPosSlot = 128u;                    // LDS: counters [2][16] at 0, the job's position behind them
 constexpr uint32_t kBinLdsBytes = 256u;
-constexpr int kOnesLog2Max = 19;                          // registers of a row whose rho = 1 updates are bits in LDS (ONES below)
+constexpr int kOnesLog2Max = 19;                          // registers of a row whose rho = 1 updates are bits in LDS (below)
 
-// ONES (round 5, ScatterParams::presorted 5): HALF of all updates have rho = 1, and all a register can learn from them is that it
+// Updates of rho = 1 (round 5): HALF of all updates have rho = 1, and all a register can learn from them is that it
 // is not empty.  They leave no record: the workgroup keeps one bit per register of its row in LDS (m / 8 bytes behind the
 // counters, 64 KiB at most), sets it with a ds_or and ORs the words into the row's bitmap in HBM
 // when its job ends (BucketRow::ones; 32 K atomics per job against the ~330 K four-byte stores they stand for); the replay
 // raises a register that is still 0 behind a set bit to 1 when it writes the tile back.  Exact: max(rho) over a register's
 // updates is 1 iff there is an update and none has rho >= 2.
-template <int KC, bool CANON, bool ONES = false>
+template <int KC, bool CANON>
 __global__ __launch_bounds__(1024) void scatter_first_bin_kernel(
     const SweepGenome* __restrict__ genomes, const SweepJob* __restrict__ jobs, int p, ScatterParams sp) {
     const SweepJob job = jobs[blockIdx.x];
@@ -1632,9 +1150,8 @@ __global__ __launch_bounds__(1024) void scatter_first_bin_kernel(
     if (threadIdx.x == 0) lds32(kBinPosSlot) = gadd32(row.cursor, (job.tile_end - job.tile_begin) * kBinChunkRecords);
     // (at most 2^19 bits = 64 KiB, so that two workgroups still share a CU: at log2m 20 only the updates of the lower half of the
     // row's registers are bits, the others stay records -- one workgroup per CU costs this kernel 6 %, profiles/r05_bucket_path.txt)
-    const uint32_t ones_regs = ONES ? 1u << (p < kOnesLog2Max ? p : kOnesLog2Max) : 0u, ones_words = ones_regs >> 5;
-    if (ONES)
-        for (uint32_t w = threadIdx.x; w < ones_words; w += blockDim.x) lds32(kBinLdsBytes + 4u * w) = 0;
+    const uint32_t ones_regs = 1u << (p < kOnesLog2Max ? p : kOnesLog2Max), ones_words = ones_regs >> 5;
+    for (uint32_t w = threadIdx.x; w < ones_words; w += blockDim.x) lds32(kBinLdsBytes + 4u * w) = 0;
     __syncthreads();
     const uint32_t pos0 = __builtin_amdgcn_readfirstlane(lds32(kBinPosSlot));
     const uint32_t copy = lane & ((1u << cshift) - 1u);
@@ -1659,7 +1176,7 @@ __global__ __launch_bounds__(1024) void scatter_first_bin_kernel(
                 const Probe q = probe(win.template hash<CANON>(k), p);
                 if (!valid) return;
                 const uint32_t rho = rho_of(q, p);
-                if (ONES && rho == 1u && (q.hi >> (32 - p)) < ones_regs) {
+                if (rho == 1u && (q.hi >> (32 - p)) < ones_regs) {
                     const uint32_t idx = q.hi >> (32 - p);
                     atomicOr(&lds32(kBinLdsBytes + ((idx >> 5) << 2)), 1u << (idx & 31u));
                     return;
@@ -1709,173 +1226,11 @@ __global__ __launch_bounds__(1024) void scatter_first_bin_kernel(
             if (room) ((DD_GLOBAL uint16_t*)counts)[(size_t)(cpos / kBinChunkRecords) * 16u + lane] = (uint16_t)(c < kBinCap ? c : kBinCap);
         }
     }
-    if (ONES) {   // (behind the last tile's barrier: every ds_or of the job is in)
-        uint32_t* const ones = uniform_ptr(row.ones);
-        for (uint32_t w = threadIdx.x; w < ones_words; w += blockDim.x) {
-            const uint32_t v = lds32(kBinLdsBytes + 4u * w);
-            if (v) atomicOr(ones + w, v);
-        }
-    }
-}
-
-// ---- first epoch, PACKED binned tiles (round 5; DD_FIRST_WG=4: exact, but measured slower than the 4-byte bins -- kept for A/B) ----
-// The binned form above is bound by what it writes: 4 bytes per record at ~2.4-2.7 TB/s, whatever the instruction count
-// (timing-only builds of round 4: hash only 2.09 ms, perfectly coalesced 4-byte stores 3.33, bins 3.76 for the class-0 launch of
-// 64 x 5 Mbp at log2m 20 -- the launch takes what 9 GB of writes take), and the replay by reading them back at 5.2 TB/s.  A
-// record inside its bin (index tile x copy) is 16 bits of index and 6 of rho: 3 bytes in two streams, u16 index + u8 rho.
-// Two sub-dword stores per record from the hash loop would double the L2 write requests (already ~19 per wave-update), so
-// the records are STAGED IN LDS and leave in whole lines: the workgroup's counters hand out ring slots (the one returning
-// LDS atomic per record that the binned form has too), a record is one ds_write, and every kPackPeriod updates, behind one
-// workgroup barrier, wave b packs bin b's records of the period -- eight per lane: one 16-byte store of indices, one 8-byte
-// store of rhos, contiguous across the lanes -- while the others already fill the ring's other half.  A period's records
-// per bin are padded with null records (rho 0) to a multiple of eight, so every store is whole and aligned and the replay
-// needs no tail handling.  MEASURED (profiles/r05_bucket_path.txt): 64 x 5 Mbp at log2m 20 31.0 ms against 23.8 with the 4-byte
-// bins -- the scatter launches 4.8 / 11.7 / 6.9 ms against 3.6 / 8.1 / 4.3 (16 barriers and flushes per tile of tokens), the
-// replay 2.47 against 2.58 ms per launch: 25 % fewer bytes buy it 4 %, it is bound by its LDS compare-and-swaps and their
-// ~26 VALU instructions per record, not by HBM (plain fills run at 6.8 TB/s on this chip: scripts/hbm_probe.py).
-// A bin that overflows its ring half (mean 256 of 384: +8 sigma; a low-complexity stretch can) or
-// its region of the stream sends the record to its register by compare-and-swap, exactly.
-constexpr uint32_t kPackPeriod = 4;                       // updates per thread between flushes: 4096 records per workgroup
-constexpr uint32_t kPackRing = 384;                       // ring slots per (half, bin)
-constexpr uint32_t kPackBinBytes = kBinCap * 3u;          // a bin's region of the stream: u16 [kBinCap] indices, u8 [kBinCap] rhos
-constexpr uint32_t kPackChunkUnits = 16u * kPackBinBytes / 4u;   // 53 760: stream space of one tile of tokens, in 4-byte units (52.5 x 1024)
-constexpr uint32_t kPackCtr = 0u;                         // LDS: counters [2][16] at 0, the job's position at 128, the ring behind
-constexpr uint32_t kPackRingAt = 256u;
-constexpr uint32_t kPackLdsBytes = kPackRingAt + 2u * 16u * kPackRing * 4u;   // 49 408
-static_assert(kBinCap % 8u == 0 && kPackBinBytes % 16u == 0 && (kBinCap * 2u) % 16u == 0, "packed bins: aligned 16-byte pieces");
-
-template <int KC, bool CANON>
-__global__ __launch_bounds__(1024) void scatter_first_pack_kernel(
-    const SweepGenome* __restrict__ genomes, const SweepJob* __restrict__ jobs, int p, ScatterParams sp) {
-    const SweepJob job = jobs[blockIdx.x];
-    if (job.tile_begin >= job.tile_end) return;  // filler of the XCD-affine order
-    lds_starts_at_zero();
-    const SweepGenome g = genomes[job.genome];
-    const int k = job.kfirst;
-    const unsigned long long ntok = uniform64(gload8u(g.ntok));
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-
-    struct TileIn {
-        uint4 hc, sc;
-        uint2 hb, sb;
-        bool live;
-    };
-    auto fetch = [&](unsigned tile, TileIn& t) {
-        const unsigned long long seg = (unsigned long long)tile * blockDim.x + threadIdx.x;
-        t.live = tile < job.tile_end && seg * kSegTokens < ntok;
-        t.hc = make_uint4(0, 0, 0, 0);
-        t.hb = make_uint2(~0u, ~0u);
-        t.sc = make_uint4(0, 0, 0, 0);
-        t.sb = make_uint2(~0u, ~0u);
-        if (!t.live) return;
-        if (seg > 0) {
-            t.hc = gload16(g.codes + (seg - 1) * 4);
-            t.hb = gload8(g.bad + (seg - 1) * 2);
-        }
-        t.sc = gload16(g.codes + seg * 4);
-        t.sb = gload8(g.bad + seg * 2);
-    };
-    TileIn next;
-    fetch(job.tile_begin, next);
-
-    const BucketRow row = sp.rows[(size_t)job.genome * sp.K + job.krow];
-    uint8_t* const area = reinterpret_cast<uint8_t*>(uniform_ptr(row.area));
-    uint16_t* const counts = uniform_ptr(row.seg);  // [chunk][16]: records (nulls included) in each bin
-    uint8_t* const regs = uniform_ptr(row.regs);
-    const uint32_t cap_records = sp.cap_chunks * kChunkRecords;
-    const int cshift = 4 - sp.nb_log2, tile_sh = 32 - sp.nb_log2;
-    if (threadIdx.x < 32u) lds32(kPackCtr + 4u * threadIdx.x) = 0;
-    if (threadIdx.x == 0) lds32(kBinPosSlot) = gadd32(row.cursor, (job.tile_end - job.tile_begin) * kPackChunkUnits);
-    __syncthreads();
-    const uint32_t pos0 = __builtin_amdgcn_readfirstlane(lds32(kBinPosSlot));
-    const uint32_t copy = lane & ((1u << cshift) - 1u);
-    auto to_register = [&](uint32_t rec) {   // the exact way out: straight to the row
-        uint8_t* a = regs + (rec & 0xFFFFFFu);
-        (void)cas_raise<RegsGlobal>(a, RegsGlobal::load32(a), rec >> 24);
-    };
-
-    for (unsigned tile = job.tile_begin; tile < job.tile_end; ++tile) {
-        const TileIn in = next;
-        fetch(tile + 1, next);
-        const uint32_t t = tile - job.tile_begin;
-        const uint32_t cpos = pos0 + t * kPackChunkUnits;
-        const bool room = cpos + kPackChunkUnits <= cap_records;  // else: the stream is full, records go to the registers (exact, slow, rare)
-        const bool any_live = __any(in.live);
-        const uint4 hc = in.hc, sc = in.sc;
-        const uint2 hb = in.hb, sb = in.sb;
-        const uint32_t cw[4] = {sc.x, sc.y, sc.z, sc.w};
-        Windows<KC == 1 ? 5 : (KC == 3 ? 6 : (KC == 2 ? 7 : KC))> win;
-        win.prime(hc);
-        const bool clean = __all((hb.x | hb.y | sb.x | sb.y) == 0u);
-        int run = hb.y ? __builtin_clz(hb.y) : 32 + (hb.x ? __builtin_clz(hb.x) : 32);
-        uint8_t* const mybin = area + (size_t)cpos * 4u + (size_t)wave * kPackBinBytes;   // wave b owns bin b of the chunk
-        uint32_t placed = 0;     // records (nulls included) of this wave's bin stored so far: a multiple of 8
-        uint32_t par = 0;
-        auto update = [&](bool valid, uint32_t ctr, uint32_t ring) {
-            const Probe q = probe(win.template hash<CANON>(k), p);
-            if (!valid) return;
-            const uint32_t rec = (q.hi >> (32 - p)) | (rho_of(q, p) << 24);
-            const uint32_t bin = ((q.hi >> tile_sh) << cshift) | copy;
-            uint32_t slot = kPackRing;
-            if (room) slot = atomicAdd(&lds32(ctr + (bin << 2)), 1u);
-            if (__builtin_expect(slot < kPackRing, 1)) lds32(ring + ((bin * kPackRing + slot) << 2)) = rec;
-            else to_register(rec);
-        };
-        // wave b: bin b's records of the period that has just ended leave for the stream
-        auto flush = [&](uint32_t ctr, uint32_t ring) {
-            uint32_t c = __builtin_amdgcn_readfirstlane(lds32(ctr + 4u * wave));
-            if (c == 0u) return;
-            if (lane == 0u) lds32(ctr + 4u * wave) = 0;
-            c = c < kPackRing ? c : kPackRing;                  // (what came later went to the registers)
-            const uint32_t cp = (c + 7u) & ~7u, i0 = 8u * lane;
-            if (i0 < cp) {
-                const uint32_t src = ring + ((wave * kPackRing + i0) << 2);
-                uint32_t r[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) r[j] = i0 + (uint32_t)j < c ? lds32(src + 4u * (uint32_t)j) : 0u;   // (two ds_read_b128; past c: null records)
-                if (__builtin_expect(placed + i0 + 8u <= kBinCap, 1)) {
-                    const uint4 idx = make_uint4((r[0] & 0xFFFFu) | (r[1] << 16), (r[2] & 0xFFFFu) | (r[3] << 16), (r[4] & 0xFFFFu) | (r[5] << 16), (r[6] & 0xFFFFu) | (r[7] << 16));
-                    const uint2 rho = make_uint2((r[0] >> 24) | ((r[1] >> 24) << 8) | ((r[2] >> 24) << 16) | (r[3] & 0xFF000000u),
-                                                 (r[4] >> 24) | ((r[5] >> 24) << 8) | ((r[6] >> 24) << 16) | (r[7] & 0xFF000000u));
-                    gstore16(mybin + 2u * (placed + i0), idx);
-                    gstore8(mybin + 2u * kBinCap + placed + i0, rho);
-                } else {   // the bin's region of the stream is full
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (r[j] >> 24) to_register(r[j]);
-                }
-            }
-            placed = placed + cp < kBinCap ? placed + cp : kBinCap;
-        };
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const uint32_t bw = ((w & 2) ? sb.y : sb.x) >> ((w & 1) * 16);
-#pragma unroll 1
-            for (uint32_t q4 = 0; q4 < 16u / kPackPeriod; ++q4) {
-                const uint32_t ctr = kPackCtr + par * 64u, ring = kPackRingAt + par * (16u * kPackRing * 4u);
-                if (any_live) {
-                    if (clean) {
-#pragma unroll 1
-                        for (uint32_t j = 0; j < kPackPeriod; ++j) {
-                            win.push((cw[w] >> (2u * (q4 * kPackPeriod + j))) & 3u);
-                            update(true, ctr, ring);
-                        }
-                    } else {
-#pragma unroll 1
-                        for (uint32_t j = 0; j < kPackPeriod; ++j) {
-                            const uint32_t i = q4 * kPackPeriod + j;
-                            run = ((bw >> i) & 1u) ? 0 : run + 1;
-                            win.push((cw[w] >> (2u * i)) & 3u);
-                            update(run >= k, ctr, ring);
-                        }
-                    }
-                }
-                __syncthreads();   // the period's records are in the ring; the other half and its counters are free again
-                flush(ctr, ring);
-                par ^= 1u;
-            }
-        }
-        if (room && lane == 0u) ((DD_GLOBAL uint16_t*)counts)[(size_t)(cpos / kPackChunkUnits) * 16u + wave] = (uint16_t)placed;
+    // (behind the last tile's barrier: every ds_or of the job is in)
+    uint32_t* const ones = uniform_ptr(row.ones);
+    for (uint32_t w = threadIdx.x; w < ones_words; w += blockDim.x) {
+        const uint32_t v = lds32(kBinLdsBytes + 4u * w);
+        if (v) atomicOr(ones + w, v);
     }
 }
 
@@ -1944,18 +1299,15 @@ __global__ __launch_bounds__(256) void sort_chunks_kernel(const BucketRow* __res
 }
 
 // One workgroup per (row, index tile); LDS: the tile (64 KiB, or m bytes if smaller); two workgroups per
-// CU.  A wave takes every 16th chunk of the row's stream, U at a time, and reads only the segment of its
-// own tile (all of a chunk when the row is a single tile and nothing was sorted); segment headers, records
-// and the LDS work of three consecutive steps overlap.
-// FORM 2: the stream holds the first epoch's WORKGROUP chunks (scatter_first_wg_kernel: 16 384 records each, segment table and
-// fill count at the entries of the chunk's first 1024 records): a wave takes every 16th of them and streams its tile's
-// segment -- 4 KiB on average at log2m 20 -- with 16-byte loads, two 1 KiB pieces per step and the next step's in flight.
-// FORM 3: the first epoch's binned tiles (scatter_first_bin_kernel): chunk C = 16 bins of kBinCap records' room, counts in
-// seg[C][16]; unit u = (chunk, copy of this tile's bin); the 512-record pieces of a unit go round the 16 waves, so every
-// wave has a 2 KiB piece in flight while it applies the previous one.
-template <int FORM>
+// CU.  BINS = false (filtered epochs): a wave takes every 16th chunk of the row's stream, U at a time, and reads only the
+// segment of its own tile that sort_chunks_kernel left; segment headers, records and the LDS work of three consecutive steps
+// overlap.  BINS = true (the first epoch's binned tiles, scatter_first_bin_kernel): chunk C = 16 bins of kBinCap records'
+// room, counts in seg[C][16]; unit u = (chunk, copy of this tile's bin); the 512-record pieces of a unit go round the 16
+// waves, so every wave has a 2 KiB piece in flight while it applies the previous one; the rho = 1 updates, which left a bit
+// instead of a record, are applied when the tile is written back.
+template <bool BINS>
 __global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restrict__ rows, RowSet rs, int p, int logg,
-                                                     int nb_log2, uint32_t cap_chunks, int fbits) {
+                                                     int nb_log2, uint32_t cap_chunks) {
     lds_starts_at_zero();
     const uint32_t nb = 1u << nb_log2;
     const uint32_t within = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
@@ -2006,59 +1358,7 @@ __global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restric
                 if ((retry >> i) & 1u) (void)cas_raise<RegsLds>(e[i] & (tile - 1u), wd[i], e[i] >> 24);
         }
     };
-    if (FORM == 4) {
-        // the first epoch's PACKED bins (scatter_first_pack_kernel): chunk C = 16 bins of kPackBinBytes, each u16 [kBinCap]
-        // indices in the tile + u8 [kBinCap] rhos, counts (multiples of 8, null records included) in seg[C][16]; units and
-        // pieces as in FORM 3: 512 records = 1 KiB of indices + 512 B of rhos per piece, 8 records per lane
-        const int cshift = 4 - nb_log2;
-        const uint32_t nunits = (nrec / kPackChunkUnits) << cshift;
-        const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        struct Piece {
-            uint4 idx;
-            uint2 rho;
-            bool any;   // wave-uniform
-        };
-        auto header = [&](uint32_t u) -> uint32_t {  // records in unit u's bin
-            return u < nunits ? (uint32_t)seg[(size_t)(u >> cshift) * 16u + ((b << cshift) | (u & ((1u << cshift) - 1u)))] : 0u;
-        };
-        auto issue = [&](uint32_t u, uint32_t cnt, Piece& P) {
-            const uint32_t off = ((wave - u) & 15u) * 512u;
-            cnt = __builtin_amdgcn_readfirstlane(cnt);
-            P.idx = make_uint4(0, 0, 0, 0);
-            P.rho = make_uint2(0, 0);
-            P.any = off < cnt;
-            if (!P.any) return;
-            const uint8_t* base = reinterpret_cast<const uint8_t*>(row.area) + (size_t)(u >> cshift) * (kPackChunkUnits * 4u) +
-                                  (size_t)((b << cshift) | (u & ((1u << cshift) - 1u))) * kPackBinBytes;
-            const uint32_t i = off + 8u * lane;
-            if (i < cnt) {   // (counts are multiples of 8: a lane's eight records are all there)
-                P.idx = gload16(base + 2u * i);
-                P.rho = gload8(base + 2u * kBinCap + i);
-            }
-        };
-        uint32_t c1 = header(1), c2 = header(2);
-        Piece cur, nxt;
-        issue(0, header(0), cur);
-        for (uint32_t u = 0; u < nunits; ++u) {
-            issue(u + 1u, c1, nxt);
-            c1 = c2;
-            c2 = header(u + 3u);
-            if (cur.any) {
-                const uint32_t ix[4] = {cur.idx.x, cur.idx.y, cur.idx.z, cur.idx.w};
-                uint32_t ea[U], eb[U];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    ea[2 * j] = (ix[j] & 0xFFFFu) | (((cur.rho.x >> (16 * j)) & 0xFFu) << 24);
-                    ea[2 * j + 1] = (ix[j] >> 16) | (((cur.rho.x >> (16 * j + 8)) & 0xFFu) << 24);
-                    eb[2 * j] = (ix[2 + j] & 0xFFFFu) | (((cur.rho.y >> (16 * j)) & 0xFFu) << 24);
-                    eb[2 * j + 1] = (ix[2 + j] >> 16) | (((cur.rho.y >> (16 * j + 8)) & 0xFFu) << 24);
-                }
-                apply_u(ea);
-                apply_u(eb);
-            }
-            cur = nxt;
-        }
-    } else if (FORM == 3 || FORM == 5) {
+    if (BINS) {
         const int cshift = 4 - nb_log2;
         const uint32_t nunits = (nrec / kBinChunkRecords) << cshift;
         const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2098,64 +1398,6 @@ __global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restric
                 apply_u(ea);
                 apply_u(eb);
             }
-            cur = nxt;
-        }
-    } else if (FORM == 2) {
-        const uint32_t nbig = nrec / kWgChunkRecords;  // (a chunk the capacity cut short went to the registers directly)
-        struct Piece {
-            uint4 a, b;
-            uint32_t i, st, en;  // wave-uniform: lane 0's first record of `a`, the segment's bounds; en = 0: nothing
-        };
-        auto header = [&](uint32_t C, uint32_t& st, uint32_t& en) {
-            st = en = 0;
-            if (C < nbig) {
-                st = seg[(size_t)C * 256u + b];
-                en = b + 1u < nb ? (uint32_t)seg[(size_t)C * 256u + b + 1u] : gload4(row.fill + (size_t)C * 16u);
-            }
-        };
-        uint32_t C = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        uint32_t st, en, st1, en1, st2, en2;
-        header(C, st, en);
-        header(C + 16u, st1, en1);
-        header(C + 32u, st2, en2);
-        st = __builtin_amdgcn_readfirstlane(st);
-        en = __builtin_amdgcn_readfirstlane(en);
-        uint32_t i = st & ~3u;
-        auto issue = [&](Piece& P) {
-            P.i = i, P.st = st, P.en = C < nbig ? en : 0u;
-            const uint32_t* base = row.area + (size_t)C * kWgChunkRecords;
-            const uint32_t ia = i + 4u * lane, ib = ia + 256u;
-            P.a = P.b = make_uint4(0, 0, 0, 0);
-            if (ia < P.en) P.a = gload16(base + ia);  // (a quad may straddle the segment's end: still inside the chunk)
-            if (ib < P.en) P.b = gload16(base + ib);
-            i += 512u;
-            if (C < nbig && i >= en) {  // on to this wave's next chunk; its header was fetched two chunks ago
-                C += 16u;
-                st = __builtin_amdgcn_readfirstlane(st1);
-                en = __builtin_amdgcn_readfirstlane(en1);
-                st1 = st2, en1 = en2;
-                header(C + 32u, st2, en2);
-                i = st & ~3u;
-            }
-        };
-        Piece cur, nxt;
-        bool more = C < nbig;
-        issue(cur);
-        while (more) {
-            more = C < nbig;
-            issue(nxt);
-            uint32_t ea[U] = {cur.a.x, cur.a.y, cur.a.z, cur.a.w}, eb[U] = {cur.b.x, cur.b.y, cur.b.z, cur.b.w};
-            if (!(cur.i >= cur.st && cur.i + 512u <= cur.en)) {
-                // a piece that holds an end of the segment: records of the neighbouring tiles (or beyond) are nulled
-                const uint32_t d = cur.i + 4u * lane - cur.st, len = cur.en - cur.st;
-#pragma unroll
-                for (int j = 0; j < U; ++j) {
-                    ea[j] = d + (uint32_t)j < len ? ea[j] : 0u;
-                    eb[j] = d + 256u + (uint32_t)j < len ? eb[j] : 0u;
-                }
-            }
-            apply_u(ea);
-            apply_u(eb);
             cur = nxt;
         }
     } else {
@@ -2213,8 +1455,8 @@ __global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restric
     }
     }
     __syncthreads();
-    if (FORM == 5) {
-        // the updates with rho = 1 left no record, only a bit (scatter_first_bin_kernel<.., ONES>): a register still 0 behind
+    if (BINS) {
+        // the updates with rho = 1 left no record, only a bit (scatter_first_bin_kernel): a register still 0 behind
         // a set bit becomes 1.  Thread i holds registers 16 i .. 16 i + 15 of the tile = halfword i of the tile's bits.
         const DD_GLOBAL uint16_t* bits = (const DD_GLOBAL uint16_t*)row.ones + (((size_t)b * tile) >> 4);
         for (uint32_t i = threadIdx.x; i < (tile >> 4); i += blockDim.x) {
@@ -2232,8 +1474,7 @@ __global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restric
         __syncthreads();
     }
     for (uint32_t i = threadIdx.x; i < (tile >> 4); i += blockDim.x) gstore16(tile_g + (size_t)i * 16, l4[i]);
-    // the tile's part of the filter: minimum of every group of 2^logg registers (as a byte, or saturated to 15
-    // and packed two to a byte)
+    // the tile's part of the filter: minimum of every group of 2^logg registers
     const uint32_t G = 1u << logg;
     auto group_min = [&](uint32_t f) {
         uint32_t lo = 0xFFu;
@@ -2247,16 +1488,12 @@ __global__ __launch_bounds__(1024) void replay_kernel(const BucketRow* __restric
         }
         return lo;
     };
+    // (4-bit entries, saturating at 15, two register groups per byte: measured better than byte entries at log2m 18, 19, 20)
     const uint32_t ngroups = tile >> logg;
-    if (fbits == 4) {
-        uint8_t* const flt = row.filter + ((((size_t)b * tile) >> logg) >> 1);
-        for (uint32_t f = threadIdx.x; f < (ngroups >> 1); f += blockDim.x) {
-            const uint32_t a = group_min(2u * f), c = group_min(2u * f + 1u);
-            flt[f] = (uint8_t)((a < 15u ? a : 15u) | ((c < 15u ? c : 15u) << 4));
-        }
-    } else {
-        uint8_t* const flt = row.filter + (((size_t)b * tile) >> logg);
-        for (uint32_t f = threadIdx.x; f < ngroups; f += blockDim.x) flt[f] = (uint8_t)group_min(f);
+    uint8_t* const flt = row.filter + ((((size_t)b * tile) >> logg) >> 1);
+    for (uint32_t f = threadIdx.x; f < (ngroups >> 1); f += blockDim.x) {
+        const uint32_t a = group_min(2u * f), c = group_min(2u * f + 1u);
+        flt[f] = (uint8_t)((a < 15u ? a : 15u) | ((c < 15u ? c : 15u) << 4));
     }
 }
 
@@ -2281,10 +1518,10 @@ void allow_full_lds(const void* kern, std::atomic<unsigned long long>& done, int
     }
 }
 
-template <int KC, bool CANON, int MODE>
+template <int KC, bool CANON>
 void launch_one(const SweepGenome* genomes, const SweepJob* jobs, int njobs, const SweepPlan& plan,
                 hipStream_t st) {
-    auto kern = sweep_kernel<KC, CANON, MODE>;
+    auto kern = sweep_kernel<KC, CANON>;
     static std::atomic<unsigned long long> attr_done{0};  // one bit per device: the attribute is per device
     allow_full_lds(reinterpret_cast<const void*>(kern), attr_done);
     hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3((unsigned)plan.threads),
@@ -2318,7 +1555,6 @@ void launch_bitmap_finish(const SweepGenome* genomes, int ngenomes, int kfirst, 
                        (size_t)1 << tile_log2, st, genomes, kfirst, kmin, log2m, tile_log2);
 }
 
-
 void launch_bigmap(const SweepGenome* genomes, const SweepJob* jobs, int njobs, int canonical, hipStream_t st) {
     if (njobs <= 0) return;
     static std::atomic<unsigned long long> attr_done[2] = {{0}, {0}};
@@ -2335,7 +1571,7 @@ void launch_bigmap_finish(const SweepGenome* genomes, int ngenomes, int kfirst, 
                           int canonical, hipStream_t st) {
     if (ngenomes <= 0 || klast < kfirst) return;
     // 128 KiB tiles, one workgroup per CU: every workgroup hashes the row's whole set (up to 2 M k-mers), so fewer,
-    // larger tiles are less work (1.49 -> ms with 64 KiB tiles at log2m 20)
+    // larger tiles are less work
     const int tile_log2 = std::min(log2m, 17);
     const dim3 grid((unsigned)(klast - kfirst + 1), (unsigned)ngenomes, 1u << (log2m - tile_log2));
     static std::atomic<unsigned long long> attr_done[2] = {{0}, {0}};
@@ -2346,148 +1582,74 @@ void launch_bigmap_finish(const SweepGenome* genomes, int ngenomes, int kfirst, 
         hipLaunchKernelGGL(bigmap_finish_kernel<false>, grid, dim3(1024), (size_t)1 << tile_log2, st, genomes, kfirst, kmin, log2m, tile_log2);
 }
 
+// One scatter launch of a k class (log2m >= 17).  first_epoch: every register of the call is still zero -- the unfiltered,
+// binned form (scatter_first_bin_kernel); later epochs: the filtered form (scatter_kernel).
 void launch_scatter(const SweepGenome* genomes, const SweepJob* jobs, int njobs, int kclass, const SweepPlan& plan,
                     const ScatterParams& sp, hipStream_t st, bool first_epoch) {
     if (njobs <= 0) return;
-    if (first_epoch) {
-        // (DD_FIRST_LDS_KB, experiments: more dynamic LDS than the kernel needs = fewer workgroups per CU)
-        const size_t first_lds_floor = getenv("DD_FIRST_LDS_KB") ? (size_t)atoi(getenv("DD_FIRST_LDS_KB")) << 10 : 0;
-        // every register of the call is still zero: the unfiltered form (no filter, no queues; rows of several index
-        // tiles get their chunks sorted on the way out: 4 KiB + 256 B of LDS per wave)
-#define DD_FIRST(KC, CN)                                                                                                           \
-    do {                                                                                                                           \
-        if (sp.presorted == 4) {                                                                                                   \
-            auto kern = scatter_first_pack_kernel<KC, CN>;                                                                         \
-            hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3(1024), std::max((size_t)kPackLdsBytes, first_lds_floor), st, genomes, jobs, plan.log2m, sp); \
-        } else if (sp.presorted == 5) {                                                                                            \
-            auto kern = scatter_first_bin_kernel<KC, CN, true>;                                                                    \
-            static std::atomic<unsigned long long> attr_done{0};                                                                   \
-            allow_full_lds(reinterpret_cast<const void*>(kern), attr_done);                                                        \
-            hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3(1024), std::max((size_t)kBinLdsBytes + (((size_t)1 << std::min(plan.log2m, kOnesLog2Max)) >> 3), first_lds_floor), st, genomes, jobs, plan.log2m, sp); \
-        } else if (sp.presorted == 3) {                                                                                            \
-            auto kern = scatter_first_bin_kernel<KC, CN>;                                                                          \
-            hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3(1024), std::max((size_t)kBinLdsBytes, first_lds_floor), st, genomes, jobs, plan.log2m, sp); \
-        } else if (sp.presorted == 2) {                                                                                            \
-            auto kern = scatter_first_wg_kernel<KC, CN>;                                                                           \
-            static std::atomic<unsigned long long> attr_done{0};                                                                   \
-            allow_full_lds(reinterpret_cast<const void*>(kern), attr_done);                                                        \
-            hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3(1024), std::max((size_t)kWgLdsBytes, first_lds_floor), st, genomes, jobs, plan.log2m, sp); \
-        } else if (sp.presorted) {                                                                                                        \
-            auto kern = scatter_kernel<KC, CN, true, false, 1, true>;                                                              \
-            static std::atomic<unsigned long long> attr_done{0};                                                                   \
-            allow_full_lds(reinterpret_cast<const void*>(kern), attr_done);                                                        \
-            hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3((unsigned)plan.threads),                                          \
-                               std::max((size_t)(plan.threads / 64) * (kChunkRecords * 4 + 256), first_lds_floor), st, genomes, jobs, plan.log2m, sp); \
-        } else {                                                                                                                   \
-            hipLaunchKernelGGL((scatter_kernel<KC, CN, false, false, 1, true>), dim3((unsigned)njobs), dim3((unsigned)plan.threads), 0, \
-                               st, genomes, jobs, plan.log2m, sp);                                                                 \
-        }                                                                                                                          \
+#define DD_SCATTER(KC, CN)                                                                                                      \
+    do {                                                                                                                        \
+        static std::atomic<unsigned long long> attr_done[2] = {{0}, {0}};                                                       \
+        if (first_epoch) {                                                                                                      \
+            auto kern = scatter_first_bin_kernel<KC, CN>;                                                                       \
+            allow_full_lds(reinterpret_cast<const void*>(kern), attr_done[0]);                                                  \
+            hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3(1024),                                                         \
+                               (size_t)kBinLdsBytes + (((size_t)1 << std::min(plan.log2m, kOnesLog2Max)) >> 3), st, genomes, jobs, plan.log2m, sp); \
+        } else {                                                                                                                \
+            auto kern = scatter_kernel<KC, CN>;                                                                                 \
+            allow_full_lds(reinterpret_cast<const void*>(kern), attr_done[1]);                                                  \
+            hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3((unsigned)plan.threads), (size_t)plan.lds_bytes, st, genomes, jobs, plan.log2m, sp); \
+        }                                                                                                                       \
     } while (0)
-#define DD_FIRST_KC(CN)                   \
-    do {                                  \
-        if (kclass == 0) DD_FIRST(0, CN); \
-        else if (kclass == 1) DD_FIRST(1, CN); \
-        else if (kclass == 3) DD_FIRST(3, CN); \
-        else DD_FIRST(2, CN);             \
-    } while (0)
-        if (plan.canonical) DD_FIRST_KC(true);
-        else DD_FIRST_KC(false);
-#undef DD_FIRST_KC
-#undef DD_FIRST
-        return;
-    }
-#define DD_SCATTER_NN(KC, CN, NB, PR)                                                                   \
-    do {                                                                                                \
-        auto kern = scatter_kernel<KC, CN, NB, PR, 1>;                                                  \
-        static std::atomic<unsigned long long> attr_done{0};                                            \
-        allow_full_lds(reinterpret_cast<const void*>(kern), attr_done);                                 \
-        hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3((unsigned)plan.threads), (size_t)plan.lds_bytes, st, \
-                           genomes, jobs, plan.log2m, sp);                                              \
-    } while (0)
-#define DD_SCATTER_N(KC, CN, NB)                \
-    do {                                        \
-        if (plan.probe) DD_SCATTER_NN(KC, CN, NB, true); \
-        else DD_SCATTER_NN(KC, CN, NB, false);  \
-    } while (0)
-#define DD_SCATTER_TWO(KC, CN)                                                                          \
-    do {                                                                                                \
-        auto kern = scatter_kernel<KC, CN, true, true, 2>;                                              \
-        static std::atomic<unsigned long long> attr_done{0};                                            \
-        allow_full_lds(reinterpret_cast<const void*>(kern), attr_done);                                 \
-        hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3((unsigned)plan.threads), (size_t)plan.lds_bytes, st, \
-                           genomes, jobs, plan.log2m, sp);                                              \
-    } while (0)
-#define DD_SCATTER(KC, CN)                      \
-    do {                                        \
-        if (plan.nk_job == 2) DD_SCATTER_TWO(KC, CN); \
-        else if (plan.fbits == 4) DD_SCATTER_N(KC, CN, true); \
-        else DD_SCATTER_N(KC, CN, false);       \
-    } while (0)
-#define DD_SCATTER_KC(CN)                       \
-    do {                                        \
-        if (kclass == 0) DD_SCATTER(0, CN);     \
+#define DD_SCATTER_KC(CN)                        \
+    do {                                         \
+        if (kclass == 0) DD_SCATTER(0, CN);      \
         else if (kclass == 1) DD_SCATTER(1, CN); \
         else if (kclass == 3) DD_SCATTER(3, CN); \
-        else DD_SCATTER(2, CN);                 \
+        else DD_SCATTER(2, CN);                  \
     } while (0)
     if (plan.canonical) DD_SCATTER_KC(true);
     else DD_SCATTER_KC(false);
 #undef DD_SCATTER_KC
 #undef DD_SCATTER
-#undef DD_SCATTER_TWO
-#undef DD_SCATTER_N
-#undef DD_SCATTER_NN
 }
 
-void launch_replay(const BucketRow* rows, int ngenomes, int K, int k0, int nks, const SweepPlan& plan, hipStream_t st, int presorted, int row0, int nrows) {
-    const RowSet rs{K, k0, nks, nrows >= 0 ? std::min(nrows, ngenomes * nks - row0) : ngenomes * nks, row0};
+// first_epoch: the records are the binned tiles scatter_first_bin_kernel left (+ the rows' rho = 1 bits); else the filtered
+// scatter's dense stream, whose chunks are sorted by index tile first
+void launch_replay(const BucketRow* rows, int ngenomes, int K, int k0, int nks, const SweepPlan& plan, hipStream_t st, bool first_epoch) {
+    const RowSet rs{K, k0, nks, ngenomes * nks, 0};
     if (rs.nrows <= 0) return;
     const size_t tile = (size_t)1 << (plan.log2m - plan.nb_log2);
     const unsigned blocks = (unsigned)((rs.nrows + 7) / 8) * 8u << plan.nb_log2;
-    if (plan.nb_log2 >= 1 && !presorted) {  // several tiles per row: sort every chunk by tile first (the first epoch's scatter did it itself)
+    if (!first_epoch) {
         const int wgs_per_row = 32;
         hipLaunchKernelGGL(sort_chunks_kernel, dim3((unsigned)rs.nrows * wgs_per_row), dim3(256), 0, st, rows, rs, plan.log2m,
                            plan.nb_log2, plan.cap_chunks, wgs_per_row);
     }
-    static std::atomic<unsigned long long> attr_done[5] = {{0}, {0}, {0}, {0}, {0}};
-#define DD_REPLAY(FORM, SLOT)                                                                                                   \
-    do {                                                                                                                        \
-        allow_full_lds(reinterpret_cast<const void*>(replay_kernel<FORM>), attr_done[SLOT]);                                    \
-        hipLaunchKernelGGL(replay_kernel<FORM>, dim3(blocks), dim3(1024), tile, st, rows, rs, plan.log2m, plan.logg, plan.nb_log2, \
-                           plan.cap_chunks, plan.fbits);                                                                        \
-    } while (0)
-    if (presorted == 5) DD_REPLAY(5, 4);       // the first epoch's binned tiles + the bitmap of its rho = 1 updates
-    else if (presorted == 4) DD_REPLAY(4, 3);  // ... its packed bins (3 bytes per record)
-    else if (presorted == 3) DD_REPLAY(3, 2);  // ... its binned tiles (4 bytes per record)
-    else if (presorted == 2) DD_REPLAY(2, 1);  // ... or its workgroup chunks
-    else DD_REPLAY(0, 0);
-#undef DD_REPLAY
+    static std::atomic<unsigned long long> attr_done[2] = {{0}, {0}};
+    if (first_epoch) {
+        allow_full_lds(reinterpret_cast<const void*>(replay_kernel<true>), attr_done[1]);
+        hipLaunchKernelGGL(replay_kernel<true>, dim3(blocks), dim3(1024), tile, st, rows, rs, plan.log2m, plan.logg, plan.nb_log2, plan.cap_chunks);
+    } else {
+        allow_full_lds(reinterpret_cast<const void*>(replay_kernel<false>), attr_done[0]);
+        hipLaunchKernelGGL(replay_kernel<false>, dim3(blocks), dim3(1024), tile, st, rows, rs, plan.log2m, plan.logg, plan.nb_log2, plan.cap_chunks);
+    }
     hipLaunchKernelGGL(reset_cursors_kernel, dim3((unsigned)(rs.nrows + 255) / 256), dim3(256), 0, st, rows, rs);
 }
 
 void launch_sweep(const SweepGenome* genomes, const SweepJob* jobs, int njobs, int kclass,
                   const SweepPlan& plan, hipStream_t st) {
     if (njobs <= 0) return;
-#define DD_DISPATCH(KC, CN, MD) launch_one<KC, CN, MD>(genomes, jobs, njobs, plan, st)
-#define DD_DISPATCH_KC(CN, MD)                        \
-    do {                                              \
-        if (kclass == 0) DD_DISPATCH(0, CN, MD);      \
-        else if (kclass == 1) DD_DISPATCH(1, CN, MD); \
-        else if (kclass == 3) DD_DISPATCH(3, CN, MD); \
-        else DD_DISPATCH(2, CN, MD);                  \
+#define DD_DISPATCH_KC(CN)                                                          \
+    do {                                                                            \
+        if (kclass == 0) launch_one<0, CN>(genomes, jobs, njobs, plan, st);         \
+        else if (kclass == 1) launch_one<1, CN>(genomes, jobs, njobs, plan, st);    \
+        else if (kclass == 3) launch_one<3, CN>(genomes, jobs, njobs, plan, st);    \
+        else launch_one<2, CN>(genomes, jobs, njobs, plan, st);                     \
     } while (0)
-#define DD_DISPATCH_MODE(CN)                          \
-    do {                                              \
-        switch (plan.mode) {                          \
-            case 0: DD_DISPATCH_KC(CN, 0); break;     \
-            case 1: DD_DISPATCH_KC(CN, 1); break;     \
-            case 2: DD_DISPATCH_KC(CN, 2); break;     \
-            case 3: DD_DISPATCH_KC(CN, 3); break;     \
-            default: DD_DISPATCH_KC(CN, 4); break;    \
-        }                                             \
-    } while (0)
-    if (plan.canonical) DD_DISPATCH_MODE(true);
-    else DD_DISPATCH_MODE(false);
+    if (plan.canonical) DD_DISPATCH_KC(true);
+    else DD_DISPATCH_KC(false);
+#undef DD_DISPATCH_KC
 }
 
 }  // namespace dd

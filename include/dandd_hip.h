@@ -178,10 +178,8 @@ int dd_synth_realistic_device(dd_ctx *, uint64_t seed, int genome_index, uint64_
  * these sizes.  Writes at most `cap` jobs in launch order and returns how many there are (or a
  * negative DD_E* code).  kclass: -1 small-k bitmap class (k <= 9), -2 the exact k-mer sets of k = 10 (, 11)
  * at log2m >= 19 (one job per slice of the k-mer index space: `slice`), else the window class of the launch
- * (0: k <= 16, 1: <= 32, 3: 33..48, 2: 49..64); mode: 0 registers in LDS; 5 (log2m >= 17) registers in HBM
- * through scatter + chunk sort + replay, jobs listed epoch by epoch; 1 in HBM with every update checked there
- * and 2..4 in HBM behind an LDS filter byte per 2^mode registers with compare-and-swap (round 1's paths,
- * DD_NO_FILTER / DD_NO_BUCKETS). */
+ * (0: k <= 16, 1: <= 32, 3: 33..48, 2: 49..64); mode: 0 registers in LDS (log2m <= 16); 5 (log2m >= 17) registers in HBM
+ * through scatter + chunk sort + replay, jobs listed epoch by epoch. */
 typedef struct {
     int kclass, mode, lds_bytes;
     int genome, kfirst, nk;

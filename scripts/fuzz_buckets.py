@@ -1,6 +1,6 @@
-"""Randomized parity sweep of the log2m >= 18 path (scatter + sort + replay): random log2m 16..20 (16, 17 through
-DD_GLOBAL_FROM_P), k ranges, canonical flag, batches of 1..4 genomes of random sizes and content, and random
-schedule knobs (first epoch, longest epoch, capacity -> overflow path, filter granularity and entry width):
+"""Randomized parity sweep of the log2m >= 17 path (scatter + sort + replay): random log2m 16..20, k ranges, canonical
+flag, batches of 1..4 genomes of random sizes and content, and random schedule knobs (first epoch, longest epoch,
+capacity -> overflow path, record budget, the exact-set class on small genomes):
 GPU registers of the batched call vs the oracle, bit for bit.   python scripts/fuzz_buckets.py [N] [SEED]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,46 +13,22 @@ n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 engines = {}
 alph = [np.frombuffer(b"ACGT", np.uint8), np.frombuffer(b"ACGTacgtN", np.uint8), np.frombuffer(b"ACGTACGTACGTRYKMn-* 0>@\r", np.uint8)]
-KNOBS = ["DD_BUCKET_E0", "DD_BUCKET_EMAX", "DD_BUCKET_CAP", "DD_BUCKET_LOGG", "DD_BUCKET_FBITS", "DD_NO_XCD_AFFINITY", "DD_GLOBAL_FROM_P", "DD_BIGMAP_ANY_SIZE", "DD_NO_PRESORT", "DD_BUCKET_UNIT", "DD_BUCKET_NK", "DD_BUCKET_STAGGER", "DD_SIDE_ALWAYS", "DD_BUCKET_TILE_LOG2", "DD_FIRST_WG", "DD_ROW_GROUP_MB", "DD_FIRST_ONES"]
+KNOBS = ["DD_BUCKET_E0", "DD_BUCKET_EMAX", "DD_BUCKET_CAP", "DD_BIGMAP_ANY_SIZE", "DD_BUCKET_GB"]
 t0 = time.time()
 for it in range(n_cfg):
     for k in KNOBS:
         os.environ.pop(k, None)
-    p = int(rng.choice([16, 17, 18, 19, 20]))
-    if p <= 17:
-        os.environ["DD_GLOBAL_FROM_P"] = str(p)
+    p = int(rng.choice([16, 17, 18, 19, 20]))      # (16: registers in LDS, the neighbour of the smallest record-path size)
     if rng.integers(0, 2):
         os.environ["DD_BUCKET_E0"] = str(int(rng.choice([1, 2, 3, 8])))
     if rng.integers(0, 2):
         os.environ["DD_BUCKET_EMAX"] = str(int(rng.choice([1, 2, 5])))
     if rng.integers(0, 4) == 0:
         os.environ["DD_BUCKET_CAP"] = str(int(rng.choice([1, 2, 7, 40, 75, 150])))
-    if rng.integers(0, 3) == 0:
-        os.environ["DD_BUCKET_LOGG"] = str(int(rng.choice([1, 2, 3, 5, 7])))
-    if rng.integers(0, 2):
-        os.environ["DD_BUCKET_FBITS"] = str(int(rng.choice([4, 8])))
-    if rng.integers(0, 5) == 0:
-        os.environ["DD_NO_XCD_AFFINITY"] = "1"
     if rng.integers(0, 2):
         os.environ["DD_BIGMAP_ANY_SIZE"] = "1"
-    if rng.integers(0, 4) == 0:
-        os.environ["DD_NO_PRESORT"] = "1"
-    if rng.integers(0, 3) == 0:
-        os.environ["DD_BUCKET_UNIT"] = str(int(rng.choice([1, 2, 16])))
-    if rng.integers(0, 3) == 0:
-        os.environ["DD_BUCKET_NK"] = "2"
-    if rng.integers(0, 4) == 0:
-        os.environ["DD_BUCKET_STAGGER"] = "1"
-    if rng.integers(0, 4) == 0:
-        os.environ["DD_SIDE_ALWAYS"] = "1"
-    if rng.integers(0, 5) == 0:
-        os.environ["DD_BUCKET_TILE_LOG2"] = "17"
-    if rng.integers(0, 3) == 0:
-        os.environ["DD_FIRST_WG"] = str(int(rng.choice([0, 2, 4])))       # (4 = packed bins, round 5; default: 3)
     if rng.integers(0, 6) == 0:
-        os.environ["DD_ROW_GROUP_MB"] = "1"
-    if rng.integers(0, 4) == 0:
-        os.environ["DD_FIRST_ONES"] = "0"                                   # (round 5 default: the binned first epoch's rho = 1 updates are bits)
+        os.environ["DD_BUCKET_GB"] = "1"
     canon = bool(rng.integers(0, 2))
     k1, k2 = sorted(int(x) for x in rng.integers(1, 65, size=2))
     if k2 - k1 > 6:

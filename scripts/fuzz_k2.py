@@ -15,7 +15,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 engines = {}
 t0 = time.time()
 for it in range(n_cfg):
-    p = int(rng.choice([12, 13, 14, 15, 16, 17, 18, 19, 20]))
+    p = int(rng.choice([12, 14, 16, 17, 18, 18, 19, 19, 20]))      # (the bit-plane scan runs from log2m 18 on)
     m, q = 1 << p, 64 - p
     n = int(rng.choice([2, 3, 5, 17, 30, 31, 32, 33, 63, 64, 65, 100, 129, 200]))
     K = int(rng.choice([1, 2, 3, 4, 9, 31]))
@@ -51,9 +51,7 @@ for it in range(n_cfg):
     if n <= 32:
         no = int(rng.integers(1, 14))
         ords = np.stack([rng.integers(0, n, size=n) if rng.integers(0, 3) == 0 else rng.permutation(n) for _ in range(no)]).astype(np.int32)
-        os.environ["DD_PROGRESSIVE_PSCAN"] = "1"
-        scan = eng.progressive_device(dev.data_ptr(), n, K, ords)
-        os.environ.pop("DD_PROGRESSIVE_PSCAN", None)
+        scan = eng.progressive_device(dev.data_ptr(), n, K, ords)      # (the bit-plane scan from log2m 18 on, the streaming kernel below)
         os.environ["DD_PROGRESSIVE_STREAM"] = "1"
         strm = eng.progressive_device(dev.data_ptr(), n, K, ords)
         os.environ.pop("DD_PROGRESSIVE_STREAM", None)

@@ -243,7 +243,9 @@ def test_bench_without_enough_gpus_fails_loudly():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
                        env=env, capture_output=True, text=True, timeout=240, cwd=ROOT)
     assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert "wants cuda:1" in r.stderr
+    # (either rank's refusal: on a box with no GPU both ranks refuse, and the launcher may tear one of them down before it has
+    # printed -- asserting rank 1's message alone failed once in four loaded runs)
+    assert "wants cuda:" in r.stderr
 
 
 @pytest.mark.gpu

@@ -90,41 +90,17 @@ def test_sweep_parity_ragged_registers_in_hbm(engine_factory, orc, name):
     _sweep_check(eng, orc, np.frombuffer(RAGGED[name], dtype=np.uint8), 1, 40, True)
 
 
+# (round 6: only the switches that change a LIVE path -- the schedule of epochs, the capacity of a row's stream, the exact-set
+# class on small genomes; the A/B variants earlier rounds kept behind knobs are out of the build)
 BUCKET_KNOBS = {
-    "default": {},
+    "default": {},                                                     # one unfiltered first epoch: binned tiles + rho = 1 bits
     "many_epochs": {"DD_BUCKET_E0": "1", "DD_BUCKET_EMAX": "1"},      # every tile its own epoch: filters learned 5 times
-    "overflow": {"DD_BUCKET_CAP": "1", "DD_BUCKET_E0": "2"},          # one chunk per bucket: nearly every record takes the CAS fallback
-    "coarse_filter": {"DD_BUCKET_LOGG": "6", "DD_BUCKET_E0": "1"},    # 64 registers per filter entry
-    "nibble_filter": {"DD_BUCKET_FBITS": "4", "DD_BUCKET_E0": "1"},   # 4-bit bounds (saturating), two entries per byte
-    "byte_filter": {"DD_BUCKET_FBITS": "8", "DD_BUCKET_E0": "1"},
-    "no_row_probe": {"DD_BUCKET_PROBE": "0", "DD_BUCKET_E0": "1"},    # group filter only (no second-level check against the row)
-    "no_xcd_order": {"DD_NO_XCD_AFFINITY": "1", "DD_BUCKET_E0": "1"},
-    "cas_path": {"DD_NO_BUCKETS": "1"},                               # round 1's filtered compare-and-swap path, kept for A/B
-    "exact_sets": {"DD_BIGMAP_ANY_SIZE": "1"},                        # k = 10, 11 as exact k-mer sets whatever the genome size
-    "sort_kernel_only": {"DD_NO_PRESORT": "1", "DD_BUCKET_E0": "2"},  # first-epoch chunks sorted by sort_chunks_kernel, not by the scatter
-    "single_blocks": {"DD_BUCKET_UNIT": "1", "DD_BUCKET_E0": "1"},    # one 64-record block per reservation
-    "packed_cursors": {"DD_CURSOR_STRIDE": "4"},                      # row cursors 4 bytes apart
-    "two_ks_per_job": {"DD_BUCKET_NK": "2", "DD_BUCKET_E0": "1"},      # filtered scatter jobs of two consecutive ks (A/B knob)
-    "two_ks_small_filter": {"DD_BUCKET_NK": "2", "DD_BUCKET_LOGG": "5", "DD_BUCKET_E0": "1", "DD_BUCKET_EMAX": "2"},
-    "big_tiles": {"DD_BUCKET_TILE_LOG2": "17", "DD_BUCKET_E0": "1"},    # 128 KiB index tiles: one replay workgroup per CU (A/B knob)
-    "staggered": {"DD_BUCKET_STAGGER": "1", "DD_BUCKET_E0": "1"},       # class pipelines one first-epoch scatter apart (round 3's order)
-    "one_epoch_side_streams": {"DD_SIDE_ALWAYS": "1"},                  # a single-epoch call on side streams all the same
-    "side_priorities": {"DD_SIDE_PRIO": "201", "DD_BUCKET_E0": "1"},  # class pipelines on streams of different priority
-    "wg_sorted_chunks": {"DD_FIRST_WG": "2", "DD_BUCKET_E0": "3"},    # first epoch: the workgroup's 16 384-record sorted chunks (A/B knob)
-    "wave_chunks": {"DD_FIRST_WG": "0", "DD_BUCKET_E0": "2"},          # first epoch: every wave its own 1024-record chunks (round 3's form)
+    "two_epochs": {"DD_BUCKET_E0": "3"},                               # a binned first epoch of three tiles, then filtered ones
+    "overflow": {"DD_BUCKET_CAP": "1", "DD_BUCKET_E0": "2"},          # one chunk per row's stream: nearly every record takes the CAS fallback
     "bins_tight": {"DD_BUCKET_CAP": "150", "DD_BUCKET_E0": "3"},       # binned first epoch (70 chunks of stream per tile of tokens) against a 150-chunk stream: two tiles fit, the third overflows
-    "wg_chunks_tight": {"DD_FIRST_WG": "2", "DD_BUCKET_CAP": "40", "DD_BUCKET_E0": "3"},
-    "bins_big_tiles": {"DD_BUCKET_TILE_LOG2": "17", "DD_BUCKET_E0": "3"},
-    "packed_bins": {"DD_FIRST_WG": "4", "DD_BUCKET_E0": "3"},               # round 5: the first epoch's bins packed to 3 bytes per record through an LDS ring (A/B knob: measured slower)
-    "packed_bins_one_epoch": {"DD_FIRST_WG": "4"},
-    "packed_bins_tight": {"DD_FIRST_WG": "4", "DD_BUCKET_CAP": "110", "DD_BUCKET_E0": "3"},     # packed bins take 52.5 chunks of stream per tile of tokens: two fit, the third goes to the registers
-    "row_groups": {"DD_ROW_GROUP_MB": "1"},                              # round 5: scatter -> replay per group of 8 rows, record areas a ring
-    "row_groups_two_tiles_per_job": {"DD_ROW_GROUP_MB": "1", "DD_ROW_GROUP_TPJ": "2"},
-    # round 5, the default since: the binned first epoch's updates of rho = 1 leave a bit per register, not a record each
-    "all_updates_records": {"DD_FIRST_ONES": "0"},
-    "all_updates_records_epochs": {"DD_FIRST_ONES": "0", "DD_BUCKET_E0": "3"},
-    "ones_bits_tight": {"DD_BUCKET_CAP": "150", "DD_BUCKET_E0": "1"},     # ... with the stream full from the third tile on: records go to the registers, bits stay bits
-    "ones_bits_row_groups": {"DD_ROW_GROUP_MB": "1", "DD_FIRST_ONES": "1"},
+    "ones_bits_tight": {"DD_BUCKET_CAP": "150", "DD_BUCKET_E0": "1"},  # ... with the stream full from the third tile on: records go to the registers, bits stay bits
+    "exact_sets": {"DD_BIGMAP_ANY_SIZE": "1"},                        # k = 10, 11 as exact k-mer sets whatever the genome size
+    "small_budget": {"DD_BUCKET_GB": "1", "DD_BUCKET_E0": "2"},
 }
 
 
@@ -162,26 +138,10 @@ def test_bucket_mode_batched_unequal_genomes(engine_factory, torch_cuda, orc, mo
         assert np.array_equal(got[g], orc.sketch_sweep(f, 15, 18, 19)), g
 
 
-@pytest.mark.parametrize("p", [17, 18, 20])
-def test_packed_bins_on_low_complexity_text(engine_factory, orc, monkeypatch, p):
-    """(DD_FIRST_WG=4, an A/B knob since it measured slower.)  The first epoch's packed bins stage a period's records in an LDS ring of 384 slots per bin (mean 256 for uniformly
-    spread hashes).  Homopolymer and short-period stretches put EVERY record of a period into one bin: the ring and the
-    bin's region of the stream overflow and the records go to their registers by compare-and-swap -- exactly."""
-    monkeypatch.setenv("DD_FIRST_WG", "4")
-    eng = engine_factory(p, True)
-    rng = np.random.default_rng(p)
-    mixed = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=150_000))
-    fa = np.frombuffer(b">hp\n" + b"A" * 400_000 + b"\n>di\n" + b"AC" * 150_000 + b"\n>mix\n" + mixed + b"T" * 70_000 + mixed[:50_000] + b"\n", dtype=np.uint8)
-    _sweep_check(eng, orc, fa, 15, 18, True)
-    _sweep_check(eng, orc, fa, 31, 34, True)
-    eng_nc = engine_factory(p, False)
-    _sweep_check(eng_nc, orc, fa, 20, 21, False)
-
-
-@pytest.mark.parametrize("knobs", ["default", "all_updates_records"])
+@pytest.mark.parametrize("knobs", ["default", "bins_tight"])
 @pytest.mark.parametrize("p", [17, 18, 20])
 def test_first_epoch_on_low_complexity_text(engine_factory, orc, monkeypatch, p, knobs):
-    """The binned first epoch (with its rho = 1 updates as bits, round 5, and without) over text whose records all land in one bin and
+    """The binned first epoch (its rho = 1 updates as bits) -- alone, and with a stream so short that bins overflow -- over text whose records all land in one bin and
     one register: 400 000 copies of ONE k-mer of rho 10-12 (TCCG repeated, k 17 / 18; GG..G, k 31 at log2m 20: found with the oracle),
     homopolymers of small rho (one bit set 200 000 times), a short period inside random text.  == the oracle."""
     for k, v in BUCKET_KNOBS[knobs].items():
@@ -194,38 +154,6 @@ def test_first_epoch_on_low_complexity_text(engine_factory, orc, monkeypatch, p,
     _sweep_check(eng, orc, fa, 31, 34, True)
     eng_nc = engine_factory(p, False)
     _sweep_check(eng_nc, orc, fa, 17, 18, False)
-
-
-@pytest.mark.parametrize("p", [18, 20])
-def test_row_groups_over_unequal_genomes(engine_factory, torch_cuda, orc, monkeypatch, p):
-    """DD_ROW_GROUP_MB (round 5): a single-epoch call's rows go scatter -> replay in groups of 8, on two streams in turn, and the
-    record areas of a stream's successive groups are the same ring of slots.  7 genomes of unequal length (one empty, one of a
-    single tile) x k 12..40 = 4 k classes, 203 rows, 27 groups: every row == the oracle, twice (the ring is reused by the second call)."""
-    torch = torch_cuda
-    monkeypatch.setenv("DD_ROW_GROUP_MB", "1")
-    eng = engine_factory(p, True)
-    sizes = [(0, 500_000, 3), (1, 66_000, 1), (2, 0, 1), (3, 140_000, 2), (4, 300_000, 5), (5, 420_000, 1), (6, 90_000, 2)]
-    fas = [orc.synth_fasta(SEED, g, nb, nr) for g, nb, nr in sizes]
-    bufs = [torch.from_numpy(f.copy()).cuda() if f.size else torch.empty(16, dtype=torch.uint8, device="cuda") for f in fas]
-    regs = torch.empty((len(fas), 29, eng.m), dtype=torch.uint8, device="cuda")
-    want = {}
-    for rep in range(2):
-        regs.zero_()
-        eng.sketch_device([b.data_ptr() for b in bufs], [f.size for f in fas], 12, 40, regs.data_ptr())
-        eng.synchronize()
-        got = regs.cpu().numpy()
-        for g, f in enumerate(fas):
-            for k in (12, 16, 17, 29, 32, 33, 40):
-                if (g, k) not in want:
-                    want[g, k] = orc.sketch(f, k, p, True)
-                assert np.array_equal(got[g, k - 12], want[g, k]), (rep, g, k)
-    # ... and the rows in between against a run without the knob
-    monkeypatch.delenv("DD_ROW_GROUP_MB")
-    eng2 = engine_factory(p, True)
-    regs2 = torch.empty_like(regs)
-    eng2.sketch_device([b.data_ptr() for b in bufs], [f.size for f in fas], 12, 40, regs2.data_ptr())
-    eng2.synchronize()
-    assert torch.equal(regs, regs2)
 
 
 @pytest.mark.parametrize("p", [14, 17, 19, 20])
@@ -242,13 +170,12 @@ def test_inputs_without_a_single_kmer(engine_factory, p):
             assert regs.shape == (4, 1 << p) and not regs.any(), (p, canon, fa)
 
 
-def test_log2m17_both_register_modes(engine_factory, orc, monkeypatch):
-    """log2m 17 goes through scatter + replay by default (two index tiles per row); DD_GLOBAL_FROM_P=18 keeps the
-    one-128-KiB-row-per-workgroup LDS form alive.  Same registers either way."""
+def test_log2m17_record_path(engine_factory, orc, monkeypatch):
+    """log2m 17 is the smallest register count that goes through scatter + replay (two index tiles per row): one epoch, and several."""
     fa = np.concatenate([orc.synth_fasta(SEED, 2, 400_000, 3), np.frombuffer(RAGGED["lower_and_n"], dtype=np.uint8)])
     eng = engine_factory(17, True)
     a = _sweep_check(eng, orc, fa, 8, 19, True)
-    monkeypatch.setenv("DD_GLOBAL_FROM_P", "18")
+    monkeypatch.setenv("DD_BUCKET_E0", "2")
     b = _sweep_check(eng, orc, fa, 8, 19, True)
     assert np.array_equal(a, b)
 
@@ -535,12 +462,6 @@ def test_bgzf_files_are_inflated_on_the_device(engine_factory, orc, tmp_path, mo
         cases.append((name, str(path), np.frombuffer(raw, dtype=np.uint8)))
     monkeypatch.setenv("DD_INFLATE_STRICT", "1")                 # a block the device refuses fails the call: no silent host fallback here
     got = eng.sketch_files([p for _, p, _ in cases], 19, 21)
-    for mode in ("0", "1"):                                      # the walk over a window's symbols by all lanes at once is the default (2) since round 5: the scalar walk and the adaptive mix give the same registers, the same bytes
-        monkeypatch.setenv("DD_INFLATE_PWALK", mode)
-        assert np.array_equal(eng.sketch_files([p for _, p, _ in cases], 19, 21), got), mode
-        for (name, path, fa), text in zip(cases, eng.inflate_files([p for _, p, _ in cases])):
-            assert text.tobytes() == fa.tobytes(), (name, mode)
-    monkeypatch.delenv("DD_INFLATE_PWALK")
     # ... and the inflated BYTES (dd_inflate_files: the text as K0 is about to read it, copied back from the device) are zlib's:
     # one wrong byte moves a register with p ~ m / n only, the registers alone would miss most of them
     import gzip
@@ -1030,14 +951,6 @@ def test_timing_spans_and_call_statistics(engine_factory, orc):
     sweep_ms, sweep_n = eng.timing_read(KERNEL_SWEEP)
     assert pack_n == 1 and pack_ms > 0
     assert sweep_n == 1 and sweep_ms > 0            # a small call: the four k classes run side by side, timed as one span
-    import os
-    os.environ["DD_NO_SIDE_STREAMS"] = "1"
-    try:
-        eng.timing_reset()
-        assert np.array_equal(eng.sketch_buffer(fa, 4, 40), regs)
-        assert eng.timing_read(KERNEL_SWEEP)[1] == 4    # back to back: small-k class + the 32-, 64- and 96-bit classes
-    finally:
-        del os.environ["DD_NO_SIDE_STREAMS"]
     eng.card_batch(regs)
     assert eng.timing_read(KERNEL_UNION)[1] >= 1
     eng.timing_reset()
@@ -1069,8 +982,7 @@ def test_pairwise_gram_equals_streaming_kernel(engine_factory, torch_cuda, orc, 
     """dd_pairwise_device through the int8 Gram matrices on the matrix cores (dd_gram.hip) == the streaming byte-max
     kernel (DD_PAIRWISE_STREAM=1, dd_union.hip) for every (i, j, k), as doubles -- n not a multiple of 32 or 64, more
     than one 64-row super-block (n = 70 ... 257: 128-row diagonal units in eight-wave workgroups, round 5, with an odd 64-row
-    block left over at 129 and 257, and the off-diagonal kernel without the pairs those units hold; DD_GRAM_DIAG2=0, round 4's
-    64-row diagonal units, must give the same), more than 64 k columns (the compact workgroup ids count columns in chunks of
+    block left over at 129 and 257, and the off-diagonal kernel without the pairs those units hold), more than 64 k columns (the compact workgroup ids count columns in chunks of
     64), several register ranges per row (log2m 18, 20), degenerate threshold ranges -- and == the oracle's estimator on the
     byte-max for sampled pairs."""
     torch = torch_cuda
@@ -1085,10 +997,6 @@ def test_pairwise_gram_equals_streaming_kernel(engine_factory, torch_cuda, orc, 
     bad = np.argwhere(gram != stream)
     assert bad.size == 0, f"{len(bad)} of {gram.size} entries differ, first (i, j, k) = {bad[0]}: gram {gram[tuple(bad[0])]} stream {stream[tuple(bad[0])]}"
     assert np.array_equal(gram, gram.transpose(1, 0, 2))
-    if n > 64:
-        monkeypatch.setenv("DD_GRAM_DIAG2", "0")
-        assert np.array_equal(eng.pairwise_device(dev.data_ptr(), n, K), gram)
-        monkeypatch.delenv("DD_GRAM_DIAG2")
     for _ in range(6):
         i, j, k = int(rng.integers(n)), int(rng.integers(n)), int(rng.integers(K))
         want = orc.card(np.maximum(slab[i, k], slab[j, k]), p)
@@ -1122,12 +1030,12 @@ def test_sweep_parity_on_realistic_genome(engine_factory, orc, p, krange):
     _sweep_check(eng, orc, fa, krange[0], krange[1], True)
 
 
-@pytest.mark.parametrize("p,n,K,no", [(12, 2, 3, 1), (12, 7, 4, 10), (14, 30, 5, 10), (14, 32, 3, 4), (14, 33, 2, 3), (16, 64, 2, 2),
+@pytest.mark.parametrize("p,n,K,no", [(18, 2, 3, 1), (18, 7, 4, 10), (18, 30, 5, 10), (18, 32, 3, 4), (18, 33, 2, 3),
                                        (18, 12, 2, 9), (19, 32, 2, 4), (20, 30, 3, 10), (20, 8, 2, 17)])
 def test_progressive_pscan_equals_streaming_kernel(engine_factory, torch_cuda, orc, monkeypatch, p, n, K, no):
     """dd_progressive_device through the bit-plane AND-scan (dd_pscan.hip) == the streaming running-max kernel
-    (DD_PROGRESSIVE_STREAM=1, dd_union.hip) for every (ordering, prefix, k), as doubles -- more than 32 leaves (the
-    64-prefix instantiation), more orderings than one launch holds, degenerate and full threshold ranges, repeated
+    (DD_PROGRESSIVE_STREAM=1, dd_union.hip) for every (ordering, prefix, k), as doubles -- from log2m 18 on, where the library
+    takes the scan by itself; more than 32 leaves (the streaming kernel both times), more orderings than one launch holds, degenerate and full threshold ranges, repeated
     leaves inside an ordering, plane rows of 4 (n = 32 with 51 thresholds), 8 and 32 words, i.e. both forms of the
     prefix-major scan -- and == the oracle's estimator on the running byte-max for sampled prefixes."""
     torch = torch_cuda
@@ -1138,9 +1046,8 @@ def test_progressive_pscan_equals_streaming_kernel(engine_factory, torch_cuda, o
     if no > 1 and n > 2:
         ords[-1, 1] = ords[-1, 0]            # a leaf twice in a row: the prefix does not change
     dev = torch.from_numpy(slab).cuda()
-    monkeypatch.setenv("DD_PROGRESSIVE_PSCAN", "1")      # (the library takes this path from log2m 19 on by itself)
     scan = eng.progressive_device(dev.data_ptr(), n, K, ords)
-    monkeypatch.delenv("DD_PROGRESSIVE_PSCAN")
+    assert eng.last_k2_path() == (2 if n <= 32 else 1)      # DD_K2_PROGRESSIVE_PSCAN / _STREAM (include/dandd_hip.h)
     monkeypatch.setenv("DD_PROGRESSIVE_STREAM", "1")
     stream = eng.progressive_device(dev.data_ptr(), n, K, ords)
     monkeypatch.delenv("DD_PROGRESSIVE_STREAM")

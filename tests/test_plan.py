@@ -49,20 +49,10 @@ def check(log2m, sizes, kmin, kmax):
             if j["slice"] > 0:
                 extra_slices.setdefault((g, k0, int(j["slice"])), np.zeros(ntiles[g], dtype=np.int32))[j["tile_begin"]:j["tile_end"]] += 1
                 continue
-        elif log2m >= 17 and os.environ.get("DD_NO_FILTER"):
-            assert mode == 1 and j["lds_bytes"] == 0               # every update checked in HBM
-        elif log2m >= 17 and os.environ.get("DD_NO_BUCKETS"):
-            assert mode == max(2, log2m - 16) and nk == 1          # one k per job behind the filter
-            assert j["lds_bytes"] == (m >> mode) + 16 * 128 * 4    # filter + one queue per wave
         elif log2m >= 17:
-            fbits = int(os.environ.get("DD_BUCKET_FBITS", 4))
-            logg = int(os.environ.get("DD_BUCKET_LOGG", max(1, log2m - 16 - (1 if fbits == 4 else 0))))
-            queues = 2 if os.environ.get("DD_BUCKET_PROBE", "1") != "0" else 1
-            while (m >> logg) * fbits // 8 + 16 * 1024 > LDS_MAX:
-                logg += 1
-            nkj = 1
+            logg = max(1, log2m - 17)                               # a 64 KiB filter of 4-bit entries
             assert mode == 5 and nk == 1                           # scatter + replay, one k per job
-            assert j["lds_bytes"] == nkj * ((m >> logg) * fbits // 8 + queues * 16 * 128 * 4)    # filter + the record queues of every wave
+            assert j["lds_bytes"] == (m >> logg) // 2 + 2 * 16 * 128 * 4    # the filter + two record queues per wave
         else:
             assert mode == 0 and nk * m <= j["lds_bytes"]          # the group's registers fit the LDS asked for
         cover[g][k0 - kmin:k0 - kmin + nk, j["tile_begin"]:j["tile_end"]] += 1
@@ -73,7 +63,7 @@ def check(log2m, sizes, kmin, kmax):
         for sl in range(1, 2 if k == 11 else 1):
             c = extra_slices.get((g, k, sl))
             assert c is not None and c.min() == 1 and c.max() == 1, f"genome {g} k {k} slice {sl}"
-    if log2m >= 19 and not any(os.environ.get(v) for v in ("DD_NO_BUCKETS", "DD_NO_FILTER", "DD_NO_BITMAP", "DD_NO_BIGMAP")):
+    if log2m >= 19:
         # ... for genomes with several times more tokens than the set can have members (the finish kernel hashes the
         # whole set once per 128 KiB index tile): on average >= tiles x 4^k bytes
         last, avg, tiles = (11 if log2m >= 20 else 10), sum(sizes) // max(1, len(sizes)), 1 << max(0, log2m - 17)
@@ -118,16 +108,15 @@ def test_launch_shape_of_the_headline_config():
 
 
 def test_bucket_mode_epochs(monkeypatch):
-    """log2m >= 18: jobs come epoch by epoch (launch order), epochs are the same tile ranges for every row and
-    double in length; DD_NO_BUCKETS brings back the filtered compare-and-swap path, still covering everything."""
-    for env in ({}, {"DD_BUCKET_E0": "1", "DD_BUCKET_EMAX": "3"}, {"DD_BUCKET_LOGG": "6"}, {"DD_BUCKET_GB": "1"},
-                {"DD_NO_BUCKETS": "1"}):
+    """log2m >= 17: jobs come epoch by epoch (launch order), epochs are the same tile ranges for every row and
+    double in length."""
+    for env in ({}, {"DD_BUCKET_E0": "1", "DD_BUCKET_EMAX": "3"}, {"DD_BUCKET_E0": "2"}, {"DD_BUCKET_GB": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         for log2m in (17, 18, 19, 20):
             jobs = check(log2m, SIZES["ragged"], 8, 35)
             real = jobs[(jobs["tile_end"] > jobs["tile_begin"]) & (jobs["kclass"] >= 0)]
-            if "DD_NO_BUCKETS" not in env and "DD_BUCKET_GB" not in env:
+            if "DD_BUCKET_GB" not in env:
                 e0 = int(env.get("DD_BUCKET_E0", max(8, 4 * (1 << log2m) // TILE)))
                 ntiles = [(n + TILE - 1) // TILE for n in SIZES["ragged"]]
                 if "DD_BUCKET_E0" not in env and max(ntiles) <= e0 + e0 // 4:
@@ -147,8 +136,7 @@ def test_bucket_mode_epochs(monkeypatch):
 
 
 def test_knobs_change_the_plan_not_the_coverage(monkeypatch):
-    for env in ({"DD_NO_BITMAP": "1"}, {"DD_LDS_KB": "160"}, {"DD_JOBS_PER_CU": "3"}, {"DD_NO_XCD_AFFINITY": "1"},
-                {"DD_NO_TAPER": "1"}, {"DD_NO_FILTER": "1"}, {"DD_NO_BUCKETS": "1"}, {"DD_BUCKET_E0": "2"}):
+    for env in ({"DD_BUCKET_E0": "2"}, {"DD_BUCKET_EMAX": "2", "DD_BUCKET_E0": "1"}, {"DD_BUCKET_CAP": "8"}, {"DD_BUCKET_GB": "1"}, {"DD_BIGMAP_ANY_SIZE": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         for log2m in (14, 18):
