@@ -251,6 +251,12 @@ class HipBackend:
         self._recent_bytes = 0
         self._recent_limit = int(os.environ.get("DANDD_SKETCH_CACHE_MB", "1024")) << 20
 
+    def new_command(self):
+        """A resident server calls this between commands (deltatree.new_command): the registers kept in memory are keyed by the path
+        AS GIVEN, and the next client may mean another file by the same relative path."""
+        self._recent.clear()
+        self._recent_bytes = 0
+
     def _remember(self, path, regs, k):
         if self._recent_limit <= 0:
             return
@@ -340,12 +346,35 @@ class HipBackend:
     # ---- whole union schedules in one launch (no reference equivalent: the reference runs one
     # `dashing union` + one `dashing card` process per (set, k)) -----------------------------------
     def _leaf_slab(self, leaf_paths):
-        """leaf_paths[n][K] -> uint8 [n][K][m]"""
+        """leaf_paths[n][K] -> uint8 [n][K][m].  Files this process did not handle last are read straight into their rows of
+        the slab by a few threads (readinto releases the GIL): 64 x 37 one-MiB sketches were 0.43 s of a 1.3 s `kij` one file
+        after the other through read_sketch_file, which also copies every one of them once more."""
         n, K = len(leaf_paths), len(leaf_paths[0])
-        slab = np.empty((n, K, 1 << self.log2m), dtype=np.uint8)
+        m = 1 << self.log2m
+        slab = np.empty((n, K, m), dtype=np.uint8)
+        cold = []
         for i, row in enumerate(leaf_paths):
             for kk, p in enumerate(row):
-                slab[i, kk] = self._load(p)[0]
+                if p in self._recent:
+                    slab[i, kk] = self._load(p)[0]
+                else:
+                    cold.append((i, kk, p))
+
+        def fill(item):
+            i, kk, p = item
+            with open(p, "rb", buffering=0) as f:
+                head = f.read(_HDR.size)
+                if head[:8] == MAGIC and head[8] == self.log2m and f.readinto(memoryview(slab[i, kk])) == m and not f.read(1):
+                    return
+            slab[i, kk] = read_sketch_file(p)[0]      # (Dashing's container, or a file that is not what its name says: the reader reports it)
+
+        if len(cold) * m >= (64 << 20):
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(16, (os.cpu_count() or 4))) as pool:
+                list(pool.map(fill, cold))
+        else:
+            for item in cold:
+                fill(item)
         return slab
 
     def pairwise_cards(self, leaf_paths):

@@ -123,8 +123,11 @@ def serve_command(args):
     except FileNotFoundError:
         pass
     srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
-    srv.bind(path)
-    os.chmod(path, 0o600)      # the socket runs commands as this user: nobody else may connect
+    old_mask = os.umask(0o177)   # the socket runs commands as this user: nobody else may connect, from the moment it exists
+    try:
+        srv.bind(path)
+    finally:
+        os.umask(old_mask)
     srv.listen(8)
     if args.warm:              # bring a backend up before the first command arrives: "<registers>[,nc]"
         for spec in args.warm:
@@ -132,6 +135,53 @@ def serve_command(args):
             deltatree.backend_for({"registers": int(regs), "canonicalize": flag != "nc", "tool": "dashing"})
     print(f"dandd serve: listening on {path}", flush=True)
     served, home = 0, os.getcwd()
+
+    def handle(conn):
+        """one connection = one request; -> True when the server is asked to leave"""
+        nonlocal served
+        conn.settimeout(None)
+        req = recv_msg(conn)
+        if not isinstance(req, dict):
+            return False
+        if req.get("op") == "ping":
+            send_msg(conn, {"rc": 0, "served": served, "pid": os.getpid()})
+            return False
+        if req.get("op") == "shutdown":
+            send_msg(conn, {"rc": 0, "served": served})
+            return True
+        out, err = io.StringIO(), io.StringIO()
+        saved = {k: v for k, v in os.environ.items() if k.startswith(ENV_PREFIXES)}
+        t0 = time.perf_counter()
+        rc = 1
+        try:
+            for k in saved:
+                del os.environ[k]
+            os.environ.update({k: str(v) for k, v in (req.get("env") or {}).items() if k.startswith(ENV_PREFIXES)})
+            os.chdir(req.get("cwd") or home)
+            deltatree.new_command()
+            with contextlib.redirect_stdout(out), contextlib.redirect_stderr(err):
+                try:
+                    argv = list(req.get("argv") or [])
+                    if argv[:1] == ["serve"]:
+                        raise SystemExit("dandd serve: a server does not start servers")
+                    rc = main(argv) or 0
+                except SystemExit as e:
+                    rc = e.code if isinstance(e.code, int) else (0 if e.code is None else 1)
+                    if isinstance(e.code, str):
+                        print(e.code, file=sys.stderr)
+                except BaseException:
+                    import traceback
+                    traceback.print_exc()
+                    rc = 1
+        finally:
+            for k in [k for k in os.environ if k.startswith(ENV_PREFIXES)]:
+                del os.environ[k]
+            os.environ.update(saved)
+            os.chdir(home)
+        served += 1
+        send_msg(conn, {"rc": rc, "stdout": out.getvalue(), "stderr": err.getvalue(), "seconds": time.perf_counter() - t0})
+        return False
+
     try:
         while True:
             srv.settimeout(args.idle_exit if args.idle_exit > 0 else None)
@@ -140,47 +190,13 @@ def serve_command(args):
             except socket.timeout:
                 break
             with conn:
-                conn.settimeout(None)
-                req = recv_msg(conn)
-                if req is None:
-                    continue
-                if req.get("op") == "ping":
-                    send_msg(conn, {"rc": 0, "served": served, "pid": os.getpid()})
-                    continue
-                if req.get("op") == "shutdown":
-                    send_msg(conn, {"rc": 0, "served": served})
-                    break
-                out, err = io.StringIO(), io.StringIO()
-                saved = {k: v for k, v in os.environ.items() if k.startswith(ENV_PREFIXES)}
-                t0 = time.perf_counter()
-                rc = 1
+                # a client that hangs up mid-command (Ctrl-C, a timeout) or sends something that is not a request costs its own
+                # connection, never the server: the warm GPU context is what this process exists to keep
                 try:
-                    for k in saved:
-                        del os.environ[k]
-                    os.environ.update({k: str(v) for k, v in (req.get("env") or {}).items() if k.startswith(ENV_PREFIXES)})
-                    os.chdir(req.get("cwd") or home)
-                    deltatree.new_command()
-                    with contextlib.redirect_stdout(out), contextlib.redirect_stderr(err):
-                        try:
-                            argv = list(req.get("argv") or [])
-                            if argv[:1] == ["serve"]:
-                                raise SystemExit("dandd serve: a server does not start servers")
-                            rc = main(argv) or 0
-                        except SystemExit as e:
-                            rc = e.code if isinstance(e.code, int) else (0 if e.code is None else 1)
-                            if isinstance(e.code, str):
-                                print(e.code, file=sys.stderr)
-                        except BaseException:
-                            import traceback
-                            traceback.print_exc()
-                            rc = 1
-                finally:
-                    for k in [k for k in os.environ if k.startswith(ENV_PREFIXES)]:
-                        del os.environ[k]
-                    os.environ.update(saved)
-                    os.chdir(home)
-                served += 1
-                send_msg(conn, {"rc": rc, "stdout": out.getvalue(), "stderr": err.getvalue(), "seconds": time.perf_counter() - t0})
+                    if handle(conn):
+                        break
+                except (OSError, ValueError) as e:   # (BrokenPipeError, ConnectionResetError; JSONDecodeError, UnicodeDecodeError)
+                    print(f"dandd serve: connection dropped: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
     finally:
         srv.close()
         try:

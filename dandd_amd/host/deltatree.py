@@ -158,9 +158,17 @@ def write_listdict_to_csv(outfile, listdict, suffix="", last_col=None):
         names.append(last_col)
     out = sys.stdout if outfile in (None, "-") else open(outfile + suffix, "w", newline="")
     try:
-        w = csv.DictWriter(out, fieldnames=names)
-        w.writeheader()
-        w.writerows(listdict)
+        if len(names) > 1 and all(len(row) == len(names) for row in listdict):
+            # every row has every column: the same bytes as DictWriter's, from C all the way (a `kij --jaccard` over 64
+            # genomes writes 62 496 rows of 10 cells)
+            from operator import itemgetter
+            w = csv.writer(out)
+            w.writerow(names)
+            w.writerows(map(itemgetter(*names), listdict))
+        else:
+            w = csv.DictWriter(out, fieldnames=names)
+            w.writeheader()
+            w.writerows(listdict)
     finally:
         if out is not sys.stdout:
             out.close()
@@ -439,6 +447,111 @@ class DeltaTreeNode:
 
 
 # ---------------------------------------------------------------------------------------------
+class _FlatUnion:
+    """The body node of a SubSpider as NUMBERS.  When a whole union schedule has come back from the GPU as one table of
+    cardinalities (prefetch_union_cards: every pair x k of `kij`, every prefix x k of `progressive`), a SubSpider per pair or
+    prefix -- a DeltaTreeNode, a Sketch object and a SketchPath per (set, k), 76 608 of them for 64 genomes -- computes nothing:
+    it walks dictionaries.  This class goes through the same steps on the table itself -- find_delta / find_delta_helper with
+    their `<=` ties and the kstart they move (lib/huffman_dandd.py:106-146), node_ksweep's k-1..k+1 window (:117), fill_tree's
+    update_node of every bestk (:451-457), summarize (:289-301) -- and leaves the same traces a tree save reads: the base names in
+    the experiment's base set, their sketchinfo entries, the ngen*/k* directories.  A k outside the table goes through the
+    file-based backend (leaf sketches, union, card) as the object path does."""
+
+    def __init__(self, tree, kids, experiment, table_row, lo, hi):
+        sp = tree.speciesinfo
+        self.sp, self.experiment, self.kids = sp, experiment, list(kids)
+        self.row, self.lo, self.hi = table_row, int(lo), int(hi)
+        self.fastas = [leaf.fastas[0] for c in self.kids for leaf in c.progeny]
+        self.ngen = len(self.fastas)
+        self.title = "_".join(os.path.basename(c.node_title) for c in self.kids)
+        self.tmpl = SketchPath(self.fastas, 0, sp, experiment)   # (the '{}' form: registers its base as the node's placeholder sketch does)
+        experiment["baseset"].add(self.tmpl.base)
+        self.delta, self.bestk, self.mink, self.maxk = 0, 0, 0, 0
+        self._touched = set()
+        self._be = backend_for(experiment)
+
+    def touch(self, k):
+        """what update_node(k) leaves behind besides the Sketch object"""
+        if k in self._touched:
+            return
+        self._touched.add(k)
+        ktxt = str(k)
+        base = self.tmpl.base.replace("{}", ktxt)
+        self.experiment["baseset"].add(base)
+        ensure_dir(self.tmpl.dir.replace("{}", ktxt))
+        if base not in self.sp.sketchinfo:
+            self.sp.sketchinfo[base] = {"sketchbase": base, "files": self.tmpl.files, "ngen": self.ngen, "kval": k,
+                                        "registers": self.experiment["registers"]}
+
+    def card(self, k):
+        if self.row is not None and self.lo <= k <= self.hi:
+            return float(self.row[k - self.lo])
+        path = self.tmpl.with_k(k)
+        cards = self.sp.cardkey
+        if float(cards.get(path) or 0) > 0:
+            return float(cards[path])
+        # outside the table: the files, as DeltaTreeNode.ksweep_update_node + Sketch would (a hill-climb that leaves the window)
+        for c in self.kids:
+            c.ksweep_update_node(k, k)
+        if self.ngen > 1 and not sketch_exists(path):
+            ensure_dir(self.tmpl.dir.replace("{}", str(k)))
+            self._be.union([c.ksketches[0].sfp.with_k(k) for c in self.kids], path)
+        cards[path] = float(self._be.card(path))
+        return cards[path]
+
+    def command(self, k):
+        op = "sketch" if self.ngen == 1 else "union"
+        return self._be.describe(op, k=k, out=os.path.basename(self.tmpl.with_k(k))) if hasattr(self._be, "describe") else op
+
+    def node_ksweep(self, mink, maxk):
+        for k in range(max(1, mink), maxk + 1):
+            self.touch(k)
+        self.mink, self.maxk = mink, maxk
+
+    def find_delta_helper(self, kval, direction):
+        while True:
+            if self.experiment["tool"] == "dashing" and kval > 32 and not self.experiment.get("allow_k64"):
+                raise ValueError("Exploratory k value is too high for dashing. Either something is amiss "
+                                 "with your data or you need to be using --exact mode")
+            if kval < 1:
+                return
+            self.node_ksweep(kval - 1, kval + 1)
+            if direction < 0:
+                self.mink = kval
+            else:
+                self.maxk = kval
+            candidate = self.card(kval) / kval
+            if not self.delta <= candidate:  # ties keep climbing
+                return
+            self.sp.kstart = kval
+            self.bestk = kval
+            self.delta = candidate
+            kval += direction
+
+    def find_delta(self, kval):
+        self.find_delta_helper(kval, 1)
+        self.find_delta_helper(kval, -1)
+
+    def fill(self):
+        """SubSpider.fill_tree in a hill-climb run: the root brought up to date at every node's argmax-k"""
+        for k in sorted({c.bestk for c in self.kids} | {self.bestk}):
+            if k > 0:
+                self.touch(k)
+
+    def summarize(self, mink, maxk, ordering_number):
+        rows = []
+        for k in range(mink, maxk + 1):
+            if k == 0:   # the placeholder sketch (a hill-climb run's summary is made of these: SURVEY.md section 9)
+                rows.append({"ngen": self.ngen, "kval": 0, "card": 0, "delta_pos": 0, "title": self.title, "command": None,
+                             "ordering": ordering_number})
+                continue
+            c = self.card(k)
+            rows.append({"ngen": self.ngen, "kval": k, "card": c, "delta_pos": c / k, "title": self.title,
+                         "command": self.command(k), "ordering": ordering_number})
+        return rows
+
+
+# ---------------------------------------------------------------------------------------------
 DEFAULT_EXPERIMENT = {"tool": "dashing", "registers": 20, "canonicalize": True, "debug": False, "nthreads": 0,
                       "baseset": set(), "safety": False, "fast": False, "verbose": False, "ksweep": None,
                       "lowmem": False}
@@ -696,21 +809,26 @@ class DeltaTree:
             rows.append([tmpl.with_k(k) for k in range(lo, hi + 1)])
         return rows
 
-    def prefetch_union_cards(self, groups, lo, hi, experiment):
+    def prefetch_union_cards(self, groups, lo, hi, experiment, schedule=False):
         """Cardinalities of the unions `groups` (lists of leaf nodes) for k in [lo, hi], computed by
         ONE batched GPU launch per schedule instead of one union + one card per (set, k), and stored
         in the cardinality cache under the names the union sketches would have.  A backend without
-        batch entry points (the CPU checkers used in tests) makes this a no-op."""
+        batch entry points (the CPU checkers used in tests) makes this a no-op.
+        schedule=True: the table itself comes back -- {"table", "index" (id(leaf) -> row), "lo", "hi", "orders" (ordering as a
+        tuple of rows -> its number in the table)} or None -- and the CALLER stores what it uses in the cache (the summaries
+        below work on the table: _FlatUnion)."""
         be = backend_for(experiment)
         if lo < 1 or hi < lo or not groups or os.environ.get("DD_NO_PREFETCH"):
-            return 0
+            return None if schedule else 0
         pair_mode = all(len(g) == 2 for g in groups)
         if not hasattr(be, "pairwise_cards" if pair_mode else "progressive_cards"):
-            return 0
+            return None if schedule else 0
         leaves = []
+        seen = set()
         for g in groups:
             for leaf in g:
-                if leaf not in leaves:
+                if id(leaf) not in seen:
+                    seen.add(id(leaf))
                     leaves.append(leaf)
         index = {id(leaf): i for i, leaf in enumerate(leaves)}
         paths = self._leaf_files(leaves, lo, hi)
@@ -718,6 +836,9 @@ class DeltaTree:
         filled = 0
         if pair_mode:
             table = be.pairwise_cards(paths)
+            if schedule:
+                experiment["prefetched"] = True
+                return {"table": table, "index": index, "lo": lo, "hi": hi, "orders": {}}
             for a, b in groups:
                 tmpl = SketchPath([a.fastas[0], b.fastas[0]], 0, self.speciesinfo, experiment)
                 row = table[index[id(a)], index[id(b)]]
@@ -733,8 +854,11 @@ class DeltaTree:
                     ords.append([index[id(leaf)] for leaf in g])
                     used.append(g)
             if not ords:
-                return 0
+                return None if schedule else 0
             table = be.progressive_cards(paths, ords)
+            if schedule:
+                experiment["prefetched"] = True
+                return {"table": table, "index": index, "lo": lo, "hi": hi, "orders": {tuple(o): i for i, o in enumerate(ords)}}
             for o, g in enumerate(used):
                 for j in range(1, n):
                     fastas = [leaf.fastas[0] for leaf in g[: j + 1]]
@@ -785,7 +909,8 @@ class DeltaTree:
     def progressive_union(self, flist, orderings, step):
         spider = DeltaSpider(fasta_files=flist, speciesinfo=self.speciesinfo, experiment=self.experiment)
         # all prefix unions of all orderings in one GPU launch (running max == flat union)
-        if step == 1 and len(flist) > 1:
+        sched = None
+        if step == 1 and len(flist) > 1 and not self.experiment.get("safety"):
             by_fasta = {leaf.fastas[0]: leaf for leaf in spider.leaf_nodes()}
             if self.experiment["ksweep"] is not None:
                 lo, hi = self.experiment["ksweep"]
@@ -795,12 +920,12 @@ class DeltaTree:
                 if self.experiment["tool"] == "dashing":
                     hi = min(hi, 32)
             groups = [[by_fasta[spider.fastas[j]] for j in ordering] for ordering in orderings]
-            spider.prefetch_union_cards(groups, int(lo), int(hi), self.experiment)
+            sched = spider.prefetch_union_cards(groups, int(lo), int(hi), self.experiment, schedule=True)
         results, summary = [], []
         for i, ordering in enumerate(orderings):
             if self.experiment["verbose"]:
                 print(f"Now sweeping for ordering {i + 1}")
-            rows, srows = spider.sketch_ordering(ordering, ordering_number=i + 1, step=step)
+            rows, srows = spider.sketch_ordering(ordering, ordering_number=i + 1, step=step, schedule=sched)
             results.extend(rows)
             summary.extend(srows)
             self.speciesinfo.save_references(fast=self.experiment["fast"])
@@ -808,15 +933,42 @@ class DeltaTree:
         self.experiment.pop("prefetched", None)  # the trust flag must not outlive this run (the tree is pickled)
         return results, summary
 
-    def sketch_ordering(self, ordering, ordering_number, step=1):
+    def sketch_ordering(self, ordering, ordering_number, step=1, schedule=None):
         """Flat union of every prefix of the ordering (NOT previous union + one)."""
         krange = self.experiment["ksweep"] or (self.mink, self.maxk)
         lo, hi = int(krange[0]), int(krange[1])
         rows, summary = [], []
+        leaves = self.leaf_nodes()
+        # the schedule's table holds this ordering: every prefix is a row of numbers, not a SubSpider of objects (_FlatUnion)
+        o = None
+        if schedule is not None and step == 1:
+            by_fasta = {leaf.fastas[0]: leaf for leaf in leaves}
+            key = tuple(schedule["index"].get(id(by_fasta.get(self.fastas[j]))) for j in ordering)
+            o = schedule["orders"].get(key)
         for i in range(1, len(ordering) + 1):
             if i % step:
                 continue
             prefix = [self.fastas[j] for j in ordering[:i]]
+            if o is not None:
+                inside = set(prefix)
+                kids = [leaf for leaf in leaves if leaf.fastas[0] in inside]      # tree order, as nodes_from_fastas gives them
+                sub = _FlatUnion(self, kids, self.experiment, schedule["table"][o, i - 1], schedule["lo"], schedule["hi"])
+                if i > 1 and sub.row is not None:   # what the union sketches' cardinalities would have been cached as
+                    cards = self.speciesinfo.cardkey
+                    for kk, k in enumerate(range(sub.lo, sub.hi + 1)):
+                        cards[sub.tmpl.with_k(k)] = float(sub.row[kk])
+                if i == 1:
+                    sub.row = None                   # a single leaf: its own sketch files and cached cardinalities
+                if self.experiment["ksweep"] is None:
+                    sub.find_delta(self.speciesinfo.kstart)
+                    sub.fill()
+                    delta = sub.delta
+                else:
+                    sub.node_ksweep(lo, hi)
+                    delta = None
+                rows.append({"ngen": i, "kval": sub.bestk, "delta": delta, "ordering": ordering_number, "fastas": prefix})
+                summary.extend(sub.summarize(lo, hi, ordering_number))
+                continue
             sub = SubSpider(self.nodes_from_fastas(prefix), self.speciesinfo, self.experiment)
             sub.ksweep(mink=lo, maxk=hi)
             rows.append({"ngen": i, "kval": sub.root_k(), "delta": sub.delta, "ordering": ordering_number,
@@ -840,9 +992,46 @@ class DeltaTree:
                 jaccard = False
         kij_rows, j_rows = [], []
         # every 2-way union of every pair at every k in one GPU launch
+        sched = None
         if mink and maxk and len(leaves) > 1:
-            self.prefetch_union_cards([[a, b] for i, a in enumerate(leaves) for b in leaves[i + 1:]],
-                                      int(mink), min(int(maxk), 64), pair_exp)
+            sched = self.prefetch_union_cards([[a, b] for i, a in enumerate(leaves) for b in leaves[i + 1:]],
+                                              int(mink), min(int(maxk), 64), pair_exp,
+                                              schedule=int(maxk) <= 64 and not pair_exp.get("safety"))
+        if isinstance(sched, dict):
+            # ... and every pair's summary from that table (_FlatUnion): the steps SubSpider + find_delta + kij_summarize +
+            # jaccard_summarize take (lib/huffman_dandd.py:685-690, 772-815), in the same order -- the climbs move
+            # speciesinfo.kstart, which the next pair starts from --, without a SubSpider, a node and a Sketch per (pair, k)
+            table, index, lo, hi = sched["table"], sched["index"], sched["lo"], sched["hi"]
+            cards = self.speciesinfo.cardkey
+            if jaccard:
+                for leaf in leaves:
+                    leaf.node_ksweep(mink=mink, maxk=maxk)     # (once per leaf: what every pair's ksweep asks of its two leaves)
+            for i, a in enumerate(leaves):
+                for b in leaves[i + 1:]:
+                    pair = _FlatUnion(self, [a, b], pair_exp, table[index[id(a)], index[id(b)]], lo, hi)
+                    for kk, k in enumerate(range(lo, hi + 1)):   # what the union sketches' cardinalities would have been cached as
+                        cards[pair.tmpl.with_k(k)] = float(pair.row[kk])
+                    pair.find_delta(self.speciesinfo.kstart)       # SubSpider.__init__ ...
+                    pair.fill()
+                    pair.find_delta(self.root_k())                 # ... and the climb from the tree's own argmax-k
+                    if pair.bestk > 0:
+                        pair.touch(pair.bestk)
+                    a.update_node(a.bestk)
+                    b.update_node(b.bestk)
+                    x, y = (a, b) if [a.node_title, b.node_title] == sorted([a.node_title, b.node_title]) else (b, a)
+                    row = {"A": x.fastas[0], "B": y.fastas[0], "Adelta": x.delta, "Bdelta": y.delta, "Ak": x.bestk,
+                           "Bk": y.bestk, "ABdelta": pair.delta, "ABk": pair.bestk, "Atitle": x.node_title,
+                           "Btitle": y.node_title}
+                    row["KIJ"] = (row["Adelta"] + row["Bdelta"] - row["ABdelta"]) / row["ABdelta"]
+                    kij_rows.append(row)
+                    if jaccard:
+                        pair.node_ksweep(mink, maxk)
+                        for k in range(mink, maxk + 1):   # tree order, never swapped (lib/huffman_dandd.py:804)
+                            jrow = {"A": a.fastas[0], "B": b.fastas[0], "Atitle": a.node_title, "Btitle": b.node_title, "kval": k,
+                                    "Acard": a.ksketches[k].card, "Bcard": b.ksketches[k].card, "ABcard": pair.card(k)}
+                            jrow["jaccard"] = (jrow["Acard"] + jrow["Bcard"] - jrow["ABcard"]) / jrow["ABcard"]
+                            j_rows.append(jrow)
+            return kij_rows, j_rows
         for i, a in enumerate(leaves):
             for b in leaves[i + 1:]:
                 pair = SubSpider([a, b], self.speciesinfo, pair_exp)

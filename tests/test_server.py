@@ -86,6 +86,14 @@ def _run_both(tmp_path, backend_env, regs, timeout=600):
                 # a command that fails in the server comes back as a status and a message, and the server lives on
                 r = subprocess.run([sys.executable, "-m", "dandd_amd.host.client", "tree", "-o", out], env=cenv, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
                 assert r.returncode == 1 and "ERROR: You must provide" in r.stdout
+                # clients that send something that is not a request, or hang up in the middle of one, cost their own connection only
+                import socket as socketlib
+                for junk in (b"\x05\x00\x00\x00notjs", b"\x40\x00\x00\x00{\"op\": \"run\"", b"\x02\x00\x00\x00\xff\xfe", b"\x04\x00\x00\x00[1]\n"):
+                    c = socketlib.socket(socketlib.AF_UNIX, socketlib.SOCK_STREAM)
+                    c.connect(sock)
+                    c.sendall(junk)
+                    c.close()
+                assert oct(os.stat(sock).st_mode & 0o777) == "0o600"
                 from dandd_amd.host.client import request
                 assert request(sock, {"op": "ping"})["served"] == 7
                 assert request(sock, {"op": "shutdown"})["rc"] == 0
