@@ -451,7 +451,7 @@ def _ingest_compact(e):
     if "error" in e:
         return {"error": str(e["error"])[:120]}
     out = _pick(e, ("value", "ms", "best_value", "host_decoder_value", "host_parallel_decoder_value", "serial_decoder_value"))
-    for sub in ("small_files", "gzip_files", "bgzf_files", "one_big_gzip_file", "gzip_fastq_files", "multi_member_gzip_files"):
+    for sub in ("small_files", "gzip_files", "bgzf_files", "one_big_gzip_file", "gzip_fastq_files", "multi_member_gzip_files", "big_dir", "big_dir_gzip"):
         if sub in e:
             out[sub] = _ingest_compact(e[sub])
     return out
@@ -626,7 +626,7 @@ def ingest_probe(eng, ng, nb, nrec, kmin, kmax, torch, gz=False, reps=10, varian
     try:
         n = synth_size(nb, nrec)
         buf = torch.empty(n + 16, dtype=torch.uint8, device="cuda")
-        paths = []
+        paths, deferred = [], []
         for g in range(ng):
             eng.synth_fasta_device(SEED, g, nb, nrec, buf.data_ptr())
             eng.synchronize()
@@ -653,6 +653,8 @@ def ingest_probe(eng, ng, nb, nrec, kmin, kmax, torch, gz=False, reps=10, varian
             elif gz == "bgzf":
                 with open(p, "wb") as f:
                     f.write(bgzf_bytes(buf[:n].cpu().numpy().tobytes()))
+            elif gz == "gzip6":   # one gzip member, level 6 (what plain `gzip` writes), compressed below by a thread per file
+                deferred.append((p, buf[:n].cpu().numpy().tobytes()))
             elif gz:  # one gzip member, level 1 (what `gzip -1` writes)
                 co = zlib.compressobj(1, zlib.DEFLATED, 31)
                 with open(p, "wb") as f:
@@ -660,6 +662,20 @@ def ingest_probe(eng, ng, nb, nrec, kmin, kmax, torch, gz=False, reps=10, varian
             else:
                 buf[:n].cpu().numpy().tofile(p)
             paths.append(p)
+        if deferred:     # (zlib releases the GIL: 8 x 250 MB at level 6 take ~20 s this way instead of minutes)
+            from concurrent.futures import ThreadPoolExecutor
+
+            def squeeze(job):
+                path, raw = job
+                co = zlib.compressobj(6, zlib.DEFLATED, 31)
+                with open(path, "wb") as f:
+                    for a in range(0, len(raw), 1 << 24):
+                        f.write(co.compress(raw[a:a + (1 << 24)]))
+                    f.write(co.flush())
+            with ThreadPoolExecutor(max_workers=min(len(deferred), usable_cpus())) as pool:
+                list(pool.map(squeeze, deferred))
+            deferred.clear()
+
         def timed(n):
             times = []
             for _ in range(n):  # the context's host buffers are pinned as they are reused: steady from the 4th call on
@@ -688,7 +704,7 @@ def ingest_probe(eng, ng, nb, nrec, kmin, kmax, torch, gz=False, reps=10, varian
                         os.environ[k] = v
         return {**other, "value": ng * nb / med / 1e9, "unit": "Gbp/s", "ms": med * 1e3, "best_value": ng * nb / best / 1e9, "best_ms": best * 1e3,
                 "launches": batches, "fasta_MB": nbytes / 1e6,
-                "what": f"dd_sketch_files: {ng} x {nb/1e6:g} Mbp {'BGZF (bgzip -6; blocks inflated on the GPU, dd_ginflate.hip)' if gz == 'bgzf' else 'gzip -1 (one member per file; inflated on the GPU in pieces, dd_ginflate.hip, unless DD_NO_GPU_GUNZIP)' if gz else 'plain'} FASTA files in {base or 'the temp dir'} (warm page cache) -> "
+                "what": f"dd_sketch_files: {ng} x {nb/1e6:g} Mbp {'BGZF (bgzip -6; blocks inflated on the GPU, dd_ginflate.hip)' if gz == 'bgzf' else 'gzip -6 (one member per file; inflated on the GPU in pieces, dd_ginflate.hip)' if gz == 'gzip6' else 'gzip -1 (one member per file; inflated on the GPU in pieces, dd_ginflate.hip, unless DD_NO_GPU_GUNZIP)' if gz else 'plain'} FASTA files in {base or 'the temp dir'} (warm page cache) -> "
                         f"pinned host buffers -> H2D on a copy stream overlapped with K0/K1 -> registers back to the host; "
                         + ("[four-line FASTQ, 150-base reads, gzip -6: inflated AND resolved on the device, dd_fastq.hip] " if gz == "fastq" else
                            "[two gzip -6 members per file] " if gz == "members" else "") +
@@ -966,6 +982,15 @@ def main():
                                                          variants=[host("host_decoder_value", sw, 4)])
                 except Exception as e:
                     extras["ingest"][key] = {"error": f"{type(e).__name__}: {e}"}
+            # ... and at STEADY STATE (round 6): 8 x 250 Mbp = 2 GB of text, plain and as plain `gzip` writes it (level 6, one member) --
+            # the ten-file probes above are 20-40 ms calls, a third of which is the pipeline filling and draining
+            if args.config == "cfg2" and args.genomes is None and args.mbp is None:
+                try:
+                    extras["ingest"]["big_dir"] = ingest_probe(eng, 8, 250_000_000, 1, kmin, kmax, torch, reps=6)
+                    extras["ingest"]["big_dir_gzip"] = ingest_probe(eng, 8, 250_000_000, 1, kmin, kmax, torch, gz="gzip6", reps=6)
+                except Exception as e:
+                    extras["ingest"].setdefault("big_dir", {"error": f"{type(e).__name__}: {e}"})
+                    extras["ingest"].setdefault("big_dir_gzip", {"error": f"{type(e).__name__}: {e}"})
             # ... and ONE large .gz (a whole assembly as NCBI ships it: a single gzip member): its deflate stream is cut at
             # block boundaries and the pieces are decoded in parallel without their history -- on the GPU (dd_ginflate.hip), by
             # the host's loader threads (dd_inflate.h), or serially by one thread (libdeflate)

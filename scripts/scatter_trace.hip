@@ -1,0 +1,370 @@
+// scatter_trace.hip -- where the cycles of the first-epoch scatter go (VERDICT r05 #1a: "nobody has looked at an instruction-level
+// trace of one scatter workgroup").  There is no thread-trace decoder in this image (rocprofv3 --att needs
+// librocprof-trace-decoder, absent), so this is the other instrument the verdict names: the product's own inner loop -- this file
+// INCLUDES dandd_amd/csrc/dd_sweep.hip, so Windows<5>, wang64_fast, probe, rho_of are the shipped code -- rebuilt as a ladder of
+// variants that add one stage each, timed on the whole chip with the launch shape of scatter_first_bin_kernel<1, true> over
+// 64 x 5 Mbp at log2m 20 (78 848 tiles of 65 536 tokens, ~10 tiles per job, 1024 threads, two workgroups per CU), plus
+// s_memtime stamps around the stages of the full kernel (per wave: issue of hash / wait for the slot / issue of the store).
+//   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I dandd_amd/csrc scripts/scatter_trace.hip -o scripts/build/scatter_trace
+//   run  : scripts/build/scatter_trace [tiles=78848] [tiles_per_job=10]      (needs ~23 GB of HBM for the record areas)
+// Not part of the product; nothing here is linked into libdandd_hip.so.
+#include "../dandd_amd/csrc/dd_sweep.hip"
+
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <vector>
+
+namespace dd {
+namespace {
+
+struct TraceOut {
+    unsigned long long hash_cycles, slot_cycles, store_cycles, barrier_cycles, total_cycles, updates;
+};
+
+// V 0: hash only                         V 1: + rho, record, the rho = 1 bits (ds_or)        V 2: + the slot (returning LDS atomic)
+// V 3: + the 4-byte store into the bin   V 4: + barrier and counter save per tile = the shipped kernel's structure
+// V 5: V 4 with s_memtime stamps         V 6: V 3 with counters per JOB (bins of tiles x kBinCap, no barrier per tile)
+// V 7: V 4 without the rho = 1 bits (every update a record: round 4's kernel)
+// V 8: V 4 with the slot's atomic NOT returning (slot from a per-lane counter: wrong, timing only): what the returning round trip costs
+// V 9: V 4 with the rho = 1 bits of ALL 2^20 registers (128 KiB of LDS: one workgroup per CU)
+// V 10: V 9 with two tiles of tokens per thread in flight (two windows, two hash chains interleaved): 4 waves per SIMD with twice the work each
+template <int V>
+__global__ __launch_bounds__(1024) void trace_kernel(const uint4* __restrict__ codes, uint32_t* __restrict__ area, uint32_t* __restrict__ sink,
+                                                    int tiles_per_job, int p, TraceOut* __restrict__ out) {
+    lds_starts_at_zero();
+    const int k = 24;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t ones_regs = 1u << ((V == 9 || V == 10) ? 20 : kOnesLog2Max), ones_words = ones_regs >> 5;   // (V 9, 10: the whole row's bits = 128 KiB = one workgroup per CU)
+    if (threadIdx.x < 32u) lds32(4u * threadIdx.x) = 0;
+    if (V >= 1 && V != 7)
+        for (uint32_t w = threadIdx.x; w < ones_words; w += blockDim.x) lds32(kBinLdsBytes + 4u * w) = 0;
+    __syncthreads();
+    const size_t job_records = (size_t)tiles_per_job * kBinChunkRecords;
+    uint32_t* const job_area = area + (size_t)blockIdx.x * job_records;
+    const int tile_sh = 32 - 4;
+    uint32_t acc = 0;
+    unsigned long long c_hash = 0, c_slot = 0, c_store = 0, c_bar = 0;
+    const unsigned long long t_begin = __builtin_readcyclecounter();
+    uint4 next = codes[((size_t)blockIdx.x * tiles_per_job) * 1024 + threadIdx.x];
+    if (V == 10) {
+        for (int t = 0; t + 1 < tiles_per_job; t += 2) {
+            const uint4 sa = codes[((size_t)blockIdx.x * tiles_per_job + t) * 1024 + threadIdx.x];
+            const uint4 sb = codes[((size_t)blockIdx.x * tiles_per_job + t + 1) * 1024 + threadIdx.x];
+            const uint32_t ca[4] = {sa.x, sa.y, sa.z, sa.w}, cb[4] = {sb.x, sb.y, sb.z, sb.w};
+            uint8_t* const chunk_a = reinterpret_cast<uint8_t*>(job_area + (size_t)t * kBinChunkRecords);
+            uint8_t* const chunk_b = chunk_a + (size_t)kBinChunkRecords * 4u;
+            Windows<5> wa, wb;
+            wa.prime(make_uint4(sa.w, sa.z, sa.y, sa.x));
+            wb.prime(make_uint4(sb.w, sb.z, sb.y, sb.x));
+            auto update = [&](const Probe& q, uint32_t ctr, uint8_t* chunk) {
+                const uint32_t rho = rho_of(q, p);
+                if (rho == 1u) {
+                    const uint32_t idx = q.hi >> (32 - p);
+                    atomicOr(&lds32(kBinLdsBytes + ((idx >> 5) << 2)), 1u << (idx & 31u));
+                    return;
+                }
+                const uint32_t rec = (q.hi >> (32 - p)) | (rho << 24), bin = q.hi >> tile_sh;
+                const uint32_t slot = atomicAdd(&lds32(ctr + (bin << 2)), 1u);
+                if (slot < kBinCap) gstore4(chunk + (__umul24(bin, kBinCap) + slot) * 4u, rec);
+            };
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+#pragma unroll 1
+                for (int i = 0; i < 16; ++i) {
+                    wa.push((ca[w] >> (2 * i)) & 3u);
+                    wb.push((cb[w] >> (2 * i)) & 3u);
+                    const Probe qa = probe(wa.template hash<true>(k), p), qb = probe(wb.template hash<true>(k), p);
+                    update(qa, 0u, chunk_a);
+                    update(qb, 64u, chunk_b);
+                }
+            }
+            __syncthreads();
+            if (wave == 0u && lane < 32u) {
+                acc ^= lds32(4u * lane);
+                lds32(4u * lane) = 0;
+            }
+            __syncthreads();
+        }
+    } else
+    for (int t = 0; t < tiles_per_job; ++t) {
+        const uint4 sc = next;
+        if (t + 1 < tiles_per_job) next = codes[((size_t)blockIdx.x * tiles_per_job + t + 1) * 1024 + threadIdx.x];
+        const uint32_t cw[4] = {sc.x, sc.y, sc.z, sc.w};
+        const uint32_t ctr = (V == 6) ? 0u : ((uint32_t)t & 1u) * 64u;
+        uint8_t* const chunk = reinterpret_cast<uint8_t*>(V == 6 ? job_area : job_area + (size_t)t * kBinChunkRecords);
+        const uint32_t cap = V == 6 ? (uint32_t)tiles_per_job * kBinCap : kBinCap;
+        Windows<5> win;
+        win.prime(make_uint4(sc.w, sc.z, sc.y, sc.x));
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+#pragma unroll 1
+            for (int i = 0; i < 16; ++i) {
+                unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+                if (V == 5) t0 = __builtin_readcyclecounter();
+                win.push((cw[w] >> (2 * i)) & 3u);
+                const Probe q = probe(win.template hash<true>(k), p);
+                if (V == 0) {
+                    acc ^= q.hi ^ q.lz;
+                    continue;
+                }
+                const uint32_t rho = rho_of(q, p);
+                if (V != 7 && rho == 1u && (q.hi >> (32 - p)) < ones_regs) {
+                    const uint32_t idx = q.hi >> (32 - p);
+                    atomicOr(&lds32(kBinLdsBytes + ((idx >> 5) << 2)), 1u << (idx & 31u));
+                    continue;
+                }
+                const uint32_t rec = (q.hi >> (32 - p)) | (rho << 24);
+                const uint32_t bin = q.hi >> tile_sh;
+                if (V == 1) {
+                    acc ^= rec + bin;
+                    continue;
+                }
+                if (V == 5) {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    t1 = __builtin_readcyclecounter();
+                }
+                uint32_t slot;
+                if (V == 8) {
+                    atomicAdd(&lds32(ctr + (bin << 2)), 1u);                 // not returning
+                    slot = (acc++ * 16u + (lane & 15u)) % cap;              // (a slot from nowhere: timing only)
+                } else {
+                    slot = atomicAdd(&lds32(ctr + (bin << 2)), 1u);
+                }
+                if (V == 5) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    t2 = __builtin_readcyclecounter();
+                }
+                if (V == 2) {
+                    acc ^= rec + slot;
+                    continue;
+                }
+                if (V == 3) slot &= 4095u;   // (no barrier, so no counter reset: wrap inside the bin, or every tile after the second would skip its stores)
+                if (slot < cap) gstore4(chunk + (__umul24(bin, cap) + slot) * 4u, rec);
+                if (V == 5) {
+                    t3 = __builtin_readcyclecounter();
+                    c_hash += t1 - t0, c_slot += t2 - t1, c_store += t3 - t2;
+                }
+            }
+        }
+        if (V == 4 || V == 5 || V == 7 || V == 8 || V == 9) {
+            unsigned long long b0 = 0;
+            if (V == 5) b0 = __builtin_readcyclecounter();
+            __syncthreads();
+            if (wave == 0u && lane < 16u) {
+                acc ^= lds32(ctr + 4u * lane);
+                lds32(ctr + 4u * lane) = 0;
+            }
+            if (V == 5) c_bar += __builtin_readcyclecounter() - b0;
+        }
+    }
+    if (V >= 1 && V != 7) {
+        __syncthreads();
+        for (uint32_t w = threadIdx.x; w < ones_words; w += blockDim.x) acc ^= lds32(kBinLdsBytes + 4u * w);
+    }
+    if (acc == 0x12345678u) sink[0] = acc;   // (keeps the work alive)
+    if (V == 5 && lane == 0u) {
+        atomicAdd(&out->hash_cycles, c_hash);
+        atomicAdd(&out->slot_cycles, c_slot);
+        atomicAdd(&out->store_cycles, c_store);
+        atomicAdd(&out->barrier_cycles, c_bar);
+        atomicAdd(&out->total_cycles, __builtin_readcyclecounter() - t_begin);
+        atomicAdd(&out->updates, (unsigned long long)tiles_per_job * 64ull);
+    }
+}
+
+// Several ks per first-epoch job (NK consecutive ks from ONE window push and ONE token decode; every k its own row: own counters,
+// own bins).  ONES_LOG2 = 0: every update a record; else each k keeps 2^ONES_LOG2 rho = 1 bits in LDS.  PAIR: the hashes of two ks
+// are computed side by side (two chains in flight) before their records leave.
+template <int NK, int ONES_LOG2, bool PAIR>
+__global__ __launch_bounds__(1024) void multik_kernel(const uint4* __restrict__ codes, uint32_t* __restrict__ area, uint32_t* __restrict__ sink,
+                                                     int tiles_per_job, int p, size_t row_records) {
+    lds_starts_at_zero();
+    const int k0 = 24;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    constexpr uint32_t kCtrBytes = 2u * NK * 64u;                       // [parity][k][16]
+    constexpr uint32_t ones_regs = ONES_LOG2 ? 1u << ONES_LOG2 : 0u, ones_words = ones_regs >> 5;
+    for (uint32_t w = threadIdx.x; w < kCtrBytes / 4u + NK * ones_words; w += blockDim.x) lds32(4u * w) = 0;
+    __syncthreads();
+    const size_t job_records = (size_t)tiles_per_job * kBinChunkRecords;
+    const int tile_sh = 32 - 4;
+    uint32_t acc = 0;
+    uint4 next = codes[((size_t)blockIdx.x * tiles_per_job) * 1024 + threadIdx.x];
+    for (int t = 0; t < tiles_per_job; ++t) {
+        const uint4 sc = next;
+        if (t + 1 < tiles_per_job) next = codes[((size_t)blockIdx.x * tiles_per_job + t + 1) * 1024 + threadIdx.x];
+        const uint32_t cw[4] = {sc.x, sc.y, sc.z, sc.w};
+        const uint32_t par = ((uint32_t)t & 1u) * (NK * 64u);
+        Windows<5> win;
+        win.prime(make_uint4(sc.w, sc.z, sc.y, sc.x));
+        auto emit = [&](const Probe& q, int j) {
+            const uint32_t rho = rho_of(q, p);
+            if (ONES_LOG2 && rho == 1u && (q.hi >> (32 - p)) < ones_regs) {
+                const uint32_t idx = q.hi >> (32 - p);
+                atomicOr(&lds32(kCtrBytes + (uint32_t)j * (ones_words * 4u) + ((idx >> 5) << 2)), 1u << (idx & 31u));
+                return;
+            }
+            const uint32_t rec = (q.hi >> (32 - p)) | (rho << 24), bin = q.hi >> tile_sh;
+            const uint32_t slot = atomicAdd(&lds32(par + (uint32_t)j * 64u + (bin << 2)), 1u);
+            uint8_t* const chunk = reinterpret_cast<uint8_t*>(area + (size_t)j * row_records + (size_t)blockIdx.x * job_records + (size_t)t * kBinChunkRecords);
+            if (slot < kBinCap) gstore4(chunk + (__umul24(bin, kBinCap) + slot) * 4u, rec);
+        };
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+#pragma unroll 1
+            for (int i = 0; i < 16; ++i) {
+                win.push((cw[w] >> (2 * i)) & 3u);
+                if (PAIR) {
+#pragma unroll
+                    for (int j = 0; j < NK; j += 2) {
+                        const Probe qa = probe(win.template hash<true>(k0 + j), p), qb = probe(win.template hash<true>(k0 + j + 1), p);
+                        emit(qa, j);
+                        emit(qb, j + 1);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NK; ++j) emit(probe(win.template hash<true>(k0 + j), p), j);
+                }
+            }
+        }
+        __syncthreads();
+        if (wave == 0u && lane < NK * 16u) {
+            acc ^= lds32(par + 4u * lane);
+            lds32(par + 4u * lane) = 0;
+        }
+    }
+    if (ONES_LOG2) {
+        __syncthreads();
+        for (uint32_t w = threadIdx.x; w < NK * ones_words; w += blockDim.x) acc ^= lds32(kCtrBytes + 4u * w);
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+__global__ void fill_kernel(uint4* codes, size_t n, uint64_t seed) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t x = seed + i * 0x9E3779B97F4A7C15ull;
+    auto next = [&]() {
+        x += 0x9E3779B97F4A7C15ull;
+        uint64_t z = x;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    };
+    const uint64_t a = next(), b = next();
+    codes[i] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+}
+
+}  // namespace
+}  // namespace dd
+
+#define CK(x)                                                                   \
+    do {                                                                        \
+        hipError_t e_ = (x);                                                    \
+        if (e_ != hipSuccess) {                                                 \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));             \
+            return 1;                                                           \
+        }                                                                       \
+    } while (0)
+
+template <int V>
+static int run(const char* what, const uint4* codes, uint32_t* area, uint32_t* sink, int njobs, int tpj, dd::TraceOut* out_dev, size_t lds, double updates) {
+    auto kern = dd::trace_kernel<V>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipMemset(out_dev, 0, sizeof(dd::TraceOut)));
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3(1024), lds, 0, codes, area, sink, tpj, 20, out_dev);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        CK(hipGetLastError());
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+    }
+    printf("V%d %-78s %7.3f ms  %6.1f G updates/s\n", V, what, best, updates / best / 1e6);
+    if (V == 5) {
+        dd::TraceOut o;
+        CK(hipMemcpy(&o, out_dev, sizeof o, hipMemcpyDeviceToHost));
+        const double wu = (double)o.updates;   // wave-updates
+        const double tot = (double)o.total_cycles;
+        printf("   s_memtime ticks per wave-update: to the record %.1f | the slot's round trip %.1f | store issue %.1f | barrier + counter save %.2f | wave lifetime %.1f\n",
+               o.hash_cycles / wu, o.slot_cycles / wu, o.store_cycles / wu, o.barrier_cycles / wu, tot / wu);
+        printf("   as shares of the wave's lifetime: %.1f %% | %.1f %% | %.1f %% | %.1f %% (rest: token loads, loop, the stamps themselves)\n",
+               100.0 * o.hash_cycles / tot, 100.0 * o.slot_cycles / tot, 100.0 * o.store_cycles / tot, 100.0 * o.barrier_cycles / tot);
+    }
+    return 0;
+}
+
+template <int NK, int ONES_LOG2, bool PAIR>
+static int run_multik(const char* what, const uint4* codes, uint32_t* area, uint32_t* sink, int njobs1, int tpj, double updates) {
+    auto kern = dd::multik_kernel<NK, ONES_LOG2, PAIR>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const int njobs = njobs1 / NK;                               // the same number of updates as the one-k ladder
+    const size_t row_records = (size_t)njobs * tpj * dd::kBinChunkRecords;
+    const size_t lds = 2u * NK * 64u + (ONES_LOG2 ? NK * (((size_t)1 << ONES_LOG2) >> 3) : 0);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(kern, dim3((unsigned)njobs), dim3(1024), lds, 0, codes, area, sink, tpj, 20, row_records);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        CK(hipGetLastError());
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+    }
+    const double u = (double)njobs * NK * tpj * 65536.0;
+    printf("NK=%d ones=2^%d pair=%d  %-58s %7.3f ms  %6.1f G updates/s   (%.2f ms per %.2f G updates)\n", NK, ONES_LOG2, (int)PAIR, what, best, u / best / 1e6,
+           best * updates / u, updates / 1e9);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    const int tiles = argc > 1 ? atoi(argv[1]) : 78848, tpj = argc > 2 ? atoi(argv[2]) : 10;
+    const int njobs = tiles / tpj;
+    const size_t ncodes = (size_t)njobs * tpj * 1024;
+    uint4* codes;
+    uint32_t *area, *sink;
+    dd::TraceOut* out_dev;
+    CK(hipMalloc(&codes, ncodes * sizeof(uint4)));
+    CK(hipMalloc(&area, (size_t)njobs * tpj * dd::kBinChunkRecords * 4));
+    CK(hipMalloc(&sink, 256));
+    CK(hipMalloc(&out_dev, sizeof(dd::TraceOut)));
+    hipLaunchKernelGGL(dd::fill_kernel, dim3((unsigned)((ncodes + 255) / 256)), dim3(256), 0, 0, codes, ncodes, 0xD4ADDull);
+    CK(hipDeviceSynchronize());
+    const double updates = (double)njobs * tpj * 65536.0;
+    const size_t lds_bits = dd::kBinLdsBytes + (((size_t)1 << dd::kOnesLog2Max) >> 3), lds_plain = dd::kBinLdsBytes;
+    printf("%d jobs x %d tiles x 65536 updates (k = 24, canonical, log2m 20): %.2f G updates, record areas %.1f GB\n", njobs, tpj, updates / 1e9,
+           (double)njobs * tpj * dd::kBinChunkRecords * 4 / 1e9);
+    int rc = 0;
+    rc |= run<0>("hash only (window push, canonical min, Wang-64, probe)", codes, area, sink, njobs, tpj, out_dev, lds_bits, updates);
+    rc |= run<1>("+ rho, record, rho = 1 updates as LDS bits (ds_or)", codes, area, sink, njobs, tpj, out_dev, lds_bits, updates);
+    rc |= run<2>("+ the slot: one returning LDS atomic on the bin's counter", codes, area, sink, njobs, tpj, out_dev, lds_bits, updates);
+    rc |= run<3>("+ the 4-byte store into the bin", codes, area, sink, njobs, tpj, out_dev, lds_bits, updates);
+    rc |= run<4>("+ workgroup barrier and counter save per tile (the shipped structure)", codes, area, sink, njobs, tpj, out_dev, lds_bits, updates);
+    rc |= run<6>("V3 with counters per JOB: bins of tiles x 4480, no barrier per tile", codes, area, sink, njobs, tpj, out_dev, lds_bits, updates);
+    rc |= run<7>("V4 without the rho = 1 bits (every update a record; 256 B of LDS)", codes, area, sink, njobs, tpj, out_dev, lds_plain, updates);
+    const size_t lds_full = dd::kBinLdsBytes + (((size_t)1 << 20) >> 3);
+    rc |= run<9>("V4 with the rho = 1 bits of all 2^20 registers (128 KiB: ONE workgroup per CU)", codes, area, sink, njobs, tpj, out_dev, lds_full, updates);
+    rc |= run<10>("V9 with two tiles per thread in flight (two hash chains interleaved)", codes, area, sink, njobs, tpj, out_dev, lds_full, updates);
+    printf("-- several ks per job: one window push and one token decode for NK hashes; every k its own counters and bins --\n");
+    rc |= run_multik<1, 0, false>("one k per job, every update a record (= V7)", codes, area, sink, njobs, tpj, updates);
+    rc |= run_multik<1, 19, false>("one k per job, rho = 1 bits of half the registers (= V4)", codes, area, sink, njobs, tpj, updates);
+    rc |= run_multik<2, 0, false>("two ks per job, every update a record", codes, area, sink, njobs, tpj, updates);
+    rc |= run_multik<2, 0, true>("two ks per job, hashed side by side", codes, area, sink, njobs, tpj, updates);
+    rc |= run_multik<2, 18, true>("two ks, side by side, 2 x 32 KiB of rho = 1 bits (a quarter each)", codes, area, sink, njobs, tpj, updates);
+    rc |= run_multik<4, 0, false>("four ks per job, every update a record", codes, area, sink, njobs, tpj, updates);
+    rc |= run_multik<4, 0, true>("four ks per job, hashed in pairs", codes, area, sink, njobs, tpj, updates);
+    rc |= run_multik<4, 17, true>("four ks, in pairs, 4 x 16 KiB of rho = 1 bits (an eighth each)", codes, area, sink, njobs, tpj, updates);
+    rc |= run_multik<8, 0, true>("eight ks per job, hashed in pairs", codes, area, sink, njobs, tpj, updates);
+    rc |= run<5>("V4 with s_memtime stamps (perturbed: a wait for everything in flight before each stamp)", codes, area, sink, njobs, tpj, out_dev, lds_bits, updates);
+    return rc;
+}

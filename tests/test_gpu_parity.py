@@ -1047,7 +1047,7 @@ def test_progressive_pscan_equals_streaming_kernel(engine_factory, torch_cuda, o
         ords[-1, 1] = ords[-1, 0]            # a leaf twice in a row: the prefix does not change
     dev = torch.from_numpy(slab).cuda()
     scan = eng.progressive_device(dev.data_ptr(), n, K, ords)
-    assert eng.last_k2_path() == (2 if n <= 32 else 1)      # DD_K2_PROGRESSIVE_PSCAN / _STREAM (include/dandd_hip.h)
+    assert eng.last_k2_path() == ("progressive_pscan" if n <= 32 else "progressive_stream")
     monkeypatch.setenv("DD_PROGRESSIVE_STREAM", "1")
     stream = eng.progressive_device(dev.data_ptr(), n, K, ords)
     monkeypatch.delenv("DD_PROGRESSIVE_STREAM")
