@@ -1295,8 +1295,16 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             // Gbp/s with 16 / 8 KiB, gzip -6 11.1 -> 11.5 / 11.3, 64 x 5 Mbp 9.1 -> 9.2 / 9.6; profiles/r05_gunzip.txt)
             return (size_t)(getenv("DD_GUNZIP_GUESS_KB") ? std::max(4, atoi(getenv("DD_GUNZIP_GUESS_KB"))) : (file_bytes >= ((size_t)400 << 20) ? 128 : 16)) << 13;
         };
-        // a range's symbols: 5 x its compressed bytes (DNA inflates 3-4 x) + 32 Ki; a piece that needs more takes the arena
-        auto range_syms_of = [&](size_t guess_bits) { return 5 * (guess_bits / 8) + 32768; };
+        // a range's symbols: 5 x its compressed bytes (DNA inflates 3-4 x) + 32 Ki; a piece that needs more takes the arena -- and a
+        // second and third pass of the decoder over it (count, then write).  Round 6: the factor follows the MEMBER's own ratio
+        // (ISIZE / compressed length, + 25 %) when that is larger -- four-line FASTQ whose quality text compresses well inflates 7 x,
+        // every piece overflowed, and inflate_kernel<1> + <2> cost a batch 12.5 ms beside the 9.9 of <3> (profiles/r06_ingest.txt);
+        // capped at 64 x: beyond that (runs of N) the arena is the right place
+        auto range_syms_of = [&](size_t guess_bits, size_t isize, size_t clen) {
+            const double ratio = clen ? 1.25 * (double)isize / (double)clen : 0.0;
+            const double f = std::min(64.0, std::max(5.0, ratio));
+            return (size_t)(f * (double)(guess_bits / 8)) + 32768;
+        };
         size_t nmem = 0, npieces = 0, nchunks = 0, sym_tot = 0, win_tot = 0, ngroups = 0;
         for (int j = 0; j < count; ++j) {
             const Slot& sj = slots[i + j];
@@ -1310,7 +1318,7 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
             }
             if (sj.dev_gunzip)
                 for (const GzMember& gm : sj.gms) {   // every member a "file" of the decoder's tables
-                    const size_t guess_bits = guess_bits_of(gm.end - gm.first_bit / 8), range_syms = range_syms_of(guess_bits);
+                    const size_t guess_bits = guess_bits_of(gm.end - gm.first_bit / 8), range_syms = range_syms_of(guess_bits, gm.isize, gm.end - gm.first_bit / 8);
                     const size_t bits = gm.end * 8 - gm.first_bit;
                     const size_t ng = (bits + guess_bits - 1) / guess_bits;
                     ++nmem;
@@ -1390,7 +1398,7 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
                 size_t text_at = 0;   // the members' texts one behind the other
                 for (const GzMember& gm : sj.gms) {
                     dd::RawFile& rf = raw_host[mi];
-                    const size_t guess_bits = guess_bits_of(gm.end - gm.first_bit / 8), range_syms = range_syms_of(guess_bits);
+                    const size_t guess_bits = guess_bits_of(gm.end - gm.first_bit / 8), range_syms = range_syms_of(guess_bits, gm.isize, gm.end - gm.first_bit / 8);
                     const size_t ng = (gm.end * 8 - gm.first_bit + guess_bits - 1) / guess_bits;
                     rf.in = gz;                       // (positions are the FILE's: its bytes start on a 256-byte boundary, a member's need not)
                     rf.in_len = (uint32_t)gm.end;     // ... and the member ends here: CRC-32 and ISIZE right behind its final block

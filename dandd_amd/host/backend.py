@@ -250,6 +250,7 @@ class HipBackend:
         self._recent = OrderedDict()  # path -> (registers, k, (file size, mtime))
         self._recent_bytes = 0
         self._recent_limit = int(os.environ.get("DANDD_SKETCH_CACHE_MB", "1024")) << 20
+        self._slab_buf = None
 
     def new_command(self):
         """A resident server calls this between commands (deltatree.new_command): the registers kept in memory are keyed by the path
@@ -351,7 +352,11 @@ class HipBackend:
         after the other through read_sketch_file, which also copies every one of them once more."""
         n, K = len(leaf_paths), len(leaf_paths[0])
         m = 1 << self.log2m
-        slab = np.empty((n, K, m), dtype=np.uint8)
+        # (the buffer of the last schedule is kept: a resident server's second `kij` does not fault 2 GB of fresh pages in again)
+        if self._slab_buf is None or self._slab_buf.size < n * K * m:
+            self._slab_buf = None
+            self._slab_buf = np.empty(n * K * m, dtype=np.uint8)
+        slab = self._slab_buf[: n * K * m].reshape(n, K, m)
         cold = []
         for i, row in enumerate(leaf_paths):
             for kk, p in enumerate(row):

@@ -469,16 +469,18 @@ class _FlatUnion:
         self.delta, self.bestk, self.mink, self.maxk = 0, 0, 0, 0
         self._touched = set()
         self._be = backend_for(experiment)
+        self._base = self.tmpl.base.split("{}")       # the base name around its k
 
     def touch(self, k):
-        """what update_node(k) leaves behind besides the Sketch object"""
+        """what update_node(k) leaves behind besides the Sketch object: the base name in the experiment's base set and its
+        sketchinfo entry (a tree save lists them: <prefix>_sketchdb.txt).  NOT the ngen<N>/k<K> directory the reference makes
+        for every k it looks at (lib/huffman_dandd.py:171-174): no file of this union is written unless card() has to build
+        one, which makes the directory then -- 2 046 empty directories were 0.1 s of a 64-genome `progressive`."""
         if k in self._touched:
             return
         self._touched.add(k)
-        ktxt = str(k)
-        base = self.tmpl.base.replace("{}", ktxt)
+        base = str(k).join(self._base)
         self.experiment["baseset"].add(base)
-        ensure_dir(self.tmpl.dir.replace("{}", ktxt))
         if base not in self.sp.sketchinfo:
             self.sp.sketchinfo[base] = {"sketchbase": base, "files": self.tmpl.files, "ngen": self.ngen, "kval": k,
                                         "registers": self.experiment["registers"]}
@@ -504,8 +506,23 @@ class _FlatUnion:
         return self._be.describe(op, k=k, out=os.path.basename(self.tmpl.with_k(k))) if hasattr(self._be, "describe") else op
 
     def node_ksweep(self, mink, maxk):
-        for k in range(max(1, mink), maxk + 1):
-            self.touch(k)
+        lo = max(1, mink)
+        if maxk - lo >= 4:
+            # a whole window at once (every pair of `kij --jaccard`, every prefix of a k-sweep `progressive`): the same traces as
+            # touch(k) for each k, without a call per k
+            pre, post = self._base
+            seen = self._touched
+            ks = [k for k in range(lo, maxk + 1) if k not in seen]
+            bases = [pre + str(k) + post for k in ks]
+            self._touched.update(ks)
+            self.experiment["baseset"].update(bases)
+            info, files, ngen, regs = self.sp.sketchinfo, self.tmpl.files, self.ngen, self.experiment["registers"]
+            for k, base in zip(ks, bases):
+                if base not in info:
+                    info[base] = {"sketchbase": base, "files": files, "ngen": ngen, "kval": k, "registers": regs}
+        else:
+            for k in range(lo, maxk + 1):
+                self.touch(k)
         self.mink, self.maxk = mink, maxk
 
     def find_delta_helper(self, kval, direction):
