@@ -291,10 +291,10 @@ def cpu_baseline(nbases, nrec, kmin, kmax, log2m, ngenomes=4):
 
 
 def load_counters(genomes, mbp, kmin, kmax, p):
-    """The committed rocprofv3 passes over this very workload -- profiles/r0[45]_k1_counters_*.json, the newest round first (scripts/profile_k1_counters.sh:
+    """The committed rocprofv3 passes over this very workload -- profiles/r0[456]_k1_counters_*.json, the newest round first (scripts/profile_k1_counters.sh:
     FETCH_SIZE, WRITE_SIZE, SQ and TCC in separate --pmc passes, round-4 kernels) -- or None when no file matches."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[45]_k1_counters_*.json")), reverse=True):   # the newest round's first
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[456]_k1_counters_*.json")), reverse=True):   # the newest round's first
         try:
             with open(path) as f:
                 cj = json.load(f)
@@ -310,7 +310,7 @@ def load_counters(genomes, mbp, kmin, kmax, p):
 def isa_table():
     """profiles/r0N_isa_classes.json: instruction classes of K1's hot loops, counted by scripts/isa_classes.py in the ISA of
     the shipped build and priced with the measured issue costs (profiles/r01_ubench_issue_costs.txt)."""
-    for rnd in ("r05", "r04"):      # the newest round's table first
+    for rnd in ("r06", "r05", "r04"):      # the newest round's table first
         try:
             with open(os.path.join(ROOT, "profiles", f"{rnd}_isa_classes.json")) as f:
                 t = json.load(f)

@@ -1297,11 +1297,12 @@ static int sketch_files_impl(dd_ctx* c, const char* const* paths, int nfiles, in
         };
         // a range's symbols: 5 x its compressed bytes (DNA inflates 3-4 x) + 32 Ki; a piece that needs more takes the arena -- and a
         // second and third pass of the decoder over it (count, then write).  Round 6: the factor follows the MEMBER's own ratio
-        // (ISIZE / compressed length, + 25 %) when that is larger -- four-line FASTQ whose quality text compresses well inflates 7 x,
-        // every piece overflowed, and inflate_kernel<1> + <2> cost a batch 12.5 ms beside the 9.9 of <3> (profiles/r06_ingest.txt);
+        // (twice ISIZE / compressed length: a piece runs from the first block start of its range to the first of the next, up to
+        // two ranges' worth of bits) when that is larger -- four-line FASTQ whose quality text compresses well inflates 6 x, most
+        // pieces overflowed, and inflate_kernel<1> + <2> cost a batch 12.5 ms beside the 9.9 of <3> (profiles/r06_ingest.txt);
         // capped at 64 x: beyond that (runs of N) the arena is the right place
         auto range_syms_of = [&](size_t guess_bits, size_t isize, size_t clen) {
-            const double ratio = clen ? 1.25 * (double)isize / (double)clen : 0.0;
+            const double ratio = clen ? 2.0 * (double)isize / (double)clen : 0.0;
             const double f = std::min(64.0, std::max(5.0, ratio));
             return (size_t)(f * (double)(guess_bits / 8)) + 32768;
         };

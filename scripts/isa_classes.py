@@ -89,7 +89,7 @@ def innermost_loops(body):
     return [l for l in loops if not any(o != l and l[0] <= o[0] and o[1] <= l[1] for o in loops)]
 
 
-def hot_path(body, lo, hi, must=()):
+def hot_path(body, lo, hi, must=(), skip=None):
     """The lines one pass of the loop [lo, hi] executes when nothing rare happens: `s_cbranch_execz` (no lane needs the
     guarded block -- a register that must rise, the long form of rho) is TAKEN, every other conditional branch falls
     through unless it is the loop's back edge, unconditional branches are followed.  A guarded block that holds one of the
@@ -126,7 +126,31 @@ def hot_path(body, lo, hi, must=()):
                     break
                 guarded.append(body[j])
                 j += 1
-        if op == "s_cbranch_execz" and any(re.match(r"\s+" + pre, l) for l in guarded for pre in must):
+        if op == "s_cbranch_execnz" and skip is not None:
+            # (the compiler put the update BEHIND a taken branch: "some lane has a record" -> the block with the slot's atomic and
+            # the store; follow it when what stands there, read through uniform vcc / scc branches, holds one of `must`)
+            ahead, j = [], tgt
+            while len(ahead) < 60 and 0 <= j < len(body):
+                mb = re.match(r"\s+(s_c?branch\S*)\s+(\.LBB[0-9_]+)", body[j])
+                if mb and mb.group(1) == "s_branch":
+                    j = labels.get(mb.group(2), -1)
+                    continue
+                if mb and mb.group(1) in ("s_cbranch_execz", "s_cbranch_execnz"):
+                    break
+                if not mb:
+                    ahead.append(body[j])
+                j += 1
+            if any(re.match(r"\s+" + pre, l) for l in ahead for pre in must):
+                i = tgt
+            else:
+                i += 1
+        elif op == "s_cbranch_execz" and skip is not None:
+            # (a kernel whose update sits behind nested guards: every guarded block is entered except those that hold one of `skip`)
+            if any(re.match(r"\s+" + pre, l) for l in guarded for pre in skip):
+                i = tgt
+            else:
+                i += 1
+        elif op == "s_cbranch_execz" and any(re.match(r"\s+" + pre, l) for l in guarded for pre in must):
             i += 1
         elif tgt == lo:
             return out           # back to the loop's head: one pass done
@@ -192,23 +216,24 @@ def main():
     # e.g. the `valid` guard of a BREAK-aware variant, is not the hot path -- and operations that mark a guarded block as
     # part of the update: the record's store behind `slot < capacity`)
     want = [
-        (r"sweep_kernel<(\d), true, 0>", 2, "registers in LDS (log2m <= 16): the k-pair loop of sweep_token, two updates per pass", ("ds_read",), ()),
-        (r"scatter_kernel<(\d), true, true, true, 1, false>", 1, "filtered epochs (log2m >= 17): one update per pass of the token loop", ("ds_read",), ()),
-        (r"scatter_first_bin_kernel<(\d), true>", 1, "first epoch (log2m >= 17): one update per pass of the token loop", ("ds_add_rtn", "global_store"), ("global_store",)),
+        (r"sweep_kernel<(\d), true>", 2, "registers in LDS (log2m <= 16): the k-pair loop of sweep_token, two updates per pass", ("ds_read",), ()),
+        (r"scatter_kernel<(\d), true>", 1, "filtered epochs (log2m >= 17): one update per pass of the token loop", ("ds_read",), ()),
+        (r"scatter_first_bin_kernel<(\d), true>", 1, "first epoch (log2m >= 17): one update per pass of the token loop -- the record's path (the rho = 1 lanes' ds_or block is the one skipped)", ("ds_add_rtn", "global_store"), (), ("ds_or",)),
     ]
     kc_name = {"0": "k <= 16 (32-bit windows)", "1": "k 17-32 (64-bit)", "3": "k 33-48 (96-bit)", "2": "k 49-64 (128-bit)"}
     out = {"made_by": "scripts/isa_classes.py over `hipcc -save-temps` of dandd_amd/csrc/dd_sweep.hip (the flags of dandd_amd/build.py)",
            "issue_costs": costs, "kernels": {}}
     for mangled, body in fns.items():
         name = re.sub(r"\(anonymous namespace\)::|dd::|void ", "", pretty[mangled]).split("(")[0]
-        for pat, per_pass, what, must, enter in want:
+        for pat, per_pass, what, must, enter, *rest in want:
+            skip = rest[0] if rest else None
             m = re.fullmatch(pat, name)
             if not m:
                 continue
             need_mads = 2 * per_pass
             cands = []
             for lo, hi in all_loops(body):
-                path = hot_path(body, lo, hi, enter)
+                path = hot_path(body, lo, hi, enter if skip is None else must, skip)
                 if path is None:
                     continue
                 c = count_lines(path)
