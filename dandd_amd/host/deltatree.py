@@ -147,9 +147,31 @@ def dist_barrier():
     set_dist_active(False)
 
 
+class RowTable:
+    """Rows of ONE shape held as columns: what a list of dicts holds, for tables of tens of thousands of rows that are made
+    column-wise anyway (`kij --jaccard` over 64 genomes: 62 496 rows of 9 cells).  Iterating or indexing gives the dicts;
+    write_listdict_to_csv writes the columns without ever making them."""
+
+    def __init__(self, names):
+        self.cols = {n: [] for n in names}
+
+    def __len__(self):
+        return len(next(iter(self.cols.values()))) if self.cols else 0
+
+    def __iter__(self):
+        names = list(self.cols)
+        for values in zip(*self.cols.values()):
+            yield dict(zip(names, values))
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return list(self)[i]
+        return {n: c[i] for n, c in self.cols.items()}
+
+
 def write_listdict_to_csv(outfile, listdict, suffix="", last_col=None):
     """Rows as CSV, union of keys as header, `fastas`/`files` last (they may contain commas)."""
-    names = sorted({k for row in listdict for k in row})
+    names = sorted(listdict.cols) if isinstance(listdict, RowTable) else sorted({k for row in listdict for k in row})
     for special in ("fastas", "files"):
         if special in names:
             last_col = special
@@ -158,7 +180,35 @@ def write_listdict_to_csv(outfile, listdict, suffix="", last_col=None):
         names.append(last_col)
     out = sys.stdout if outfile in (None, "-") else open(outfile + suffix, "w", newline="")
     try:
-        if len(names) > 1 and all(len(row) == len(names) for row in listdict):
+        if isinstance(listdict, RowTable):
+            # The csv module's "excel" dialect written by hand, a COLUMN at a time: a cell is str(value); it is quoted (quotes
+            # doubled) iff it holds a comma, a quote or a line break; rows end in \r\n.  A column of few distinct values -- the
+            # two paths and titles of a pair stand in each of its rows, a leaf's cardinality at k in every pair's row -- is
+            # formatted once per value.  62 496 rows of 9 cells: 0.12 s through csv.writer, 0.03 s this way; same bytes
+            # (tests/test_store.py::test_rowtable_csv_is_the_csv_modules).
+            import re
+            needs_quote = re.compile('[,"\r\n]').search
+
+            def cell(v):
+                t = v if isinstance(v, str) else ("" if v is None else str(v))
+                return '"' + t.replace('"', '""') + '"' if needs_quote(t) else t
+            text_cols = []
+            for n in names:
+                col = listdict.cols[n]
+                kinds = set(map(type, col))
+                # (by OBJECT, not by value: 0.0 == -0.0 == 0 and nan != nan; the repeats are the same objects)
+                repeats = len(col) > 256 and 4 * len(set(map(id, col[:256]))) < 256    # (judged on the first 256 cells)
+                if repeats:
+                    memo = {i: cell(v) for i, v in {id(v): v for v in col}.items()}
+                    text_cols.append(list(map(memo.__getitem__, map(id, col))))
+                elif kinds <= {float, int}:
+                    text_cols.append(list(map(str, col)))       # (numbers never need quoting)
+                else:
+                    text_cols.append([cell(v) for v in col])
+            out.write(",".join(cell(n) for n in names) + "\r\n")
+            if text_cols and text_cols[0]:
+                out.write("\r\n".join(map(",".join, zip(*text_cols))) + "\r\n")
+        elif len(names) > 1 and all(len(row) == len(names) for row in listdict):
             # every row has every column: the same bytes as DictWriter's, from C all the way (a `kij --jaccard` over 64
             # genomes writes 62 496 rows of 10 cells)
             from operator import itemgetter
@@ -1023,6 +1073,10 @@ class DeltaTree:
             if jaccard:
                 for leaf in leaves:
                     leaf.node_ksweep(mink=mink, maxk=maxk)     # (once per leaf: what every pair's ksweep asks of its two leaves)
+                j_rows = RowTable(("A", "B", "Atitle", "Btitle", "kval", "Acard", "Bcard", "ABcard", "jaccard"))
+                jc = j_rows.cols
+                ks = list(range(mink, maxk + 1))
+                leaf_cards = {id(leaf): [leaf.ksketches[k].card for k in ks] for leaf in leaves}
             for i, a in enumerate(leaves):
                 for b in leaves[i + 1:]:
                     pair = _FlatUnion(self, [a, b], pair_exp, table[index[id(a)], index[id(b)]], lo, hi)
@@ -1043,11 +1097,18 @@ class DeltaTree:
                     kij_rows.append(row)
                     if jaccard:
                         pair.node_ksweep(mink, maxk)
-                        for k in range(mink, maxk + 1):   # tree order, never swapped (lib/huffman_dandd.py:804)
-                            jrow = {"A": a.fastas[0], "B": b.fastas[0], "Atitle": a.node_title, "Btitle": b.node_title, "kval": k,
-                                    "Acard": a.ksketches[k].card, "Bcard": b.ksketches[k].card, "ABcard": pair.card(k)}
-                            jrow["jaccard"] = (jrow["Acard"] + jrow["Bcard"] - jrow["ABcard"]) / jrow["ABcard"]
-                            j_rows.append(jrow)
+                        # tree order, never swapped (lib/huffman_dandd.py:804); a column at a time
+                        ac, bc, abc = leaf_cards[id(a)], leaf_cards[id(b)], [pair.card(k) for k in ks]
+                        nk = len(ks)
+                        jc["A"] += [a.fastas[0]] * nk
+                        jc["B"] += [b.fastas[0]] * nk
+                        jc["Atitle"] += [a.node_title] * nk
+                        jc["Btitle"] += [b.node_title] * nk
+                        jc["kval"] += ks
+                        jc["Acard"] += ac
+                        jc["Bcard"] += bc
+                        jc["ABcard"] += abc
+                        jc["jaccard"] += [(x + y - z) / z for x, y, z in zip(ac, bc, abc)]
             return kij_rows, j_rows
         for i, a in enumerate(leaves):
             for b in leaves[i + 1:]:

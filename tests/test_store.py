@@ -170,3 +170,32 @@ def test_exact_databases_identify_genomes_by_name_and_size(tmp_path, monkeypatch
     # a round-2 file
     json.dump({"k": 7, "canonical": True, "names": ["h.fa"], "dirs": [str(moved)]}, open(db("old"), "w"))
     assert be.card(db("old")) == float(os.path.getsize(moved / "h.fa"))
+
+
+def test_rowtable_csv_is_the_csv_modules(tmp_path):
+    """RowTable (columns instead of a list of dicts: the 62 496 Jaccard rows of a 64-genome `kij`) is written by hand; the bytes must
+    be csv.DictWriter's for the same rows -- floats of every shape, ints, None, strings that need quoting."""
+    import csv
+    import math
+    from dandd_amd.host.deltatree import RowTable, write_listdict_to_csv
+    vals = [0.0, -0.0, 1.0, 1e16, 1.5e-7, 123456789.123456789, 0.1 + 0.2, float("inf"), float("nan"), 3, -7, None, "plain", "with,comma",
+            'with "quote"', "line\nbreak", "cr\rhere", "", " spaced ", "tab\there"]
+    t = RowTable(("b", "a", "fastas", "k"))
+    for i, v in enumerate(vals * 20):      # (400 rows of 20 objects: the memoised path; `fastas` goes last as for lists of dicts)
+        t.cols["a"].append(v)
+        t.cols["b"].append(f"/some/path, with comma/g{i % 3}.fasta" if i % 2 else 1.25 * i)
+        t.cols["fastas"].append("x|y")
+        t.cols["k"].append(i)
+    write_listdict_to_csv(str(tmp_path / "cols.csv"), t)
+    rows = list(t)
+    assert len(rows) == len(t) == 20 * len(vals) and rows[3] == t[3]
+    with open(tmp_path / "dicts.csv", "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=["a", "b", "k", "fastas"])
+        w.writeheader()
+        w.writerows(rows)
+    assert (tmp_path / "cols.csv").read_bytes() == (tmp_path / "dicts.csv").read_bytes()
+    write_listdict_to_csv(str(tmp_path / "list.csv"), rows)            # (the list-of-dicts path: the same file again)
+    assert (tmp_path / "list.csv").read_bytes() == (tmp_path / "dicts.csv").read_bytes()
+    empty = RowTable(("x", "y"))
+    write_listdict_to_csv(str(tmp_path / "empty.csv"), empty)
+    assert (tmp_path / "empty.csv").read_bytes() == b"x,y\r\n" and not math.isnan(len(empty))
