@@ -225,6 +225,45 @@ class Engine:
             self._lib.dd_destroy(self._ctx)
             self._ctx = None
 
+    # -- plain device memory for callers without torch (the host layer keeps a collection's leaf slab resident) --------------
+    _hip = None
+
+    @classmethod
+    def _hip_runtime(cls):
+        """The HIP runtime libdandd_hip.so is bound to (same SONAME -> the copy already mapped), for hipMalloc / hipMemcpy / hipFree."""
+        if cls._hip is None:
+            for name in ("libamdhip64.so.7", "libamdhip64.so.6", "libamdhip64.so"):
+                try:
+                    h = C.CDLL(name)
+                    break
+                except OSError:
+                    h = None
+            if h is None:
+                raise EngineError("libamdhip64.so not found")
+            h.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+            h.hipFree.argtypes = [C.c_void_p]
+            h.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            h.hipSetDevice.argtypes = [C.c_int]
+            cls._hip = h
+        return cls._hip
+
+    def device_alloc(self, nbytes):
+        h = self._hip_runtime()
+        ptr = C.c_void_p()
+        if h.hipSetDevice(self.device) != 0 or h.hipMalloc(C.byref(ptr), int(nbytes)) != 0 or not ptr.value:
+            raise EngineError(f"hipMalloc of {nbytes} bytes failed")
+        return ptr.value
+
+    def device_free(self, ptr):
+        if ptr:
+            self._hip_runtime().hipFree(C.c_void_p(int(ptr)))
+
+    def device_upload(self, ptr, host):
+        host = _u8(host)
+        self.synchronize()
+        if self._hip_runtime().hipMemcpy(C.c_void_p(int(ptr)), host.ctypes.data, host.nbytes, 1) != 0:   # hipMemcpyHostToDevice
+            raise EngineError("hipMemcpy (host to device) failed")
+
     def __del__(self):
         try:
             self.close()

@@ -251,6 +251,7 @@ class HipBackend:
         self._recent_bytes = 0
         self._recent_limit = int(os.environ.get("DANDD_SKETCH_CACHE_MB", "1024")) << 20
         self._slab_buf = None
+        self._dev = None                # (key, device address, capacity) of the leaf slab kept in HBM: _device_slab
 
     def new_command(self):
         """A resident server calls this between commands (deltatree.new_command): the registers kept in memory are keyed by the path
@@ -408,15 +409,56 @@ class HipBackend:
                 fill(item)
         return slab
 
+    def _device_slab(self, leaf_paths):
+        """The leaf slab [n][K][m] in HBM, kept between calls: a resident `dandd serve` answers a second `kij` or `progressive`
+        over the same sketch files without reading 2 GB of them and copying them to the device again (64 genomes x 37 k at -r 20:
+        0.13 s + 0.06 s of a 0.55 s command).  The copy is trusted only while every file still has the absolute path, size and
+        modification time it had when it was loaded; DANDD_DEVICE_CACHE_MB bounds it (default 16384, 0 = off).
+        -> device address, or None (too large: the caller goes through host memory)"""
+        n, K = len(leaf_paths), len(leaf_paths[0])
+        nbytes = (n * K) << self.log2m
+        limit = int(os.environ.get("DANDD_DEVICE_CACHE_MB", "16384")) << 20
+        if nbytes > limit or not hasattr(self.engine, "device_alloc"):
+            return None
+        key = []
+        for row in leaf_paths:
+            for p in row:
+                st = os.stat(p)
+                key.append((os.path.abspath(p), st.st_size, st.st_mtime_ns))
+        key = tuple(key)
+        if self._dev is not None and self._dev[0] == key:
+            return self._dev[1]
+        slab = self._leaf_slab(leaf_paths)
+        if self._dev is None or self._dev[2] < nbytes:
+            if self._dev is not None:
+                self.engine.device_free(self._dev[1])
+                self._dev = None
+            ptr, cap = self.engine.device_alloc(nbytes), nbytes
+        else:
+            ptr, cap = self._dev[1], self._dev[2]
+        self._dev = None                       # (not trusted while it is being overwritten)
+        self.engine.device_upload(ptr, slab)
+        self._dev = (key, ptr, cap)
+        return ptr
+
     def pairwise_cards(self, leaf_paths):
         """|leaf_i U leaf_j| for all pairs and every k column: float64 [n][n][K]"""
-        return self.engine.pairwise(self._leaf_slab(leaf_paths))
+        ptr = self._device_slab(leaf_paths)
+        if ptr is None:
+            return self.engine.pairwise(self._leaf_slab(leaf_paths))
+        return self.engine.pairwise_device(ptr, len(leaf_paths), len(leaf_paths[0]))
 
     def progressive_cards(self, leaf_paths, orderings):
         """|union of the first j+1 leaves of ordering o| : float64 [o][n][K]"""
-        return self.engine.progressive(self._leaf_slab(leaf_paths), orderings)
+        ptr = self._device_slab(leaf_paths)
+        if ptr is None:
+            return self.engine.progressive(self._leaf_slab(leaf_paths), orderings)
+        return self.engine.progressive_device(ptr, len(leaf_paths), len(leaf_paths[0]), orderings)
 
     def close(self):
+        if self._dev is not None:
+            self.engine.device_free(self._dev[1])
+            self._dev = None
         self.engine.close()
 
 

@@ -462,3 +462,43 @@ def test_backend_keeps_written_sketches_and_batch_cards(tmp_path, torch_cuda):
     assert not be2._recent
     assert np.array_equal(read_sketch_file(os.path.join(str(tmp_path), "u11.hll"))[0], read_sketch_file(os.path.join(str(tmp_path), "v11.hll"))[0])
     assert be.card(os.path.join(str(tmp_path), "u11.hll")) == be2.card(os.path.join(str(tmp_path), "v11.hll"))
+
+
+@pytest.mark.gpu
+def test_leaf_slab_stays_in_hbm_between_schedules(tmp_path, torch_cuda, monkeypatch):
+    """HipBackend keeps the leaf slab of a schedule on the device: a second `pairwise_cards` / `progressive_cards` over the same
+    sketch files reads no file and copies nothing, a file that changed behind its back is loaded again, and DANDD_DEVICE_CACHE_MB=0
+    gives the same tables through host memory."""
+    import numpy as np
+    from dandd_amd.host import backend as B
+    rng = np.random.default_rng(11)
+    fastas = []
+    for g in range(5):
+        p = os.path.join(str(tmp_path), f"g{g}.fasta")
+        with open(p, "wb") as f:
+            f.write(b">g\n" + rng.choice(np.frombuffer(b"ACGT", np.uint8), size=30000 + 5000 * g).tobytes() + b"\n")
+        fastas.append(p)
+    be = B.HipBackend(12, True)
+    path_of = lambda i, k: os.path.join(str(tmp_path), f"s{i}.w.{k}.spacing.12.hll")
+    be.leaf_many(fastas, 9, 12, path_of)
+    paths = [[path_of(i, k) for k in range(9, 13)] for i in range(5)]
+    ords = [[0, 1, 2, 3, 4], [4, 2, 0, 3, 1]]
+    pair1, prog1 = be.pairwise_cards(paths), be.progressive_cards(paths, ords)
+    reads = []
+    real = B.read_sketch_file
+    monkeypatch.setattr(B, "read_sketch_file", lambda p: reads.append(p) or real(p))
+    be._recent.clear()                                          # (nothing in host memory either: a read would have to go to the files)
+    be._recent_bytes = 0
+    assert np.array_equal(be.pairwise_cards(paths), pair1) and np.array_equal(be.progressive_cards(paths, ords), prog1)
+    assert not reads and be._dev is not None
+    # one file replaced: another size-preserving content, a new mtime
+    other = real(path_of(4, 12))[0]
+    os.utime(path_of(0, 12), ns=(1, 1))
+    B.write_sketch_file(path_of(0, 12), other, 12, 12, True)
+    pair2 = be.pairwise_cards(paths)
+    assert pair2[0, 0, 3] == pair1[4, 4, 3] and np.array_equal(pair2[1:, 1:], pair1[1:, 1:])
+    monkeypatch.setenv("DANDD_DEVICE_CACHE_MB", "0")
+    be2 = B.HipBackend(12, True)
+    assert np.array_equal(be2.pairwise_cards(paths), pair2) and be2._dev is None
+    be.close()
+    be2.close()
