@@ -414,21 +414,27 @@ class HipBackend:
         over the same sketch files without reading 2 GB of them and copying them to the device again (64 genomes x 37 k at -r 20:
         0.13 s + 0.06 s of a 0.55 s command).  The copy is trusted only while every file still has the absolute path, size and
         modification time it had when it was loaded; DANDD_DEVICE_CACHE_MB bounds it (default 16384, 0 = off).
-        -> device address, or None (too large: the caller goes through host memory)"""
+        -> (device address, permutation), or (None, None) (too large: the caller goes through host memory)"""
         n, K = len(leaf_paths), len(leaf_paths[0])
         nbytes = (n * K) << self.log2m
         limit = int(os.environ.get("DANDD_DEVICE_CACHE_MB", "16384")) << 20
         if nbytes > limit or not hasattr(self.engine, "device_alloc"):
-            return None
+            return None, None
+        # (the slab is kept in the order of its rows' first paths, whatever order the caller lists the leaves in: `progressive`
+        # names them in its first ordering's order, `kij` in the tree's -- the same files, one copy)
+        order = sorted(range(n), key=lambda i: leaf_paths[i][0])
+        perm = np.empty(n, dtype=np.int64)
+        perm[order] = np.arange(n)                       # caller's leaf i is row perm[i] of the slab
+        rows = [leaf_paths[i] for i in order]
         key = []
-        for row in leaf_paths:
+        for row in rows:
             for p in row:
                 st = os.stat(p)
                 key.append((os.path.abspath(p), st.st_size, st.st_mtime_ns))
         key = tuple(key)
         if self._dev is not None and self._dev[0] == key:
-            return self._dev[1]
-        slab = self._leaf_slab(leaf_paths)
+            return self._dev[1], perm
+        slab = self._leaf_slab(rows)
         if self._dev is None or self._dev[2] < nbytes:
             if self._dev is not None:
                 self.engine.device_free(self._dev[1])
@@ -439,21 +445,23 @@ class HipBackend:
         self._dev = None                       # (not trusted while it is being overwritten)
         self.engine.device_upload(ptr, slab)
         self._dev = (key, ptr, cap)
-        return ptr
+        return ptr, perm
 
     def pairwise_cards(self, leaf_paths):
         """|leaf_i U leaf_j| for all pairs and every k column: float64 [n][n][K]"""
-        ptr = self._device_slab(leaf_paths)
+        ptr, perm = self._device_slab(leaf_paths)
         if ptr is None:
             return self.engine.pairwise(self._leaf_slab(leaf_paths))
-        return self.engine.pairwise_device(ptr, len(leaf_paths), len(leaf_paths[0]))
+        table = self.engine.pairwise_device(ptr, len(leaf_paths), len(leaf_paths[0]))
+        return table[np.ix_(perm, perm)]
 
     def progressive_cards(self, leaf_paths, orderings):
         """|union of the first j+1 leaves of ordering o| : float64 [o][n][K]"""
-        ptr = self._device_slab(leaf_paths)
+        ptr, perm = self._device_slab(leaf_paths)
         if ptr is None:
             return self.engine.progressive(self._leaf_slab(leaf_paths), orderings)
-        return self.engine.progressive_device(ptr, len(leaf_paths), len(leaf_paths[0]), orderings)
+        ords = perm[np.asarray(orderings, dtype=np.int64).reshape(-1, len(leaf_paths))]
+        return self.engine.progressive_device(ptr, len(leaf_paths), len(leaf_paths[0]), ords)
 
     def close(self):
         if self._dev is not None:

@@ -491,6 +491,13 @@ def test_leaf_slab_stays_in_hbm_between_schedules(tmp_path, torch_cuda, monkeypa
     be._recent_bytes = 0
     assert np.array_equal(be.pairwise_cards(paths), pair1) and np.array_equal(be.progressive_cards(paths, ords), prog1)
     assert not reads and be._dev is not None
+    # the same files named in another order (progressive lists the leaves in its first ordering's order, kij in the tree's): same copy
+    shuffled = [3, 0, 4, 1, 2]
+    pair_s = be.pairwise_cards([paths[i] for i in shuffled])
+    assert not reads and np.array_equal(pair_s, pair1[np.ix_(shuffled, shuffled)])
+    inv = {g: i for i, g in enumerate(shuffled)}
+    prog_s = be.progressive_cards([paths[i] for i in shuffled], [[inv[g] for g in o] for o in ords])
+    assert not reads and np.array_equal(prog_s, prog1)
     # one file replaced: another size-preserving content, a new mtime
     other = real(path_of(4, 12))[0]
     os.utime(path_of(0, 12), ns=(1, 1))
