@@ -252,6 +252,7 @@ class HipBackend:
         self._recent_limit = int(os.environ.get("DANDD_SKETCH_CACHE_MB", "1024")) << 20
         self._slab_buf = None
         self._dev = None                # (key, device address, capacity) of the leaf slab kept in HBM: _device_slab
+        self.resident = False           # set by `dandd serve`: leaf_many leaves the slab it has just made on the device
 
     def new_command(self):
         """A resident server calls this between commands (deltatree.new_command): the registers kept in memory are keyed by the path
@@ -346,7 +347,36 @@ class HipBackend:
         keep = max(0, self._recent_limit // max(1, regs.shape[-1]))
         for path, row, k in jobs[len(jobs) - min(len(jobs), keep):]:
             self._remember(path, row, k)
+        if self.resident and n > 1:
+            self._seed_device_slab([[path_of(i, k) for k in range(kmin, kmax + 1)] for i in range(n)], regs)
         return cards
+
+    def _seed_device_slab(self, leaf_paths, regs):
+        """A resident server that has just sketched a collection leaves its leaf slab in HBM (_device_slab's layout and key): the
+        `progressive` / `kij` that follow find it there."""
+        n, K = len(leaf_paths), len(leaf_paths[0])
+        nbytes = (n * K) << self.log2m
+        limit = int(os.environ.get("DANDD_DEVICE_CACHE_MB", "16384")) << 20
+        if nbytes > limit or not hasattr(self.engine, "device_alloc"):
+            return
+        order = sorted(range(n), key=lambda i: leaf_paths[i][0])
+        key = []
+        for i in order:
+            for p in leaf_paths[i]:
+                st = os.stat(p)
+                key.append((os.path.abspath(p), st.st_size, st.st_mtime_ns))
+        if self._dev is None or self._dev[2] < nbytes:
+            if self._dev is not None:
+                self.engine.device_free(self._dev[1])
+                self._dev = None
+            ptr, cap = self.engine.device_alloc(nbytes), nbytes
+        else:
+            ptr, cap = self._dev[1], self._dev[2]
+        self._dev = None
+        per_leaf = K << self.log2m
+        for rank, i in enumerate(order):
+            self.engine.device_upload(ptr + rank * per_leaf, regs[i])
+        self._dev = (tuple(key), ptr, cap)
 
     def union(self, in_paths, out_path):
         cold = [p for p in in_paths if p not in self._recent]

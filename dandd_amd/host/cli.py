@@ -133,6 +133,7 @@ def serve_command(args):
         for spec in args.warm:
             regs, _, flag = spec.partition(",")
             deltatree.backend_for({"registers": int(regs), "canonicalize": flag != "nc", "tool": "dashing"})
+    deltatree.RESIDENT = True
     print(f"dandd serve: listening on {path}", flush=True)
     served, home = 0, os.getcwd()
 

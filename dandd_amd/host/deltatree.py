@@ -30,6 +30,7 @@ from .store import Catalog, SketchPath, ensure_dir, forget_sketch, sketch_exists
 # ---------------------------------------------------------------------------------------------
 _backend_factory = None
 _backends = {}
+RESIDENT = False    # `dandd serve` sets it: backends outlive commands, so what a command leaves on the device is worth keeping
 _SWEPT = weakref.WeakKeyDictionary()   # DeltaTreeNode -> the ks its subtree has been brought up to date for, in this command
 
 
@@ -104,6 +105,8 @@ def backend_for(experiment):
         _backends[key] = box[0]
     if key not in _backends:
         _backends[key] = _backend_factory(key[0], key[1]) if _backend_factory is not None else _make_backend(key)
+    if RESIDENT and hasattr(_backends[key], "resident"):
+        _backends[key].resident = True
     return _backends[key]
 
 

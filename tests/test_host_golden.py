@@ -509,3 +509,16 @@ def test_leaf_slab_stays_in_hbm_between_schedules(tmp_path, torch_cuda, monkeypa
     assert np.array_equal(be2.pairwise_cards(paths), pair2) and be2._dev is None
     be.close()
     be2.close()
+    # a resident backend (what `dandd serve` makes of it) leaves the slab on the device when it sketches: same tables, no read at all
+    monkeypatch.delenv("DANDD_DEVICE_CACHE_MB")
+    res = B.HipBackend(12, True)
+    res.resident = True
+    path_r = lambda i, k: os.path.join(str(tmp_path), f"r{i}.w.{k}.spacing.12.hll")
+    res.leaf_many(fastas, 9, 12, path_r)
+    res._recent.clear()
+    res._recent_bytes = 0
+    del reads[:]
+    paths_r = [[path_r(i, k) for k in range(9, 13)] for i in range(5)]
+    assert res._dev is not None and np.array_equal(res.pairwise_cards(paths_r), pair1) and np.array_equal(res.progressive_cards(paths_r, ords), prog1)
+    assert not reads
+    res.close()
