@@ -147,6 +147,8 @@ def hot_path(body, lo, hi, must=(), skip=None):
         elif op == "s_cbranch_execz" and skip is not None:
             # (a kernel whose update sits behind nested guards: every guarded block is entered except those that hold one of `skip`)
             if any(re.match(r"\s+" + pre, l) for l in guarded for pre in skip):
+                if tgt == lo:
+                    return out       # (the skipped block was the pass's last: back at the loop's head)
                 i = tgt
             else:
                 i += 1

@@ -548,17 +548,16 @@ int main(int argc, char** argv) {
         }
     check_plan(20, std::vector<size_t>(13, 3040000000ull), 4, 64, base);
     dd::PlanKnobs k2 = base;
-    k2.buckets = false;
-    check_plan(19, ragged, 8, 35, k2);
-    k2 = base;
     k2.bucket_e0_tiles = 1;
     k2.bucket_emax_tiles = 2;
-    k2.xcd_affinity = false;
     check_plan(18, ragged, 8, 35, k2);
     k2 = base;
-    k2.filter = false;
-    k2.use_bitmaps = false;
-    check_plan(18, ragged, 2, 20, k2);
+    k2.bucket_cap_chunks = 3;                      // (a stream so short that records overflow into the registers)
+    k2.bigmap_any_size = true;
+    check_plan(19, ragged, 8, 35, k2);
+    k2 = base;
+    k2.bucket_budget = (size_t)1 << 30;            // (a budget that cuts the first epoch short)
+    check_plan(20, ragged, 2, 20, k2);
     check_loaders(argv[1]);
     check_gzip_edges(argv[1]);
     check_parallel_inflate();

@@ -137,14 +137,15 @@ def test_bench_progressive_line_names_the_bit_plane_scan_at_log2m_20(torch_cuda,
 
 
 def test_committed_counter_files_feed_the_issue_model():
-    """bench.py's valu_bound is computed from COMMITTED evidence only: profiles/r0[45]_k1_counters_*.json (PMC passes; the newest round first) and
-    profiles/r0[45]_isa_classes.json (instruction classes of the hot loops in the shipped ISA x measured issue costs).
+    """bench.py's valu_bound is computed from COMMITTED evidence only: profiles/r0[456]_k1_counters_*.json (PMC passes; the newest round first) and
+    profiles/r0[456]_isa_classes.json (instruction classes of the hot loops in the shipped ISA x measured issue costs).
     On the CPU: the files load for the headline workload, for DandD's default registers, for the small-genome
     regime and for the cfg 5 share; the log2m 14 kernels come out at 90-105 % of issue for their own instruction mix."""
     sys.path.insert(0, ROOT)
     import bench
     isa = bench.isa_table()
-    assert isa and {"sweep_kernel<0, true, 0>", "sweep_kernel<1, true, 0>", "sweep_kernel<3, true, 0>", "sweep_kernel<2, true, 0>"} <= set(isa["kernels"])
+    assert isa and isa["_file"] == "profiles/r06_isa_classes.json"       # (the round's own table: the kernels of the pruned build)
+    assert {f"{k}<{c}, true>" for k in ("sweep_kernel", "scatter_kernel", "scatter_first_bin_kernel") for c in range(4)} <= set(isa["kernels"])
     assert 2.2 < isa["issue_costs"]["cheap_cycles"] < 2.7 and 4.0 < isa["issue_costs"]["dear_cycles"] < 4.5
     for args in ((10, 50.0, 4, 40, 14), (10, 50.0, 4, 40, 16), (10, 50.0, 4, 40, 20), (64, 5.0, 4, 40, 20),
                  (13, 3000.0, 4, 64, 14), (13, 3000.0, 4, 64, 16), (13, 3000.0, 4, 64, 20)):
