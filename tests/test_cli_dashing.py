@@ -212,3 +212,19 @@ def test_one_process_per_command_like_the_reference(dashing, tmp_path, orc, torc
     assert np.array_equal(regs, want) and (log2m, kk, canon) == (12, k, True)
     r = subprocess.run([dashing, "card", "--presketched", out], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and float(r.stdout.splitlines()[1].split("\t")[1]) == orc.card(want, 12)
+    # several FASTAs in one `sketch` (Dashing takes them; the reference never does): one file each, through the ingestion pipeline,
+    # non-canonical, k and S as separate arguments; a multi-path `card` over them in Dashing's plain layout
+    many = os.path.join(work, "many")
+    os.makedirs(many)
+    fastas = [os.path.join(work, "data", f"g{g}.fasta") for g in (0, 2, 4)]
+    penv = dict(env, DANDD_SKETCH_FORMAT="dashing-plain")
+    r = subprocess.run([dashing, "sketch", "--no-canon", "-k", "13", "-S", "10", "--prefix", many] + fastas, env=penv, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    outs = [os.path.join(many, os.path.basename(f) + ".w.13.spacing.10.hll") for f in fastas]
+    for f, o in zip(fastas, outs):
+        regs, log2m, kk, _canon = read_sketch_file(o)
+        assert (log2m, kk) == (10, 13) and np.array_equal(regs, orc.sketch(np.fromfile(f, dtype=np.uint8), 13, 10, False))
+    r = subprocess.run([dashing, "card", "--presketched"] + outs, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and len(r.stdout.splitlines()) == 4
+    for line, f in zip(r.stdout.splitlines()[1:], fastas):
+        assert float(line.split("\t")[1]) == orc.card(orc.sketch(np.fromfile(f, dtype=np.uint8), 13, 10, False), 10)

@@ -105,10 +105,11 @@ BUCKET_KNOBS = {
 
 
 @pytest.mark.parametrize("knobs", sorted(BUCKET_KNOBS))
-@pytest.mark.parametrize("p", [18, 20])
+@pytest.mark.parametrize("p", [17, 18, 19, 20])
 def test_bucket_mode_knobs(engine_factory, orc, monkeypatch, knobs, p):
-    """log2m >= 18 (scatter + replay): multi-epoch schedules, bucket overflow, coarse filters and the old
-    path all give the oracle's registers -- ragged records, N runs, k classes 0/1/3 and the bitmap class."""
+    """log2m >= 17 (scatter + sort + replay), every register count of the record path: one-epoch and multi-epoch schedules, streams and
+    bins that overflow, a tight record budget, the exact-set class -- all give the oracle's registers; ragged records, N runs,
+    k classes 0 / 1 / 3 and the bitmap class."""
     for k, v in BUCKET_KNOBS[knobs].items():
         monkeypatch.setenv(k, v)
     eng = engine_factory(p, True)
