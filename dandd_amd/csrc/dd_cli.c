@@ -185,6 +185,8 @@ static int sketch_write(const char *path, const unsigned char *regs, int log2m, 
 }
 
 /* ---- the three commands ---------------------------------------------------------------------------------------------- */
+static int threads_glued(const char *a) { return a[0] == '-' && a[1] == 'p' && a[2] >= '0' && a[2] <= '9'; }
+
 static int cmd_sketch(int argc, char **argv, sink *s) {
     int k = 0, p = 0, canon = 1, i, npaths = 0, rc = 0;
     const char *prefix = ".";
@@ -200,6 +202,7 @@ static int cmd_sketch(int argc, char **argv, sink *s) {
         else if ((!strcmp(argv[i], "--prefix") || !strcmp(argv[i], "-P")) && i + 1 < argc) prefix = argv[++i];
         else if (!strcmp(argv[i], "--no-canon") || !strcmp(argv[i], "-C")) canon = 0;
         else if (!strcmp(argv[i], "-z")) continue;
+        else if (threads_glued(argv[i])) continue; /* (-p<N>, the form lib/sketch_classes.py:361 has commented out) */
         else if ((!strcmp(argv[i], "-p") || !strcmp(argv[i], "--nthreads")) && i + 1 < argc) ++i; /* (threads: the GPU does not care) */
         else if (argv[i][0] == '-' && argv[i][1]) {
             text_add(&s->err, "dashing sketch: unknown option %s\n", argv[i]);
@@ -241,7 +244,7 @@ static int cmd_union(int argc, char **argv, sink *s) {
     if (!in) return 1;
     for (i = 0; i < argc && !rc; ++i) {
         if (!strcmp(argv[i], "-o") && i + 1 < argc) out = argv[++i];
-        else if (!strcmp(argv[i], "-z")) continue;
+        else if (!strcmp(argv[i], "-z") || threads_glued(argv[i])) continue;
         else if ((!strcmp(argv[i], "-p") || !strcmp(argv[i], "--nthreads")) && i + 1 < argc) ++i;
         else if (argv[i][0] == '-' && argv[i][1]) {
             text_add(&s->err, "dashing union: unknown option %s\n", argv[i]);
@@ -289,7 +292,7 @@ static int cmd_card(int argc, char **argv, sink *s) {
         unsigned char *regs;
         dd_ctx *ctx;
         double est = 0.0;
-        if (!strcmp(argv[i], "--presketched") || !argv[i][0]) continue;
+        if (!strcmp(argv[i], "--presketched") || !argv[i][0] || threads_glued(argv[i])) continue;
         if ((!strcmp(argv[i], "-p") || !strcmp(argv[i], "--nthreads")) && i + 1 < argc) {
             ++i;
             continue;

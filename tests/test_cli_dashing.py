@@ -71,6 +71,11 @@ def test_cli_without_gpu_fails_loudly(dashing, tmp_path):
                        env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "no CPU path" in r.stderr, (r.returncode, r.stderr)
     assert not os.listdir(tmp_path)                               # nothing half-written takes a sketch's name
+    # the thread flag the reference has commented out (lib/sketch_classes.py:313,361,370) parses, glued or apart: the call gets as far as the GPU
+    for threads in (["-p10"], ["-p", "10"]):
+        r = subprocess.run([dashing, "sketch"] + threads + ["-k9", "-S", "12", "--prefix", str(tmp_path), os.path.join(GOLD, "fasta", "g0.fasta")],
+                           env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 1 and "no CPU path" in r.stderr, (threads, r.returncode, r.stderr)
     for bad in (["frobnicate"], ["sketch", "-k9", "--prefix", str(tmp_path)], ["sketch", "-k99", "-S", "12", "x.fa"], ["union", "-o"],
                 ["card", "--frob", "x"], []):
         r = subprocess.run([dashing] + bad, env=env, capture_output=True, text=True, timeout=120)
