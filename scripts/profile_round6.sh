@@ -4,7 +4,7 @@
 # workload, the world-1 RCCL line through torch.distributed and through the C ABI, the CLI end to end one-shot and through the server.
 # usage: profile_round6.sh OUTNAME     (results under gpurun_out/OUTNAME; copy into profiles/ as r06_<v>_*)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/${1:-r06_v1}; mkdir -p $OUT
+OUT=gpurun_out/${1:-r06_v2}; mkdir -p $OUT
 timeout 900 python3 bench.py --detail $OUT/bench_default_detail.json > $OUT/bench_default_line.json 2> $OUT/bench_default.err
 for P in 14 20; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats$P -o st -- python3 bench.py --steps 5 --warmup 1 --log2m $P --no-cpu-baseline --no-accuracy --no-secondary --no-ingest --detail $OUT/bench_prof_p${P}_detail.json > $OUT/bench_prof_p$P.json 2> $OUT/bench_prof_p$P.err
