@@ -233,3 +233,46 @@ def test_one_process_per_command_like_the_reference(dashing, tmp_path, orc, torc
     assert r.returncode == 0 and len(r.stdout.splitlines()) == 4
     for line, f in zip(r.stdout.splitlines()[1:], fastas):
         assert float(line.split("\t")[1]) == orc.card(orc.sketch(np.fromfile(f, dtype=np.uint8), 13, 10, False), 10)
+
+
+@pytest.mark.gpu
+def test_cli_at_baseline_genome_size_and_default_registers(dashing, tmp_path, orc, engine_factory):
+    """Three 50 Mbp genomes (BASELINE cfg 2's genome size) at DandD's default `-S 20` through the executable, one process per
+    command: each payload == the library called directly == (for one genome) the oracle; the union's payload is the byte-wise
+    max of its inputs; `card` prints the double the library's estimator returns, and it is within 3 sigma (1.04 / sqrt(2^20))
+    of the distinct canonical 21-mers of a uniform random genome (~ its length less its N blocks)."""
+    env = dict(os.environ)
+    env.pop("DANDD_DASHING_SERVER", None)
+    env.pop("DANDD_SKETCH_FORMAT", None)
+    k, p, nb = 21, 20, 50_000_000
+    data = tmp_path / "data"
+    data.mkdir()
+    fastas = []
+    for g in range(3):
+        f = data / f"big{g}.fasta"
+        f.write_bytes(orc.synth_fasta(424242, g, nb, 7).tobytes())
+        fastas.append(str(f))
+    eng = engine_factory(p, True)
+    direct = eng.sketch_files(fastas, k, k)                            # [3][1][2^20]
+    outs = []
+    for g, f in enumerate(fastas):
+        r = subprocess.run([dashing, "sketch", f"-k{k}", "-S", str(p), "--prefix", str(tmp_path), f], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        out = str(tmp_path / f"big{g}.fasta.w.{k}.spacing.{p}.hll")
+        regs = np.fromfile(out, dtype=np.uint8)[NATIVE_HEAD:]
+        assert regs.size == 1 << p and np.array_equal(regs, direct[g, 0])
+        outs.append(out)
+    assert np.array_equal(direct[0, 0], orc.sketch(np.fromfile(fastas[0], dtype=np.uint8), k, p, True))
+    u = str(tmp_path / "u.hll")
+    r = subprocess.run([dashing, "union", "-z", "-o", u] + outs, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    merged = np.fromfile(u, dtype=np.uint8)[NATIVE_HEAD:]
+    assert np.array_equal(merged, np.maximum.reduce([direct[g, 0] for g in range(3)]))
+    r = subprocess.run([dashing, "card", "--presketched", u] + outs, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    got = [float(line.split("\t")[1]) for line in r.stdout.splitlines()[1:]]
+    assert got == [float(eng.card(merged))] + [float(eng.card(direct[g, 0])) for g in range(3)]
+    sigma = 1.04 / (1 << p) ** 0.5
+    for est in got[1:]:                                             # (the three genomes are 1 % apart: their union is not 3 x nb)
+        assert abs(est / nb - 1.0) < 3 * sigma + 3e-3, est          # (3e-3: the 0.1 % of 100-base blocks that are N take ~120 windows each)
+    assert max(got[1:]) < got[0] < sum(got[1:])
