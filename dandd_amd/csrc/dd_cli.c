@@ -21,6 +21,7 @@
  * Without a reachable server they run here.  Exit status: 0, 1 on a failed command (message on stderr), 64 on a bad command line. */
 #define _POSIX_C_SOURCE 200809L
 #include <errno.h>
+#include <signal.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -384,6 +385,7 @@ static int serve(int argc, char **argv) {
         return 1;
     }
     umask(old);
+    signal(SIGPIPE, SIG_IGN); /* a client that hangs up before its reply is written costs a failed write(), not the server */
     printf("dashing serve: listening on %s\n", path);
     fflush(stdout);
     while (!leave) {
@@ -406,6 +408,12 @@ static int serve(int argc, char **argv) {
             break;
         }
         memset(&s, 0, sizeof s);
+        {   /* ... and one that connects and then says nothing holds the (single) line for ten seconds, not for ever */
+            struct timeval patience;
+            patience.tv_sec = 10, patience.tv_usec = 0;
+            (void)setsockopt(conn, SOL_SOCKET, SO_RCVTIMEO, &patience, sizeof patience);
+            (void)setsockopt(conn, SOL_SOCKET, SO_SNDTIMEO, &patience, sizeof patience);
+        }
         /* a client that goes away or sends nonsense costs its own connection, never the server (its contexts are the point) */
         if (io_all(conn, &n, 4, 0) == 0 && n <= 65536 && (av = (char **)calloc((size_t)n + 1, sizeof *av)) != NULL) {
             for (j = 0; j < n && (av[j] = get_blob(conn, 1u << 20)) != NULL; ++j) {}

@@ -102,6 +102,16 @@ def test_resident_form_answers_and_survives_bad_clients(dashing, tmp_path):
             s.connect(sock)
             s.sendall(junk)
             s.close()
+        # clients that send a whole request and hang up before the reply is written (a DandD killed mid-command): the write fails,
+        # the server stays (it died of SIGPIPE before round 6's review of its own code)
+        import struct
+        blob = lambda b: struct.pack("<I", len(b)) + b
+        for _ in range(300):
+            s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            s.connect(sock)
+            s.sendall(struct.pack("<I", 3) + blob(b"card") + blob(b"--presketched") + blob(b"no/such.hll") + blob(str(tmp_path).encode()))
+            s.close()
+        assert srv.poll() is None
         r = subprocess.run([dashing, "card", "--presketched", "no/such.hll"], env=cenv, capture_output=True, text=True, timeout=60, cwd=str(tmp_path))
         assert r.returncode == 1 and "no/such.hll" in r.stderr and r.stdout == "#Path\tSize (est.)\n"
         r = subprocess.run([dashing, "sketch", "-k9", "-S", "12", "--prefix", ".", os.path.join(GOLD, "fasta", "g0.fasta")], env=cenv,
