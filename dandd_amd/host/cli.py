@@ -140,7 +140,7 @@ def serve_command(args):
     def handle(conn):
         """one connection = one request; -> True when the server is asked to leave"""
         nonlocal served
-        conn.settimeout(None)
+        conn.settimeout(10.0)      # a client that connects and then says nothing (or never reads its reply) holds the single line ten seconds, not for ever
         req = recv_msg(conn)
         if not isinstance(req, dict):
             return False
@@ -158,10 +158,10 @@ def serve_command(args):
             for k in saved:
                 del os.environ[k]
             os.environ.update({k: str(v) for k, v in (req.get("env") or {}).items() if k.startswith(ENV_PREFIXES)})
-            os.chdir(req.get("cwd") or home)
             deltatree.new_command()
             with contextlib.redirect_stdout(out), contextlib.redirect_stderr(err):
                 try:
+                    os.chdir(req.get("cwd") or home)      # (a directory that is gone: the client gets the message, like any failed command)
                     argv = list(req.get("argv") or [])
                     if argv[:1] == ["serve"]:
                         raise SystemExit("dandd serve: a server does not start servers")

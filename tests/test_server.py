@@ -95,7 +95,9 @@ def _run_both(tmp_path, backend_env, regs, timeout=600):
                     c.close()
                 assert oct(os.stat(sock).st_mode & 0o777) == "0o600"
                 from dandd_amd.host.client import request
-                assert request(sock, {"op": "ping"})["served"] == 7
+                gone = request(sock, {"argv": ["tree", "-o", out], "cwd": os.path.join(base, "no", "such", "dir"), "env": {}})
+                assert gone["rc"] == 1 and "FileNotFoundError" in gone["stderr"]      # (a working directory that is gone: a message, not a dropped line)
+                assert request(sock, {"op": "ping"})["served"] == 8
                 assert request(sock, {"op": "shutdown"})["rc"] == 0
                 srv.wait(timeout=60)
             finally:
