@@ -485,6 +485,8 @@ int main(int argc, char **argv) {
     if (s.out.p) fputs(s.out.p, stdout);
     if (s.err.p) fputs(s.err.p, stderr);
     fflush(stdout);
+    free(s.out.p);
+    free(s.err.p);
     contexts_destroy();
     return rc;
 }
