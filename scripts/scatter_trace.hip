@@ -29,6 +29,7 @@ struct TraceOut {
 // V 8: V 4 with the slot's atomic NOT returning (slot from a per-lane counter: wrong, timing only): what the returning round trip costs
 // V 9: V 4 with the rho = 1 bits of ALL 2^20 registers (128 KiB of LDS: one workgroup per CU)
 // V 10: V 9 with two tiles of tokens per thread in flight (two windows, two hash chains interleaved): 4 waves per SIMD with twice the work each
+// V 11: V 4 with 64 bins (of 1120 records per tile) instead of 16: what scripts/replay_probe.hip's word-per-register replay would ask of the scatter
 template <int V>
 __global__ __launch_bounds__(1024) void trace_kernel(const uint4* __restrict__ codes, uint32_t* __restrict__ area, uint32_t* __restrict__ sink,
                                                     int tiles_per_job, int p, TraceOut* __restrict__ out) {
@@ -36,13 +37,15 @@ __global__ __launch_bounds__(1024) void trace_kernel(const uint4* __restrict__ c
     const int k = 24;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     const uint32_t ones_regs = 1u << ((V == 9 || V == 10) ? 20 : kOnesLog2Max), ones_words = ones_regs >> 5;   // (V 9, 10: the whole row's bits = 128 KiB = one workgroup per CU)
-    if (threadIdx.x < 32u) lds32(4u * threadIdx.x) = 0;
+    constexpr int kBinsLog2 = V == 11 ? 6 : 4;                                   // V 11: 64 bins of 1120 records per tile (a replay tile of 16 Ki registers)
+    constexpr uint32_t ones_base = V == 11 ? 512u : kBinLdsBytes;                // (two parities x 64 counters)
+    if (threadIdx.x < (V == 11 ? 128u : 32u)) lds32(4u * threadIdx.x) = 0;
     if (V >= 1 && V != 7)
-        for (uint32_t w = threadIdx.x; w < ones_words; w += blockDim.x) lds32(kBinLdsBytes + 4u * w) = 0;
+        for (uint32_t w = threadIdx.x; w < ones_words; w += blockDim.x) lds32(ones_base + 4u * w) = 0;
     __syncthreads();
     const size_t job_records = (size_t)tiles_per_job * kBinChunkRecords;
     uint32_t* const job_area = area + (size_t)blockIdx.x * job_records;
-    const int tile_sh = 32 - 4;
+    const int tile_sh = 32 - kBinsLog2;
     uint32_t acc = 0;
     unsigned long long c_hash = 0, c_slot = 0, c_store = 0, c_bar = 0;
     const unsigned long long t_begin = __builtin_readcyclecounter();
@@ -91,9 +94,9 @@ __global__ __launch_bounds__(1024) void trace_kernel(const uint4* __restrict__ c
         const uint4 sc = next;
         if (t + 1 < tiles_per_job) next = codes[((size_t)blockIdx.x * tiles_per_job + t + 1) * 1024 + threadIdx.x];
         const uint32_t cw[4] = {sc.x, sc.y, sc.z, sc.w};
-        const uint32_t ctr = (V == 6) ? 0u : ((uint32_t)t & 1u) * 64u;
+        const uint32_t ctr = (V == 6) ? 0u : ((uint32_t)t & 1u) * (4u << kBinsLog2);
         uint8_t* const chunk = reinterpret_cast<uint8_t*>(V == 6 ? job_area : job_area + (size_t)t * kBinChunkRecords);
-        const uint32_t cap = V == 6 ? (uint32_t)tiles_per_job * kBinCap : kBinCap;
+        const uint32_t cap = V == 6 ? (uint32_t)tiles_per_job * kBinCap : (kBinCap >> (kBinsLog2 - 4));
         Windows<5> win;
         win.prime(make_uint4(sc.w, sc.z, sc.y, sc.x));
 #pragma unroll
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(1024) void trace_kernel(const uint4* __restrict__ c
                 const uint32_t rho = rho_of(q, p);
                 if (V != 7 && rho == 1u && (q.hi >> (32 - p)) < ones_regs) {
                     const uint32_t idx = q.hi >> (32 - p);
-                    atomicOr(&lds32(kBinLdsBytes + ((idx >> 5) << 2)), 1u << (idx & 31u));
+                    atomicOr(&lds32(ones_base + ((idx >> 5) << 2)), 1u << (idx & 31u));
                     continue;
                 }
                 const uint32_t rec = (q.hi >> (32 - p)) | (rho << 24);
@@ -147,11 +150,11 @@ __global__ __launch_bounds__(1024) void trace_kernel(const uint4* __restrict__ c
                 }
             }
         }
-        if (V == 4 || V == 5 || V == 7 || V == 8 || V == 9) {
+        if (V == 4 || V == 5 || V == 7 || V == 8 || V == 9 || V == 11) {
             unsigned long long b0 = 0;
             if (V == 5) b0 = __builtin_readcyclecounter();
             __syncthreads();
-            if (wave == 0u && lane < 16u) {
+            if (wave == 0u && lane < (1u << kBinsLog2)) {
                 acc ^= lds32(ctr + 4u * lane);
                 lds32(ctr + 4u * lane) = 0;
             }
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(1024) void trace_kernel(const uint4* __restrict__ c
     }
     if (V >= 1 && V != 7) {
         __syncthreads();
-        for (uint32_t w = threadIdx.x; w < ones_words; w += blockDim.x) acc ^= lds32(kBinLdsBytes + 4u * w);
+        for (uint32_t w = threadIdx.x; w < ones_words; w += blockDim.x) acc ^= lds32(ones_base + 4u * w);
     }
     if (acc == 0x12345678u) sink[0] = acc;   // (keeps the work alive)
     if (V == 5 && lane == 0u) {
@@ -355,6 +358,7 @@ int main(int argc, char** argv) {
     const size_t lds_full = dd::kBinLdsBytes + (((size_t)1 << 20) >> 3);
     rc |= run<9>("V4 with the rho = 1 bits of all 2^20 registers (128 KiB: ONE workgroup per CU)", codes, area, sink, njobs, tpj, out_dev, lds_full, updates);
     rc |= run<10>("V9 with two tiles per thread in flight (two hash chains interleaved)", codes, area, sink, njobs, tpj, out_dev, lds_full, updates);
+    rc |= run<11>("V4 with 64 bins of 1120 records per tile (what a replay tile of 16 Ki registers needs)", codes, area, sink, njobs, tpj, out_dev, lds_bits + 256, updates);
     printf("-- several ks per job: one window push and one token decode for NK hashes; every k its own counters and bins --\n");
     rc |= run_multik<1, 0, false>("one k per job, every update a record (= V7)", codes, area, sink, njobs, tpj, updates);
     rc |= run_multik<1, 19, false>("one k per job, rho = 1 bits of half the registers (= V4)", codes, area, sink, njobs, tpj, updates);
