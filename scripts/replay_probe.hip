@@ -12,7 +12,9 @@
 //   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I dandd_amd/csrc scripts/replay_probe.hip -o scripts/build/replay_probe
 //   run  : scripts/build/replay_probe [records_in_millions=2400]
 // Not part of the product; nothing here is linked into libdandd_hip.so.
+#ifndef REPLAY_PROBE_NO_MAIN   // (scripts/scatter_trace.hip includes this file for its overlap experiment: the kernels only)
 #include "../dandd_amd/csrc/dd_sweep.hip"
+#endif
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -121,6 +123,7 @@ __global__ __launch_bounds__(1024) void replay_probe(const uint32_t* __restrict_
 }  // namespace
 }  // namespace dd
 
+#ifndef REPLAY_PROBE_NO_MAIN
 #define CK(x)                                                                         \
     do {                                                                              \
         hipError_t e_ = (x);                                                          \
@@ -207,3 +210,4 @@ int main(int argc, char** argv) {
     rc |= run<3>("words, 32 768 per tile (128 KiB, ONE workgroup per CU): one ds_max_u32, no return", recs, nrec, regs, regs_bytes, sink, &s[3]);
     return rc;
 }
+#endif

@@ -9,6 +9,8 @@
 //   run  : scripts/build/scatter_trace [tiles=78848] [tiles_per_job=10]      (needs ~23 GB of HBM for the record areas)
 // Not part of the product; nothing here is linked into libdandd_hip.so.
 #include "../dandd_amd/csrc/dd_sweep.hip"
+#define REPLAY_PROBE_NO_MAIN
+#include "replay_probe.hip"   // fill_records, replay_probe<V>: the overlap experiment at the end of main
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -330,6 +332,73 @@ static int run_multik(const char* what, const uint4* codes, uint32_t* area, uint
     return 0;
 }
 
+// Can a replay run UNDER a scatter?  The replay is bound by reading its records (scripts/replay_probe.hip), the scatter by VALU issue:
+// on two streams they could share the chip -- if a CU holds both.  Two scatter workgroups of 1024 threads fill a CU's 32 wave slots,
+// so the scatter is held to ONE workgroup per CU here by asking for `scatter_lds` bytes of LDS (96 KiB + a replay tile of 64 KiB =
+// 160 KiB exactly).  Times: scatter alone (at that occupancy), replay alone, both started together.
+template <int V>
+static int overlap(const char* what, const uint4* codes, uint32_t* area, uint32_t* sink, int njobs, int tpj, dd::TraceOut* out_dev, size_t scatter_lds,
+                   double updates) {
+    auto sk = dd::trace_kernel<V>;
+    auto rk = dd::replay_probe<1>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(rk), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    const size_t nrec = (size_t)(updates * 0.75) / 262144 * 262144;          // the records such a scatter leaves
+    const unsigned rblocks = (unsigned)(nrec / 262144);
+    uint32_t* recs;
+    uint8_t* regs;
+    CK(hipMalloc(&recs, nrec * 4));
+    CK(hipMalloc(&regs, (size_t)rblocks * 65536));
+    hipLaunchKernelGGL(dd::fill_records, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, 0, recs, nrec, 65535u, 0xD4ADDull);
+    CK(hipDeviceSynchronize());
+    hipStream_t s1, s2;
+    CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    hipEvent_t a0, a1, b0, b1;
+    CK(hipEventCreate(&a0)); CK(hipEventCreate(&a1)); CK(hipEventCreate(&b0)); CK(hipEventCreate(&b1));
+    float t_s = 1e30f, t_r = 1e30f, t_both = 1e30f, t_both_s = 0, t_both_r = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        float ms;
+        CK(hipMemset(regs, 0, (size_t)rblocks * 65536));
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(a0, s1));
+        hipLaunchKernelGGL(sk, dim3((unsigned)njobs), dim3(1024), scatter_lds, s1, codes, area, sink, tpj, 20, out_dev);
+        CK(hipEventRecord(a1, s1));
+        CK(hipEventSynchronize(a1));
+        CK(hipEventElapsedTime(&ms, a0, a1));
+        t_s = ms < t_s ? ms : t_s;
+        CK(hipEventRecord(b0, s2));
+        hipLaunchKernelGGL(rk, dim3(rblocks), dim3(1024), 65536, s2, recs, 32u, regs, sink);
+        CK(hipEventRecord(b1, s2));
+        CK(hipEventSynchronize(b1));
+        CK(hipEventElapsedTime(&ms, b0, b1));
+        t_r = ms < t_r ? ms : t_r;
+        // both: the scatter first (it takes its one workgroup per CU), the replay beside it
+        CK(hipMemset(regs, 0, (size_t)rblocks * 65536));
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(a0, s1));
+        CK(hipEventRecord(b0, s2));
+        hipLaunchKernelGGL(sk, dim3((unsigned)njobs), dim3(1024), scatter_lds, s1, codes, area, sink, tpj, 20, out_dev);
+        hipLaunchKernelGGL(rk, dim3(rblocks), dim3(1024), 65536, s2, recs, 32u, regs, sink);
+        CK(hipEventRecord(a1, s1));
+        CK(hipEventRecord(b1, s2));
+        CK(hipEventSynchronize(a1));
+        CK(hipEventSynchronize(b1));
+        float fs, fr, span1, span2;
+        CK(hipEventElapsedTime(&fs, a0, a1));
+        CK(hipEventElapsedTime(&fr, b0, b1));
+        CK(hipEventElapsedTime(&span1, a0, b1));
+        CK(hipEventElapsedTime(&span2, a0, a1));
+        const float span = span1 > span2 ? span1 : span2;
+        if (span < t_both) t_both = span, t_both_s = fs, t_both_r = fr;
+    }
+    printf("overlap V%d %-60s scatter alone %6.2f ms | replay of %.2f G records alone %5.2f | together %6.2f (scatter %5.2f, replay %5.2f)  sum %6.2f\n", V, what,
+           t_s, nrec / 1e9, t_r, t_both, t_both_s, t_both_r, t_s + t_r);
+    CK(hipFree(recs));
+    CK(hipFree(regs));
+    return 0;
+}
+
 int main(int argc, char** argv) {
     const int tiles = argc > 1 ? atoi(argv[1]) : 78848, tpj = argc > 2 ? atoi(argv[2]) : 10;
     const int njobs = tiles / tpj;
@@ -369,6 +438,11 @@ int main(int argc, char** argv) {
     rc |= run_multik<4, 0, true>("four ks per job, hashed in pairs", codes, area, sink, njobs, tpj, updates);
     rc |= run_multik<4, 17, true>("four ks, in pairs, 4 x 16 KiB of rho = 1 bits (an eighth each)", codes, area, sink, njobs, tpj, updates);
     rc |= run_multik<8, 0, true>("eight ks per job, hashed in pairs", codes, area, sink, njobs, tpj, updates);
+    printf("-- a replay under a scatter (two streams) --\n");
+    rc |= overlap<4>("V4 at two workgroups per CU (no room for a replay tile)", codes, area, sink, njobs, tpj, out_dev, lds_bits, updates);
+    rc |= overlap<4>("V4 held to ONE workgroup per CU (96 KiB asked)", codes, area, sink, njobs, tpj, out_dev, 96 * 1024, updates);
+    rc |= overlap<7>("V7 (no bits, 256 B of LDS) at two workgroups per CU", codes, area, sink, njobs, tpj, out_dev, lds_plain, updates);
+    rc |= overlap<7>("V7 held to ONE workgroup per CU (96 KiB asked)", codes, area, sink, njobs, tpj, out_dev, 96 * 1024, updates);
     rc |= run<5>("V4 with s_memtime stamps (perturbed: a wait for everything in flight before each stamp)", codes, area, sink, njobs, tpj, out_dev, lds_bits, updates);
     return rc;
 }
