@@ -120,6 +120,30 @@ __global__ __launch_bounds__(1024) void replay_probe(const uint32_t* __restrict_
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// how fast can ANY kernel read 9.6 GB?  (the ceiling the replay's record loads are held against)
+// SHAPE 0: grid-stride, 16 bytes per lane per step, 4 steps in flight | 1: each workgroup its own contiguous MiB, 4 loads in flight
+// per lane | 2: as 1 with 256-thread workgroups
+template <int SHAPE>
+__global__ __launch_bounds__(1024) void read_probe(const uint4* __restrict__ src, size_t n16, uint32_t* __restrict__ sink) {
+    uint32_t acc = 0;
+    if (SHAPE == 0) {
+        const size_t stride = (size_t)gridDim.x * blockDim.x;
+        size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        for (; i + 3 * stride < n16; i += 4 * stride) {
+            const uint4 a = gload16(src + i), b = gload16(src + i + stride), c = gload16(src + i + 2 * stride), d = gload16(src + i + 3 * stride);
+            acc ^= a.x ^ a.w ^ b.x ^ b.w ^ c.x ^ c.w ^ d.x ^ d.w;
+        }
+    } else {
+        const size_t per = (1u << 20) / 16;   // one MiB per workgroup
+        const uint4* mine = src + (size_t)blockIdx.x * per;
+        for (uint32_t i = threadIdx.x; i + 3u * blockDim.x < per; i += 4u * blockDim.x) {
+            const uint4 a = gload16(mine + i), b = gload16(mine + i + blockDim.x), c = gload16(mine + i + 2u * blockDim.x), d = gload16(mine + i + 3u * blockDim.x);
+            acc ^= a.x ^ a.w ^ b.x ^ b.w ^ c.x ^ c.w ^ d.x ^ d.w;
+        }
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 }  // namespace
 }  // namespace dd
 
@@ -192,6 +216,27 @@ static int run(const char* what, uint32_t* recs, size_t nrec, uint8_t* regs, siz
     return 0;
 }
 
+template <int SHAPE>
+static int run_read(const char* what, const uint32_t* recs, size_t nrec, uint32_t* sink, unsigned threads, unsigned blocks_or_0) {
+    const size_t n16 = nrec / 4;
+    const unsigned blocks = blocks_or_0 ? blocks_or_0 : (unsigned)(n16 / ((1u << 20) / 16));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(dd::read_probe<SHAPE>, dim3(blocks), dim3(threads), 0, 0, reinterpret_cast<const uint4*>(recs), n16, sink);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep && ms < best) best = ms;
+    }
+    printf("read %-86s %7.2f ms  %5.2f TB/s\n", what, best, nrec * 4.0 / best / 1e9);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     const size_t nrec = (size_t)(argc > 1 ? atof(argv[1]) : 2400.0) * 1000000ull / 262144ull * 262144ull;
     uint32_t *recs, *sink;
@@ -208,6 +253,11 @@ int main(int argc, char** argv) {
     rc |= run<1>("bytes, 65 536 per tile: read, compare, CAS, retries (the SHIPPED inner loop)", recs, nrec, regs, regs_bytes, sink, &s[1]);
     rc |= run<2>("words, 16 384 per tile (64 KiB, two workgroups per CU): one ds_max_u32, no return", recs, nrec, regs, regs_bytes, sink, &s[2]);
     rc |= run<3>("words, 32 768 per tile (128 KiB, ONE workgroup per CU): one ds_max_u32, no return", recs, nrec, regs, regs_bytes, sink, &s[3]);
+    printf("-- the ceiling: plain reads of the same %.1f GB --\n", nrec * 4 / 1e9);
+    rc |= run_read<0>("grid-stride, 2048 workgroups of 1024, four 16-byte loads in flight per lane", recs, nrec, sink, 1024, 2048);
+    rc |= run_read<0>("grid-stride, 8192 workgroups of 256", recs, nrec, sink, 256, 8192);
+    rc |= run_read<1>("one contiguous MiB per workgroup of 1024, four loads in flight per lane", recs, nrec, sink, 1024, 0);
+    rc |= run_read<1>("one contiguous MiB per workgroup of 256", recs, nrec, sink, 256, 0);
     return rc;
 }
 #endif
