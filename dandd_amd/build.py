@@ -50,19 +50,27 @@ def needs_build():
 BINDIR = os.path.join(HERE, "bin")
 CLI = os.path.join(BINDIR, "dashing")
 CLI_SRC = os.path.join(CSRC, "dd_cli.c")
+# the same program under GNU parallel's name, in a directory of its own (on PATH only for who wants DandD's k-batches fused:
+# what is not `parallel [-j N] '<dashing ... {} ...>' ::: k ...` it hands to the next `parallel` on PATH)
+FUSED_PARALLEL = os.path.join(BINDIR, "fused", "parallel")
 
 
 def build_cli(force=False):
     """gcc, C99, linked against the library next to it (rpath $ORIGIN/../lib); needs build() to have run."""
     inc = os.path.join(HERE, "..", "include")
     deps = [CLI_SRC, os.path.join(inc, "dandd_hip.h"), LIB]
-    if not force and os.path.exists(CLI) and all(os.path.getmtime(d) <= os.path.getmtime(CLI) for d in deps):
+    if (not force and os.path.exists(CLI) and os.path.exists(FUSED_PARALLEL)
+            and all(os.path.getmtime(d) <= min(os.path.getmtime(CLI), os.path.getmtime(FUSED_PARALLEL)) for d in deps)):
         return CLI
-    os.makedirs(BINDIR, exist_ok=True)
+    os.makedirs(os.path.dirname(FUSED_PARALLEL), exist_ok=True)
     cmd = [os.environ.get("CC", "gcc"), "-std=c99", "-O2", "-Wall", "-Wextra", "-pedantic", "-I" + inc, CLI_SRC, "-o", CLI + ".tmp",
-           "-L" + LIBDIR, "-ldandd_hip", "-lz", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link," + LIBDIR]
+           "-L" + LIBDIR, "-ldandd_hip", "-lz", "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,$ORIGIN/../../lib", "-Wl,-rpath,/opt/rocm/lib",
+           "-Wl,-rpath-link," + LIBDIR]
     subprocess.check_call(cmd)
     os.replace(CLI + ".tmp", CLI)
+    import shutil
+    shutil.copy2(CLI, FUSED_PARALLEL + ".tmp")          # (a copy, not a link: the tree travels as files)
+    os.replace(FUSED_PARALLEL + ".tmp", FUSED_PARALLEL)
     return CLI
 
 

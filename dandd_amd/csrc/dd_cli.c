@@ -18,7 +18,16 @@
  * A process per command is a hipInit per command.  `dashing serve --socket <path> [--idle-exit <seconds>]` keeps one process
  * with its GPU contexts alive; with DANDD_DASHING_SERVER=<path> in the environment the three commands above are forwarded to it
  * (argv + working directory over a unix socket; exit status, stdout and stderr come back) and run by the same functions.
- * Without a reachable server they run here.  Exit status: 0, 1 on a failed command (message on stderr), 64 on a bad command line. */
+ * Without a reachable server they run here.  Exit status: 0, 1 on a failed command (message on stderr), 64 on a bad command line.
+ *
+ * The k-batch.  DandD does not call `dashing sketch` K times: it calls GNU parallel once per node,
+ *   parallel -j 95% ' dashing sketch -k{} -S <R> --prefix <dir/k{}> <fasta> ' ::: k1 k2 ...      lib/huffman_dandd.py:214-218,233
+ * (and the same around `dashing union`).  Installed under the name `parallel` (dandd_amd/bin/fused/parallel; or `dashing parallel
+ * ...`) this program takes that one call as what it is: ONE fused k-sweep over the FASTA (dd_sketch_fasta over every run of
+ * consecutive ks: the file read once, all ks in one launch per window class) that leaves the K files the K processes would have
+ * left; a `union` template is run k by k in this process.  Any other use -- options other than -j, a command that is not one
+ * `dashing sketch | union | card` with plain words -- goes to the next `parallel` on PATH unchanged, or, where there is none, is run
+ * value by value through /bin/sh (exit status = failed jobs, as GNU parallel counts them). */
 #define _POSIX_C_SOURCE 200809L
 #include <errno.h>
 #include <signal.h>
@@ -314,7 +323,171 @@ static int cmd_card(int argc, char **argv, sink *s) {
     return rc;
 }
 
+/* ---- `parallel -j N '<dashing ... {} ...>' ::: k ...`: the k-batch of lib/huffman_dandd.py:214-233, fused ------------------------ */
+typedef struct {
+    char **tok;   /* the command template's words ({} still in them) */
+    int ntok;
+    char **val;   /* what follows ::: */
+    int nval;
+    char *buf;    /* the words' storage */
+} kbatch;
+static void kbatch_free(kbatch *b) {
+    free(b->tok);
+    free(b->buf);
+    memset(b, 0, sizeof *b);
+}
+/* argv after the program name.  -> 1: a k-batch of `dashing sketch|union|card` this program can run itself (b filled); 0: anything else */
+static int kbatch_parse(int argc, char **argv, kbatch *b) {
+    int i = 0, n = 0;
+    const char *tmpl, *c;
+    char *w;
+    memset(b, 0, sizeof *b);
+    while (i < argc && argv[i][0] == '-' && argv[i][1]) { /* -j N | -jN | --jobs N: how many at once is the GPU's business */
+        if ((!strcmp(argv[i], "-j") || !strcmp(argv[i], "--jobs")) && i + 1 < argc) i += 2;
+        else if (!strncmp(argv[i], "-j", 2) && argv[i][2]) i += 1;
+        else return 0;
+    }
+    if (i + 2 >= argc || strcmp(argv[i + 1], ":::") != 0) return 0;
+    tmpl = argv[i];
+    for (c = tmpl; *c; ++c) /* a word is a word only where the shell would leave it alone */
+        if (strchr("|&;<>()$`\\\"'*?[]#~", *c)) return 0;
+    b->val = argv + i + 2, b->nval = argc - i - 2;
+    for (i = 0; i < b->nval; ++i) { /* ks: positive integers */
+        const char *v = b->val[i];
+        if (!*v || strlen(v) > 3) return 0;
+        for (c = v; *c; ++c)
+            if (*c < '0' || *c > '9') return 0;
+        if (atoi(v) < 1) return 0;
+    }
+    b->buf = (char *)malloc(strlen(tmpl) + 1);
+    b->tok = (char **)calloc(strlen(tmpl) / 2 + 2, sizeof *b->tok);
+    if (!b->buf || !b->tok) {
+        kbatch_free(b);
+        return 0;
+    }
+    strcpy(b->buf, tmpl);
+    for (w = strtok(b->buf, " \t\n"); w; w = strtok(NULL, " \t\n")) b->tok[n++] = w;
+    b->ntok = n;
+    if (n >= 2) {
+        const char *base = strrchr(b->tok[0], '/');
+        base = base ? base + 1 : b->tok[0];
+        if (!strcmp(base, "dashing") && (!strcmp(b->tok[1], "sketch") || !strcmp(b->tok[1], "union") || !strcmp(b->tok[1], "card"))) return 1;
+    }
+    kbatch_free(b);
+    return 0;
+}
+/* word with every {} replaced by v, malloc'd */
+static char *subst(const char *word, const char *v) {
+    size_t n = 1, lv = strlen(v);
+    const char *c;
+    char *out, *o;
+    for (c = word; *c; ++c) n += (c[0] == '{' && c[1] == '}') ? lv : 1;
+    out = o = (char *)malloc(n + 1);
+    if (!out) return NULL;
+    for (c = word; *c;) {
+        if (c[0] == '{' && c[1] == '}') memcpy(o, v, lv), o += lv, c += 2;
+        else *o++ = *c++;
+    }
+    *o = 0;
+    return out;
+}
+static int by_int(const void *a, const void *b) { return *(const int *)a - *(const int *)b; }
+
+static int run_command(int argc, char **argv, sink *s);
+static int cmd_parallel(int argc, char **argv, sink *s) {
+    kbatch b;
+    int rc = 0, i, j;
+    if (!kbatch_parse(argc, argv, &b)) {
+        text_add(&s->err, "dashing parallel: only  [-j N] '<dashing sketch|union|card ... {} ...>' ::: k ...  is run here\n");
+        return 64;
+    }
+    if (!strcmp(b.tok[1], "sketch")) {
+        /* the fused form: k only in -k{} and in the prefix; one FASTA (what DandD passes) or several */
+        int p = 0, canon = 1, npaths = 0, fusable = 1, *ks = (int *)malloc((size_t)b.nval * sizeof *ks);
+        const char *prefix = ".";
+        char **paths = (char **)calloc((size_t)b.ntok + 1, sizeof *paths);
+        if (!ks || !paths) rc = 1;
+        for (i = 2; i < b.ntok && !rc; ++i) {
+            const char *t = b.tok[i];
+            if (!strcmp(t, "-k{}")) continue;
+            if (!strcmp(t, "-k") && i + 1 < b.ntok && !strcmp(b.tok[i + 1], "{}")) ++i;
+            else if (!strncmp(t, "-S", 2) && t[2]) p = atoi(t + 2);
+            else if (!strcmp(t, "-S") && i + 1 < b.ntok) p = atoi(b.tok[++i]);
+            else if ((!strcmp(t, "--prefix") || !strcmp(t, "-P")) && i + 1 < b.ntok) prefix = b.tok[++i];
+            else if (!strcmp(t, "--no-canon") || !strcmp(t, "-C")) canon = 0;
+            else if (!strcmp(t, "-z") || threads_glued(t)) continue;
+            else if ((!strcmp(t, "-p") || !strcmp(t, "--nthreads")) && i + 1 < b.ntok) ++i;
+            else if (t[0] == '-' || strstr(t, "{}")) fusable = 0; /* (k somewhere this form does not know: each k through cmd_sketch below) */
+            else paths[npaths++] = b.tok[i];
+        }
+        if (!rc && fusable && npaths && p >= 4 && p <= 20) {
+            dd_ctx *ctx = context(p, canon, s);
+            const size_t m = (size_t)1 << p;
+            for (i = 0; i < b.nval; ++i) ks[i] = atoi(b.val[i]);
+            qsort(ks, (size_t)b.nval, sizeof *ks, by_int);
+            if (!ctx) rc = 1;
+            for (i = 0; i < b.nval && !rc;) { /* every run of consecutive ks: one sweep */
+                int hi = i, K, q;
+                unsigned char *regs;
+                while (hi + 1 < b.nval && ks[hi + 1] <= ks[hi] + 1) ++hi;
+                K = ks[hi] - ks[i] + 1;
+                if (ks[i] < 1 || ks[hi] > 64) {
+                    text_add(&s->err, "dashing parallel: k %d..%d is outside 1..64\n", ks[i], ks[hi]);
+                    rc = 1;
+                    break;
+                }
+                regs = (unsigned char *)malloc((size_t)npaths * (size_t)K * m);
+                if (!regs) rc = 1;
+                else if ((npaths == 1 ? dd_sketch_fasta(ctx, paths[0], ks[i], ks[hi], regs)
+                                      : dd_sketch_files(ctx, (const char *const *)paths, npaths, ks[i], ks[hi], regs, 0)) != DD_OK) {
+                    text_add(&s->err, "dashing parallel: %s\n", dd_last_error());
+                    rc = 1;
+                }
+                for (q = 0; q < npaths && !rc; ++q)
+                    for (j = 0; j < K && !rc; ++j) {
+                        char kstr[8], out[4096], *dir;
+                        const char *base = strrchr(paths[q], '/');
+                        base = base ? base + 1 : paths[q];
+                        snprintf(kstr, sizeof kstr, "%d", ks[i] + j);
+                        dir = subst(prefix, kstr);
+                        if (!dir || snprintf(out, sizeof out, "%s/%s.w.%d.spacing.%d.hll", dir, base, ks[i] + j, p) >= (int)sizeof out) {
+                            text_add(&s->err, "dashing parallel: %s: name too long\n", paths[q]);
+                            rc = 1;
+                        } else rc = sketch_write(out, regs + ((size_t)q * (size_t)K + (size_t)j) * m, p, ks[i] + j, canon, s);
+                        free(dir);
+                    }
+                free(regs);
+                i = hi + 1;
+            }
+            free(ks);
+            free(paths);
+            kbatch_free(&b);
+            return rc;
+        }
+        free(ks);
+        free(paths);
+        if (rc) {
+            kbatch_free(&b);
+            return rc;
+        }
+    }
+    /* union, card, and sketch templates the fused form does not cover: value by value, in this process */
+    for (i = 0; i < b.nval; ++i) {
+        char **av = (char **)calloc((size_t)b.ntok + 1, sizeof *av);
+        int one = av ? 0 : 1;
+        for (j = 1; j < b.ntok && !one; ++j)
+            if (!(av[j - 1] = subst(b.tok[j], b.val[i]))) one = 1;
+        if (!one) one = run_command(b.ntok - 1, av, s);
+        for (j = 0; av && j < b.ntok; ++j) free(av[j]);
+        free(av);
+        if (one) ++rc; /* (GNU parallel's exit status: the number of jobs that failed) */
+    }
+    kbatch_free(&b);
+    return rc > 101 ? 101 : rc;
+}
+
 static int run_command(int argc, char **argv, sink *s) {
+    if (argc >= 1 && !strcmp(argv[0], "parallel")) return cmd_parallel(argc - 1, argv + 1, s);
     if (argc >= 1 && !strcmp(argv[0], "sketch")) return cmd_sketch(argc - 1, argv + 1, s);
     if (argc >= 1 && !strcmp(argv[0], "union")) return cmd_union(argc - 1, argv + 1, s);
     if (argc >= 1 && !strcmp(argv[0], "card")) return cmd_card(argc - 1, argv + 1, s);
@@ -467,21 +640,104 @@ static int forward(const char *path, int argc, char **argv) {
     return ok ? (int)rc : -1;
 }
 
+/* ---- under the name `parallel`: what is not the k-batch goes to the real one ---------------------------------------------- */
+static int named_parallel(const char *argv0) {
+    const char *base = strrchr(argv0, '/');
+    return !strcmp(base ? base + 1 : argv0, "parallel");
+}
+/* the next `parallel` on PATH that is not this program (malloc'd), or NULL */
+static char *next_parallel(void) {
+    const char *path = getenv("PATH"), *c;
+    char self[4096], cand[4096], real[4096];
+    ssize_t n = readlink("/proc/self/exe", self, sizeof self - 1);
+    if (!path) return NULL;
+    self[n > 0 ? n : 0] = 0;
+    for (c = path; *c;) {
+        const char *e = strchr(c, ':');
+        const size_t len = e ? (size_t)(e - c) : strlen(c);
+        if (len && len + 10 < sizeof cand) {
+            memcpy(cand, c, len);
+            strcpy(cand + len, "/parallel");
+            if (access(cand, X_OK) == 0 && realpath(cand, real) && strcmp(real, self) != 0) {
+                char *out = (char *)malloc(strlen(cand) + 1);
+                if (out) strcpy(out, cand);
+                return out;
+            }
+        }
+        if (!e) break;
+        c = e + 1;
+    }
+    return NULL;
+}
+/* (nothing in this process has touched the GPU yet: replacing it is safe) */
+static int other_parallel(int argc, char **argv) {
+    char *real = next_parallel();
+    int i = 0, failed = 0;
+    if (real) {
+        char **av = (char **)calloc((size_t)argc + 2, sizeof *av);
+        if (!av) return 255;
+        av[0] = real;
+        memcpy(av + 1, argv, (size_t)argc * sizeof *av);
+        execv(real, av);
+        perror(real);
+        return 127;
+    }
+    /* no GNU parallel here: its simplest form, one job at a time */
+    while (i < argc && argv[i][0] == '-' && argv[i][1]) {
+        if ((!strcmp(argv[i], "-j") || !strcmp(argv[i], "--jobs")) && i + 1 < argc) i += 2;
+        else if (!strncmp(argv[i], "-j", 2) && argv[i][2]) i += 1;
+        else break;
+    }
+    if (i + 2 >= argc || strcmp(argv[i + 1], ":::") != 0) {
+        fprintf(stderr, "parallel (dandd_amd): only  [-j N] '<command with {}>' ::: value ...  is understood here, and no other `parallel` is on PATH\n");
+        return 255;
+    }
+    {
+        const char *tmpl = argv[i];
+        for (i += 2; i < argc; ++i) {
+            char *cmd = subst(tmpl, argv[i]);
+            const int st = cmd ? system(cmd) : -1;
+            free(cmd);
+            if (st != 0) ++failed;
+        }
+    }
+    return failed > 101 ? 101 : failed;
+}
+
 int main(int argc, char **argv) {
     const char *server = getenv("DANDD_DASHING_SERVER");
     sink s;
-    int rc;
-    if (argc >= 2 && !strcmp(argv[1], "serve")) return serve(argc - 2, argv + 2);
-    if (server && *server && argc >= 2) {
-        rc = forward(server, argc - 1, argv + 1);
-        if (rc >= 0) return rc;
+    int rc, nc = argc - 1;
+    char **cv = argv + 1, **owned = NULL;
+    if (argc >= 2 && !strcmp(argv[1], "serve") && !named_parallel(argv[0])) return serve(argc - 2, argv + 2);
+    if (named_parallel(argv[0]) || (argc >= 2 && !strcmp(argv[1], "parallel"))) {
+        const int skip = named_parallel(argv[0]) ? 1 : 2;
+        kbatch b;
+        if (!kbatch_parse(argc - skip, argv + skip, &b)) return other_parallel(argc - skip, argv + skip);
+        kbatch_free(&b);
+        if (skip == 1) { /* the command as the server and run_command know it: "parallel" first */
+            owned = (char **)calloc((size_t)argc + 1, sizeof *owned);
+            if (!owned) return 1;
+            owned[0] = (char *)"parallel";
+            memcpy(owned + 1, argv + 1, (size_t)(argc - 1) * sizeof *owned);
+            cv = owned, nc = argc;
+        }
+    }
+    if (server && *server && nc >= 1) {
+        rc = forward(server, nc, cv);
+        if (rc >= 0) {
+            free(owned);
+            return rc;
+        }
         if (getenv("DANDD_SERVER_REQUIRED") && !strcmp(getenv("DANDD_SERVER_REQUIRED"), "1")) {
             fprintf(stderr, "dashing: no server at %s\n", server);
+            free(owned);
             return 111;
         }
     }
     memset(&s, 0, sizeof s);
-    rc = run_command(argc - 1, argv + 1, &s);
+    rc = run_command(nc, cv, &s);
+    free(owned);
     if (s.out.p) fputs(s.out.p, stdout);
     if (s.err.p) fputs(s.err.p, stderr);
     fflush(stdout);

@@ -97,11 +97,14 @@ else:
 '''
 
 PARALLEL_SHIM = r'''#!/usr/bin/env python3
-import subprocess, sys
+import json, os, subprocess, sys
 a = sys.argv[1:]
 assert a[0] == "-j", a
 cmd = a[2]
 sep = a.index(":::")
+if os.environ.get("DD_SHIM_LOG"):     # the k-batch call itself (lib/huffman_dandd.py:217), as the reference's shell handed it over
+    with open(os.environ["DD_SHIM_LOG"], "a") as f:
+        f.write(json.dumps({"parallel_argv": ["parallel"] + a}) + "\n")
 for x in a[sep + 1:]:
     subprocess.call(cmd.replace("{}", x), shell=True)
 '''
@@ -256,7 +259,14 @@ def scenario(backend, fdir, registers):
         out["tree_flist_label_fast"] = read_csv(os.path.join(o11, "gold_lab_4_dashing_deltas.csv"))
         out["tree_flist_label_fast_files"] = sorted(os.listdir(o11))
         with open(os.path.join(work, "trace.log")) as f:
-            trace = [json.loads(line) for line in f]
+            raw = [json.loads(line) for line in f]
+        # `parallel` calls are noted where they stand: each covers the next len(values) commands of the trace
+        trace, batches = [], []
+        for e in raw:
+            if "parallel_argv" in e:
+                batches.append({"argv": e["parallel_argv"], "first": len(trace), "n": len(e["parallel_argv"]) - 1 - e["parallel_argv"].index(":::")})
+            else:
+                trace.append(e)
         out["_n_external_commands"] = len(trace)
         if backend == "hll":
             # The command trace itself: every `dashing ...` line the unmodified reference issued (after the `parallel` shim put
@@ -278,7 +288,7 @@ def scenario(backend, fdir, registers):
                             caches[rel(os.path.join(dirpath, fn))] = {rel(k): repr(v) for k, v in sorted(pickle.load(f).items())}
             with open(os.path.join(HERE, "ref_trace_hll.json"), "w") as f:
                 json.dump({"registers": registers, "fastas": sorted(os.listdir(data)), "data": "@W@/data",
-                           "commands": rel(trace), "cardinality_caches": caches}, f, indent=0, sort_keys=True)
+                           "commands": rel(trace), "parallel_calls": rel(batches), "cardinality_caches": caches}, f, indent=0, sort_keys=True)
         return out
     finally:
         shutil.rmtree(work, ignore_errors=True)

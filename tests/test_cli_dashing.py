@@ -29,6 +29,13 @@ def dashing():
     return build.build_cli()
 
 
+@pytest.fixture(scope="module")
+def parallel(dashing):
+    from dandd_amd import build
+    assert os.path.exists(build.FUSED_PARALLEL)
+    return build.FUSED_PARALLEL
+
+
 def _trace():
     with open(os.path.join(GOLD, "ref_trace_hll.json")) as f:
         return json.load(f)
@@ -62,6 +69,15 @@ def test_trace_fixture_is_the_reference_grammar():
     for table in t["cardinality_caches"].values():
         cached.update(table)
     assert cached and all(printed.get(p) == v for p, v in cached.items())
+    # the k-batches: every `sketch` and `union` reached Dashing through ONE `parallel -j 95% '<template>' ::: k ...` per node
+    # (lib/huffman_dandd.py:214-218); the fixture keeps those calls as the reference's shell handed them over
+    covered = set()
+    for b in t["parallel_calls"]:
+        assert b["argv"][:3] == ["parallel", "-j", "95%"] and b["argv"][4] == ":::" and b["n"] == len(b["argv"]) - 5
+        for j, v in enumerate(b["argv"][5:]):
+            assert t["commands"][b["first"] + j]["argv"] == b["argv"][3].replace("{}", v).split()
+            covered.add(b["first"] + j)
+    assert covered == {i for i, c in enumerate(t["commands"]) if c["argv"][1] in ("sketch", "union")}
 
 
 def test_cli_without_gpu_fails_loudly(dashing, tmp_path):
@@ -83,6 +99,38 @@ def test_cli_without_gpu_fails_loudly(dashing, tmp_path):
     r = subprocess.run([dashing, "card", "--presketched", os.path.join(GOLD, "fasta", "g0.fasta")], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "neither a dandd_amd nor a Dashing sketch file" in r.stderr
     assert r.stdout == "#Path\tSize (est.)\n"
+
+
+def test_parallel_name_takes_only_the_k_batch(parallel, dashing, tmp_path):
+    """dandd_amd/bin/fused/parallel: DandD's k-batch is run here (without a GPU: fails loudly, writes nothing); anything else goes
+    to the next `parallel` on PATH with its argv untouched, or -- none there -- value by value through /bin/sh with GNU parallel's
+    exit status (the number of failed jobs)."""
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    env.pop("DANDD_DASHING_SERVER", None)
+    fasta = os.path.join(GOLD, "fasta", "g0.fasta")
+    batch = ["-j", "95%", f" dashing sketch  -k{{}} -S 12 --prefix {tmp_path}/k{{}} {fasta} ", ":::", "9", "10", "11"]
+    for exe in ([parallel], [dashing, "parallel"]):
+        r = subprocess.run(exe + batch, env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 1 and "no CPU path" in r.stderr and not os.listdir(tmp_path), (exe, r.returncode, r.stderr)
+    # no other `parallel` on PATH: the simplest GNU-parallel form, one job at a time
+    bare = dict(env, PATH=os.path.dirname(parallel) + ":/usr/bin:/bin")
+    if not any(os.path.exists(os.path.join(d, "parallel")) for d in ("/usr/bin", "/bin")):
+        r = subprocess.run([parallel, "-j", "2", "echo a{}b; test {} != 2", ":::", "1", "2", "3"], env=bare, capture_output=True, text=True, timeout=120)
+        assert r.stdout == "a1b\na2b\na3b\n" and r.returncode == 1, (r.returncode, r.stdout, r.stderr)
+        r = subprocess.run([parallel, "--bar", "echo {}", ":::", "1"], env=bare, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 255 and "no other `parallel`" in r.stderr
+    # another `parallel` further down PATH: it gets everything that is not the k-batch, argv as given
+    other = tmp_path / "gnu"
+    other.mkdir()
+    (other / "parallel").write_text("#!/bin/sh\necho REAL \"$@\"\nexit 7\n")
+    os.chmod(other / "parallel", 0o755)
+    withreal = dict(env, PATH=os.path.dirname(parallel) + ":" + str(other) + ":/usr/bin:/bin")
+    for args in (["-j", "4", "gzip {}", ":::", "a.txt", "b.txt"], ["--bar", "-j", "95%", " dashing sketch -k{} -S 12 x.fa ", ":::", "9"],
+                 ["-j", "95%", " dashing sketch -k{} -S 12 x.fa | tee log ", ":::", "9"], ["-j", "95%", " dashing card --presketched {} ", ":::", "a.hll"]):
+        r = subprocess.run([parallel] + args, env=withreal, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 7 and r.stdout == "REAL " + " ".join(args) + "\n", (args, r.returncode, r.stdout, r.stderr)
+    r = subprocess.run([parallel] + batch, env=withreal, capture_output=True, text=True, timeout=120)      # (the k-batch stays here)
+    assert r.returncode == 1 and "no CPU path" in r.stderr and "REAL" not in r.stdout
 
 
 def test_resident_form_answers_and_survives_bad_clients(dashing, tmp_path):
@@ -127,25 +175,21 @@ def test_resident_form_answers_and_survives_bad_clients(dashing, tmp_path):
             srv.kill()
 
 
-def _replay(dashing, work, commands, env, orc, check_oracle):
-    """run every traced line in `work`; -> number of commands run"""
+def _replay(dashing, work, commands, env, orc, check_oracle, batches=(), parallel=None):
+    """run every traced line in `work`; -> number of processes started.  With `batches` (the fixture's parallel_calls) the lines
+    that went through GNU parallel are run as the ONE `parallel` call the reference made, by `parallel` (the product's
+    dandd_amd/bin/fused/parallel), and checked output by output as if each had run alone."""
     regs_of = {}                                                   # output path -> registers, for checking unions against their inputs
-    for c in commands:
-        argv = [x.replace("@W@", work) for x in c["argv"]]
+    starts = {b["first"]: b for b in batches}
+    started = 0
+
+    def prepare(argv):
         if argv[1] == "sketch":
             os.makedirs(argv[argv.index("--prefix") + 1], exist_ok=True)     # (the reference makes the per-k directories itself: lib/huffman_dandd.py:171-174)
         elif argv[1] == "union":
             os.makedirs(os.path.dirname(argv[argv.index("-o") + 1]), exist_ok=True)
-        r = subprocess.run([dashing] + argv[1:], env=env, capture_output=True, text=True, timeout=300, cwd=work)
-        assert r.returncode == 0, (argv, r.returncode, r.stdout, r.stderr)
-        if argv[1] == "card":
-            lines = r.stdout.splitlines()
-            assert lines[0] == "#Path\tSize (est.)" and len(lines) == 1 + len(c["cards"])
-            for line, (path, want) in zip(lines[1:], c["cards"].items()):
-                got_path, got = line.split("\t")
-                assert got_path == path.replace("@W@", work)
-                assert float(got) == float(want), (argv, got, want)      # the double the reference put in its cardkey (lib/sketch_classes.py:318-321)
-            continue
+
+    def check_output(c, argv):
         out = c["out"].replace("@W@", work)
         raw = np.fromfile(out, dtype=np.uint8)
         assert raw[:8].tobytes() == b"DDHLL\x01\x00\x00"
@@ -162,7 +206,39 @@ def _replay(dashing, work, commands, env, orc, check_oracle):
                 ins = argv[argv.index("-o") + 2:]
                 want = np.maximum.reduce([regs_of[i] if i in regs_of else np.fromfile(i, dtype=np.uint8)[NATIVE_HEAD:] for i in ins])
             assert np.array_equal(regs, want), argv
-    return len(commands)
+
+    i = 0
+    while i < len(commands):
+        if i in starts:
+            b = starts[i]
+            covered = commands[i:i + b["n"]]
+            argvs = [[x.replace("@W@", work) for x in c["argv"]] for c in covered]
+            for argv in argvs:
+                prepare(argv)
+            r = subprocess.run([parallel] + [x.replace("@W@", work) for x in b["argv"][1:]], env=env, capture_output=True, text=True, timeout=300, cwd=work)
+            assert r.returncode == 0, (b["argv"], r.returncode, r.stdout, r.stderr)
+            started += 1
+            for c, argv in zip(covered, argvs):
+                check_output(c, argv)
+            i += b["n"]
+            continue
+        c = commands[i]
+        i += 1
+        argv = [x.replace("@W@", work) for x in c["argv"]]
+        prepare(argv)
+        r = subprocess.run([dashing] + argv[1:], env=env, capture_output=True, text=True, timeout=300, cwd=work)
+        started += 1
+        assert r.returncode == 0, (argv, r.returncode, r.stdout, r.stderr)
+        if argv[1] == "card":
+            lines = r.stdout.splitlines()
+            assert lines[0] == "#Path\tSize (est.)" and len(lines) == 1 + len(c["cards"])
+            for line, (path, want) in zip(lines[1:], c["cards"].items()):
+                got_path, got = line.split("\t")
+                assert got_path == path.replace("@W@", work)
+                assert float(got) == float(want), (argv, got, want)      # the double the reference put in its cardkey (lib/sketch_classes.py:318-321)
+            continue
+        check_output(c, argv)
+    return started
 
 
 @pytest.mark.gpu
@@ -286,3 +362,49 @@ def test_cli_at_baseline_genome_size_and_default_registers(dashing, tmp_path, or
     for est in got[1:]:                                             # (the three genomes are 1 % apart: their union is not 3 x nb)
         assert abs(est / nb - 1.0) < 3 * sigma + 3e-3, est          # (3e-3: the 0.1 % of 100-base blocks that are N take ~120 windows each)
     assert max(got[1:]) < got[0] < sum(got[1:])
+
+
+@pytest.mark.gpu
+def test_reference_k_batches_run_fused(dashing, parallel, tmp_path, orc, torch_cuda):
+    """The reference's k-batch call site itself (lib/huffman_dandd.py:214-218,233): each of the 163 `parallel -j 95% '<dashing ...
+    {} ...>' ::: k ...` calls the unmodified reference made goes, argv as its shell handed it over, to the product's `parallel`
+    (one process, ONE fused sweep over the node's FASTA for all its ks / its unions k by k), the 371 `card` lines to `dashing`.
+    Every file a batch leaves is checked as if its K processes had run: digest == the fixture's, registers == the oracle's.
+    Through the resident form, then the first batches as fresh processes."""
+    t = _trace()
+    work = str(tmp_path / "w")
+    shutil.copytree(os.path.join(GOLD, "fasta"), os.path.join(work, "data"))
+    sock = str(tmp_path / "d.sock")
+    env = dict(os.environ)
+    env.pop("DANDD_DASHING_SERVER", None)
+    env.pop("DANDD_SKETCH_FORMAT", None)
+    srv = _start_server(dashing, sock, env)
+    try:
+        cenv = dict(env, DANDD_DASHING_SERVER=sock, DANDD_SERVER_REQUIRED="1")
+        t0 = time.perf_counter()
+        n = _replay(dashing, work, t["commands"], cenv, orc, check_oracle=True, batches=t["parallel_calls"], parallel=parallel)
+        dt = time.perf_counter() - t0
+        assert n == len(t["parallel_calls"]) + sum(c["argv"][1] == "card" for c in t["commands"])
+        print(f"replayed {len(t['commands'])} traced commands as {n} processes ({len(t['parallel_calls'])} fused k-batches) in {dt:.1f} s")
+        r = subprocess.run([dashing, "shutdown"], env=cenv, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and int(r.stdout) == n
+        assert srv.wait(timeout=60) == 0
+    finally:
+        if srv.poll() is None:
+            srv.kill()
+    work2 = str(tmp_path / "w2")
+    shutil.copytree(os.path.join(GOLD, "fasta"), os.path.join(work2, "data"))
+    upto = t["parallel_calls"][5]["first"]
+    _replay(dashing, work2, t["commands"][:upto], env, orc, check_oracle=True, batches=t["parallel_calls"][:5], parallel=parallel)
+    # a batch whose ks are not consecutive and come unsorted, non-canonical: two sweeps, five files
+    many = os.path.join(work2, "many")
+    fasta = os.path.join(work2, "data", "g3.fasta")
+    for k in (7, 8, 9, 21, 22):
+        os.makedirs(os.path.join(many, f"k{k}"))
+    r = subprocess.run([parallel, "-j", "95%", f" dashing sketch --no-canon -k{{}} -S 11 --prefix {many}/k{{}} {fasta} ", ":::", "22", "7", "9", "8", "21"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for k in (7, 8, 9, 21, 22):
+        raw = np.fromfile(os.path.join(many, f"k{k}", f"g3.fasta.w.{k}.spacing.11.hll"), dtype=np.uint8)
+        assert raw[8] == 11 and raw[9] == k and raw[10] == 0
+        assert np.array_equal(raw[NATIVE_HEAD:], orc.sketch(np.fromfile(fasta, dtype=np.uint8), k, 11, False))
