@@ -19,6 +19,7 @@ FUZZ = [
     ("fuzz_damage.py", 300, 508, "damaged .gz files: the call raises exactly when zlib's gzread fails, else the registers of gzread's text"),
     ("fuzz_fastq.py", 250, 510, "FASTQ-like texts in .gz / BGZF / two members, clean and broken: whichever of the device's rules or the host's kseq state machine takes a text, registers == the oracle's kseq reading"),
     ("fuzz_k2.py", 50, 509, "Gram all-pairs == streaming kernel, bit-plane progressive scan == streaming kernel"),
+    ("fuzz_cli.py", 40, 511, "the command-line boundary through one `dashing serve`: k-batches via dandd_amd/bin/fused/parallel == one `dashing sketch` per k == oracle, unions, multi-path card, three sketch containers"),
 ]
 
 
