@@ -408,3 +408,37 @@ def test_reference_k_batches_run_fused(dashing, parallel, tmp_path, orc, torch_c
         raw = np.fromfile(os.path.join(many, f"k{k}", f"g3.fasta.w.{k}.spacing.11.hll"), dtype=np.uint8)
         assert raw[8] == 11 and raw[9] == k and raw[10] == 0
         assert np.array_equal(raw[NATIVE_HEAD:], orc.sketch(np.fromfile(fasta, dtype=np.uint8), k, 11, False))
+
+
+@pytest.mark.gpu
+def test_forty_clients_at_once_like_gnu_parallel(dashing, tmp_path, orc, torch_cuda):
+    """What GNU parallel does to a resident `dashing serve` when DandD's k-batch is NOT taken by dandd_amd/bin/fused/parallel: K client
+    processes started together, one listening socket.  All forty are answered, every file is the oracle's."""
+    from concurrent.futures import ThreadPoolExecutor
+    sock = str(tmp_path / "d.sock")
+    env = dict(os.environ)
+    env.pop("DANDD_DASHING_SERVER", None)
+    env.pop("DANDD_SKETCH_FORMAT", None)
+    fasta = os.path.join(GOLD, "fasta", "g1.fasta")
+    srv = _start_server(dashing, sock, env)
+    try:
+        cenv = dict(env, DANDD_DASHING_SERVER=sock, DANDD_SERVER_REQUIRED="1")
+        for k in range(1, 41):
+            os.makedirs(tmp_path / f"k{k}")
+
+        def one(k):
+            return subprocess.run([dashing, "sketch", f"-k{k}", "-S", "12", "--prefix", str(tmp_path / f"k{k}"), fasta], env=cenv, capture_output=True, text=True, timeout=300)
+        with ThreadPoolExecutor(max_workers=40) as pool:
+            results = list(pool.map(one, range(1, 41)))
+        assert all(r.returncode == 0 for r in results), [(r.returncode, r.stderr) for r in results if r.returncode]
+        buf = np.fromfile(fasta, dtype=np.uint8)
+        want = orc.sketch_sweep(buf, 1, 40, 12, True)
+        for k in range(1, 41):
+            raw = np.fromfile(tmp_path / f"k{k}" / f"g1.fasta.w.{k}.spacing.12.hll", dtype=np.uint8)
+            assert np.array_equal(raw[NATIVE_HEAD:], want[k - 1]), k
+        r = subprocess.run([dashing, "shutdown"], env=cenv, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and int(r.stdout) == 40
+        assert srv.wait(timeout=60) == 0
+    finally:
+        if srv.poll() is None:
+            srv.kill()
