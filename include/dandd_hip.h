@@ -59,7 +59,8 @@ int dd_synchronize(dd_ctx *);
 int dd_sketch_buffer(dd_ctx *, const uint8_t *fasta, size_t nbytes, int kmin, int kmax,
                      uint8_t *regs);
 /* path may be plain or gzip-compressed (DandD's inputs are .fa/.fasta/.fna[.gz],
- * lib/species_specifics.py:93); inflated on the host with zlib. */
+ * lib/species_specifics.py:93).  Files under 4 MiB: one read, .gz inflated on the host with zlib;
+ * larger ones take dd_sketch_files' pipeline (below) as a directory of one. */
 int dd_sketch_fasta(dd_ctx *, const char *path, int kmin, int kmax, uint8_t *regs);
 /* Ingestion pipeline for a whole directory of genomes: `nthreads` loader threads (0 = auto) read
  * and inflate into pinned host buffers ahead of the GPU (bounded pool); a copy stream moves batch b+1

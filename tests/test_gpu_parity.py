@@ -798,11 +798,15 @@ def test_gunzip_isize_smaller_than_the_text_cannot_write_past_the_arena(orc, tor
 
 
 def test_large_gzip_files_are_inflated_in_parallel(engine_factory, orc, tmp_path, monkeypatch):
-    """One big .gz through dd_sketch_fasta / dd_sketch_files: a single gzip member cut at deflate block boundaries and
-    decoded piecewise without its history (dd_inflate.h), a BGZF file block by block, a realistic (repeat-rich: long,
-    far matches) genome too -- registers == the sketch of the uncompressed bytes, and == the serial decoder's."""
+    """One big .gz through dd_sketch_fasta / dd_sketch_files with the HOST decoders (the device ones switched off: they have
+    their own tests below): a single gzip member cut at deflate block boundaries and decoded piecewise without its history
+    (dd_inflate.h), a BGZF file block by block, a realistic (repeat-rich: long, far matches) genome too -- registers == the
+    sketch of the uncompressed bytes, and == the serial decoder's.  (dd_sketch_fasta hands files of 4 MiB and more to
+    dd_sketch_files' pipeline since round 6; the last lines call it with the device decoders on as well.)"""
     import zlib
-    eng = engine_factory(14, True)
+    monkeypatch.setenv("DD_NO_GPU_INFLATE", "1")
+    monkeypatch.setenv("DD_NO_GPU_GUNZIP", "1")
+    eng = engine_factory(14, True)                            # (the decoder knobs are read by every call)
     cases = {"uniform": orc.synth_fasta(SEED, 0, 40_000_000, 7), "realistic": orc.synth_realistic(SEED, 1, 30_000_000)}
     for name, fa in cases.items():
         raw = fa.tobytes()
@@ -820,6 +824,17 @@ def test_large_gzip_files_are_inflated_in_parallel(engine_factory, orc, tmp_path
         assert np.array_equal(eng.sketch_files([str(b), str(tmp_path / f"{name}.1.fa.gz")], 19, 21)[1], want), name
     monkeypatch.setenv("DD_NO_PARALLEL_GZIP", "1")
     assert np.array_equal(eng.sketch_fasta(str(tmp_path / "uniform.1.fa.gz"), 19, 21), eng.sketch_buffer(cases["uniform"], 19, 21))
+    monkeypatch.delenv("DD_NO_GPU_INFLATE")
+    monkeypatch.delenv("DD_NO_GPU_GUNZIP")
+    monkeypatch.delenv("DD_NO_PARALLEL_GZIP")
+    dev = engine_factory(14, True)                             # device decoders on: the same files through dd_sketch_fasta's new route
+    for name, fa in cases.items():
+        want = dev.sketch_buffer(fa, 19, 21)
+        for f in (f"{name}.1.fa.gz", f"{name}.6.fa.gz", f"{name}.bgzf.fa.gz"):
+            assert np.array_equal(dev.sketch_fasta(str(tmp_path / f), 19, 21), want), f
+        plain = tmp_path / f"{name}.fa"
+        plain.write_bytes(fa.tobytes())
+        assert np.array_equal(dev.sketch_fasta(str(plain), 19, 21), want), name
 
 
 def test_full_size_properties_cfg2(engine_factory, torch_cuda, orc):
