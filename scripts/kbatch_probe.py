@@ -64,6 +64,25 @@ try:
     fused("warm2", cenv)
     t_srv_fused, d3 = fused("srv_fused", cenv)
     same(d0, d2), same(d0, d3)
+    # the `card` DandD asks for after a k-batch: all K sketches in one command (lib/sketch_classes.py:306-316), through a resident
+    # server of the build under test (KBATCH_OTHER_DASHING: another build's executable, for an A/B on the same files)
+    sketches = [os.path.join(d3, f"k{k}", f"g.fasta.w.{k}.spacing.{p}.hll") for k in ks]
+    t_card = []
+    for n, exe in enumerate([dashing] + ([os.environ["KBATCH_OTHER_DASHING"]] if os.environ.get("KBATCH_OTHER_DASHING") else [])):
+        s2 = os.path.join(work, f"card{n}.sock")
+        srv2 = subprocess.Popen([exe, "serve", "--socket", s2], stdout=subprocess.PIPE, text=True, env=env)
+        assert "listening" in srv2.stdout.readline()
+        e2 = dict(env, DANDD_DASHING_SERVER=s2, DANDD_SERVER_REQUIRED="1")
+        best = 1e9
+        for _ in range(6):
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, "card", "--presketched"] + sketches, env=e2, capture_output=True, text=True)
+            best = min(best, time.perf_counter() - t0)
+            assert r.returncode == 0 and len(r.stdout.splitlines()) == len(ks) + 1, r.stderr
+        subprocess.run([exe, "shutdown"], env=e2, capture_output=True)
+        srv2.wait(timeout=60)
+        t_card.append((exe, best, r.stdout))
+    assert all(o == t_card[0][2] for _, _, o in t_card)
     subprocess.run([dashing, "shutdown"], env=cenv, capture_output=True)
     srv.wait(timeout=60)
     K = len(ks)
@@ -72,5 +91,7 @@ try:
     print(f"  the same K as clients of `dashing serve`                     : {t_srv:7.3f} s")
     print(f"  ONE fused `parallel` process                                  : {t_fused:7.3f} s   ({mbp / 1e3 / t_fused:.2f} Gbp/s of sequence, all K ks, end to end)")
     print(f"  ONE fused `parallel` through `dashing serve`                  : {t_srv_fused:7.3f} s   ({mbp / 1e3 / t_srv_fused:.2f} Gbp/s of sequence, all K ks, end to end)")
+    for exe, best, _ in t_card:
+        print(f"  `card --presketched` of the K sketches, client {os.path.relpath(exe, ROOT):32s}: {best:7.3f} s (best of 6, through its own resident server)")
 finally:
     shutil.rmtree(work, ignore_errors=True)
